@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_golden.py [--only NAME]
+
+The reference (f78bono/deep-cine-cardiac-mri) is imported unmodified with the
+three shims of SURVEY.md appendix C (stub ``bart``/``h5py`` at import time,
+``Tensor.cuda`` -> identity).  Every .npz holds inputs, the reference's
+outputs, and (for modules) the full reference state_dict, so tests can replay
+them anywhere without the reference.  Only data is written -- no reference
+source text.
+"""
+import argparse
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("CINE_REFERENCE_ROOT", "/root/reference")
+
+for _m in ("bart", "h5py"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+torch.Tensor.cuda = lambda self, *a, **k: self
+sys.path.insert(0, REF)
+import reconstruction.utils as RU            # noqa: E402
+import reconstruction.models as RM           # noqa: E402
+from reconstruction.models.denoisers import unet as r_unet, norm_unet as r_norm_unet  # noqa: E402
+from reconstruction.data import subsample as r_sub, transforms as r_tf                 # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "deep-cine-cardiac-mri_amd"))
+from cine_hip import synth                    # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def rnd(seed, *shape):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32))
+
+
+def sd_np(module, prefix="sd::"):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays)")
+
+
+def tiny_mask(t, h, rows_extra=(2, 5, 20), centre=(10, 14)):
+    m = torch.zeros(1, t, 1, h, 1, 1, dtype=torch.uint8)
+    m[:, :, :, centre[0]:centre[1]] = 1
+    for f in range(t):
+        for r in rows_extra:
+            m[:, f, :, (r + 3 * f) % h] = 1
+    m[:, :, :, centre[0]:centre[1]] = 1
+    m[:, 0, :, centre[0] - 1] = 0      # frame 0 needs zeros either side of the centre
+    m[:, 0, :, centre[1]] = 0
+    return m
+
+
+# ------------------------------------------------------------------ generators
+def g_ops():
+    """fftc.py / math.py / coil_combine.py / transforms.mask_center."""
+    a = {}
+    for tag, shape in (("odd", (2, 5, 7, 2)), ("t15", (3, 4, 15, 2)), ("even", (2, 24, 20, 2)),
+                       ("mixed", (1, 3, 9, 16, 2))):
+        x = rnd(zlib.crc32(tag.encode()) % 1000, *shape)
+        a[f"{tag}_x"] = x
+        a[f"{tag}_fft1c"] = RU.fft1c(x)
+        a[f"{tag}_ifft1c"] = RU.ifft1c(x)
+        a[f"{tag}_fft2c"] = RU.fft2c(x)
+        a[f"{tag}_ifft2c"] = RU.ifft2c(x)
+        a[f"{tag}_fftshift"] = RU.fftshift(x, dim=[-3, -2])
+        a[f"{tag}_ifftshift"] = RU.ifftshift(x, dim=[-3, -2])
+    # one full-size 200x200 pair, input regenerated from RandomState(7)
+    x = rnd(7, 2, 200, 200, 2)
+    a["full200_seed"] = 7
+    a["full200_fft2c"] = RU.fft2c(x)
+    a["full200_ifft2c"] = RU.ifft2c(x)
+    x, y = rnd(11, 2, 3, 6, 5, 2), rnd(12, 2, 1, 6, 5, 2)
+    a.update(cm_x=x, cm_y=y, cm_mul=RU.complex_mul(x, y), cm_conj=RU.complex_conj(x),
+             cm_abs=RU.complex_abs(x), cm_abs_sq=RU.complex_abs_sq(x),
+             cm_rss=RU.rss(x, dim=1), cm_rss_complex=RU.rss_complex(x, dim=1))
+    r = rnd(13, 2, 4, 5, 12)
+    z = RU.real_to_complex_multi_ch(r, 6)
+    a.update(mc_r=r, mc_z_re=z.real, mc_z_im=z.imag, mc_back=RU.complex_to_real_multi_ch(z))
+    k = rnd(14, 1, 3, 12, 10, 2)
+    a.update(mcen_x=k, mcen_out=r_tf.mask_center(k, 4, 9))
+    save("ops", **a)
+
+
+def g_unet():
+    """ConvBlock / TransposeConvBlock / Unet / NormUnet / NormUnet3D (tiny widths)."""
+    a = {}
+    cb = r_unet.ConvBlock(3, 8, 0.0, 2).eval(); synth.fill_parameters_(cb, 21)
+    x = rnd(21, 2, 3, 12, 10)
+    a.update(sd_np(cb, "cb::")); a.update(cb_x=x, cb_y=cb(x))
+    tb = r_unet.TransposeConvBlock(8, 4, 2).eval(); synth.fill_parameters_(tb, 22)
+    x = rnd(22, 2, 8, 6, 5)
+    a.update(sd_np(tb, "tb::")); a.update(tb_x=x, tb_y=tb(x))
+    un = r_unet.Unet(chans=4, num_pool_layers=2, in_chans=2, out_chans=2).eval()
+    synth.fill_parameters_(un, 23)
+    x = rnd(23, 3, 2, 16, 16)
+    a.update(sd_np(un, "un::")); a.update(un_x=x, un_y=un(x))
+    # odd sizes exercise the up-path zero pad (unet.py:106-120)
+    x = rnd(24, 2, 2, 13, 10)
+    a.update(un_odd_x=x, un_odd_y=un(x))
+    nu = r_norm_unet.NormUnet(4, 2).eval(); synth.fill_parameters_(nu, 25)
+    x = rnd(25, 3, 1, 20, 5, 2) * 3 + 1.5
+    xn, mean, std = nu.norm(nu.complex_to_chan_dim(x))
+    a.update(sd_np(nu, "nu::")); a.update(nu_x=x, nu_y=nu(x), nu_norm=xn, nu_mean=mean, nu_std=std)
+    nu3 = r_norm_unet.NormUnet3D(4, 2).eval(); synth.fill_parameters_(nu3, 26)
+    x = rnd(26, 1, 1, 5, 12, 10, 2)
+    a.update(sd_np(nu3, "nu3::")); a.update(nu3_x=x, nu3_y=nu3(x))
+    save("unet", **a)
+
+
+def g_varnet_block():
+    """VarNetBlock pieces + SensitivityModel at tiny shape (t5 c3 24x20)."""
+    t, c, h, w = 5, 3, 24, 20
+    a = {}
+    k = rnd(31, 1, t, c, h, w, 2)
+    mask = tiny_mask(t, h)
+    sens = rnd(32, 1, 1, c, h, w, 2) * 0.5
+    kref = k * mask
+    a.update(k=k, kref=kref, mask=mask, sens=sens)
+    for dyn in ("XF", "XT", "2D", "3D"):
+        net = RM.VarNet(1, 4, 2, 4, 2, dyn).eval()
+        synth.fill_parameters_(net, 33)
+        blk = net.cascades[0]
+        blk.lambda_reg.fill_(0.3)
+        a.update(sd_np(net, f"{dyn}::sd::"))
+        img = blk.sens_reduce(k, sens)
+        a[f"{dyn}_reduce"] = img
+        a[f"{dyn}_expand"] = blk.sens_expand(img, sens)
+        if dyn in ("XF", "XT"):
+            a[f"{dyn}_xfyf"] = blk.xfyf_transform(img.squeeze(2))
+        a[f"{dyn}_block"] = blk(k, kref, mask, sens)
+    net = RM.VarNet(1, 4, 2, 4, 2, "XF").eval()
+    synth.fill_parameters_(net, 34)
+    a.update(sd_np(net.sens_net, "sens::sd::"))
+    a["sens_out"] = net.sens_net(kref, mask)
+    save("varnet_block", **a)
+
+
+def g_varnet_tiny():
+    """Whole VarNet forward, all dynamic types (+weight sharing), tiny shape."""
+    t, c, h, w = 5, 3, 24, 20
+    k = rnd(41, 1, t, c, h, w, 2)
+    mask = tiny_mask(t, h)
+    mk = k * mask
+    a = dict(masked_kspace=mk, mask=mask)
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False),
+                         ("3D", "3D", False), ("XFws", "XF", True)):
+        net = RM.VarNet(2, 4, 2, 4, 2, dyn, ws).eval()
+        synth.fill_parameters_(net, 42)
+        for i, cas in enumerate(net.cascades):
+            cas.lambda_reg.fill_(0.2 + 0.5 * i)
+        a.update(sd_np(net, f"{tag}::sd::"))
+        a[f"{tag}_out"] = net(mk, mask)
+        a[f"{tag}_sens"] = net.sens_net(mk, mask)
+    save("varnet_tiny", **a)
+
+
+def g_masks():
+    """RandomMaskFunc / EquispacedMaskFunc / apply_mask."""
+    a = {}
+    for seed, acc, nx, nt in ((0, 4, 200, 15), (3, 8, 200, 15), (5, 6, 64, 4)):
+        np.random.seed(seed)
+        mf = r_sub.create_mask_for_mask_type("random", [10], [acc])
+        a[f"random_s{seed}_a{acc}_n{nx}"] = mf((nt, 1, nx, 7, 2), None)
+    mf = r_sub.create_mask_for_mask_type("equispaced", [0.08], [4])
+    a["equi_s9"] = mf((15, 1, 200, 7, 2), 9)
+    np.random.seed(2)
+    data = rnd(51, 4, 2, 32, 6, 2)
+    mf = r_sub.create_mask_for_mask_type("random", [4], [4])
+    md, m = r_tf.apply_mask(data, mf, None)
+    a.update(am_data=data, am_masked=md, am_mask=m)
+    save("masks", **a)
+
+
+def g_varnet_full():
+    """cfg 2 fingerprint: XF-VarNet 6 cascades, 15 coils, 15 frames, 200x200, R=4.
+    Inputs/weights are regenerated from seeds (data 0, weights 1); only the
+    strided output fingerprint and scalar summaries are stored."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+    net = RM.VarNet(6, 8, 3, 16, 3, "XF").eval()
+    synth.fill_parameters_(net, 1)
+    out = net(ex["masked_kspace"], ex["mask"])
+    sens = net.sens_net(ex["masked_kspace"], ex["mask"])
+    save("varnet_cfg2", out_strided=out[:, :, ::4, ::4].contiguous(),
+         out_sum=out.double().sum(), out_l2=out.double().norm(), out_max=out.max(),
+         sens_strided=sens[:, :, :, ::8, ::8].contiguous(),
+         mask=ex["mask"], data_seed=0, weight_seed=1)
+
+
+def g_varnet_cfg1():
+    """cfg 1: 2D VarNet, 2 cascades, 8 coils, single 200x200 frame, R=4."""
+    ex = synth.make_cine_slice(1, 8, 200, 200, accel=4, seed=0)
+    net = RM.VarNet(2, 8, 3, 16, 3, "2D").eval()
+    synth.fill_parameters_(net, 1)
+    out = net(ex["masked_kspace"], ex["mask"])
+    save("varnet_cfg1", out=out, out_sum=out.double().sum(), mask=ex["mask"],
+         data_seed=0, weight_seed=1)
+
+
+GENERATORS = dict(ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+                  varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
+                  varnet_cfg1=g_varnet_cfg1)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    for name, fn in GENERATORS.items():
+        if args.only and name not in args.only:
+            continue
+        print(f"[{name}]")
+        fn()

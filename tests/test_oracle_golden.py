@@ -1,0 +1,127 @@
+"""Pin the CPU oracle (oracle/) against the reference's own outputs.
+
+The golden vectors were produced by importing the reference in the build
+container (tests/golden/make_golden.py).  CPU only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, rnd, state_dict_from
+from oracle import centered_fft as cf, complex_ops as co
+from oracle import regularisers as R, varnet_ref as V
+
+OP_TOL = 1e-5      # op-level relative tolerance
+
+
+@pytest.mark.parametrize("tag", ["odd", "t15", "even", "mixed"])
+def test_centered_ffts(golden, tag):
+    g = golden("ops")
+    x = torch.from_numpy(g[f"{tag}_x"])
+    for name, fn in (("fft1c", cf.fft1c), ("ifft1c", cf.ifft1c), ("fft2c", cf.fft2c),
+                     ("ifft2c", cf.ifft2c)):
+        assert rel_err(fn(x), g[f"{tag}_{name}"]) < OP_TOL, name
+    assert torch.equal(cf.fftshift(x, [-3, -2]), torch.from_numpy(g[f"{tag}_fftshift"]))
+    assert torch.equal(cf.ifftshift(x, [-3, -2]), torch.from_numpy(g[f"{tag}_ifftshift"]))
+
+
+def test_fft2c_200(golden):
+    g = golden("ops")
+    x = rnd(int(g["full200_seed"]), 2, 200, 200, 2)
+    assert rel_err(cf.fft2c(x), g["full200_fft2c"]) < OP_TOL
+    assert rel_err(cf.ifft2c(x), g["full200_ifft2c"]) < OP_TOL
+    assert rel_err(cf.ifft2c(cf.fft2c(x)), x) < OP_TOL
+
+
+def test_fft_rejects_non_pair():
+    with pytest.raises(ValueError):
+        cf.fft2c(torch.zeros(4, 4, 3))
+    with pytest.raises(ValueError):
+        co.complex_mul(torch.zeros(4, 2), torch.zeros(4, 3))
+
+
+def test_complex_ops(golden):
+    g = golden("ops")
+    x, y = torch.from_numpy(g["cm_x"]), torch.from_numpy(g["cm_y"])
+    assert rel_err(co.complex_mul(x, y), g["cm_mul"]) < 1e-6
+    assert torch.equal(co.complex_conj(x), torch.from_numpy(g["cm_conj"]))
+    assert rel_err(co.complex_abs(x), g["cm_abs"]) < 1e-6
+    assert rel_err(co.complex_abs_sq(x), g["cm_abs_sq"]) < 1e-6
+    assert rel_err(co.rss(x, 1), g["cm_rss"]) < 1e-6
+    assert rel_err(co.rss_complex(x, 1), g["cm_rss_complex"]) < 1e-6
+    z = co.real_to_complex_multi_ch(torch.from_numpy(g["mc_r"]), 6)
+    assert np.array_equal(z.real.numpy(), g["mc_z_re"]) and np.array_equal(z.imag.numpy(), g["mc_z_im"])
+    assert np.array_equal(co.complex_to_real_multi_ch(z).numpy(), g["mc_back"])
+    assert np.array_equal(co.mask_center(torch.from_numpy(g["mcen_x"]), 4, 9).numpy(), g["mcen_out"])
+
+
+def test_unet_blocks(golden):
+    g = golden("unet")
+    cb = R.ConvBlock(3, 8, 0.0, 2).eval()
+    cb.load_state_dict(state_dict_from(g, "cb::"), strict=True)
+    tb = R.TransposeConvBlock(8, 4, 2).eval()
+    tb.load_state_dict(state_dict_from(g, "tb::"), strict=True)
+    un = R.Unet(chans=4, num_pool_layers=2).eval()
+    un.load_state_dict(state_dict_from(g, "un::"), strict=True)
+    with torch.no_grad():
+        assert rel_err(cb(torch.from_numpy(g["cb_x"])), g["cb_y"]) < OP_TOL
+        assert rel_err(tb(torch.from_numpy(g["tb_x"])), g["tb_y"]) < OP_TOL
+        assert rel_err(un(torch.from_numpy(g["un_x"])), g["un_y"]) < OP_TOL
+        assert rel_err(un(torch.from_numpy(g["un_odd_x"])), g["un_odd_y"]) < OP_TOL
+
+
+def test_norm_unets(golden):
+    g = golden("unet")
+    nu = R.NormUnet(4, 2).eval()
+    nu.load_state_dict(state_dict_from(g, "nu::"), strict=True)
+    nu3 = R.NormUnet3D(4, 2).eval()
+    nu3.load_state_dict(state_dict_from(g, "nu3::"), strict=True)
+    with torch.no_grad():
+        x = torch.from_numpy(g["nu_x"])
+        b, c, h, w, _ = x.shape
+        xn, mean, std = nu.norm(x.permute(0, 4, 1, 2, 3).reshape(b, 2 * c, h, w))
+        assert rel_err(xn, g["nu_norm"]) < OP_TOL
+        assert rel_err(mean, g["nu_mean"]) < OP_TOL and rel_err(std, g["nu_std"]) < OP_TOL
+        assert rel_err(nu(x), g["nu_y"]) < OP_TOL
+        assert rel_err(nu3(torch.from_numpy(g["nu3_x"])), g["nu3_y"]) < OP_TOL
+    with pytest.raises(ValueError):
+        nu(torch.zeros(1, 1, 8, 8, 3))
+
+
+@pytest.mark.parametrize("dyn", ["XF", "XT", "2D", "3D"])
+def test_varnet_block(golden, dyn):
+    g = golden("varnet_block")
+    net = V.VarNet(1, 4, 2, 4, 2, dyn).eval()
+    net.load_state_dict(state_dict_from(g, f"{dyn}::sd::"), strict=True)
+    blk = net.cascades[0]
+    k, kref, sens = (torch.from_numpy(g[n]) for n in ("k", "kref", "sens"))
+    mask = torch.from_numpy(g["mask"])
+    with torch.no_grad():
+        img = blk.sens_reduce(k, sens)
+        assert rel_err(img, g[f"{dyn}_reduce"]) < OP_TOL
+        assert rel_err(blk.sens_expand(img, sens), g[f"{dyn}_expand"]) < OP_TOL
+        if dyn in ("XF", "XT"):
+            assert rel_err(blk.xfyf_transform(img.squeeze(2)), g[f"{dyn}_xfyf"]) < 2e-5
+        assert rel_err(blk(k, kref, mask, sens), g[f"{dyn}_block"]) < 2e-5
+
+
+def test_sensitivity_model(golden):
+    g = golden("varnet_block")
+    sm = V.SensitivityModel(4, 2).eval()
+    sm.load_state_dict(state_dict_from(g, "sens::sd::"), strict=True)
+    with torch.no_grad():
+        out = sm(torch.from_numpy(g["kref"]), torch.from_numpy(g["mask"]))
+    assert rel_err(out, g["sens_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False),
+                                        ("3D", "3D", False), ("XFws", "XF", True)])
+def test_varnet_tiny(golden, tag, dyn, ws):
+    g = golden("varnet_tiny")
+    net = V.VarNet(2, 4, 2, 4, 2, dyn, ws).eval()
+    missing = net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"]))
+    assert out.shape == g[f"{tag}_out"].shape
+    assert rel_err(out, g[f"{tag}_out"]) < 1e-4

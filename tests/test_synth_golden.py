@@ -1,0 +1,70 @@
+"""Host-side input preparation (masks, apply_mask, seeded weights) vs the reference,
+and the oracle on the full-size BASELINE configs (fingerprints)."""
+import numpy as np
+import torch
+
+from conftest import rel_err, rnd
+from cine_hip import synth
+from oracle import varnet_ref as V
+
+
+def test_random_masks_bit_exact(golden):
+    g = golden("masks")
+    for seed, acc, nx, nt in ((0, 4, 200, 15), (3, 8, 200, 15), (5, 6, 64, 4)):
+        np.random.seed(seed)
+        mf = synth.create_mask_for_mask_type("random", [10], [acc])
+        m = mf((nt, 1, nx, 7, 2), None)
+        assert np.array_equal(m.numpy(), g[f"random_s{seed}_a{acc}_n{nx}"])
+        assert int(m.sum()) == nt * int(nx / acc)            # lines per frame incl. centre
+
+
+def test_equispaced_and_apply_mask(golden):
+    g = golden("masks")
+    mf = synth.create_mask_for_mask_type("equispaced", [0.08], [4])
+    assert np.array_equal(mf((15, 1, 200, 7, 2), 9).numpy(), g["equi_s9"])
+    np.random.seed(2)
+    mf = synth.create_mask_for_mask_type("random", [4], [4])
+    md, m = synth.apply_mask(torch.from_numpy(g["am_data"]), mf, None)
+    assert np.array_equal(m.numpy(), g["am_mask"]) and np.array_equal(md.numpy(), g["am_masked"])
+
+
+def test_make_cine_slice_shapes():
+    ex = synth.make_cine_slice(5, 3, 24, 20, accel=4, center_lines=4, seed=0)
+    assert ex["masked_kspace"].shape == (1, 5, 3, 24, 20, 2)
+    assert ex["mask"].shape == (1, 5, 1, 24, 1, 1) and ex["mask"].dtype == torch.uint8
+    assert ex["sens_maps"].shape == (1, 1, 3, 24, 20, 2)
+    # zero rows where the mask is zero
+    m = ex["mask"].float()
+    assert torch.all(ex["masked_kspace"] * (1 - m) == 0)
+
+
+def test_fill_parameters_is_name_keyed():
+    a = V.VarNet(1, 4, 2, 4, 2, "XF"); b = V.VarNet(1, 4, 2, 4, 2, "XF")
+    synth.fill_parameters_(a, 5); synth.fill_parameters_(b, 5)
+    for (n1, p1), (n2, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+
+
+def test_oracle_cfg1_full(golden):
+    """BASELINE configs[0]: 2D VarNet, 2 cascades, 8 coils, one 200x200 frame, R=4."""
+    g = golden("varnet_cfg1")
+    ex = synth.make_cine_slice(1, 8, 200, 200, accel=4, seed=int(g["data_seed"]))
+    assert np.array_equal(ex["mask"].numpy(), g["mask"])
+    net = V.VarNet(2, 8, 3, 16, 3, "2D").eval()
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    with torch.no_grad():
+        out = net(ex["masked_kspace"], ex["mask"])
+    assert rel_err(out, g["out"]) < 1e-4
+
+
+def test_oracle_cfg2_full(golden):
+    """BASELINE configs[1]: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, R=4."""
+    g = golden("varnet_cfg2")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=int(g["data_seed"]))
+    assert np.array_equal(ex["mask"].numpy(), g["mask"])
+    net = V.VarNet(6, 8, 3, 16, 3, "XF").eval()
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    with torch.no_grad():
+        out = net(ex["masked_kspace"], ex["mask"])
+    assert rel_err(out[:, :, ::4, ::4], g["out_strided"]) < 1e-4
+    assert abs(float(out.double().sum()) - float(g["out_sum"])) / float(g["out_sum"]) < 1e-5
