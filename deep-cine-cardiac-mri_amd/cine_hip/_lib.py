@@ -1,0 +1,85 @@
+"""ctypes binding of libcine_hip.so (C ABI: include/cine_hip.h).
+
+The library is looked up next to this file (built in-tree by
+``make -C deep-cine-cardiac-mri_amd/csrc`` or ``__graft_entry__.build()``).
+Loading is lazy so host-only helpers (synth, metrics) import without it, but
+every compute call goes through ``lib()`` and raises ``CineHipError`` if the
+library is missing -- there is no CPU fallback.
+"""
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcine_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "cine_hip.h"))
+
+
+class CineHipError(RuntimeError):
+    pass
+
+
+P = c_void_p
+_SIGS = {
+    "cine_version": (c_int, []),
+    "cine_last_error": (c_char_p, []),
+    "cine_build_arch": (c_char_p, []),
+    "cine_pad16": (c_int, [c_int]),
+    "cine_fft2c": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "cine_fft1c": (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
+    "cine_sens_reduce": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_sens_expand_dc": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_sens_prologue": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_rss_normalise": (c_int, [P, c_int, c_int, c_int, c_int, P]),
+    "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "cine_normunet_unpack": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "cine_xfyf_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cine_xfyf_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_xfyf_unpack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_conv3x3_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_pack_conv3x3": (c_int, [P, P, c_int, c_int, P]),
+    "cine_conv3x3_in": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int,
+                                P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_tconv2x2_in": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_conv1x1_bias": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
+    "cine_instnorm_stats": (c_int, [P, P, c_long, c_long, c_float, P]),
+    "cine_instnorm_lrelu_apply": (c_int, [P, P, P, c_long, c_long, c_float, P]),
+    "cine_unet2d_ws_bytes": (c_size_t, [c_int] * 7),
+    "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_complex_abs": (c_int, [P, P, c_long, P]),
+    "cine_profile_begin": (c_int, []),
+    "cine_profile_end": (c_int, [P, P, c_int]),
+    "cine_profile_families": (c_int, []),
+    "cine_profile_family_name": (c_char_p, [c_int]),
+}
+
+_lib = None
+
+
+def declared_symbols(header_path: str = HEADER_PATH):
+    """Every function name include/cine_hip.h declares (used by the symbol-export test)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cine_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CineHipError(
+                f"{LIB_PATH} not found: build it with `make -C deep-cine-cardiac-mri_amd/csrc` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = lib().cine_last_error().decode(errors="replace")
+        raise CineHipError(f"{what or 'cine_hip'} failed ({code}): {msg}")

@@ -1,0 +1,326 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs, pass raw pointers.
+
+PyTorch is plumbing here (device memory + the current HIP stream); all
+arithmetic happens in libcine_hip.so.  Inputs must be CUDA(HIP) float32
+tensors; anything else raises -- there is no CPU path.
+"""
+from typing import Optional, Sequence
+
+import ctypes
+import torch
+
+from ._lib import CineHipError, check, lib
+
+IN_EPS = 1e-5       # nn.InstanceNorm2d default eps (reference unet.py:161)
+LRELU_SLOPE = 0.2   # nn.LeakyReLU(0.2)            (reference unet.py:162)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(x: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not x.is_cuda:
+        raise CineHipError(f"{name}: tensor is on {x.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if x.dtype != dtype:
+        raise CineHipError(f"{name}: dtype {x.dtype}, expected {dtype}")
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def _pair(x: torch.Tensor, msg="Tensor does not have separate complex dim."):
+    if x.shape[-1] != 2:
+        raise ValueError(msg)
+
+
+def _p(x: Optional[torch.Tensor]):
+    return None if x is None else x.data_ptr()
+
+
+# ------------------------------------------------------------------ centered FFTs
+def fft2c(x: torch.Tensor, inverse: bool = False) -> torch.Tensor:
+    """reference utils/fftc.py:59-110."""
+    _pair(x)
+    x = _dev(x, "fft2c input")
+    if x.dim() < 3:
+        raise ValueError("fft2c needs (..., h, w, 2)")
+    h, w = x.shape[-3], x.shape[-2]
+    out = torch.empty_like(x)
+    nimg = x.numel() // (h * w * 2)
+    check(lib().cine_fft2c(x.data_ptr(), out.data_ptr(), nimg, h, w, int(inverse), _stream()), "cine_fft2c")
+    return out
+
+
+def fft1c(x: torch.Tensor, inverse: bool = False, variant: int = 0) -> torch.Tensor:
+    """reference utils/fftc.py:5-56 (variant 0) / xpdnet.py:466,500 (variant 1); acts on dim -2."""
+    _pair(x)
+    x = _dev(x, "fft1c input")
+    n = x.shape[-2]
+    out = torch.empty_like(x)
+    check(lib().cine_fft1c(x.data_ptr(), out.data_ptr(), x.numel() // (2 * n), n, int(inverse), variant, _stream()),
+          "cine_fft1c")
+    return out
+
+
+# ------------------------------------------------------------------ coil operators
+def sens_reduce(k: torch.Tensor, sens: torch.Tensor, magnitude: bool = False,
+                destroy_input: bool = False) -> torch.Tensor:
+    """reference varnet.py:187-194 (and :150-151 with magnitude=True).
+    k (b,t,c,h,w,2), sens (b,1,c,h,w,2) -> (b,t,1,h,w,2) or (b,t,h,w)."""
+    _pair(k); _pair(sens)
+    k = _dev(k, "k-space"); sens = _dev(sens, "sens_maps")
+    b, t, c, h, w, _ = k.shape
+    if sens.shape != (b, 1, c, h, w, 2):
+        raise ValueError(f"sens_maps shape {tuple(sens.shape)} does not match k-space {tuple(k.shape)}")
+    tmp = k if destroy_input else torch.empty_like(k)
+    out = torch.empty((b, t, h, w) if magnitude else (b, t, 1, h, w, 2), device=k.device, dtype=k.dtype)
+    check(lib().cine_sens_reduce(k.data_ptr(), sens.data_ptr(), out.data_ptr(), tmp.data_ptr(),
+                                 b, t, c, h, w, int(magnitude), _stream()), "cine_sens_reduce")
+    return out
+
+
+def sens_expand_dc(img: torch.Tensor, sens: torch.Tensor, kref: Optional[torch.Tensor] = None,
+                   mask: Optional[torch.Tensor] = None, lambda_reg: Optional[torch.Tensor] = None,
+                   hard_mask: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reference varnet.py:181-185 fused with the DC of :281-282 (or cinenet.py:129 with hard_mask)."""
+    _pair(img); _pair(sens)
+    img = _dev(img, "image"); sens = _dev(sens, "sens_maps")
+    b, _, c, h, w, _ = sens.shape
+    t = img.shape[1]
+    if img.numel() != b * t * h * w * 2:
+        raise ValueError(f"image shape {tuple(img.shape)} does not match sens_maps {tuple(sens.shape)}")
+    if kref is not None:
+        kref = _dev(kref, "ref_kspace")
+        if kref.shape != (b, t, c, h, w, 2):
+            raise ValueError("ref_kspace shape mismatch")
+    if mask is not None:
+        mask = _dev(mask, "mask", torch.uint8)
+        if mask.numel() != b * t * h:
+            raise ValueError(f"mask shape {tuple(mask.shape)}: expected (b, t, 1, h, 1, 1)")
+    if lambda_reg is not None:
+        lambda_reg = _dev(lambda_reg.detach(), "lambda_reg")
+    if out is None:
+        out = torch.empty((b, t, c, h, w, 2), device=img.device, dtype=img.dtype)
+    check(lib().cine_sens_expand_dc(img.data_ptr(), sens.data_ptr(), _p(kref), _p(mask), _p(lambda_reg),
+                                    out.data_ptr(), b, t, c, h, w, int(hard_mask), _stream()),
+          "cine_sens_expand_dc")
+    return out
+
+
+def sens_prologue(masked_kspace: torch.Tensor, row_lo: int, row_hi: int) -> torch.Tensor:
+    """reference varnet.py:71-74: ifft2c(mask_center(mean_t(k)))."""
+    k = _dev(masked_kspace, "masked_kspace")
+    b, t, c, h, w, _ = k.shape
+    out = torch.empty((b, c, h, w, 2), device=k.device, dtype=k.dtype)
+    check(lib().cine_sens_prologue(k.data_ptr(), out.data_ptr(), b, t, c, h, w, int(row_lo), int(row_hi), _stream()),
+          "cine_sens_prologue")
+    return out
+
+
+def rss_normalise_(x: torch.Tensor) -> torch.Tensor:
+    """reference varnet.py:58-59, in place on (b,c,h,w,2)."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+    b, c, h, w, _ = x.shape
+    check(lib().cine_rss_normalise(x.data_ptr(), b, c, h, w, _stream()), "cine_rss_normalise")
+    return x
+
+
+def complex_abs(x: torch.Tensor) -> torch.Tensor:
+    """reference utils/math.py:48-62."""
+    _pair(x)
+    x = _dev(x, "complex_abs input")
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=x.dtype)
+    check(lib().cine_complex_abs(x.data_ptr(), out.data_ptr(), out.numel(), _stream()), "cine_complex_abs")
+    return out
+
+
+# ------------------------------------------------------------------ NormUnet halves / rotations
+def pad16(n: int) -> int:
+    return ((n - 1) | 15) + 1
+
+
+def normunet_pack(x: torch.Tensor):
+    """(n,h,w,2) -> planes (n,2,hp,wp), stats (n,2,2); reference norm_unet.py:48-86."""
+    x = _dev(x, "normunet_pack input")
+    n, h, w, _ = x.shape
+    planes = torch.empty((n, 2, pad16(h), pad16(w)), device=x.device, dtype=x.dtype)
+    stats = torch.empty((n, 2, 2), device=x.device, dtype=x.dtype)
+    check(lib().cine_normunet_pack(x.data_ptr(), planes.data_ptr(), stats.data_ptr(), n, h, w, _stream()),
+          "cine_normunet_pack")
+    return planes, stats
+
+
+def normunet_unpack(planes: torch.Tensor, stats: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """reference norm_unet.py:88-96, 71-74, 53-57."""
+    planes = _dev(planes, "planes"); stats = _dev(stats, "stats")
+    n = planes.shape[0]
+    y = torch.empty((n, h, w, 2), device=planes.device, dtype=planes.dtype)
+    check(lib().cine_normunet_unpack(planes.data_ptr(), stats.data_ptr(), y.data_ptr(), n, h, w, _stream()),
+          "cine_normunet_unpack")
+    return y
+
+
+def xfyf_pack(img: torch.Tensor, xf: bool):
+    """reference varnet.py:202-217 + NormUnet front halves. img (b,t,h,w,2)."""
+    _pair(img)
+    img = _dev(img, "image")
+    b, t, h, w, _ = img.shape
+    dev, dt = img.device, img.dtype
+    if pad16(w) == pad16(h):
+        # one allocation so equal-sized x-f / y-f plane sets can go through the U-Net launches together
+        joint = torch.empty((b * h + b * w, 2, pad16(w), pad16(t)), device=dev, dtype=dt)
+        pxf, pyf = joint[:b * h], joint[b * h:]
+    else:
+        pxf = torch.empty((b * h, 2, pad16(w), pad16(t)), device=dev, dtype=dt)
+        pyf = torch.empty((b * w, 2, pad16(h), pad16(t)), device=dev, dtype=dt)
+    sxf = torch.empty((b * h, 2, 2), device=dev, dtype=dt)
+    syf = torch.empty((b * w, 2, 2), device=dev, dtype=dt)
+    mean = torch.empty((b, h, w, 2), device=dev, dtype=dt)
+    nbytes = lib().cine_xfyf_ws_bytes(b, t, h, w)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    check(lib().cine_xfyf_pack(img.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), sxf.data_ptr(), syf.data_ptr(),
+                               mean.data_ptr(), b, t, h, w, int(xf), ws.data_ptr(), nbytes, _stream()),
+          "cine_xfyf_pack")
+    return pxf, pyf, sxf, syf, mean
+
+
+def xfyf_unpack(pxf, pyf, sxf, syf, mean, b: int, t: int, h: int, w: int, xf: bool) -> torch.Tensor:
+    """reference varnet.py:229-241 + NormUnet back halves -> (b,t,1,h,w,2)."""
+    out = torch.empty((b, t, 1, h, w, 2), device=pxf.device, dtype=pxf.dtype)
+    check(lib().cine_xfyf_unpack(_dev(pxf, "pxf").data_ptr(), _dev(pyf, "pyf").data_ptr(), sxf.data_ptr(),
+                                 syf.data_ptr(), mean.data_ptr(), out.data_ptr(), b, t, h, w, int(xf), _stream()),
+          "cine_xfyf_unpack")
+    return out
+
+
+# ------------------------------------------------------------------ U-Net pieces
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    w = _dev(w.detach(), "conv weight")
+    cout, cin, kh, kw = w.shape
+    if (kh, kw) != (3, 3):
+        raise ValueError("pack_conv3x3 expects a (cout, cin, 3, 3) weight")
+    out = torch.empty(lib().cine_conv3x3_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
+    check(lib().cine_pack_conv3x3(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv3x3")
+    return out
+
+
+def conv3x3_in(srcs: Sequence, wpacked: torch.Tensor, cout: int, h: int, w: int, want_stats: bool = True):
+    """srcs: one or two (x, stats|None, mode) with x (n, c, hs, ws). Returns (y, stats_y)."""
+    (x0, s0, m0) = srcs[0]
+    x0 = _dev(x0, "conv source 0")
+    n = x0.shape[0]
+    if len(srcs) > 1:
+        (x1, s1, m1) = srcs[1]
+        x1 = _dev(x1, "conv source 1")
+        c1, h1, w1 = x1.shape[1:]
+    else:
+        x1 = s1 = None; m1 = c1 = h1 = w1 = 0
+    y = torch.empty((n, cout, h, w), device=x0.device, dtype=x0.dtype)
+    sy = torch.empty((n, cout, 2), device=x0.device, dtype=x0.dtype) if want_stats else None
+    check(lib().cine_conv3x3_in(x0.data_ptr(), _p(s0), x0.shape[1], m0, x0.shape[2], x0.shape[3],
+                                _p(x1), _p(s1), c1, m1, h1, w1, wpacked.data_ptr(), y.data_ptr(), _p(sy),
+                                n, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3x3_in")
+    return y, sy
+
+
+def tconv2x2_in(x, stats, mode: int, wt: torch.Tensor):
+    x = _dev(x, "tconv source"); wt = _dev(wt.detach(), "tconv weight")
+    n, cin, h, w = x.shape
+    cout = wt.shape[1]
+    y = torch.empty((n, cout, 2 * h, 2 * w), device=x.device, dtype=x.dtype)
+    sy = torch.empty((n, cout, 2), device=x.device, dtype=x.dtype)
+    check(lib().cine_tconv2x2_in(x.data_ptr(), _p(stats), mode, wt.data_ptr(), y.data_ptr(), sy.data_ptr(),
+                                 n, cin, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_tconv2x2_in")
+    return y, sy
+
+
+def conv1x1_bias(x, stats, mode: int, wt: torch.Tensor, bias: torch.Tensor):
+    x = _dev(x, "conv1x1 source")
+    wt = _dev(wt.detach().reshape(wt.shape[0], -1), "conv1x1 weight"); bias = _dev(bias.detach(), "conv1x1 bias")
+    n, cin, h, w = x.shape
+    cout = wt.shape[0]
+    y = torch.empty((n, cout, h, w), device=x.device, dtype=x.dtype)
+    check(lib().cine_conv1x1_bias(x.data_ptr(), _p(stats), mode, wt.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                  n, cin, cout, h, w, LRELU_SLOPE, _stream()), "cine_conv1x1_bias")
+    return y
+
+
+def instnorm_stats(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "instnorm source")
+    n, c = x.shape[:2]
+    pe = x.numel() // (n * c)
+    st = torch.empty((n, c, 2), device=x.device, dtype=x.dtype)
+    check(lib().cine_instnorm_stats(x.data_ptr(), st.data_ptr(), n * c, pe, IN_EPS, _stream()), "cine_instnorm_stats")
+    return st
+
+
+def instnorm_lrelu_apply(x: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "instnorm source")
+    n, c = x.shape[:2]
+    y = torch.empty_like(x)
+    check(lib().cine_instnorm_lrelu_apply(x.data_ptr(), stats.data_ptr(), y.data_ptr(), n * c,
+                                          x.numel() // (n * c), LRELU_SLOPE, _stream()), "cine_instnorm_lrelu_apply")
+    return y
+
+
+class UnetWeights:
+    """Device-side weight pointers of one (or several) reference ``Unet`` modules in the
+    order ``cine_unet2d_forward`` expects; 3x3 weights are repacked once and re-packed
+    automatically when a parameter is modified in place (``Tensor._version``)."""
+
+    def __init__(self, unets: Sequence[torch.nn.Module]):
+        self.unets = list(unets)
+        u0 = self.unets[0]
+        self.chans, self.pools = u0.chans, u0.num_pool_layers
+        self.in_ch, self.out_ch = u0.in_chans, u0.out_chans
+        self._key = None
+        self._keep = []
+        self._ptrs = None
+
+    def _params(self):
+        out = []
+        for u in self.unets:
+            seq = []
+            for blk in list(u.down_sample_layers) + [u.conv]:
+                seq += [("c3", blk.layers[0].weight), ("c3", blk.layers[4].weight)]
+            for i, (tc, uc) in enumerate(zip(u.up_transpose_conv, u.up_conv)):
+                last = i == len(u.up_conv) - 1
+                blk = uc[0] if last else uc
+                seq += [("raw", tc.layers[0].weight), ("c3", blk.layers[0].weight), ("c3", blk.layers[4].weight)]
+            fin = u.up_conv[-1][1]
+            seq += [("raw", fin.weight), ("raw", fin.bias)]
+            out.append(seq)
+        return out
+
+    def pointers(self):
+        params = self._params()
+        key = tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
+        if key != self._key:
+            keep, ptrs = [], []
+            for seq in params:
+                for kind, p in seq:
+                    t = pack_conv3x3(p) if kind == "c3" else _dev(p.detach(), "unet weight")
+                    keep.append(t); ptrs.append(t.data_ptr())
+            self._keep, self._key = keep, key
+            self._ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        return self._ptrs
+
+
+def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reference denoisers/unet.py:73-125 on (n, in_ch, h, w) planes."""
+    x = _dev(x, "unet input")
+    n, cin, h, w = x.shape
+    nsets = len(weights.unets)
+    if cin != weights.in_ch:
+        raise ValueError(f"unet input has {cin} channels, expected {weights.in_ch}")
+    need = lib().cine_unet2d_ws_bytes(n // nsets, h, w, cin, weights.out_ch, weights.chans, weights.pools)
+    if need == 0:
+        raise CineHipError("cine_unet2d_ws_bytes rejected the shape")
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, device=x.device, dtype=torch.uint8)
+    y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
+    check(lib().cine_unet2d_forward(x.data_ptr(), y.data_ptr(), weights.pointers(), nsets, n, h, w, cin,
+                                    weights.out_ch, weights.chans, weights.pools, workspace.data_ptr(),
+                                    workspace.numel(), _stream()), "cine_unet2d_forward")
+    return y

@@ -1,0 +1,417 @@
+// fft_kernels.hip -- batched centered ortho FFTs fused with the coil operators.
+//
+// A 2-D centered FFT is two line passes over LDS tiles (fft_core.h):
+//   column pass: one workgroup = one image x LINES adjacent columns, transform along h
+//   row pass   : one workgroup = LINES rows, transform along w (contiguous)
+// The reference's ifftshift / fftshift copies (fftc.py:119-213) become index
+// rotations on the tile load / store; the ortho scale rides on the twiddles.
+// Fusions (reference lines in include/cine_hip.h):
+//   row pass load  : S * img                (sens_expand, varnet.py:181-185)
+//   col pass store : soft / hard DC blend   (varnet.py:281-282, cinenet.py:129)
+//   row pass store : conj(S) * x, coil sum, optional magnitude (varnet.py:187-194, 150-151)
+// N == 200 uses the 10 x 20 Cooley-Tukey engine; any other N <= 400 a direct DFT.
+#include "common.h"
+#include "fft_core.h"
+
+namespace cine {
+
+__device__ const float2 TW200[200] = {
+#include "tw200.inc"
+};
+
+constexpr int kLines200 = 32, kThreads200 = 320;   // 640 r10 items = 2 rounds, 320 r20 items = 1 round
+constexpr int kLinesGen = 8, kThreadsGen = 256;
+constexpr int kMaxGenericN = 400;
+constexpr int kMaxOut = 4;                          // reduce outputs per thread
+
+enum { POST_NONE = 0, POST_DC = 1, POST_HARD = 2 };
+enum { PRE_NONE = 0, PRE_SMUL = 1 };
+enum { RPOST_NONE = 0, RPOST_REDUCE = 1, RPOST_REDUCE_ABS = 2 };
+
+template <bool F200> __device__ __forceinline__ void load_twiddles(cf* tw, int n) {
+    if (F200) {
+        for (int j = threadIdx.x; j < 200; j += blockDim.x) tw[j] = TW200[j];
+    } else {
+        const double s = 1.0 / sqrt((double)n);
+        for (int j = threadIdx.x; j < n; j += blockDim.x) {
+            double sn, cs;
+            sincospi(2.0 * (double)j / (double)n, &sn, &cs);
+            tw[j] = mk((float)(cs * s), (float)(-sn * s));
+        }
+    }
+}
+
+// Transform every line of the tile along p; returns the tile that holds the result
+// (natural order for the direct engine, Fft200::pos_of order for the 200 engine).
+template <bool F200, int DIR, int LINES>
+__device__ __forceinline__ cf* run_lines(cf* t0, cf* t1, int n, const cf* tw) {
+    constexpr int LP = LINES + 1;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    if (F200) {
+        for (int i = tid; i < Fft200::items_r10(LINES); i += nt)
+            Fft200::stage_r10<DIR, false, true>(t0, LP, i, LINES, tw);
+        __syncthreads();
+        for (int i = tid; i < Fft200::items_r20(LINES); i += nt) Fft200::stage_r20<DIR>(t0, LP, i, LINES);
+        __syncthreads();
+        return t0;
+    } else {
+        for (int i = tid; i < DirectDft::items(LINES, n); i += nt)
+            DirectDft::stage<DIR>(t0, t1, LP, i, LINES, n, tw);
+        __syncthreads();
+        return t1;
+    }
+}
+template <bool F200> __device__ __forceinline__ int res_pos(int k) { return F200 ? Fft200::pos_of(k) : k; }
+
+__device__ __forceinline__ float softplus1(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// ------------------------------------------------------------------ column pass
+struct ColArgs {
+    const cf* in; cf* out;
+    int H, W;
+    int s_in, s_out;
+    const cf* kref; const uint8_t* mask; const float* lam;
+    int coils;            // images per mask row-set (mask index = img / coils)
+};
+
+template <bool F200, int DIR, int POST, int LINES>
+__global__ void col_pass_kernel(ColArgs a) {
+    constexpr int LP = LINES + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int H = F200 ? 200 : a.H;
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    cf* t1 = t0 + (F200 ? 0 : H * LP);
+    cf* tw = t1 + H * LP;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int w0 = blockIdx.x * LINES;
+    const long img = blockIdx.y;
+    const cf* in = a.in + img * H * a.W;
+    cf* out = a.out + img * H * a.W;
+
+    load_twiddles<F200>(tw, H);
+    for (int e = tid; e < H * LINES; e += nt) {
+        const int g = e / LINES, l = e % LINES, col = w0 + l;
+        cf v = mk(0.f, 0.f);
+        if (col < a.W) v = in[(long)g * a.W + col];
+        int n = g + a.s_in; if (n >= H) n -= H;
+        t0[n * LP + l] = v;
+    }
+    __syncthreads();
+    cf* res = run_lines<F200, DIR, LINES>(t0, t1, H, tw);
+
+    float v = 0.f, inv1v = 1.f;
+    if (POST == POST_DC) { v = softplus1(*a.lam); }
+    const uint8_t* mrow = (POST != POST_NONE) ? a.mask + (img / a.coils) * H : nullptr;
+    const cf* kref = (POST == POST_DC) ? a.kref + img * H * a.W : nullptr;
+    for (int e = tid; e < H * LINES; e += nt) {
+        const int i = e / LINES, l = e % LINES, col = w0 + l;
+        if (col >= a.W) continue;
+        int k = i - a.s_out; if (k < 0) k += H;
+        cf val = res[res_pos<F200>(k) * LP + l];
+        if (POST == POST_DC) {
+            if (mrow[i]) {
+                cf r = kref[(long)i * a.W + col];
+                val = mk((val.x + v * r.x) / (1.f + v), (val.y + v * r.y) / (1.f + v));
+            }
+        } else if (POST == POST_HARD) {
+            if (!mrow[i]) val = mk(0.f, 0.f);
+        }
+        out[(long)i * a.W + col] = val;
+    }
+    (void)inv1v;
+}
+
+// ------------------------------------------------------------------ row pass
+struct RowArgs {
+    const cf* in; cf* out; float* out_abs;
+    long nlines;          // plain mode: total lines
+    int W;
+    int s_in, s_out;
+    // coil modes
+    const cf* sens; const cf* img;
+    int T, C, H, rpw, cc;  // rows per workgroup, coils per chunk
+};
+
+template <bool F200, int DIR, int PRE, int POST, int LINES>
+__global__ void row_pass_kernel(RowArgs a) {
+    constexpr int LP = LINES + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int W = F200 ? 200 : a.W;
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    cf* t1 = t0 + (F200 ? 0 : W * LP);
+    cf* tw = t1 + W * LP;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    load_twiddles<F200>(tw, W);
+
+    if (PRE == PRE_NONE && POST == RPOST_NONE) {
+        // ---- plain: LINES consecutive lines of W points
+        const long L0 = (long)blockIdx.x * LINES;
+        for (int e = tid; e < LINES * W; e += nt) {
+            const int l = e / W, g = e - l * W;
+            cf v = mk(0.f, 0.f);
+            if (L0 + l < a.nlines) v = a.in[(L0 + l) * W + g];
+            int n = g + a.s_in; if (n >= W) n -= W;
+            t0[n * LP + l] = v;
+        }
+        __syncthreads();
+        cf* res = run_lines<F200, DIR, LINES>(t0, t1, W, tw);
+        for (int e = tid; e < LINES * W; e += nt) {
+            const int l = e / W, i = e - l * W;
+            if (L0 + l >= a.nlines) continue;
+            int k = i - a.s_out; if (k < 0) k += W;
+            a.out[(L0 + l) * W + i] = res[res_pos<F200>(k) * LP + l];
+        }
+        return;
+    }
+
+    // ---- coil modes: lines = (coil within chunk, row within group)
+    const int bt = blockIdx.y, b = bt / a.T;
+    const int h0 = blockIdx.x * a.rpw;
+    const long HW = (long)a.H * W;
+    cf acc[kMaxOut];
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) acc[o] = mk(0.f, 0.f);
+
+    for (int c0 = 0; c0 < a.C; c0 += a.cc) {
+        const int nc = min(a.cc, a.C - c0);
+        // load
+        for (int e = tid; e < LINES * W; e += nt) {
+            const int l = e / W, g = e - l * W;
+            const int cl = l / a.rpw, r = l - cl * a.rpw;
+            const int h = h0 + r;
+            cf v = mk(0.f, 0.f);
+            if (cl < nc && h < a.H) {
+                const int c = c0 + cl;
+                if (PRE == PRE_SMUL) {
+                    cf s = a.sens[((long)b * a.C + c) * HW + (long)h * W + g];
+                    cf x = a.img[(long)bt * HW + (long)h * W + g];
+                    v = cmul(x, s);
+                } else {
+                    v = a.in[((long)bt * a.C + c) * HW + (long)h * W + g];
+                }
+            }
+            int n = g + a.s_in; if (n >= W) n -= W;
+            t0[n * LP + l] = v;
+        }
+        __syncthreads();
+        cf* res = run_lines<F200, DIR, LINES>(t0, t1, W, tw);
+        if (POST == RPOST_NONE) {
+            for (int e = tid; e < LINES * W; e += nt) {
+                const int l = e / W, i = e - l * W;
+                const int cl = l / a.rpw, r = l - cl * a.rpw;
+                const int h = h0 + r;
+                if (cl >= nc || h >= a.H) continue;
+                int k = i - a.s_out; if (k < 0) k += W;
+                a.out[((long)bt * a.C + c0 + cl) * HW + (long)h * W + i] = res[res_pos<F200>(k) * LP + l];
+            }
+        } else {
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) {
+                const int e = tid + o * nt;
+                if (e >= a.rpw * W) break;
+                const int r = e / W, i = e - r * W;
+                const int h = h0 + r;
+                if (h >= a.H) continue;
+                int k = i - a.s_out; if (k < 0) k += W;
+                const int p = res_pos<F200>(k) * LP;
+                cf s_acc = acc[o];
+                for (int cl = 0; cl < nc; ++cl) {
+                    cf x = res[p + cl * a.rpw + r];
+                    cf s = a.sens[((long)b * a.C + c0 + cl) * HW + (long)h * W + i];
+                    cf m = cmulc(x, s);       // x * conj(s)
+                    s_acc.x += m.x; s_acc.y += m.y;
+                }
+                acc[o] = s_acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (POST != RPOST_NONE) {
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            const int e = tid + o * nt;
+            if (e >= a.rpw * W) break;
+            const int r = e / W, i = e - r * W;
+            const int h = h0 + r;
+            if (h >= a.H) continue;
+            if (POST == RPOST_REDUCE_ABS)
+                a.out_abs[(long)bt * HW + (long)h * W + i] = sqrtf(acc[o].x * acc[o].x + acc[o].y * acc[o].y);
+            else
+                a.out[(long)bt * HW + (long)h * W + i] = acc[o];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static size_t lds_bytes(bool f200, int n, int lines) {
+    const size_t tile = (size_t)n * (lines + 1) * sizeof(cf);
+    return (f200 ? tile : 2 * tile) + (size_t)n * sizeof(cf);
+}
+
+static int check_n(int n, const char* what) {
+    CINE_REQUIRE(n >= 1, CINE_EINVAL, "%s: length %d < 1", what, n);
+    CINE_REQUIRE(n == 200 || n <= kMaxGenericN, CINE_EUNSUPPORTED,
+                 "%s: FFT length %d unsupported (200, or <= %d via the direct engine)", what, n, kMaxGenericN);
+    return CINE_OK;
+}
+
+template <int POST>
+static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st) {
+    if (nimg == 0) return CINE_OK;
+    const bool f200 = a.H == 200;
+    const int lines = f200 ? kLines200 : kLinesGen;
+    dim3 grid(ceil_div(a.W, lines), (unsigned)nimg);
+    CINE_REQUIRE(nimg <= 65535, CINE_EUNSUPPORTED, "column pass: %ld images > 65535", nimg);
+    const size_t lds = lds_bytes(f200, a.H, lines);
+    ProfScope prof(F_FFT_COL, st);
+    if (f200) {
+        if (inverse) hipLaunchKernelGGL((col_pass_kernel<true, -1, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
+        else hipLaunchKernelGGL((col_pass_kernel<true, 1, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
+    } else {
+        if (inverse) hipLaunchKernelGGL((col_pass_kernel<false, -1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        else hipLaunchKernelGGL((col_pass_kernel<false, 1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+    }
+    return check_launch("col_pass_kernel");
+}
+
+template <int PRE, int POST>
+static int launch_row(RowArgs a, dim3 grid, bool inverse, hipStream_t st) {
+    if (grid.x == 0 || grid.y == 0) return CINE_OK;
+    const bool f200 = a.W == 200;
+    const int lines = f200 ? kLines200 : kLinesGen;
+    const size_t lds = lds_bytes(f200, a.W, lines);
+    ProfScope prof(F_FFT_ROW, st);
+    if (f200) {
+        if (inverse) hipLaunchKernelGGL((row_pass_kernel<true, -1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
+        else hipLaunchKernelGGL((row_pass_kernel<true, 1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
+    } else {
+        if (inverse) hipLaunchKernelGGL((row_pass_kernel<false, -1, PRE, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        else hipLaunchKernelGGL((row_pass_kernel<false, 1, PRE, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+    }
+    return check_launch("row_pass_kernel");
+}
+
+// rows per workgroup / coils per chunk for the coil-mode row pass
+static void coil_tiling(int C, int W, int& rpw, int& cc) {
+    const bool f200 = W == 200;
+    const int lines = f200 ? kLines200 : kLinesGen;
+    const int nt = f200 ? kThreads200 : kThreadsGen;
+    cc = C < lines ? C : lines;
+    rpw = lines / cc;
+    while (rpw > 1 && (long)rpw * W > (long)kMaxOut * nt) --rpw;
+}
+
+int plain_rows(const cf* in, cf* out, long nlines, int n, bool inverse, int s_in, int s_out, hipStream_t st) {
+    RowArgs r{};
+    r.in = in; r.out = out; r.nlines = nlines; r.W = n; r.s_in = s_in; r.s_out = s_out;
+    const int lines = n == 200 ? kLines200 : kLinesGen;
+    const long blocks = ceil_div(nlines, (long)lines);
+    CINE_REQUIRE(blocks <= 0x7fffffffL, CINE_EUNSUPPORTED, "row pass: too many lines");
+    return launch_row<PRE_NONE, RPOST_NONE>(r, dim3((unsigned)blocks, 1), inverse, st);
+}
+
+}  // namespace cine
+
+using namespace cine;
+
+extern "C" int cine_fft2c(const float* in, float* out, int nimg, int h, int w, int inverse, void* stream) {
+    CINE_REQUIRE(in && out, CINE_EINVAL, "cine_fft2c: null pointer");
+    CINE_REQUIRE(nimg >= 0 && h > 0 && w > 0, CINE_EINVAL, "cine_fft2c: bad sizes nimg=%d h=%d w=%d", nimg, h, w);
+    if (int e = check_n(h, "cine_fft2c(h)")) return e;
+    if (int e = check_n(w, "cine_fft2c(w)")) return e;
+    hipStream_t st = as_stream(stream);
+    // the 65535 grid.y limit: split the image batch
+    for (long i0 = 0; i0 < nimg; i0 += 32768) {
+        const long ni = (nimg - i0) < 32768 ? (nimg - i0) : 32768;
+        ColArgs c{};
+        c.in = reinterpret_cast<const cf*>(in) + i0 * h * w;
+        c.out = reinterpret_cast<cf*>(out) + i0 * h * w;
+        c.H = h; c.W = w; c.s_in = (h + 1) / 2; c.s_out = h / 2; c.coils = 1;
+        if (int e = launch_col<POST_NONE>(c, ni, inverse != 0, st)) return e;
+    }
+    return plain_rows(reinterpret_cast<cf*>(out), reinterpret_cast<cf*>(out), (long)nimg * h, w, inverse != 0,
+                      (w + 1) / 2, w / 2, st);
+}
+
+extern "C" int cine_fft1c(const float* in, float* out, long nlines, int n, int inverse, int variant, void* stream) {
+    CINE_REQUIRE(in && out, CINE_EINVAL, "cine_fft1c: null pointer");
+    CINE_REQUIRE(nlines >= 0 && n > 0, CINE_EINVAL, "cine_fft1c: bad sizes");
+    CINE_REQUIRE(variant == 0 || variant == 1, CINE_EINVAL, "cine_fft1c: variant %d", variant);
+    if (int e = check_n(n, "cine_fft1c")) return e;
+    // variant 1, forward = ifftshift(fft(fftshift(x))) (xpdnet.py:466): pre-roll n/2, post-roll (n+1)/2.
+    // variant 1, inverse = fftshift(ifft(ifftshift(x))) (xpdnet.py:500) has the fftc.py shift order.
+    const bool swapped = variant == 1 && !inverse;
+    const int s_in = swapped ? n / 2 : (n + 1) / 2;
+    const int s_out = swapped ? (n + 1) / 2 : n / 2;
+    return plain_rows(reinterpret_cast<const cf*>(in), reinterpret_cast<cf*>(out), nlines, n, inverse != 0, s_in, s_out,
+                      as_stream(stream));
+}
+
+extern "C" int cine_sens_reduce(const float* k, const float* sens, float* out, float* tmp,
+                                int b, int t, int c, int h, int w, int magnitude, void* stream) {
+    CINE_REQUIRE(k && sens && out && tmp, CINE_EINVAL, "cine_sens_reduce: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_reduce: bad sizes");
+    if (int e = check_n(h, "cine_sens_reduce(h)")) return e;
+    if (int e = check_n(w, "cine_sens_reduce(w)")) return e;
+    hipStream_t st = as_stream(stream);
+    const long nimg = (long)b * t * c;
+    for (long i0 = 0; i0 < nimg; i0 += 32768) {
+        const long ni = (nimg - i0) < 32768 ? (nimg - i0) : 32768;
+        ColArgs ca{};
+        ca.in = reinterpret_cast<const cf*>(k) + i0 * h * w;
+        ca.out = reinterpret_cast<cf*>(tmp) + i0 * h * w;
+        ca.H = h; ca.W = w; ca.s_in = (h + 1) / 2; ca.s_out = h / 2; ca.coils = 1;
+        if (int e = launch_col<POST_NONE>(ca, ni, true, st)) return e;
+    }
+    RowArgs r{};
+    r.in = reinterpret_cast<const cf*>(tmp);
+    r.out = reinterpret_cast<cf*>(out); r.out_abs = out;
+    r.W = w; r.s_in = (w + 1) / 2; r.s_out = w / 2;
+    r.sens = reinterpret_cast<const cf*>(sens);
+    r.T = t; r.C = c; r.H = h;
+    coil_tiling(c, w, r.rpw, r.cc);
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_sens_reduce: b*t > 65535");
+    dim3 grid(ceil_div(h, r.rpw), b * t);
+    return magnitude ? launch_row<PRE_NONE, RPOST_REDUCE_ABS>(r, grid, true, st)
+                     : launch_row<PRE_NONE, RPOST_REDUCE>(r, grid, true, st);
+}
+
+extern "C" int cine_sens_expand_dc(const float* img, const float* sens, const float* kref, const uint8_t* mask,
+                                   const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
+                                   int hard_mask, void* stream) {
+    CINE_REQUIRE(img && sens && out, CINE_EINVAL, "cine_sens_expand_dc: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_expand_dc: bad sizes");
+    CINE_REQUIRE(!hard_mask || mask, CINE_EINVAL, "cine_sens_expand_dc: hard_mask needs mask");
+    CINE_REQUIRE(!kref || hard_mask || (mask && lambda_dev), CINE_EINVAL,
+                 "cine_sens_expand_dc: soft DC needs mask and lambda_dev");
+    if (int e = check_n(h, "cine_sens_expand_dc(h)")) return e;
+    if (int e = check_n(w, "cine_sens_expand_dc(w)")) return e;
+    hipStream_t st = as_stream(stream);
+    RowArgs r{};
+    r.out = reinterpret_cast<cf*>(out);
+    r.W = w; r.s_in = (w + 1) / 2; r.s_out = w / 2;
+    r.sens = reinterpret_cast<const cf*>(sens);
+    r.img = reinterpret_cast<const cf*>(img);
+    r.T = t; r.C = c; r.H = h;
+    coil_tiling(c, w, r.rpw, r.cc);
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_sens_expand_dc: b*t > 65535");
+    if (int e = launch_row<PRE_SMUL, RPOST_NONE>(r, dim3(ceil_div(h, r.rpw), b * t), false, st)) return e;
+    const long nimg = (long)b * t * c;
+    for (long i0 = 0; i0 < nimg; i0 += 32768 / c * c) {
+        const long step = 32768 / c * c;
+        const long ni = (nimg - i0) < step ? (nimg - i0) : step;
+        ColArgs ca{};
+        ca.in = reinterpret_cast<const cf*>(out) + i0 * h * w;
+        ca.out = reinterpret_cast<cf*>(out) + i0 * h * w;
+        ca.H = h; ca.W = w; ca.s_in = (h + 1) / 2; ca.s_out = h / 2; ca.coils = c;
+        ca.kref = kref ? reinterpret_cast<const cf*>(kref) + i0 * h * w : nullptr;
+        ca.mask = mask ? mask + (i0 / c) * h : nullptr;
+        ca.lam = lambda_dev;
+        int e;
+        if (hard_mask) e = launch_col<POST_HARD>(ca, ni, false, st);
+        else if (kref) e = launch_col<POST_DC>(ca, ni, false, st);
+        else e = launch_col<POST_NONE>(ca, ni, false, st);
+        if (e) return e;
+    }
+    return CINE_OK;
+}

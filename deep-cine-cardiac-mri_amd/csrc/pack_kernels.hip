@@ -1,0 +1,386 @@
+// pack_kernels.hip -- NormUnet front/back halves, XT/XF rotations, sens-map prologue.
+//
+// These are the small HBM-bound byte-moving steps around the regulariser
+// (SURVEY.md K3/K4/K5/K13/K14): every tensor here is a few MB, so the kernels
+// favour simplicity; each reads/writes with the fastest-varying index on lanes.
+#include "common.h"
+#include "fft_core.h"
+
+namespace cine {
+
+// ---------------------------------------------------------------- block reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sum over the workgroup; `red` holds >= 16 floats; all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// ---------------------------------------------------------------- NormUnet pack / unpack
+// Generic strided gather of sample n, channel ch (re|im), plane element (i, j):
+//   x[(n / ninner) * s_outer + (n % ninner) * s_inner + i * si + j * sj + ch]
+struct PackArgs {
+    const float* x; float* planes; float* stats;
+    int n, I, J, Ip, Jp, pad_i, pad_j;
+    int ninner; long s_outer, s_inner, si, sj;
+};
+
+__global__ void normunet_pack_kernel(PackArgs a) {
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    const float* src = a.x + (long)(n / a.ninner) * a.s_outer + (long)(n % a.ninner) * a.s_inner;
+    const int cnt = a.I * a.J;
+    // pass 1: means (norm_unet.py:64)
+    float sr = 0.f, si_ = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const int i = e / a.J, j = e - i * a.J;
+        const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+        sr += v.x; si_ += v.y;
+    }
+    const float mr = block_sum(sr, red) / cnt;
+    const float mi = block_sum(si_, red) / cnt;
+    // pass 2: unbiased std (norm_unet.py:65, torch.std default)
+    float qr = 0.f, qi = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const int i = e / a.J, j = e - i * a.J;
+        const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+        qr += (v.x - mr) * (v.x - mr); qi += (v.y - mi) * (v.y - mi);
+    }
+    const float sdr = sqrtf(block_sum(qr, red) / (cnt - 1));
+    const float sdi = sqrtf(block_sum(qi, red) / (cnt - 1));
+    if (threadIdx.x == 0) {
+        float* st = a.stats + (long)n * 4;
+        st[0] = mr; st[1] = sdr; st[2] = mi; st[3] = sdi;
+    }
+    // pass 3: (x - mean) / std into the zero-padded planes (norm_unet.py:69, 76-86)
+    float* pr = a.planes + (long)n * 2 * a.Ip * a.Jp;
+    float* pi = pr + (long)a.Ip * a.Jp;
+    for (int e = threadIdx.x; e < a.Ip * a.Jp; e += blockDim.x) {
+        const int ip = e / a.Jp, jp = e - ip * a.Jp;
+        const int i = ip - a.pad_i, j = jp - a.pad_j;
+        float vr = 0.f, vi = 0.f;
+        if (i >= 0 && i < a.I && j >= 0 && j < a.J) {
+            const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+            vr = (v.x - mr) / sdr; vi = (v.y - mi) / sdi;
+        }
+        pr[e] = vr; pi[e] = vi;
+    }
+}
+
+__global__ void normunet_unpack_kernel(const float* planes, const float* stats, float* y,
+                                       int I, int J, int Ip, int Jp, int pad_i, int pad_j) {
+    const int n = blockIdx.y;
+    const float* st = stats + (long)n * 4;
+    const float mr = st[0], sdr = st[1], mi = st[2], sdi = st[3];
+    const float* pr = planes + (long)n * 2 * Ip * Jp;
+    const float* pi = pr + (long)Ip * Jp;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I * J; e += gridDim.x * blockDim.x) {
+        const int i = e / J, j = e - i * J;
+        const int q = (i + pad_i) * Jp + (j + pad_j);
+        float2 v;
+        v.x = pr[q] * sdr + mr;          // norm_unet.py:71-74
+        v.y = pi[q] * sdi + mi;
+        reinterpret_cast<float2*>(y)[(long)n * I * J + e] = v;
+    }
+}
+
+// ---------------------------------------------------------------- temporal front half
+// One workgroup = PIX consecutive pixels of (b, h*w); LDS holds [T][PIX] complex.
+// X[b][pix][k] = centered ortho DFT over t of (img - mean_t), or just img - mean_t (XT).
+constexpr int kPix = 64;
+
+__device__ __forceinline__ void temporal_table(cf* tw, int T) {
+    const double s = 1.0 / sqrt((double)T);
+    for (int j = threadIdx.x; j < T; j += blockDim.x) {
+        double sn, cs;
+        sincospi(2.0 * (double)j / (double)T, &sn, &cs);
+        tw[j] = mk((float)(cs * s), (float)(-sn * s));
+    }
+}
+
+__global__ void temporal_fwd_kernel(const cf* img, cf* X, cf* mean_img, int T, long HW, int xf) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);          // [T][kPix]
+    cf* tw = buf + T * kPix;                        // [T]
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * kPix;
+    const int np = (int)min((long)kPix, HW - p0);
+    if (xf) temporal_table(tw, T);
+    for (int e = threadIdx.x; e < T * kPix; e += blockDim.x) {
+        const int t = e / kPix, p = e - t * kPix;
+        buf[e] = p < np ? img[((long)b * T + t) * HW + p0 + p] : mk(0.f, 0.f);
+    }
+    __syncthreads();
+    // temporal mean per pixel (varnet.py:205-206); kept in the extra row after use
+    if (threadIdx.x < kPix) {
+        const int p = threadIdx.x;
+        float sx = 0.f, sy = 0.f;
+        for (int t = 0; t < T; ++t) { sx += buf[t * kPix + p].x; sy += buf[t * kPix + p].y; }
+        const cf m = mk(sx / T, sy / T);
+        for (int t = 0; t < T; ++t) buf[t * kPix + p] = csub(buf[t * kPix + p], m);   // :207
+        if (p < np) mean_img[(long)b * HW + p0 + p] = m;
+    }
+    __syncthreads();
+    const int s_in = (T + 1) / 2, s_out = T / 2;
+    // output element (p, i): X[(b*HW + p0 + p) * T + i]; lanes run over i fastest for coalescing
+    for (int e = threadIdx.x; e < np * T; e += blockDim.x) {
+        const int p = e / T, i = e - p * T;
+        cf r;
+        if (xf) {                                    // fft1c over t, varnet.py:209-213
+            int k = i - s_out; if (k < 0) k += T;
+            float ax = 0.f, ay = 0.f;
+            int idx = (s_in * k) % T;                // n = (g + s_in) % T  ->  (n * k) % T
+            for (int g = 0; g < T; ++g) {
+                const cf w = tw[idx];
+                const cf x = buf[g * kPix + p];
+                ax += x.x * w.x - x.y * w.y; ay += x.x * w.y + x.y * w.x;
+                idx += k; if (idx >= T) idx -= T;
+            }
+            r = mk(ax, ay);
+        } else {
+            r = buf[i * kPix + p];
+        }
+        X[((long)b * HW + p0 + p) * T + i] = r;
+    }
+}
+
+// back half: avg of unnormalised xf / yf planes -> inverse temporal DFT -> + mean
+struct UnpackArgs {
+    const float* pxf; const float* pyf; const float* sxf; const float* syf;
+    const cf* mean_img; cf* out;
+    int T, H, W, Tp, Hp, Wp, pad_t, pad_h, pad_w, xf;
+};
+
+__global__ void xfyf_unpack_kernel(UnpackArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf* buf = reinterpret_cast<cf*>(smem);          // [T][kPix]
+    cf* tw = buf + a.T * kPix;
+    const int T = a.T, H = a.H, W = a.W;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int w0 = blockIdx.x * kPix;
+    const int np = min(kPix, W - w0);
+    if (a.xf) temporal_table(tw, T);
+    // xf plane sample n = b*H + h: (2, Wp, Tp), element [ch][w + pad_w][t + pad_t]
+    // yf plane sample n = b*W + w: (2, Hp, Tp), element [ch][h + pad_h][t + pad_t]
+    const long nxf = (long)b * H + h;
+    const float* sx = a.sxf + nxf * 4;
+    const float xmr = sx[0], xsr = sx[1], xmi = sx[2], xsi = sx[3];
+    const float* pxr = a.pxf + nxf * 2 * a.Wp * a.Tp;
+    const float* pxi = pxr + (long)a.Wp * a.Tp;
+    for (int e = threadIdx.x; e < np * T; e += blockDim.x) {
+        const int p = e / T, t = e - p * T;
+        const int w = w0 + p;
+        const int qx = (w + a.pad_w) * a.Tp + t + a.pad_t;
+        const float xr = pxr[qx] * xsr + xmr, xi = pxi[qx] * xsi + xmi;      // norm_unet.py:71-74
+        const long nyf = (long)b * W + w;
+        const float* sy = a.syf + nyf * 4;
+        const float* pyr = a.pyf + nyf * 2 * a.Hp * a.Tp;
+        const float* pyi = pyr + (long)a.Hp * a.Tp;
+        const int qy = (h + a.pad_h) * a.Tp + t + a.pad_t;
+        const float yr = pyr[qy] * sy[1] + sy[0], yi = pyi[qy] * sy[3] + sy[2];
+        buf[t * kPix + p] = mk(0.5f * (xr + yr), 0.5f * (xi + yi));          // varnet.py:232
+    }
+    __syncthreads();
+    const int s_in = (T + 1) / 2, s_out = T / 2;
+    const long HW = (long)H * W;
+    for (int e = threadIdx.x; e < T * np; e += blockDim.x) {
+        const int i = e / np, p = e - i * np;       // lanes over pixels: coalesced stores
+        cf r;
+        if (a.xf) {                                  // ifft1c over t, varnet.py:234-238
+            int k = i - s_out; if (k < 0) k += T;
+            float ax = 0.f, ay = 0.f;
+            int idx = (s_in * k) % T;
+            for (int g = 0; g < T; ++g) {
+                const cf w = tw[idx];
+                const cf x = buf[g * kPix + p];
+                ax += x.x * w.x + x.y * w.y; ay += x.y * w.x - x.x * w.y;     // x * conj(w)
+                idx += k; if (idx >= T) idx -= T;
+            }
+            r = mk(ax, ay);
+        } else {
+            r = buf[i * kPix + p];
+        }
+        const long pix = (long)h * W + w0 + p;
+        const cf m = a.mean_img[(long)b * HW + pix];
+        a.out[((long)b * T + i) * HW + pix] = cadd(r, m);                    // varnet.py:241
+    }
+}
+
+// ---------------------------------------------------------------- sens-map prologue
+// mean over frames of the rows kept by mask_center (varnet.py:71, transforms.py:95-108)
+__global__ void time_mean_center_kernel(const cf* k, cf* out, int T, int C, int H, int W, int lo, int hi) {
+    const long HW = (long)H * W;
+    const long total = (long)C * HW;                // per batch element
+    const int b = blockIdx.y;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e / HW);
+        const long pix = e - (long)c * HW;
+        const int h = (int)(pix / W);
+        cf r = mk(0.f, 0.f);
+        if (h >= lo && h < hi) {
+            float sx = 0.f, sy = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const cf v = k[(((long)b * T + t) * C + c) * HW + pix];
+                sx += v.x; sy += v.y;
+            }
+            r = mk(sx / T, sy / T);
+        }
+        out[((long)b * C + c) * HW + pix] = r;
+    }
+}
+
+// x / rss_complex(x, coil dim) (varnet.py:58-59)
+__global__ void rss_normalise_kernel(cf* x, int C, long HW) {
+    const int b = blockIdx.y;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const cf v = x[((long)b * C + c) * HW + p];
+            s += v.x * v.x + v.y * v.y;
+        }
+        const float r = sqrtf(s);
+        for (int c = 0; c < C; ++c) {
+            cf v = x[((long)b * C + c) * HW + p];
+            x[((long)b * C + c) * HW + p] = mk(v.x / r, v.y / r);
+        }
+    }
+}
+
+__global__ void complex_abs_kernel(const cf* x, float* y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const cf v = x[i];
+        y[i] = sqrtf(v.x * v.x + v.y * v.y);
+    }
+}
+
+static unsigned grid_for(long n, int threads, long cap = 4096) {
+    long g = ceil_div(n, (long)threads);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace cine
+
+using namespace cine;
+
+static void pad_split(int n, int& np, int& lo) {
+    np = cine_pad16(n);
+    lo = (np - n) / 2;            // floor on the left/top, ceil on the right/bottom (norm_unet.py:82-83)
+}
+
+extern "C" int cine_normunet_pack(const float* x, float* planes, float* stats, int n, int h, int w, void* stream) {
+    CINE_REQUIRE(x && planes && stats, CINE_EINVAL, "cine_normunet_pack: null pointer");
+    CINE_REQUIRE(n > 0 && h > 0 && w > 0 && (long)h * w > 1, CINE_EINVAL, "cine_normunet_pack: bad sizes");
+    PackArgs a{};
+    a.x = x; a.planes = planes; a.stats = stats; a.n = n; a.I = h; a.J = w;
+    pad_split(h, a.Ip, a.pad_i); pad_split(w, a.Jp, a.pad_j);
+    a.ninner = 1; a.s_outer = (long)h * w * 2; a.s_inner = 0; a.si = (long)w * 2; a.sj = 2;
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(normunet_pack_kernel, dim3(n), dim3(256), 0, as_stream(stream), a);
+    return check_launch("normunet_pack_kernel");
+}
+
+extern "C" int cine_normunet_unpack(const float* planes, const float* stats, float* y, int n, int h, int w, void* stream) {
+    CINE_REQUIRE(planes && stats && y, CINE_EINVAL, "cine_normunet_unpack: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && h > 0 && w > 0, CINE_EINVAL, "cine_normunet_unpack: bad sizes");
+    int hp, ph, wp, pw;
+    pad_split(h, hp, ph); pad_split(w, wp, pw);
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(normunet_unpack_kernel, dim3(grid_for((long)h * w, 256, 64), n), dim3(256), 0, as_stream(stream),
+                       planes, stats, y, h, w, hp, wp, ph, pw);
+    return check_launch("normunet_unpack_kernel");
+}
+
+extern "C" size_t cine_xfyf_ws_bytes(int b, int t, int h, int w) {
+    return (size_t)b * t * h * w * 2 * sizeof(float);
+}
+
+extern "C" int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_yf, float* stats_xf, float* stats_yf,
+                              float* mean_img, int b, int t, int h, int w, int xf, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(img && planes_xf && planes_yf && stats_xf && stats_yf && mean_img && ws, CINE_EINVAL,
+                 "cine_xfyf_pack: null pointer");
+    CINE_REQUIRE(b > 0 && t > 1 && h > 0 && w > 0, CINE_EINVAL, "cine_xfyf_pack: bad sizes");
+    CINE_REQUIRE(t <= 64, CINE_EUNSUPPORTED, "cine_xfyf_pack: %d frames > 64", t);
+    CINE_REQUIRE(ws_bytes >= cine_xfyf_ws_bytes(b, t, h, w), CINE_EWORKSPACE, "cine_xfyf_pack: workspace too small");
+    hipStream_t st = as_stream(stream);
+    cf* X = reinterpret_cast<cf*>(ws);          // [b][h][w][t]
+    const long HW = (long)h * w;
+    const size_t lds = ((size_t)t * kPix + t) * sizeof(cf);
+    ProfScope prof(F_PACK, st);
+    hipLaunchKernelGGL(temporal_fwd_kernel, dim3((unsigned)ceil_div(HW, (long)kPix), b), dim3(256), lds, st,
+                       reinterpret_cast<const cf*>(img), X, reinterpret_cast<cf*>(mean_img), t, HW, xf);
+    if (int e = check_launch("temporal_fwd_kernel")) return e;
+    // xf planes: sample (b, h), rows = w, cols = t          (varnet.py:216)
+    PackArgs a{};
+    a.x = reinterpret_cast<const float*>(X); a.planes = planes_xf; a.stats = stats_xf;
+    a.n = b * h; a.I = w; a.J = t;
+    pad_split(w, a.Ip, a.pad_i); pad_split(t, a.Jp, a.pad_j);
+    a.ninner = h; a.s_outer = HW * t * 2; a.s_inner = (long)w * t * 2; a.si = (long)t * 2; a.sj = 2;
+    hipLaunchKernelGGL(normunet_pack_kernel, dim3(a.n), dim3(256), 0, st, a);
+    if (int e = check_launch("normunet_pack_kernel(xf)")) return e;
+    // yf planes: sample (b, w), rows = h, cols = t          (varnet.py:217)
+    a.planes = planes_yf; a.stats = stats_yf;
+    a.n = b * w; a.I = h; a.J = t;
+    pad_split(h, a.Ip, a.pad_i); pad_split(t, a.Jp, a.pad_j);
+    a.ninner = w; a.s_outer = HW * t * 2; a.s_inner = (long)t * 2; a.si = (long)w * t * 2; a.sj = 2;
+    hipLaunchKernelGGL(normunet_pack_kernel, dim3(a.n), dim3(256), 0, st, a);
+    return check_launch("normunet_pack_kernel(yf)");
+}
+
+extern "C" int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, const float* stats_xf,
+                                const float* stats_yf, const float* mean_img, float* out,
+                                int b, int t, int h, int w, int xf, void* stream) {
+    CINE_REQUIRE(planes_xf && planes_yf && stats_xf && stats_yf && mean_img && out, CINE_EINVAL,
+                 "cine_xfyf_unpack: null pointer");
+    CINE_REQUIRE(b > 0 && t > 1 && t <= 64 && h > 0 && w > 0 && h <= 65535 && b <= 65535, CINE_EINVAL,
+                 "cine_xfyf_unpack: bad sizes");
+    UnpackArgs a{};
+    a.pxf = planes_xf; a.pyf = planes_yf; a.sxf = stats_xf; a.syf = stats_yf;
+    a.mean_img = reinterpret_cast<const cf*>(mean_img); a.out = reinterpret_cast<cf*>(out);
+    a.T = t; a.H = h; a.W = w; a.xf = xf;
+    pad_split(t, a.Tp, a.pad_t); pad_split(h, a.Hp, a.pad_h); pad_split(w, a.Wp, a.pad_w);
+    const size_t lds = ((size_t)t * kPix + t) * sizeof(cf);
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(xfyf_unpack_kernel, dim3(ceil_div(w, kPix), h, b), dim3(256), lds, as_stream(stream), a);
+    return check_launch("xfyf_unpack_kernel");
+}
+
+extern "C" int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,
+                                  int row_lo, int row_hi, void* stream) {
+    CINE_REQUIRE(k && out, CINE_EINVAL, "cine_sens_prologue: null pointer");
+    CINE_REQUIRE(b > 0 && b <= 65535 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_prologue: bad sizes");
+    { ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(time_mean_center_kernel, dim3(grid_for((long)c * h * w, 256), b), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const cf*>(k), reinterpret_cast<cf*>(out), t, c, h, w, row_lo, row_hi); }
+    if (int e = check_launch("time_mean_center_kernel")) return e;
+    return cine_fft2c(out, out, b * c, h, w, 1, stream);
+}
+
+extern "C" int cine_rss_normalise(float* x, int b, int c, int h, int w, void* stream) {
+    CINE_REQUIRE(x, CINE_EINVAL, "cine_rss_normalise: null pointer");
+    CINE_REQUIRE(b > 0 && b <= 65535 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_rss_normalise: bad sizes");
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(rss_normalise_kernel, dim3(grid_for((long)h * w, 256), b), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<cf*>(x), c, (long)h * w);
+    return check_launch("rss_normalise_kernel");
+}
+
+extern "C" int cine_complex_abs(const float* x, float* y, long n, void* stream) {
+    CINE_REQUIRE(x && y && n >= 0, CINE_EINVAL, "cine_complex_abs: bad arguments");
+    if (n == 0) return CINE_OK;
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(complex_abs_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const cf*>(x), y, n);
+    return check_launch("complex_abs_kernel");
+}

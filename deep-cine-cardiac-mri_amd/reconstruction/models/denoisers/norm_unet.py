@@ -1,0 +1,41 @@
+"""NormUnet: group-normalise, pad to x16, U-Net, unpad, un-normalise -- on the HIP kernels.
+
+Mirrors the reference's denoisers/norm_unet.py (NormUnet :12-114, NormUnet3D
+:117-219): same constructor and ``unet.*`` state-dict keys.
+"""
+import torch
+from torch import nn
+
+from cine_hip import ops
+from .unet import Unet
+
+
+class NormUnet(nn.Module):
+    def __init__(self, chans: int, num_pools: int, in_chans: int = 2, out_chans: int = 2, drop_prob: float = 0.0):
+        super().__init__()
+        self.unet = Unet(in_chans=in_chans, out_chans=out_chans, chans=chans, num_pool_layers=num_pools,
+                         drop_prob=drop_prob, dims=2)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.shape[-1] == 2:
+            raise ValueError("Last dimension must be 2 for complex.")
+        b, c, h, w, _ = x.shape
+        if c != 1:
+            raise NotImplementedError("HIP NormUnet handles one complex channel per sample (all reference call sites)")
+        planes, stats = ops.normunet_pack(x.reshape(b, h, w, 2))
+        planes = self.unet(planes)
+        return ops.normunet_unpack(planes, stats, h, w).view(b, 1, h, w, 2)
+
+
+class NormUnet3D(nn.Module):
+    """Parameter-compatible holder; the Conv3d path is not implemented on HIP yet."""
+
+    def __init__(self, chans: int, num_pools: int, in_chans: int = 2, out_chans: int = 2, drop_prob: float = 0.0):
+        super().__init__()
+        self.unet = Unet(in_chans=in_chans, out_chans=out_chans, chans=chans, num_pool_layers=num_pools,
+                         drop_prob=drop_prob, dims=3)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.shape[-1] == 2:
+            raise ValueError("Last dimension must be 2 for complex.")
+        raise NotImplementedError("NormUnet3D (Conv3d U-Net) is not on the HIP path yet")

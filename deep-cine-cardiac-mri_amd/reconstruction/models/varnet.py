@@ -1,0 +1,132 @@
+"""Dynamic end-to-end VarNet on the MI355X kernels.
+
+Drop-in for the reference's models/varnet.py (SensitivityModel :14, VarNet :91,
+VarNetBlock :154): same constructors, ``forward`` signatures, tensor layouts
+(k-space (b,t,c,h,w,2) f32, mask (b,t,1,h,1,1) uint8) and state-dict keys,
+including the aliased ``cascades.N.model.*`` entries.
+
+What differs is where the arithmetic runs.  Per cascade the HIP path issues
+  sens_reduce   : column IFFT pass + row IFFT pass fused with conj(S) x, coil sum
+  regulariser   : temporal mean/DFT + x-f / y-f rotation + group norm (pack),
+                  both U-Nets in one launch sequence, inverse (unpack)
+  sens_expand+DC: row FFT pass fused with S x, column FFT pass fused with the soft DC
+and never materialises shifted copies, stacked complex temporaries or normalised
+activations.  Inference only (no autograd); GPU tensors only.
+"""
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from cine_hip import ops
+from .denoisers.norm_unet import NormUnet, NormUnet3D
+
+
+class SensitivityModel(nn.Module):
+    def __init__(self, chans: int, num_pools: int, in_chans: int = 2, out_chans: int = 2, drop_prob: float = 0.0):
+        super().__init__()
+        self.norm_unet = NormUnet(chans, num_pools, in_chans=in_chans, out_chans=out_chans, drop_prob=drop_prob)
+
+    @staticmethod
+    def acs_window(mask: torch.Tensor):
+        """Rows [pad, pad + n_low) to keep (reference varnet.py:64-68: frame 0's mask only).
+        Data dependent, so it reads the 1-D mask back to the host."""
+        rows = mask[:, 0].reshape(-1).cpu()
+        cent = mask.shape[-3] // 2
+        left = int(torch.nonzero(rows[:cent] == 0)[-1])
+        right = int(torch.nonzero(rows[cent:] == 0)[0]) + cent
+        n_low = right - left
+        return (mask.shape[-3] - n_low + 1) // 2, n_low
+
+    def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
+        pad, n_low = self.acs_window(mask) if acs is None else acs
+        x = ops.sens_prologue(masked_kspace, pad, pad + n_low)            # (b, c, h, w, 2)
+        b, c, h, w, _ = x.shape
+        x = self.norm_unet(x.view(b * c, 1, h, w, 2)).view(b, c, h, w, 2)
+        return ops.rss_normalise_(x).unsqueeze(1)
+
+
+class VarNetBlock(nn.Module):
+    def __init__(self, model: nn.Module, dynamic_type: str, weight_sharing: bool):
+        super().__init__()
+        self.model = model
+        self.dynamic_type = dynamic_type
+        self.weight_sharing = weight_sharing
+        self.Softplus = nn.Softplus(1.)
+        self.lambda_reg = nn.Parameter(torch.full((1,), math.log(math.e - 1.0)))   # softplus -> 1
+        self._uw = None
+
+    # -- pieces, same names as the reference ------------------------------------------------
+    def sens_expand(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        return ops.sens_expand_dc(x, sens_maps)
+
+    def sens_reduce(self, x: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        return ops.sens_reduce(x, sens_maps)
+
+    def _xfyf_weights(self):
+        if self._uw is None:
+            nets = [self.model, self.model] if self.weight_sharing else [self.model[0], self.model[1]]
+            self._uw = (ops.UnetWeights([nets[0].unet, nets[1].unet]),
+                        ops.UnetWeights([nets[0].unet]), ops.UnetWeights([nets[1].unet]))
+        return self._uw
+
+    def xfyf_transform(self, image_combined: torch.Tensor) -> torch.Tensor:
+        """(b, t, h, w, 2) -> (b, t, 1, h, w, 2)."""
+        b, t, h, w, _ = image_combined.shape
+        xf = self.dynamic_type == 'XF'
+        pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image_combined, xf)
+        both, wx, wy = self._xfyf_weights()
+        if pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr():
+            joint = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+            out = ops.unet2d_forward(joint, both)
+            oxf, oyf = out[:pxf.shape[0]], out[pxf.shape[0]:]
+        else:
+            oxf, oyf = ops.unet2d_forward(pxf, wx), ops.unet2d_forward(pyf, wy)
+        return ops.xfyf_unpack(oxf, oyf, sxf, syf, mean, b, t, h, w, xf)
+
+    def regularise(self, image_combined: torch.Tensor) -> torch.Tensor:
+        """(b, t, 1, h, w, 2) -> same; the dynamic-type switch of reference varnet.py:255-278."""
+        if self.dynamic_type in ['XF', 'XT']:
+            return self.xfyf_transform(image_combined.squeeze(2))
+        if self.dynamic_type == '2D':
+            return self.model(image_combined.squeeze(0)).unsqueeze(0)
+        if self.dynamic_type == '3D':
+            return self.model(image_combined.permute(0, 2, 1, 3, 4, 5)).permute(0, 2, 1, 3, 4, 5)
+        raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
+
+    def forward(self, current_kspace, ref_kspace, mask, sens_maps, _destroy_current: bool = False):
+        image = ops.sens_reduce(current_kspace, sens_maps, destroy_input=_destroy_current)
+        model_out = self.regularise(image)
+        out = current_kspace if _destroy_current else None
+        return ops.sens_expand_dc(model_out, sens_maps, ref_kspace, mask, self.lambda_reg, out=out)
+
+
+class VarNet(nn.Module):
+    def __init__(self, num_cascades: int = 12, sens_chans: int = 8, sens_pools: int = 4, chans: int = 18,
+                 pools: int = 4, dynamic_type: str = 'XF', weight_sharing: bool = False):
+        super().__init__()
+        self.sens_net = SensitivityModel(sens_chans, sens_pools)
+        if dynamic_type in ['XF', 'XT']:
+            self.model = NormUnet(chans, pools) if weight_sharing else \
+                nn.ModuleList([NormUnet(chans, pools), NormUnet(chans, pools)])
+        elif dynamic_type == '3D':
+            self.model = NormUnet3D(chans, pools)
+        else:
+            self.model = NormUnet(chans, pools)
+        self.cascades = nn.ModuleList(
+            [VarNetBlock(self.model, dynamic_type, weight_sharing) for _ in range(num_cascades)])
+
+    @torch.no_grad()
+    def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor,
+                sens_maps: Optional[torch.Tensor] = None, acs=None) -> torch.Tensor:
+        """(b,t,c,h,w,2), (b,t,1,h,1,1) uint8 -> (b,t,h,w) magnitude.  ``sens_maps`` (optional,
+        (b,1,c,h,w,2)) bypasses the sens-map network; ``acs`` = (pad, n_low) skips the host
+        read-back of the mask (needed inside hipGraph capture)."""
+        if sens_maps is None:
+            sens_maps = self.sens_net(masked_kspace, mask, acs)
+        k = masked_kspace
+        for i, cascade in enumerate(self.cascades):
+            k = cascade(k, masked_kspace, mask, sens_maps, _destroy_current=i > 0)
+        owned = len(self.cascades) > 0
+        return ops.sens_reduce(k, sens_maps, magnitude=True, destroy_input=owned)

@@ -1,0 +1,193 @@
+/* cine_hip.h -- C ABI of libcine_hip.so, the MI355X (gfx950) cine-MRI reconstruction kernels.
+ *
+ * The reference (f78bono/deep-cine-cardiac-mri) is pure Python on PyTorch and has no
+ * FFI of its own: the boundary this library sits under is the ATen operator layer that
+ * `reconstruction.models.*` / `reconstruction.utils.*` dispatch to.  Each entry point
+ * below names the reference code it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative CINE_E* code; it never throws,
+ *     aborts, allocates device memory or synchronises.  cine_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - all pointers are DEVICE pointers owned by the caller (except where noted), fp32,
+ *     contiguous, in the reference's layouts: complex = trailing pair (re, im);
+ *     k-space (b, t, coil, h, w, 2); image (b, t, h, w, 2); mask uint8 (b, t, 1, h, 1, 1).
+ *   - `stream` is the caller's hipStream_t passed as void* (NULL = default stream);
+ *     every launch goes onto it, so the calls are hipGraph-capturable.
+ *   - scratch comes from the caller: `ws`/`ws_bytes` with a matching *_ws_bytes() query.
+ *   - re-entrant; no global mutable state besides the thread-local error string.
+ */
+#ifndef CINE_HIP_H
+#define CINE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CINE_OK 0
+#define CINE_EINVAL (-1)      /* bad argument (null pointer, non-positive size, bad enum)      */
+#define CINE_EUNSUPPORTED (-2)/* size/shape outside what the kernels implement                 */
+#define CINE_EWORKSPACE (-3)  /* workspace too small                                           */
+#define CINE_EHIP (-4)        /* a HIP launch failed; see cine_last_error()                    */
+
+/* library / build identification */
+int cine_version(void);                 /* ABI version, currently 1 */
+const char* cine_last_error(void);      /* thread-local, never NULL */
+const char* cine_build_arch(void);      /* "gfx950" */
+
+/* ------------------------------------------------------------------------------------------
+ * Centered ortho FFTs                          reference: reconstruction/utils/fftc.py
+ * ------------------------------------------------------------------------------------------ */
+
+/* fft2c (fftc.py:59-83) / ifft2c (fftc.py:86-110) over the last two spatial dims of
+ * `nimg` images of h x w complex.  inverse = 0 forward, 1 inverse.  in == out allowed. */
+int cine_fft2c(const float* in, float* out, int nimg, int h, int w, int inverse, void* stream);
+
+/* fft1c (fftc.py:5-29) / ifft1c (fftc.py:32-56): `nlines` contiguous lines of n complex.
+ * variant 0 = fftc.py shift order (ifftshift, transform, fftshift);
+ * variant 1 = XPDNet's order (xpdnet.py:466 / :500), which differs for odd n. */
+int cine_fft1c(const float* in, float* out, long nlines, int n, int inverse, int variant, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Coil operators                               reference: reconstruction/models/varnet.py
+ * ------------------------------------------------------------------------------------------ */
+
+/* VarNetBlock.sens_reduce (varnet.py:187-194): out[b,t,h,w] = sum_c conj(S[b,c]) * ifft2c(k[b,t,c]).
+ * sens (b, 1, c, h, w, 2).  out (b, t, 1, h, w, 2) complex, or with magnitude != 0 the
+ * real (b, t, h, w) of VarNet.forward's final line (varnet.py:150-151, math.py:48-62).
+ * `tmp` holds b*t*c*h*w complex (8 bytes each); tmp == k transforms k in place (k is destroyed). */
+int cine_sens_reduce(const float* k, const float* sens, float* out, float* tmp,
+                     int b, int t, int c, int h, int w, int magnitude, void* stream);
+
+/* VarNetBlock.sens_expand (varnet.py:181-185) fused with the soft data-consistency of
+ * VarNetBlock.forward (varnet.py:281-282):
+ *   kth = fft2c(S * img);  out = mask ? (kth + v * kref) / (1 + v) : kth,  v = softplus(*lambda_dev)
+ * img (b, t, 1, h, w, 2); kref (b, t, c, h, w, 2); mask uint8 (b, t, 1, h, 1, 1);
+ * lambda_dev points to ONE float in device memory (cascades.N.lambda_reg).
+ * kref == NULL  => plain sens_expand (no blend; mask / lambda_dev ignored).
+ * hard_mask != 0 => out = mask ? kth : 0  (CineNet HOperator, cinenet.py:121-133; kref ignored). */
+int cine_sens_expand_dc(const float* img, const float* sens, const float* kref, const uint8_t* mask,
+                        const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
+                        int hard_mask, void* stream);
+
+/* SensitivityModel prologue (varnet.py:62-74): mean over frames, keep rows [row_lo, row_hi) of
+ * dim h (transforms.mask_center, data/transforms.py:95-108), ifft2c.  k (b,t,c,h,w,2) -> out (b,c,h,w,2). */
+int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,
+                       int row_lo, int row_hi, void* stream);
+
+/* SensitivityModel.divide_root_sum_of_squares (varnet.py:58-59, coil_combine.py:21-34), in place
+ * on x (b, c, h, w, 2). */
+int cine_rss_normalise(float* x, int b, int c, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * NormUnet pre/post and the XT/XF rotations    reference: denoisers/norm_unet.py, varnet.py:196-241
+ * ------------------------------------------------------------------------------------------ */
+
+/* padded size of NormUnet.pad (norm_unet.py:76-86): ((n - 1) | 15) + 1 */
+int cine_pad16(int n);
+
+/* NormUnet front half on `n` complex images (n, h, w, 2): complex_to_chan_dim (:48-51), group
+ * norm with unbiased std (:59-69), zero pad to x16 (:76-86).
+ * planes (n, 2, hp, wp) fp32; stats (n, 2, 2) = {mean, std} per (sample, re|im). */
+int cine_normunet_pack(const float* x, float* planes, float* stats, int n, int h, int w, void* stream);
+
+/* NormUnet back half (:88-96 unpad, :71-74 unnorm, :53-57 chan_complex_to_last_dim). */
+int cine_normunet_unpack(const float* planes, const float* stats, float* y, int n, int h, int w, void* stream);
+
+/* VarNetBlock.xfyf_transform front half (varnet.py:202-217) + both NormUnet front halves:
+ * temporal mean subtract, (xf != 0) centered temporal DFT, rotation into x-f / y-f planes,
+ * group norm, pad.  img (b, t, h, w, 2).
+ *   planes_xf (b*h, 2, pad16(w), pad16(t)), planes_yf (b*w, 2, pad16(h), pad16(t)),
+ *   stats_xf (b*h, 2, 2), stats_yf (b*w, 2, 2), mean_img (b, h, w, 2).
+ * ws: cine_xfyf_ws_bytes(b, t, h, w). */
+size_t cine_xfyf_ws_bytes(int b, int t, int h, int w);
+int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_yf, float* stats_xf, float* stats_yf,
+                   float* mean_img, int b, int t, int h, int w, int xf, void* ws, size_t ws_bytes, void* stream);
+
+/* back half (varnet.py:229-241): unpad + unnorm both planes, un-rotate, average, inverse
+ * temporal DFT, add the temporal mean.  out (b, t, 1, h, w, 2). */
+int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, const float* stats_xf,
+                     const float* stats_yf, const float* mean_img, float* out,
+                     int b, int t, int h, int w, int xf, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * U-Net regulariser                            reference: denoisers/unet.py
+ * ------------------------------------------------------------------------------------------ */
+
+/* Repack one 3x3 conv weight (cout, cin, 3, 3) (unet.py:160,164) into the MFMA staging layout.
+ * packed must hold cine_conv3x3_packed_floats(cout, cin) floats. */
+size_t cine_conv3x3_packed_floats(int cout, int cin);
+int cine_pack_conv3x3(const float* w, float* packed, int cout, int cin, void* stream);
+
+/* One ConvBlock half (unet.py:159-162): y = conv3x3(x, pad 1, no bias), plus the InstanceNorm
+ * statistics of y (biased variance, eps) as stats (n, cout, 2) = {mean, rstd}.  The normalise +
+ * LeakyReLU(slope) is applied by whichever kernel consumes (y, stats) next.
+ * Inputs are up to two channel-concatenated sources (torch.cat, unet.py:122); source s has
+ * c_s channels, extent (h_s, w_s) and mode_s:
+ *   0 = use as is;  1 = apply (x - mean) * rstd then LeakyReLU on load (stats_s (n, c_s, 2));
+ *   2 = mode 1 followed by 2x2 average pool (unet.py:97; source extent is then (2h, 2w)-ish).
+ * A source smaller than (h, w) reads as zero outside its extent (the up-path zero pad,
+ * unet.py:106-120).  wpacked from cine_pack_conv3x3 with cin = c0 + c1. */
+int cine_conv3x3_in(const float* x0, const float* stats0, int c0, int mode0, int h0, int w0,
+                    const float* x1, const float* stats1, int c1, int mode1, int h1, int w1,
+                    const float* wpacked, float* y, float* stats_y,
+                    int n, int cout, int h, int w, float eps, float slope, void* stream);
+
+/* TransposeConvBlock (unet.py:212-217): y = conv_transpose2d(act(x), k 2, s 2, no bias) and the
+ * InstanceNorm statistics of y.  wt is the torch layout (cin, cout, 2, 2).  x mode as above (0|1). */
+int cine_tconv2x2_in(const float* x, const float* stats_x, int mode, const float* wt,
+                     float* y, float* stats_y, int n, int cin, int cout, int h, int w,
+                     float eps, float slope, void* stream);
+
+/* final 1x1 conv with bias (unet.py:69): wt (cout, cin), bias (cout). x mode as above (0|1). */
+int cine_conv1x1_bias(const float* x, const float* stats_x, int mode, const float* wt, const float* bias,
+                      float* y, int n, int cin, int cout, int h, int w, float slope, void* stream);
+
+/* InstanceNorm2d statistics (unet.py:161,165,216): stats (n*c, 2) = {mean, 1/sqrt(var_biased + eps)}. */
+int cine_instnorm_stats(const float* x, float* stats, long planes, long plane_elems, float eps, void* stream);
+
+/* materialise act(x) = LeakyReLU((x - mean) * rstd) (debug / block-level parity). */
+int cine_instnorm_lrelu_apply(const float* x, const float* stats, float* y, long planes, long plane_elems,
+                              float slope, void* stream);
+
+/* Whole 2-D U-Net (unet.py:73-125) on n planes (n, in_ch, h, w) -> (n, out_ch, h, w).
+ * `weights` is a HOST array of device pointers in this order:
+ *   for d in 0..pools-1: down[d].conv1 (packed), down[d].conv2 (packed)
+ *   bottleneck conv1 (packed), conv2 (packed)
+ *   for u in 0..pools-1: tconv[u] (torch layout), up[u].conv1 (packed), up[u].conv2 (packed)
+ *   final 1x1 weight (out_ch, chans), final bias (out_ch)
+ * i.e. 2*pools + 2 + 3*pools + 2 pointers.
+ * `nsets` > 1 runs nsets independent weight sets over consecutive groups of n/nsets planes in
+ * the same launches (the xf and yf U-Nets of one cascade, varnet.py:224-226); `weights` then
+ * holds nsets such arrays back to back. */
+size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
+int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
+                        int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * small element-wise helpers                   reference: reconstruction/utils/math.py
+ * ------------------------------------------------------------------------------------------ */
+int cine_complex_abs(const float* x, float* y, long n, void* stream);          /* math.py:48-62 */
+
+/* ------------------------------------------------------------------------------------------
+ * measurement aid (no reference counterpart; the reference only wraps time.time() around the
+ * model call, traintest_scripts/run_inference.py:53-61)
+ * ------------------------------------------------------------------------------------------ */
+/* Between cine_profile_begin() and cine_profile_end() every kernel launch made through this
+ * library is bracketed by a hipEvent pair on the stream it is launched on.  cine_profile_end()
+ * waits for them and returns, per kernel family i < nfam, the summed device time in ms and the
+ * launch count.  Not for use during graph capture. */
+int cine_profile_begin(void);
+int cine_profile_end(double* ms, long* launches, int nfam);
+int cine_profile_families(void);
+const char* cine_profile_family_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CINE_HIP_H */

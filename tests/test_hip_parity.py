@@ -1,0 +1,308 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the reference goldens.
+
+Tolerances (fp32 path): op level rel 1e-5 of the output peak, block level 5e-5,
+model level max|d|/peak <= 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, rnd, state_dict_from
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL, BLOCK_TOL, MODEL_TOL = 1e-5, 5e-5, 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def cuda(a, dev):
+    return torch.as_tensor(a).to(dev)
+
+
+# ------------------------------------------------------------------ FFT ops
+@pytest.mark.parametrize("tag", ["odd", "t15", "even", "mixed"])
+def test_ffts_vs_reference_golden(golden, dev, tag):
+    import reconstruction.utils as U
+    g = golden("ops")
+    x = cuda(g[f"{tag}_x"], dev)
+    for name, fn in (("fft1c", U.fft1c), ("ifft1c", U.ifft1c), ("fft2c", U.fft2c), ("ifft2c", U.ifft2c)):
+        assert rel_err(fn(x).cpu(), g[f"{tag}_{name}"]) < OP_TOL, name
+
+
+def test_fft2c_200_vs_reference_golden(golden, dev):
+    import reconstruction.utils as U
+    g = golden("ops")
+    x = rnd(int(g["full200_seed"]), 2, 200, 200, 2).to(dev)
+    assert rel_err(U.fft2c(x).cpu(), g["full200_fft2c"]) < OP_TOL
+    assert rel_err(U.ifft2c(x).cpu(), g["full200_ifft2c"]) < OP_TOL
+
+
+def test_fft1c_variants_and_200(dev):
+    from cine_hip import ops
+    from oracle import centered_fft as cf
+    for n in (5, 15, 16, 200):
+        x = rnd(n, 7, n, 2)
+        for inv in (False, True):
+            ref = (cf.ifft1c if inv else cf.fft1c)(x)
+            assert rel_err(ops.fft1c(x.to(dev), inverse=inv).cpu(), ref) < OP_TOL
+            z = torch.view_as_complex(x)
+            ref1 = torch.view_as_real((cf.xpd_temporal_ifft if inv else cf.xpd_temporal_fft)(z, dim=1))
+            assert rel_err(ops.fft1c(x.to(dev), inverse=inv, variant=1).cpu(), ref1) < OP_TOL
+
+
+def test_fft2c_full_batch_properties(dev):
+    """cfg-2 sized batch (225 images of 200x200): round trip, Parseval, linearity."""
+    import reconstruction.utils as U
+    x = torch.randn(225, 200, 200, 2, device=dev)
+    y = torch.randn(225, 200, 200, 2, device=dev)
+    X = U.fft2c(x)
+    assert rel_err(U.ifft2c(X).cpu(), x.cpu()) < OP_TOL
+    assert abs(float((X.double() ** 2).sum() / (x.double() ** 2).sum()) - 1) < 1e-5
+    assert rel_err(U.fft2c(2 * x - 3 * y).cpu(), (2 * X - 3 * U.fft2c(y)).cpu()) < OP_TOL
+    # in-place call
+    from cine_hip import ops, _lib
+    z = x.clone()
+    _lib.check(_lib.lib().cine_fft2c(z.data_ptr(), z.data_ptr(), 225, 200, 200, 0, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(z, X)
+
+
+def test_unsupported_length_fails_loudly(dev):
+    from cine_hip._lib import CineHipError
+    import reconstruction.utils as U
+    with pytest.raises(CineHipError):
+        U.fft2c(torch.zeros(1, 401, 8, 2, device=dev))
+
+
+# ------------------------------------------------------------------ coil operators
+def _block_inputs(g, dev):
+    return (cuda(g["k"], dev), cuda(g["kref"], dev), cuda(g["mask"], dev), cuda(g["sens"], dev))
+
+
+def test_sens_reduce_expand_dc_vs_golden(golden, dev):
+    from cine_hip import ops
+    g = golden("varnet_block")
+    k, kref, mask, sens = _block_inputs(g, dev)
+    img = ops.sens_reduce(k, sens)
+    assert rel_err(img.cpu(), g["XF_reduce"]) < OP_TOL
+    assert torch.equal(k.cpu(), torch.from_numpy(g["k"]))            # input untouched
+    assert rel_err(ops.sens_expand_dc(img, sens).cpu(), g["XF_expand"]) < OP_TOL
+    # magnitude variant == |reduce|
+    mag = ops.sens_reduce(k, sens, magnitude=True)
+    ref = torch.from_numpy(g["XF_reduce"]).squeeze(2).pow(2).sum(-1).sqrt()
+    assert rel_err(mag.cpu(), ref) < OP_TOL
+    # destroy_input variant gives the same image
+    img2 = ops.sens_reduce(k.clone(), sens, destroy_input=True)
+    assert torch.equal(img2, img)
+
+
+def test_soft_and_hard_dc_vs_oracle(dev):
+    from cine_hip import ops
+    from oracle import varnet_ref as V
+    import torch.nn.functional as F
+    t, c, h, w = 5, 3, 24, 20
+    img, sens, kref = rnd(1, 1, t, 1, h, w, 2), rnd(2, 1, 1, c, h, w, 2), rnd(3, 1, t, c, h, w, 2)
+    mask = (torch.rand(1, t, 1, h, 1, 1, generator=torch.Generator().manual_seed(0)) > 0.6).byte()
+    for lam in (-1.3, 0.5413, 25.0):
+        lam_t = torch.tensor([lam])
+        kth = V.VarNetBlock.sens_expand(img, sens)
+        v = F.softplus(lam_t)
+        ref = (1 - mask) * kth + mask * (kth + v * kref) / (1 + v)
+        out = ops.sens_expand_dc(img.to(dev), sens.to(dev), kref.to(dev), mask.to(dev), lam_t.to(dev))
+        assert rel_err(out.cpu(), ref) < OP_TOL
+    hard = ops.sens_expand_dc(img.to(dev), sens.to(dev), None, mask.to(dev), None, hard_mask=True)
+    assert rel_err(hard.cpu(), V.VarNetBlock.sens_expand(img, sens) * mask + 0.0) < OP_TOL
+
+
+def test_coil_ops_full_size_vs_oracle(dev):
+    """cfg-2 shapes: 15 frames x 15 coils x 200x200."""
+    from cine_hip import ops, synth
+    from oracle import varnet_ref as V
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+    k, sens, mask = ex["masked_kspace"], ex["sens_maps"], ex["mask"]
+    ref_img = V.VarNetBlock.sens_reduce(k, sens)
+    img = ops.sens_reduce(k.to(dev), sens.to(dev))
+    assert rel_err(img.cpu(), ref_img) < OP_TOL
+    lam = torch.tensor([0.5413])
+    kth = V.VarNetBlock.sens_expand(ref_img, sens)
+    v = torch.nn.functional.softplus(lam)
+    ref = (1 - mask) * kth + mask * (kth + v * k) / (1 + v)
+    out = ops.sens_expand_dc(img, sens.to(dev), k.to(dev), mask.to(dev), lam.to(dev))
+    assert rel_err(out.cpu(), ref) < OP_TOL
+    # adjointness <A x, y> == <x, A^H y> with A = sens_expand, A^H = sens_reduce
+    x = torch.randn_like(ref_img).to(dev); y = torch.randn_like(k).to(dev)
+    lhs = (ops.sens_expand_dc(x, sens.to(dev)).double() * y.double()).sum()
+    rhs = (x.double() * ops.sens_reduce(y, sens.to(dev)).double()).sum()
+    assert abs(float(lhs - rhs)) / abs(float(lhs)) < 1e-5
+
+
+def test_sens_prologue_and_rss(dev):
+    from cine_hip import ops
+    from oracle import centered_fft as cf, complex_ops as co
+    k = rnd(5, 2, 4, 3, 12, 10, 2)
+    ref = cf.ifft2c(co.mask_center(k.mean(dim=1), 4, 9))
+    out = ops.sens_prologue(k.to(dev), 4, 9)
+    assert rel_err(out.cpu(), ref) < OP_TOL
+    x = rnd(6, 2, 3, 12, 10, 2)
+    ref = x / co.rss_complex(x, dim=1).unsqueeze(-1).unsqueeze(1)
+    assert rel_err(ops.rss_normalise_(x.to(dev).clone()).cpu(), ref) < OP_TOL
+
+
+# ------------------------------------------------------------------ U-Net pieces
+def test_unet_blocks_vs_reference_golden(golden, dev):
+    from reconstruction.models.denoisers import unet as HU
+    g = golden("unet")
+    cb = HU.ConvBlock(3, 8, 0.0, 2); cb.load_state_dict(state_dict_from(g, "cb::"), strict=True); cb.to(dev)
+    tb = HU.TransposeConvBlock(8, 4, 2); tb.load_state_dict(state_dict_from(g, "tb::"), strict=True); tb.to(dev)
+    un = HU.Unet(chans=4, num_pool_layers=2); un.load_state_dict(state_dict_from(g, "un::"), strict=True); un.to(dev).eval()
+    assert rel_err(cb(cuda(g["cb_x"], dev)).cpu(), g["cb_y"]) < BLOCK_TOL
+    assert rel_err(tb(cuda(g["tb_x"], dev)).cpu(), g["tb_y"]) < BLOCK_TOL
+    assert rel_err(un(cuda(g["un_x"], dev)).cpu(), g["un_y"]) < BLOCK_TOL
+    assert rel_err(un(cuda(g["un_odd_x"], dev)).cpu(), g["un_odd_y"]) < BLOCK_TOL
+
+
+def test_norm_unet_vs_reference_golden(golden, dev):
+    from reconstruction.models.denoisers import NormUnet
+    from cine_hip import ops
+    g = golden("unet")
+    nu = NormUnet(4, 2); nu.load_state_dict(state_dict_from(g, "nu::"), strict=True); nu.to(dev).eval()
+    x = cuda(g["nu_x"], dev)
+    planes, stats = ops.normunet_pack(x.reshape(3, 20, 5, 2))
+    ref_norm = torch.from_numpy(g["nu_norm"])                      # (3, 2, 20, 5) before padding
+    assert rel_err(planes[:, :, 6:26, 5:10].cpu(), ref_norm) < OP_TOL   # pads: h 20->32 [6,6], w 5->16 [5,6]
+    pad_only = planes.clone(); pad_only[:, :, 6:26, 5:10] = 0
+    assert float(pad_only.abs().max()) == 0.0
+    assert rel_err(stats[:, :, 0].cpu(), g["nu_mean"].reshape(3, 2)) < OP_TOL
+    assert rel_err(stats[:, :, 1].cpu(), g["nu_std"].reshape(3, 2)) < OP_TOL
+    assert rel_err(nu(x).cpu(), g["nu_y"]) < BLOCK_TOL
+    with pytest.raises(ValueError):
+        nu(torch.zeros(1, 1, 8, 8, 3, device=dev))
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(2, 16, 208, 16), (16, 16, 208, 16), (16, 32, 104, 8), (32, 32, 104, 8),
+                                          (32, 64, 52, 4), (64, 64, 52, 4), (64, 128, 26, 2), (128, 128, 26, 2),
+                                          (128, 64, 52, 4), (64, 32, 104, 8), (32, 16, 208, 16),
+                                          (8, 8, 208, 208), (5, 10, 25, 25), (18, 36, 13, 7), (2, 8, 1, 1)])
+def test_conv3x3_shapes_vs_torch(dev, cin, cout, h, w):
+    """Every cfg-2 layer shape plus odd ones, against torch's fp32 conv on the CPU."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    n = 3
+    x = rnd(cin * 7 + h, n, cin, h, w); wt = rnd(cout, cout, cin, 3, 3) / (3 * cin ** 0.5)
+    y, st = ops.conv3x3_in([(x.to(dev), None, 0)], ops.pack_conv3x3(wt.to(dev)), cout, h, w)
+    ref = F.conv2d(x, wt, padding=1)
+    assert rel_err(y.cpu(), ref) < OP_TOL
+    if h * w > 1:
+        assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3))) < 1e-4
+        rstd = 1 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+        assert rel_err(st[..., 1].cpu(), rstd) < 1e-4
+
+
+def test_conv3x3_fused_sources_vs_torch(dev):
+    """norm+LReLU on load, pooled source, concat of two sources with a short `up` extent."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    n, c, h, w = 2, 8, 13, 10
+    skip = rnd(1, n, c, h, w); up = rnd(2, n, c, 12, 10)            # up is one row short -> zero pad
+    wt = rnd(3, 16, 2 * c, 3, 3) / 12
+    act = lambda t: F.leaky_relu(F.instance_norm(t, eps=1e-5), 0.2)
+    s_skip, s_up = ops.instnorm_stats(skip.to(dev)), ops.instnorm_stats(up.to(dev))
+    y, _ = ops.conv3x3_in([(up.to(dev), s_up, 1), (skip.to(dev), s_skip, 1)], ops.pack_conv3x3(wt.to(dev)), 16, h, w)
+    ref = F.conv2d(torch.cat([F.pad(act(up), [0, 0, 0, 1]), act(skip)], 1), wt, padding=1)
+    assert rel_err(y.cpu(), ref) < BLOCK_TOL
+    big = rnd(4, n, c, 26, 20)
+    s_big = ops.instnorm_stats(big.to(dev))
+    wt2 = rnd(5, 16, c, 3, 3) / 8
+    y, _ = ops.conv3x3_in([(big.to(dev), s_big, 2)], ops.pack_conv3x3(wt2.to(dev)), 16, 13, 10)
+    ref = F.conv2d(F.avg_pool2d(act(big), 2), wt2, padding=1)
+    assert rel_err(y.cpu(), ref) < BLOCK_TOL
+
+
+# ------------------------------------------------------------------ blocks and models
+@pytest.mark.parametrize("dyn", ["XF", "XT", "2D"])
+def test_varnet_block_vs_reference_golden(golden, dev, dyn):
+    import reconstruction.models as M
+    g = golden("varnet_block")
+    net = M.VarNet(1, 4, 2, 4, 2, dyn)
+    net.load_state_dict(state_dict_from(g, f"{dyn}::sd::"), strict=True)
+    net.to(dev).eval()
+    blk = net.cascades[0]
+    k, kref, mask, sens = _block_inputs(g, dev)
+    if dyn in ("XF", "XT"):
+        img = cuda(g[f"{dyn}_reduce"], dev)
+        assert rel_err(blk.xfyf_transform(img.squeeze(2)).cpu(), g[f"{dyn}_xfyf"]) < BLOCK_TOL
+    assert rel_err(blk(k, kref, mask, sens).cpu(), g[f"{dyn}_block"]) < BLOCK_TOL
+    assert torch.equal(k.cpu(), torch.from_numpy(g["k"]))
+
+
+def test_sensitivity_model_vs_reference_golden(golden, dev):
+    import reconstruction.models as M
+    g = golden("varnet_block")
+    sm = M.SensitivityModel(4, 2)
+    sm.load_state_dict(state_dict_from(g, "sens::sd::"), strict=True)
+    sm.to(dev).eval()
+    out = sm(cuda(g["kref"], dev), cuda(g["mask"], dev))
+    assert rel_err(out.cpu(), g["sens_out"]) < BLOCK_TOL
+
+
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+def test_varnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
+    import reconstruction.models as M
+    g = golden("varnet_tiny")
+    net = M.VarNet(2, 4, 2, 4, 2, dyn, ws)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net.to(dev).eval()
+    mk, mask = cuda(g["masked_kspace"], dev), cuda(g["mask"], dev)
+    out = net(mk, mask)
+    assert out.shape == g[f"{tag}_out"].shape
+    assert rel_err(out.cpu(), g[f"{tag}_out"]) < MODEL_TOL
+    assert torch.equal(mk.cpu(), torch.from_numpy(g["masked_kspace"]))     # caller's input not mutated
+
+
+def test_varnet_3d_not_silently_wrong(dev):
+    import reconstruction.models as M
+    net = M.VarNet(1, 4, 2, 4, 2, "3D").to(dev).eval()
+    k = torch.zeros(1, 5, 3, 24, 20, 2, device=dev)
+    m = torch.zeros(1, 5, 1, 24, 1, 1, dtype=torch.uint8, device=dev); m[:, :, :, 10:14] = 1
+    with pytest.raises(NotImplementedError):
+        net(k, m)
+
+
+def test_varnet_cfg1_vs_reference_golden(golden, dev):
+    """BASELINE configs[0]: 2D VarNet, 2 cascades, 8 coils, one 200x200 frame, R=4."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    g = golden("varnet_cfg1")
+    ex = synth.make_cine_slice(1, 8, 200, 200, accel=4, seed=int(g["data_seed"]))
+    net = M.VarNet(2, 8, 3, 16, 3, "2D")
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net.to(dev).eval()
+    out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev))
+    assert rel_err(out.cpu(), g["out"]) < MODEL_TOL
+
+
+def test_varnet_cfg2_vs_reference_golden(golden, dev):
+    """BASELINE configs[1]: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, R=4.
+    Checked against the reference's own output fingerprint: max|d|/peak, NMSE and SSIM delta."""
+    import reconstruction.models as M
+    from reconstruction.utils import evaluate
+    from cine_hip import synth
+    g = golden("varnet_cfg2")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=int(g["data_seed"]))
+    net = M.VarNet(6, 8, 3, 16, 3, "XF")
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net.to(dev).eval()
+    out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev)).cpu()
+    ref = torch.from_numpy(g["out_strided"])
+    got = out[:, :, ::4, ::4]
+    assert rel_err(got, ref) < MODEL_TOL
+    assert float(((got - ref).double() ** 2).sum() / (ref.double() ** 2).sum()) < 1e-8          # NMSE
+    assert abs(float(out.double().sum()) - float(g["out_sum"])) / float(g["out_sum"]) < 1e-5
+    tgt = ex["target"][0, :, ::4, ::4].numpy()
+    d_ssim = abs(evaluate.ssim(tgt, got[0].numpy()) - evaluate.ssim(tgt, ref[0].numpy()))
+    assert d_ssim < 1e-4
