@@ -38,13 +38,21 @@ _SIGS = {
     "cine_xfyf_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_xfyf_unpack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_conv3x3_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_tconv2x2_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_conv1x1_packed_floats": (c_size_t, [c_int, c_int]),
     "cine_pack_conv3x3": (c_int, [P, P, c_int, c_int, P]),
-    "cine_conv3x3_in": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int,
-                                P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
-    "cine_tconv2x2_in": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
-    "cine_conv1x1_bias": (c_int, [P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, P]),
-    "cine_instnorm_stats": (c_int, [P, P, c_long, c_long, c_float, P]),
-    "cine_instnorm_lrelu_apply": (c_int, [P, P, P, c_long, c_long, c_float, P]),
+    "cine_pack_tconv2x2": (c_int, [P, P, c_int, c_int, P]),
+    "cine_pack_conv1x1": (c_int, [P, P, c_int, c_int, P]),
+    "cine_conv_stat_partials": (c_int, [c_int, c_int, c_int, c_int]),
+    "cine_conv3x3_in": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int,
+                                P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_tconv2x2_in": (c_int, [P, P, c_int, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int,
+                                 c_float, c_float, P]),
+    "cine_conv1x1_bias": (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
+                                  c_float, c_float, P]),
+    "cine_instnorm_partials": (c_int, [P, P, c_long, c_long, P]),
+    "cine_instnorm_finalize": (c_int, [P, P, c_long, c_int, c_float, P]),
+    "cine_instnorm_lrelu_apply": (c_int, [P, P, c_int, P, c_long, c_long, c_float, c_float, P]),
     "cine_unet2d_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_complex_abs": (c_int, [P, P, c_long, P]),

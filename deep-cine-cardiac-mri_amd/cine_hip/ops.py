@@ -195,72 +195,110 @@ def xfyf_unpack(pxf, pyf, sxf, syf, mean, b: int, t: int, h: int, w: int, xf: bo
 
 
 # ------------------------------------------------------------------ U-Net pieces
-def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
-    w = _dev(w.detach(), "conv weight")
-    cout, cin, kh, kw = w.shape
-    if (kh, kw) != (3, 3):
-        raise ValueError("pack_conv3x3 expects a (cout, cin, 3, 3) weight")
-    out = torch.empty(lib().cine_conv3x3_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
-    check(lib().cine_pack_conv3x3(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv3x3")
+def _pack(kind: str, w: torch.Tensor) -> torch.Tensor:
+    L = lib()
+    w = _dev(w.detach(), f"{kind} weight")
+    if kind == "c3":
+        cout, cin, kh, kw = w.shape
+        if (kh, kw) != (3, 3):
+            raise ValueError("pack_conv3x3 expects a (cout, cin, 3, 3) weight")
+        out = torch.empty(L.cine_conv3x3_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_conv3x3(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv3x3")
+    elif kind == "tc":
+        cin, cout, kh, kw = w.shape
+        if (kh, kw) != (2, 2):
+            raise ValueError("pack_tconv2x2 expects a (cin, cout, 2, 2) weight")
+        out = torch.empty(L.cine_tconv2x2_packed_floats(cin, cout), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_tconv2x2(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "cine_pack_tconv2x2")
+    elif kind == "c1":
+        cout, cin = w.shape[0], w.shape[1]
+        out = torch.empty(L.cine_conv1x1_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_conv1x1(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv1x1")
+    else:
+        raise ValueError(kind)
     return out
 
 
-def conv3x3_in(srcs: Sequence, wpacked: torch.Tensor, cout: int, h: int, w: int, want_stats: bool = True):
-    """srcs: one or two (x, stats|None, mode) with x (n, c, hs, ws). Returns (y, stats_y)."""
-    (x0, s0, m0) = srcs[0]
+def pack_conv3x3(w): return _pack("c3", w)
+def pack_tconv2x2(w): return _pack("tc", w)
+def pack_conv1x1(w): return _pack("c1", w)
+
+
+def _np(part: Optional[torch.Tensor]) -> int:
+    return 0 if part is None else part.shape[2]
+
+
+def conv3x3_in(srcs: Sequence, wpacked: torch.Tensor, cout: int, h: int, w: int, want_stats: bool = True,
+               wpacked2: Optional[torch.Tensor] = None, set_split: int = 0):
+    """srcs: one or two (x, part|None, mode) with x (n, c, hs, ws), part (n, c, np, 3).
+    Returns (y, part_y): raw conv output and its partial InstanceNorm statistics."""
+    (x0, p0, m0) = srcs[0]
     x0 = _dev(x0, "conv source 0")
     n = x0.shape[0]
     if len(srcs) > 1:
-        (x1, s1, m1) = srcs[1]
+        (x1, p1, m1) = srcs[1]
         x1 = _dev(x1, "conv source 1")
         c1, h1, w1 = x1.shape[1:]
     else:
-        x1 = s1 = None; m1 = c1 = h1 = w1 = 0
+        x1 = p1 = None; m1 = c1 = h1 = w1 = 0
     y = torch.empty((n, cout, h, w), device=x0.device, dtype=x0.dtype)
-    sy = torch.empty((n, cout, 2), device=x0.device, dtype=x0.dtype) if want_stats else None
-    check(lib().cine_conv3x3_in(x0.data_ptr(), _p(s0), x0.shape[1], m0, x0.shape[2], x0.shape[3],
-                                _p(x1), _p(s1), c1, m1, h1, w1, wpacked.data_ptr(), y.data_ptr(), _p(sy),
-                                n, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3x3_in")
-    return y, sy
+    py = None
+    if want_stats:
+        py = torch.empty((n, cout, lib().cine_conv_stat_partials(cout, h, w, 0), 3), device=x0.device, dtype=x0.dtype)
+    check(lib().cine_conv3x3_in(x0.data_ptr(), _p(p0), _np(p0), x0.shape[1], m0, x0.shape[2], x0.shape[3],
+                                _p(x1), _p(p1), _np(p1), c1, m1, h1, w1, wpacked.data_ptr(), _p(wpacked2), set_split,
+                                y.data_ptr(), _p(py), n, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3x3_in")
+    return y, py
 
 
-def tconv2x2_in(x, stats, mode: int, wt: torch.Tensor):
-    x = _dev(x, "tconv source"); wt = _dev(wt.detach(), "tconv weight")
+def tconv2x2_in(x, part, mode: int, wpacked: torch.Tensor, cout: int):
+    x = _dev(x, "tconv source")
     n, cin, h, w = x.shape
-    cout = wt.shape[1]
     y = torch.empty((n, cout, 2 * h, 2 * w), device=x.device, dtype=x.dtype)
-    sy = torch.empty((n, cout, 2), device=x.device, dtype=x.dtype)
-    check(lib().cine_tconv2x2_in(x.data_ptr(), _p(stats), mode, wt.data_ptr(), y.data_ptr(), sy.data_ptr(),
-                                 n, cin, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_tconv2x2_in")
-    return y, sy
+    py = torch.empty((n, cout, lib().cine_conv_stat_partials(cout, h, w, 1), 3), device=x.device, dtype=x.dtype)
+    check(lib().cine_tconv2x2_in(x.data_ptr(), _p(part), _np(part), mode, wpacked.data_ptr(), None, 0,
+                                 y.data_ptr(), py.data_ptr(), n, cin, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()),
+          "cine_tconv2x2_in")
+    return y, py
 
 
-def conv1x1_bias(x, stats, mode: int, wt: torch.Tensor, bias: torch.Tensor):
-    x = _dev(x, "conv1x1 source")
-    wt = _dev(wt.detach().reshape(wt.shape[0], -1), "conv1x1 weight"); bias = _dev(bias.detach(), "conv1x1 bias")
+def conv1x1_bias(x, part, mode: int, wpacked: torch.Tensor, bias: torch.Tensor):
+    x = _dev(x, "conv1x1 source"); bias = _dev(bias.detach(), "conv1x1 bias")
     n, cin, h, w = x.shape
-    cout = wt.shape[0]
+    cout = bias.shape[0]
     y = torch.empty((n, cout, h, w), device=x.device, dtype=x.dtype)
-    check(lib().cine_conv1x1_bias(x.data_ptr(), _p(stats), mode, wt.data_ptr(), bias.data_ptr(), y.data_ptr(),
-                                  n, cin, cout, h, w, LRELU_SLOPE, _stream()), "cine_conv1x1_bias")
+    check(lib().cine_conv1x1_bias(x.data_ptr(), _p(part), _np(part), mode, wpacked.data_ptr(), bias.data_ptr(),
+                                  None, None, n, y.data_ptr(), n, cin, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()),
+          "cine_conv1x1_bias")
     return y
 
 
-def instnorm_stats(x: torch.Tensor) -> torch.Tensor:
+def instnorm_partials(x: torch.Tensor) -> torch.Tensor:
+    """(n, c, ...) -> partial statistics (n, c, 1, 3) = {count, mean, M2}."""
     x = _dev(x, "instnorm source")
     n, c = x.shape[:2]
     pe = x.numel() // (n * c)
-    st = torch.empty((n, c, 2), device=x.device, dtype=x.dtype)
-    check(lib().cine_instnorm_stats(x.data_ptr(), st.data_ptr(), n * c, pe, IN_EPS, _stream()), "cine_instnorm_stats")
+    part = torch.empty((n, c, 1, 3), device=x.device, dtype=x.dtype)
+    check(lib().cine_instnorm_partials(x.data_ptr(), part.data_ptr(), n * c, pe, _stream()), "cine_instnorm_partials")
+    return part
+
+
+def instnorm_finalize(part: torch.Tensor) -> torch.Tensor:
+    """(n, c, np, 3) -> (n, c, 2) = {mean, rstd} (biased variance, eps 1e-5)."""
+    n, c, npart, _ = part.shape
+    st = torch.empty((n, c, 2), device=part.device, dtype=part.dtype)
+    check(lib().cine_instnorm_finalize(_dev(part, "partials").data_ptr(), st.data_ptr(), n * c, npart, IN_EPS, _stream()),
+          "cine_instnorm_finalize")
     return st
 
 
-def instnorm_lrelu_apply(x: torch.Tensor, stats: torch.Tensor) -> torch.Tensor:
+def instnorm_lrelu_apply(x: torch.Tensor, part: torch.Tensor) -> torch.Tensor:
     x = _dev(x, "instnorm source")
     n, c = x.shape[:2]
     y = torch.empty_like(x)
-    check(lib().cine_instnorm_lrelu_apply(x.data_ptr(), stats.data_ptr(), y.data_ptr(), n * c,
-                                          x.numel() // (n * c), LRELU_SLOPE, _stream()), "cine_instnorm_lrelu_apply")
+    check(lib().cine_instnorm_lrelu_apply(x.data_ptr(), part.data_ptr(), part.shape[2], y.data_ptr(), n * c,
+                                          x.numel() // (n * c), IN_EPS, LRELU_SLOPE, _stream()),
+          "cine_instnorm_lrelu_apply")
     return y
 
 
@@ -287,9 +325,9 @@ class UnetWeights:
             for i, (tc, uc) in enumerate(zip(u.up_transpose_conv, u.up_conv)):
                 last = i == len(u.up_conv) - 1
                 blk = uc[0] if last else uc
-                seq += [("raw", tc.layers[0].weight), ("c3", blk.layers[0].weight), ("c3", blk.layers[4].weight)]
+                seq += [("tc", tc.layers[0].weight), ("c3", blk.layers[0].weight), ("c3", blk.layers[4].weight)]
             fin = u.up_conv[-1][1]
-            seq += [("raw", fin.weight), ("raw", fin.bias)]
+            seq += [("c1", fin.weight), ("raw", fin.bias)]
             out.append(seq)
         return out
 
@@ -300,7 +338,7 @@ class UnetWeights:
             keep, ptrs = [], []
             for seq in params:
                 for kind, p in seq:
-                    t = pack_conv3x3(p) if kind == "c3" else _dev(p.detach(), "unet weight")
+                    t = _dev(p.detach(), "unet weight") if kind == "raw" else _pack(kind, p)
                     keep.append(t); ptrs.append(t.data_ptr())
             self._keep, self._key = keep, key
             self._ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
@@ -314,7 +352,7 @@ def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[to
     nsets = len(weights.unets)
     if cin != weights.in_ch:
         raise ValueError(f"unet input has {cin} channels, expected {weights.in_ch}")
-    need = lib().cine_unet2d_ws_bytes(n // nsets, h, w, cin, weights.out_ch, weights.chans, weights.pools)
+    need = lib().cine_unet2d_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)
     if need == 0:
         raise CineHipError("cine_unet2d_ws_bytes rejected the shape")
     if workspace is None or workspace.numel() < need:

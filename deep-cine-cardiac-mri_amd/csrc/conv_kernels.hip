@@ -1,17 +1,24 @@
 // conv_kernels.hip -- U-Net building blocks for gfx950.
 //
-// conv3x3 (unet.py:160,164) is an implicit GEMM on the fp32 matrix cores
-// (v_mfma_f32_16x16x4_f32: exact fp32, same numerics class as the reference's fp32 conv):
-//     D[cout][pixel] += W[cout][(tap, cin)] * X[(tap, cin)][pixel]
-//   M = 16 output channels, N = 16 pixels (one "fragment": 16/TW rows x TW columns),
-//   K = 4 input channels of one tap.
-// One workgroup = WM x WN waves; it owns 16*CT*WM output channels x WN*MT fragments of one
-// sample and walks the input channels in chunks of CK: the chunk's input tile (with halo)
-// and weight slab are staged in LDS, every wave then issues 9 * CK/4 * CT * MT MFMAs with
-// operands fetched by ds_read_b32 at compile-time offsets.
-// InstanceNorm + LeakyReLU of the PREVIOUS layer, the 2x2 average pool and the skip concat
-// are applied while staging (cine_hip.h, cine_conv3x3_in), so normalised activations never
-// round-trip through HBM.
+// One implicit-GEMM kernel on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, the
+// same numerics class as the reference's fp32 convolutions) serves
+//   TAPS = 9 : conv3x3, pad 1, no bias             (unet.py:160,164)
+//   TAPS = 1 : conv-transpose k2 s2 as a 1x1 GEMM with 4*cout rows (unet.py:212-215),
+//              and the final 1x1 conv + bias         (unet.py:69)
+//     D[row][pixel] += W[row][(tap, cin)] * X[(tap, cin)][pixel]
+//   M = 16 output rows, N = 16 pixels (one "fragment" = 16/TW rows x TW columns), K = 4 input
+//   channels of one tap.
+// One workgroup = WM x WN waves; it owns 16*CT*WM output rows x WN*MT fragments of ONE sample and
+// walks the input channels in chunks of CK.  Per chunk the input tile (+halo) and the weight slab
+// are staged in LDS, then every wave issues TAPS * CK/4 * CT * MT MFMAs whose operands come from
+// ds_read_b32 at compile-time offsets.
+//
+// What is fused around the GEMM (so normalised activations never touch HBM):
+//   on load  : InstanceNorm + LeakyReLU of the producer layer, 2x2 average pool (unet.py:97),
+//              channel concat of two sources (unet.py:122), up-path zero pad (unet.py:106-120)
+//   epilogue : InstanceNorm statistics of THIS layer's raw output as per-tile partials
+//              {count, mean, M2} (exact two-pass in registers; consumers merge them with Chan's
+//              formula -- deterministic, no atomics), bias for the 1x1 conv.
 #include <mutex>
 #include "common.h"
 
@@ -19,71 +26,113 @@ namespace cine {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCK = 8;    // input channels per LDS chunk (2 MFMA k-steps per tap)
-
-struct ConvSrc {
-    const float* x; const float* stats;
-    int c, mode, h, w;
-};
-struct ConvArgs {
-    ConvSrc s0, s1;
-    const float* wp; float* y;
-    int n, cin, cout, coutp, H, W;
-    float slope;
-    int tiles_w, nchunks;
-};
+// ---------------------------------------------------------------- statistics helpers
+// partial record = {count, mean, M2}; merged InstanceNorm stats = {mean, 1/sqrt(M2/count + eps)}
+__device__ __forceinline__ float2 merge_partials(const float* p, int np, float eps) {
+    float cnt = 0.f, mean = 0.f;
+    for (int i = 0; i < np; ++i) { cnt += p[3 * i]; mean += p[3 * i] * p[3 * i + 1]; }
+    mean /= cnt;
+    float m2 = 0.f;
+    for (int i = 0; i < np; ++i) {
+        const float d = p[3 * i + 1] - mean;
+        m2 += p[3 * i + 2] + p[3 * i] * d * d;
+    }
+    return make_float2(mean, 1.0f / sqrtf(m2 / cnt + eps));
+}
 
 __device__ __forceinline__ float act(float x, float mean, float rstd, float slope) {
     const float v = (x - mean) * rstd;
     return v > 0.f ? v : v * slope;
 }
 
-// value of concatenated-input channel ci at (gy, gx) of sample n, after the source's transform
-__device__ __forceinline__ float fetch_src(const ConvSrc& s, int n, int cl, int gy, int gx, float slope) {
+struct Src {
+    const float* x; const float* part;   // raw activations (n, c, h, w); partial stats (n, c, np, 3)
+    int c, mode, h, w, np;               // mode 0 as-is, 1 norm+LReLU, 2 norm+LReLU+avgpool2
+};
+struct ConvArgs {
+    Src s0, s1;
+    const float* wp0; const float* wp1; int set_split;   // samples >= set_split use wp1
+    const float* bias;
+    float* y; float* ypart;
+    int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout for tconv), padded to 16
+    int tconv_cout;                      // > 0: transpose-conv store mapping with this many channels
+    float slope, eps;
+    int tiles_w, tiles, nchunks, fast;
+};
+
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+struct ConvCfg {
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int RPF = 16 / TW;            // rows per fragment
+    static constexpr int NF = WN * MT;             // fragments per workgroup
+    static constexpr int TH = NF * RPF;            // tile rows
+    static constexpr int ROWS = TH + 2 * HALO, COLS = TW + 2 * HALO;
+    static constexpr int PS = ((ROWS * COLS + 31) / 32) * 32 + 16;   // plane stride == 16 (mod 32)
+    static constexpr int COT = 16 * CT * WM;
+    static constexpr int COTP = (COT % 32 == 0) ? COT + 16 : COT;
+    static constexpr int PW = TW >= 4 ? 4 : TW;    // floats per staging piece
+    static constexpr int PR = TW / PW;             // pieces per row
+    static constexpr int NPIECE = CK * ROWS * PR;
+    static constexpr int NPT = (NPIECE + NT - 1) / NT;
+    static constexpr int IN_FLOATS = CK * PS;
+    static constexpr int W_FLOATS = TAPS * CK * COTP;
+    static constexpr int RED_FLOATS = WN * COT + COT;
+    static_assert(RED_FLOATS <= IN_FLOATS, "reduction scratch must fit in the input tile");
+    static size_t lds_bytes(int cin) { return (size_t)(IN_FLOATS + W_FLOATS + 2 * cin) * sizeof(float); }
+};
+
+// scalar (any shape) fetch of one transformed input value
+__device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int gy, int gx, float mean, float rstd, float slope) {
     const long plane = (long)n * s.c + cl;
     if (s.mode == 2) {
-        if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;      // outside the pooled extent
-        const float mean = s.stats[plane * 2], rstd = s.stats[plane * 2 + 1];
+        if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;
         const float* p = s.x + (plane * s.h + 2 * gy) * s.w + 2 * gx;
         return 0.25f * (act(p[0], mean, rstd, slope) + act(p[1], mean, rstd, slope) +
                         act(p[s.w], mean, rstd, slope) + act(p[s.w + 1], mean, rstd, slope));
     }
-    if (gy >= s.h || gx >= s.w) return 0.f;                           // up-path zero pad
+    if (gy >= s.h || gx >= s.w) return 0.f;
     const float v = s.x[(plane * s.h + gy) * s.w + gx];
-    if (s.mode == 0) return v;
-    return act(v, s.stats[plane * 2], s.stats[plane * 2 + 1], slope);
+    return s.mode == 0 ? v : act(v, mean, rstd, slope);
 }
 
-template <int CK, int CT, int WM, int WN, int MT, int TW>
-struct ConvCfg {
-    static constexpr int NT = 64 * WM * WN;
-    static constexpr int RPF = 16 / TW;            // rows per fragment
-    static constexpr int NF = WN * MT;             // fragments per workgroup
-    static constexpr int TH = NF * RPF;            // tile rows
-    static constexpr int ROWS = TH + 2, COLS = TW + 2;
-    static constexpr int PS = ((ROWS * COLS + 31) / 32) * 32 + 16;   // plane stride == 16 mod 32
-    static constexpr int COT = 16 * CT * WM;
-    static constexpr int COTP = (COT % 32 == 0) ? COT + 16 : COT;
-    static constexpr size_t LDS = (size_t)(CK * PS + 9 * CK * COTP) * sizeof(float);
-};
+template <int PW> struct Piece;
+template <> struct Piece<4> { typedef float4 T; };
+template <> struct Piece<2> { typedef float2 T; };
 
-template <int CK, int CT, int WM, int WN, int MT, int TW>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma_kernel(ConvArgs a) {
-    using C = ConvCfg<CK, CT, WM, WN, MT, TW>;
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
+    using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
+    constexpr int HALO = C::HALO, PW = C::PW;
+    typedef typename Piece<PW>::T piece_t;
     extern __shared__ __align__(16) float smem_f[];
     float* in_lds = smem_f;
-    float* w_lds = smem_f + CK * C::PS;
+    float* w_lds = smem_f + C::IN_FLOATS;
+    float* st_lds = w_lds + C::W_FLOATS;            // {mean, rstd} per input channel
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int ty = blockIdx.x / a.tiles_w, tx = blockIdx.x % a.tiles_w;
+    const int tile = blockIdx.x;
+    const int ty = tile / a.tiles_w, tx = tile % a.tiles_w;
     const int r0 = ty * C::TH, c0 = tx * TW;
     const int co0 = blockIdx.y * C::COT;
     const int n = blockIdx.z;
+    const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
     const int q = lane & 15, kk = lane >> 4;
     const int qr = q / TW, qc = q % TW;
     const int base_in = kk * C::PS + (wn * MT * C::RPF + qr) * C::COLS + qc;
     const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
+
+    // ---- prologue: merged InstanceNorm stats of every input channel; zero the tile once
+    for (int ci = tid; ci < a.cin; ci += C::NT) {
+        const bool first = ci < a.s0.c;
+        const Src& s = first ? a.s0 : a.s1;
+        const int cl = first ? ci : ci - a.s0.c;
+        float2 mr = make_float2(0.f, 1.f);
+        if (s.mode != 0) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+        st_lds[2 * ci] = mr.x; st_lds[2 * ci + 1] = mr.y;
+    }
+    for (int e = tid; e < C::IN_FLOATS; e += C::NT) in_lds[e] = 0.f;
 
     f32x4 acc[CT][MT];
 #pragma unroll
@@ -93,42 +142,121 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma_kernel(ConvArgs a) 
 
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         __syncthreads();
-        // ---- stage the weight slab [tap][ck][COT] (packed layout [chunk][tap][ck][coutp])
+        // ---- weight slab [tap][ck][COT] from the packed layout [chunk][tap][ck][rowsp]
         {
-            const float* wsrc = a.wp + (long)chunk * 9 * CK * a.coutp;
-            for (int e = tid; e < 9 * CK * (C::COT / 4); e += C::NT) {
+            const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
+            for (int e = tid; e < TAPS * CK * (C::COT / 4); e += C::NT) {
                 const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (co0 + c4 < a.coutp) v = *reinterpret_cast<const float4*>(wsrc + (long)row * a.coutp + co0 + c4);
+                if (co0 + c4 < a.rowsp) v = *reinterpret_cast<const float4*>(wsrc + (long)row * a.rowsp + co0 + c4);
                 *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = v;
             }
         }
-        // ---- stage the input tile with halo, transformed
-        for (int e = tid; e < CK * C::ROWS * C::COLS; e += C::NT) {
-            const int ck = e / (C::ROWS * C::COLS);
-            const int rem = e - ck * (C::ROWS * C::COLS);
-            const int row = rem / C::COLS, col = rem - row * C::COLS;
-            const int ci = chunk * CK + ck;
-            const int gy = r0 - 1 + row, gx = c0 - 1 + col;
-            float v = 0.f;
-            if (ci < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = ci < a.s0.c ? fetch_src(a.s0, n, ci, gy, gx, a.slope)
-                                : fetch_src(a.s1, n, ci - a.s0.c, gy, gx, a.slope);
-            in_lds[ck * C::PS + row * C::COLS + col] = v;
+        const int ci0 = chunk * CK;
+        const bool first = ci0 < a.s0.c;
+        const Src& s = first ? a.s0 : a.s1;
+        const int cl0 = first ? ci0 : ci0 - a.s0.c;
+        if (a.fast) {
+            // ---- vectorised staging: every piece = PW consecutive floats of one (channel, row)
+            if (s.mode != 2) {
+                piece_t raw[C::NPT];
+                bool ok[C::NPT];
+#pragma unroll
+                for (int i = 0; i < C::NPT; ++i) {
+                    const int p = tid + i * C::NT;
+                    const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
+                    const int row = rem / C::PR, j = rem % C::PR;
+                    const int gy = r0 - HALO + row, gx = c0 + PW * j;
+                    ok[i] = p < C::NPIECE && ci0 + ck < a.cin && gy >= 0 && gy < s.h && gx < a.W;
+                    const int gyc = min(max(gy, 0), s.h - 1), gxc = min(gx, a.W - PW), ckc = min(cl0 + ck, s.c - 1);
+                    raw[i] = *reinterpret_cast<const piece_t*>(s.x + (((long)n * s.c + ckc) * s.h + gyc) * a.W + gxc);
+                }
+#pragma unroll
+                for (int i = 0; i < C::NPT; ++i) {
+                    const int p = tid + i * C::NT;
+                    if (p >= C::NPIECE) break;
+                    const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
+                    const int row = rem / C::PR, j = rem % C::PR;
+                    const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
+                    const float* r = reinterpret_cast<const float*>(&raw[i]);
+                    float* dst = in_lds + ck * C::PS + row * C::COLS + HALO + PW * j;
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) {
+                        float v = s.mode == 0 ? r[u] : act(r[u], mean, rstd, a.slope);
+                        dst[u] = ok[i] ? v : 0.f;
+                    }
+                }
+            } else {
+                // pooled source (extent 2H x 2W): 2*PW floats from each of two rows per piece
+#pragma unroll 2
+                for (int i = 0; i < C::NPT; ++i) {
+                    const int p = tid + i * C::NT;
+                    if (p >= C::NPIECE) break;
+                    const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
+                    const int row = rem / C::PR, j = rem % C::PR;
+                    const int gy = r0 - HALO + row, gx = c0 + PW * j;
+                    const bool ok = ci0 + ck < a.cin && gy >= 0 && 2 * gy + 1 < s.h && gx < a.W;
+                    float* dst = in_lds + ck * C::PS + row * C::COLS + HALO + PW * j;
+                    if (ok) {
+                        const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
+                        const float* src = s.x + (((long)n * s.c + cl0 + ck) * s.h + 2 * gy) * s.w + 2 * gx;
+                        float t0[2 * PW], t1[2 * PW];
+#pragma unroll
+                        for (int u = 0; u < 2 * PW; u += 4) {
+                            *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(src + u);
+                            *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(src + s.w + u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < PW; ++u)
+                            dst[u] = 0.25f * (act(t0[2 * u], mean, rstd, a.slope) + act(t0[2 * u + 1], mean, rstd, a.slope) +
+                                              act(t1[2 * u], mean, rstd, a.slope) + act(t1[2 * u + 1], mean, rstd, a.slope));
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) dst[u] = 0.f;
+                    }
+                }
+            }
+            // halo columns (only exist as data when the image is wider than the tile)
+            if (HALO && a.W > TW) {
+                for (int e = tid; e < CK * C::ROWS * 2; e += C::NT) {
+                    const int ck = e / (C::ROWS * 2), rem = e % (C::ROWS * 2);
+                    const int row = rem >> 1, side = rem & 1;
+                    const int gy = r0 - 1 + row, gx = side ? c0 + TW : c0 - 1;
+                    float v = 0.f;
+                    if (ci0 + ck < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                        v = fetch_scalar(s, n, cl0 + ck, gy, gx, st_lds[2 * (ci0 + ck)], st_lds[2 * (ci0 + ck) + 1], a.slope);
+                    in_lds[ck * C::PS + row * C::COLS + (side ? TW + 1 : 0)] = v;
+                }
+            }
+        } else {
+            // ---- generic scalar staging (odd widths, mixed-source chunks, narrow `up` extents)
+            for (int e = tid; e < CK * C::ROWS * C::COLS; e += C::NT) {
+                const int ck = e / (C::ROWS * C::COLS);
+                const int rem = e - ck * (C::ROWS * C::COLS);
+                const int row = rem / C::COLS, col = rem - row * C::COLS;
+                const int ci = ci0 + ck;
+                const int gy = r0 - HALO + row, gx = c0 - HALO + col;
+                float v = 0.f;
+                if (ci < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    const bool f0 = ci < a.s0.c;
+                    v = fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? ci : ci - a.s0.c, gy, gx, st_lds[2 * ci], st_lds[2 * ci + 1], a.slope);
+                }
+                in_lds[ck * C::PS + row * C::COLS + col] = v;
+            }
         }
         __syncthreads();
         // ---- MFMA sweep
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
 #pragma unroll
-            for (int s = 0; s < CK / 4; ++s) {
+            for (int ks = 0; ks < CK / 4; ++ks) {
                 float af[CT], bf[MT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) af[ct] = w_lds[base_w + (tap * CK + 4 * s) * C::COTP + 16 * ct];
+                for (int ct = 0; ct < CT; ++ct) af[ct] = w_lds[base_w + (tap * CK + 4 * ks) * C::COTP + 16 * ct];
 #pragma unroll
                 for (int f = 0; f < MT; ++f)
-                    bf[f] = in_lds[base_in + (4 * s) * C::PS + (f * C::RPF + dy) * C::COLS + dx];
+                    bf[f] = in_lds[base_in + (4 * ks) * C::PS + (f * C::RPF + dy) * C::COLS + dx];
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -137,47 +265,131 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_mfma_kernel(ConvArgs a) 
             }
         }
     }
-    // ---- store raw conv output (NCHW)
+
+    // ---- epilogue.  Lane holds rows m = co0 + 16*(wm*CT+ct) + 4*kk + j, pixel q of fragment f.
+    unsigned vmask = 0;                             // which of my fragments' pixels are inside the image
+#pragma unroll
+    for (int f = 0; f < MT; ++f) {
+        const int gy = r0 + (wn * MT + f) * C::RPF + qr, gx = c0 + qc;
+        if (gy < a.H && gx < a.W) vmask |= 1u << f;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = co0 + 16 * (wm * CT + ct) + 4 * kk + j;
+                const float bv = m < a.rows ? a.bias[m] : 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f) acc[ct][f][j] += bv;
+            }
+    }
+    if (a.ypart) {
+        __syncthreads();                            // everyone is done reading in_lds
+        float* red = in_lds;                        // [WN][COT]
+        float* meanl = in_lds + WN * C::COT;        // [COT]
+        const float cnt = (float)(min(C::TH, a.H - r0) * min(TW, a.W - c0));
+        float mrow[CT][4];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int f = 0; f < MT; ++f) {
+                        float v = acc[ct][f][j];
+                        if (pass) { v -= mrow[ct][j]; v *= v; }
+                        sacc += ((vmask >> f) & 1u) ? v : 0.f;
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
+                    if (q == 0) red[wn * C::COT + 16 * (wm * CT + ct) + 4 * kk + j] = sacc;
+                }
+            __syncthreads();
+            if (tid < C::COT) {
+                float tot = 0.f;
+#pragma unroll
+                for (int w = 0; w < WN; ++w) tot += red[w * C::COT + tid];
+                const int m = co0 + tid;
+                if (pass == 0) {
+                    meanl[tid] = tot / cnt;
+                } else if (m < a.rows) {
+                    long slot;
+                    if (a.tconv_cout > 0) {
+                        const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
+                        slot = ((long)n * a.tconv_cout + co) * (a.tiles * 4) + tile * 4 + ab;
+                    } else {
+                        slot = ((long)n * a.rows + m) * a.tiles + tile;
+                    }
+                    float* o = a.ypart + slot * 3;
+                    o[0] = cnt; o[1] = meanl[tid]; o[2] = tot;
+                }
+            }
+            __syncthreads();
+            if (pass == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mrow[ct][j] = meanl[16 * (wm * CT + ct) + 4 * kk + j];
+            }
+        }
+    }
+    // ---- store raw output
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
-            const int fg = wn * MT + f;
-            const int gy = r0 + fg * C::RPF + qr, gx = c0 + qc;
-            if (gy >= a.H || gx >= a.W) continue;
+            if (!((vmask >> f) & 1u)) continue;
+            const int gy = r0 + (wn * MT + f) * C::RPF + qr, gx = c0 + qc;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = co0 + 16 * (wm * CT + ct) + 4 * kk + j;
-                if (co < a.cout) a.y[(((long)n * a.cout + co) * a.H + gy) * a.W + gx] = acc[ct][f][j];
+                const int m = co0 + 16 * (wm * CT + ct) + 4 * kk + j;
+                if (m >= a.rows) continue;
+                if (a.tconv_cout > 0) {
+                    const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
+                    a.y[(((long)n * a.tconv_cout + co) * (2 * a.H) + 2 * gy + (ab >> 1)) * (2 * a.W) + 2 * gx + (ab & 1)] = acc[ct][f][j];
+                } else {
+                    a.y[(((long)n * a.rows + m) * a.H + gy) * a.W + gx] = acc[ct][f][j];
+                }
             }
         }
 }
 
 // ---------------------------------------------------------------- weight packing
-// (cout, cin, 3, 3) -> [chunk][tap][ck][coutp], zero padded
-__global__ void pack_conv3x3_kernel(const float* w, float* p, int cout, int cin, int coutp, int nchunks) {
-    const long total = (long)nchunks * 9 * kCK * coutp;
+// conv3x3 (cout, cin, 3, 3)        -> [chunk][tap][ck][rowsp]     rows = cout
+// tconv   (cin, cout, 2, 2)        -> [chunk][1][ck][rowsp]       rows = 4*cout, row = (2a+b)*cout + co
+// conv1x1 (cout, cin)              -> [chunk][1][ck][rowsp]       rows = cout
+__global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout, int cin, int rows, int rowsp,
+                                    int taps, int ck_, int nchunks) {
+    const long total = (long)nchunks * taps * ck_ * rowsp;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(e % coutp);
-        long r = e / coutp;
-        const int ck = (int)(r % kCK); r /= kCK;
-        const int tap = (int)(r % 9);
-        const int chunk = (int)(r / 9);
-        const int ci = chunk * kCK + ck;
-        p[e] = (co < cout && ci < cin) ? w[((long)co * cin + ci) * 9 + tap] : 0.f;
+        const int m = (int)(e % rowsp);
+        long r = e / rowsp;
+        const int ck = (int)(r % ck_); r /= ck_;
+        const int tap = (int)(r % taps);
+        const int chunk = (int)(r / taps);
+        const int ci = chunk * ck_ + ck;
+        float v = 0.f;
+        if (m < rows && ci < cin) {
+            if (kind == 0) v = w[((long)m * cin + ci) * 9 + tap];
+            else if (kind == 1) { const int ab = m / cout, co = m % cout; v = w[((long)ci * cout + co) * 4 + ab]; }
+            else v = w[(long)m * cin + ci];
+        }
+        p[e] = v;
     }
 }
 
-// ---------------------------------------------------------------- InstanceNorm statistics
-// stats[plane] = {mean, 1/sqrt(biased var + eps)}; exact two-pass; one wave per plane
-// (plane_elems <= 8192) or one workgroup per plane.
+// ---------------------------------------------------------------- stand-alone statistics
+// partial record {count, mean, M2} per plane (np = 1); exact two-pass.
 __device__ __forceinline__ float wave_sum_f(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-__global__ void instnorm_stats_wave_kernel(const float* x, float* stats, long planes, int pe, float eps) {
+__global__ void instnorm_partial_wave_kernel(const float* x, float* part, long planes, int pe) {
     const long plane = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (plane >= planes) return;
     const int lane = threadIdx.x & 63;
@@ -187,11 +399,11 @@ __global__ void instnorm_stats_wave_kernel(const float* x, float* stats, long pl
     const float mean = wave_sum_f(s) / pe;
     float qv = 0.f;
     for (int i = lane; i < pe; i += 64) { const float d = p[i] - mean; qv += d * d; }
-    const float var = wave_sum_f(qv) / pe;
-    if (lane == 0) { stats[plane * 2] = mean; stats[plane * 2 + 1] = 1.0f / sqrtf(var + eps); }
+    qv = wave_sum_f(qv);
+    if (lane == 0) { part[plane * 3] = (float)pe; part[plane * 3 + 1] = mean; part[plane * 3 + 2] = qv; }
 }
 
-__global__ void instnorm_stats_block_kernel(const float* x, float* stats, long pe, float eps) {
+__global__ void instnorm_partial_block_kernel(const float* x, float* part, long pe) {
     __shared__ float red[16];
     const long plane = blockIdx.x;
     const float* p = x + plane * pe;
@@ -213,110 +425,86 @@ __global__ void instnorm_stats_block_kernel(const float* x, float* stats, long p
     if (threadIdx.x == 0) {
         float t2 = 0.f;
         for (int i = 0; i < nw; ++i) t2 += red[i];
-        stats[plane * 2] = mean;
-        stats[plane * 2 + 1] = 1.0f / sqrtf(t2 / pe + eps);
+        part[plane * 3] = (float)pe; part[plane * 3 + 1] = mean; part[plane * 3 + 2] = t2;
     }
 }
 
-__global__ void instnorm_lrelu_apply_kernel(const float* x, const float* stats, float* y, long planes, long pe, float slope) {
+// {mean, rstd} per plane from np partials
+__global__ void instnorm_finalize_kernel(const float* part, float* stats, long planes, int np, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes) return;
+    const float2 mr = merge_partials(part + i * np * 3, np, eps);
+    stats[2 * i] = mr.x; stats[2 * i + 1] = mr.y;
+}
+
+__global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, int np, float* y, long planes, long pe,
+                                            float eps, float slope) {
     const long total = planes * pe;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long plane = e / pe;
-        y[e] = act(x[e], stats[plane * 2], stats[plane * 2 + 1], slope);
-    }
-}
-
-// ---------------------------------------------------------------- transpose conv k2 s2
-// One workgroup: 64 input pixels of one sample x all cin in LDS; wave g handles output
-// channels g, g+4, ...; weights (cin, cout, 2, 2) read through the scalar cache.
-constexpr int kTPix = 64;
-__global__ __launch_bounds__(256) void tconv2x2_kernel(const float* x, const float* stats, int mode, const float* wt,
-                                                        float* y, int cin, int cout, int H, int W, float slope) {
-    extern __shared__ __align__(16) float xs[];        // [cin][kTPix]
-    const int n = blockIdx.y;
-    const int p0 = blockIdx.x * kTPix;
-    const int HW = H * W;
-    for (int e = threadIdx.x; e < cin * kTPix; e += blockDim.x) {
-        const int ci = e / kTPix, p = e % kTPix;
-        float v = 0.f;
-        if (p0 + p < HW) {
-            const long plane = (long)n * cin + ci;
-            v = x[plane * HW + p0 + p];
-            if (mode == 1) v = act(v, stats[plane * 2], stats[plane * 2 + 1], slope);
-        }
-        xs[e] = v;
-    }
-    __syncthreads();
-    const int p = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pix = p0 + p;
-    const int h = pix / W, w = pix - h * W;
-    const int OW = 2 * W;
-    for (int co = g; co < cout; co += 4) {
-        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-        const float* wc = wt + (long)co * 4;
-        for (int ci = 0; ci < cin; ++ci) {
-            const float xv = xs[ci * kTPix + p];
-            const float4 wv = *reinterpret_cast<const float4*>(wc + (long)ci * cout * 4);
-            a00 += xv * wv.x; a01 += xv * wv.y; a10 += xv * wv.z; a11 += xv * wv.w;
-        }
-        if (pix < HW) {
-            float* o = y + (((long)n * cout + co) * 2 * H + 2 * h) * OW + 2 * w;
-            *reinterpret_cast<float2*>(o) = make_float2(a00, a01);
-            *reinterpret_cast<float2*>(o + OW) = make_float2(a10, a11);
-        }
-    }
-}
-
-// ---------------------------------------------------------------- 1x1 conv + bias
-__global__ void conv1x1_bias_kernel(const float* x, const float* stats, int mode, const float* wt, const float* bias,
-                                    float* y, int cin, int cout, long HW, float slope) {
-    const int n = blockIdx.y;
-    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
-        for (int co = 0; co < cout; ++co) {
-            float acc = bias[co];
-            for (int ci = 0; ci < cin; ++ci) {
-                const long plane = (long)n * cin + ci;
-                float v = x[plane * HW + p];
-                if (mode == 1) v = act(v, stats[plane * 2], stats[plane * 2 + 1], slope);
-                acc += v * wt[co * cin + ci];
-            }
-            y[((long)n * cout + co) * HW + p] = acc;
-        }
+        const float2 mr = merge_partials(part + plane * np * 3, np, eps);
+        y[e] = act(x[e], mr.x, mr.y, slope);
     }
 }
 
 // ---------------------------------------------------------------- host dispatch
-template <int CK, int CT, int WM, int WN, int MT, int TW>
-static int launch_conv(ConvArgs a, hipStream_t st) {
-    using C = ConvCfg<CK, CT, WM, WN, MT, TW>;
+constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
+constexpr int kCK1 = 16;    // 1x1 / tconv
+
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+static int launch_cfg(ConvArgs a, hipStream_t st) {
+    using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     static std::once_flag once;
-    auto kern = conv3x3_mfma_kernel<CK, CT, WM, WN, MT, TW>;
+    auto kern = conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
     std::call_once(once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
+    const size_t lds = C::lds_bytes(a.cin);
+    CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv: %d input channels need %zu bytes of LDS", a.cin, lds);
     a.tiles_w = ceil_div(a.W, TW);
-    const int tiles_h = ceil_div(a.H, C::TH);
-    dim3 grid(a.tiles_w * tiles_h, ceil_div(a.coutp, C::COT), a.n);
-    ProfScope prof(F_CONV3, st);
-    hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS, st, a);
-    return check_launch("conv3x3_mfma_kernel");
+    a.tiles = a.tiles_w * ceil_div(a.H, C::TH);
+    // vectorised staging preconditions (see kernel): widths multiple of the piece, one source per chunk
+    const int PW = C::PW;
+    auto src_ok = [&](const Src& s) {
+        if (s.c == 0) return true;
+        if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0;
+        return s.w == a.W && s.h <= a.H;
+    };
+    a.fast = (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
+             (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
+    dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
+    ProfScope prof(TAPS == 9 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1), st);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, a);
+    return check_launch("conv_mfma_kernel");
 }
 
-template <int TW>
-static int dispatch_conv_tw(const ConvArgs& a, hipStream_t st) {
+template <int TW, int TAPS, int CK>
+static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * TW, 16) * ceil_div(a.W, TW);   // fragments per sample
-    if (a.coutp <= 16) return launch_conv<kCK, 1, 1, 4, 13, TW>(a, st);
-    if (a.coutp <= 32) return launch_conv<kCK, 2, 1, 4, 13, TW>(a, st);
-    if (a.coutp <= 64 || frags > 8) return launch_conv<kCK, 1, 4, 1, 13, TW>(a, st);
-    return launch_conv<kCK, 2, 4, 1, 4, TW>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, 4, 13, TW, TAPS>(a, st);
+    if (a.rowsp <= 32) return launch_cfg<CK, 2, 1, 4, 13, TW, TAPS>(a, st);
+    if (a.rowsp <= 64 || frags > 8) return launch_cfg<CK, 1, 4, 1, 13, TW, TAPS>(a, st);
+    return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
 }
 
-int conv3x3_dispatch(const ConvArgs& a, hipStream_t st) {
-    if (a.W > 8) return dispatch_conv_tw<16>(a, st);
-    if (a.W > 4) return dispatch_conv_tw<8>(a, st);
-    if (a.W > 2) return dispatch_conv_tw<4>(a, st);
-    return dispatch_conv_tw<2>(a, st);
+template <int TAPS, int CK>
+static int dispatch(const ConvArgs& a, hipStream_t st) {
+    if (a.W > 8) return dispatch_tw<16, TAPS, CK>(a, st);
+    if (a.W > 4) return dispatch_tw<8, TAPS, CK>(a, st);
+    if (a.W > 2) return dispatch_tw<4, TAPS, CK>(a, st);
+    return dispatch_tw<2, TAPS, CK>(a, st);
+}
+
+// tiles per sample of the configuration dispatch() picks (must mirror dispatch_tw)
+int tiles_for(int rowsp, int h, int w) {
+    const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
+    const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
+    int nf;
+    if (rowsp <= 32) nf = 52;
+    else if (rowsp <= 64 || frags > 8) nf = 13;
+    else nf = 4;
+    const int TH = nf * 16 / TW;
+    return ceil_div(w, TW) * ceil_div(h, TH);
 }
 
 static unsigned grid1d(long n, int threads, long cap = 8192) {
@@ -325,104 +513,140 @@ static unsigned grid1d(long n, int threads, long cap = 8192) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
-int instnorm_stats(const float* x, float* stats, long planes, long pe, float eps, hipStream_t st) {
-    ProfScope prof(F_STATS, st);
-    if (pe <= 8192) {
-        hipLaunchKernelGGL(instnorm_stats_wave_kernel, dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, st,
-                           x, stats, planes, (int)pe, eps);
-    } else {
-        hipLaunchKernelGGL(instnorm_stats_block_kernel, dim3((unsigned)planes), dim3(256), 0, st, x, stats, pe, eps);
-    }
-    return check_launch("instnorm_stats");
-}
-
 }  // namespace cine
 
 using namespace cine;
 
+// number of partial-statistics records per (sample, channel) that the conv / tconv kernels emit
+extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv) {
+    if (cout <= 0 || h <= 0 || w <= 0) return 0;
+    const int rows = is_tconv ? 4 * cout : cout;
+    const int rowsp = ceil_div(rows, 16) * 16;
+    return tiles_for(rowsp, h, w) * (is_tconv ? 4 : 1);
+}
+
+static size_t packed_floats(int rows, int cin, int taps, int ck) {
+    return (size_t)ceil_div(cin, ck) * taps * ck * (ceil_div(rows, 16) * 16);
+}
 extern "C" size_t cine_conv3x3_packed_floats(int cout, int cin) {
-    if (cout <= 0 || cin <= 0) return 0;
-    const int coutp = ceil_div(cout, 16) * 16, nchunks = ceil_div(cin, kCK);
-    return (size_t)nchunks * 9 * kCK * coutp;
+    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(cout, cin, 9, kCK3);
+}
+extern "C" size_t cine_tconv2x2_packed_floats(int cin, int cout) {
+    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(4 * cout, cin, 1, kCK1);
+}
+extern "C" size_t cine_conv1x1_packed_floats(int cout, int cin) {
+    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(cout, cin, 1, kCK1);
 }
 
-extern "C" int cine_pack_conv3x3(const float* w, float* packed, int cout, int cin, void* stream) {
-    CINE_REQUIRE(w && packed && cout > 0 && cin > 0, CINE_EINVAL, "cine_pack_conv3x3: bad arguments");
-    const int coutp = ceil_div(cout, 16) * 16, nchunks = ceil_div(cin, kCK);
-    const long total = (long)nchunks * 9 * kCK * coutp;
+static int pack(const float* w, float* packed, int kind, int cout, int cin, void* stream, const char* what) {
+    CINE_REQUIRE(w && packed && cout > 0 && cin > 0, CINE_EINVAL, "%s: bad arguments", what);
+    const int rows = kind == 1 ? 4 * cout : cout, taps = kind == 0 ? 9 : 1, ck = kind == 0 ? kCK3 : kCK1;
+    const int rowsp = ceil_div(rows, 16) * 16, nchunks = ceil_div(cin, ck);
+    const long total = (long)nchunks * taps * ck * rowsp;
     ProfScope prof(F_MISC, as_stream(stream));
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid1d(total, 256)), dim3(256), 0, as_stream(stream),
-                       w, packed, cout, cin, coutp, nchunks);
-    return check_launch("pack_conv3x3_kernel");
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid1d(total, 256)), dim3(256), 0, as_stream(stream),
+                       w, packed, kind, cout, cin, rows, rowsp, taps, ck, nchunks);
+    return check_launch("pack_weights_kernel");
+}
+extern "C" int cine_pack_conv3x3(const float* w, float* packed, int cout, int cin, void* stream) {
+    return pack(w, packed, 0, cout, cin, stream, "cine_pack_conv3x3");
+}
+extern "C" int cine_pack_tconv2x2(const float* w, float* packed, int cin, int cout, void* stream) {
+    return pack(w, packed, 1, cout, cin, stream, "cine_pack_tconv2x2");
+}
+extern "C" int cine_pack_conv1x1(const float* w, float* packed, int cout, int cin, void* stream) {
+    return pack(w, packed, 2, cout, cin, stream, "cine_pack_conv1x1");
 }
 
-static int check_src(const float* x, const float* stats, int c, int mode, const char* what) {
+static int check_src(const float* x, const float* part, int c, int mode, int np, const char* what) {
     CINE_REQUIRE(c >= 0, CINE_EINVAL, "%s: negative channel count", what);
     if (c == 0) return CINE_OK;
     CINE_REQUIRE(x, CINE_EINVAL, "%s: null source", what);
     CINE_REQUIRE(mode >= 0 && mode <= 2, CINE_EINVAL, "%s: mode %d", what, mode);
-    CINE_REQUIRE(mode == 0 || stats, CINE_EINVAL, "%s: mode %d needs stats", what, mode);
+    CINE_REQUIRE(mode == 0 || (part && np > 0), CINE_EINVAL, "%s: mode %d needs partial stats", what, mode);
     return CINE_OK;
 }
 
-extern "C" int cine_conv3x3_in(const float* x0, const float* stats0, int c0, int mode0, int h0, int w0,
-                               const float* x1, const float* stats1, int c1, int mode1, int h1, int w1,
-                               const float* wpacked, float* y, float* stats_y,
-                               int n, int cout, int h, int w, float eps, float slope, void* stream) {
+extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                               const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1,
+                               const float* wpacked, const float* wpacked2, int set_split,
+                               float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3x3_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3x3_in: bad sizes");
-    if (int e = check_src(x0, stats0, c0, mode0, "cine_conv3x3_in(src0)")) return e;
-    if (int e = check_src(x1, stats1, c1, mode1, "cine_conv3x3_in(src1)")) return e;
+    if (int e = check_src(x0, part0, c0, mode0, np0, "cine_conv3x3_in(src0)")) return e;
+    if (int e = check_src(x1, part1, c1, mode1, np1, "cine_conv3x3_in(src1)")) return e;
     ConvArgs a{};
-    a.s0 = ConvSrc{x0, stats0, c0, mode0, h0, w0};
-    a.s1 = ConvSrc{x1, stats1, c1, c1 > 0 ? mode1 : 0, h1, w1};
-    a.wp = wpacked; a.y = y; a.n = n; a.cin = c0 + c1; a.cout = cout;
-    a.coutp = ceil_div(cout, 16) * 16; a.H = h; a.W = w; a.slope = slope;
-    a.nchunks = ceil_div(a.cin, kCK);
-    hipStream_t st = as_stream(stream);
-    if (int e = conv3x3_dispatch(a, st)) return e;
-    if (stats_y) return instnorm_stats(y, stats_y, (long)n * cout, (long)h * w, eps, st);
-    return CINE_OK;
+    a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0};
+    a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1};
+    a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
+    a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
+    a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK3);
+    return dispatch<9, kCK3>(a, as_stream(stream));
 }
 
-extern "C" int cine_tconv2x2_in(const float* x, const float* stats_x, int mode, const float* wt,
-                                float* y, float* stats_y, int n, int cin, int cout, int h, int w,
+extern "C" int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, int mode,
+                                const float* wpacked, const float* wpacked2, int set_split,
+                                float* y, float* part_y, int n, int cin, int cout, int h, int w,
                                 float eps, float slope, void* stream) {
-    CINE_REQUIRE(x && wt && y, CINE_EINVAL, "cine_tconv2x2_in: null pointer");
+    CINE_REQUIRE(x && wpacked && y, CINE_EINVAL, "cine_tconv2x2_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_tconv2x2_in: bad sizes");
-    CINE_REQUIRE(mode == 0 || (mode == 1 && stats_x), CINE_EINVAL, "cine_tconv2x2_in: mode %d", mode);
-    const size_t lds = (size_t)cin * kTPix * sizeof(float);
-    CINE_REQUIRE(lds <= 64 * 1024, CINE_EUNSUPPORTED, "cine_tconv2x2_in: cin %d too large", cin);
-    hipStream_t st = as_stream(stream);
-    { ProfScope prof(F_TCONV, st);
-    hipLaunchKernelGGL(tconv2x2_kernel, dim3(ceil_div(h * w, kTPix), n), dim3(256), lds, st,
-                       x, stats_x, mode, wt, y, cin, cout, h, w, slope); }
-    if (int e = check_launch("tconv2x2_kernel")) return e;
-    if (stats_y) return instnorm_stats(y, stats_y, (long)n * cout, (long)4 * h * w, eps, st);
+    if (int e = check_src(x, part_x, cin, mode, np_x, "cine_tconv2x2_in")) return e;
+    CINE_REQUIRE(mode != 2, CINE_EINVAL, "cine_tconv2x2_in: mode 2 not supported");
+    ConvArgs a{};
+    a.s0 = Src{x, part_x, cin, mode, h, w, np_x};
+    a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
+    a.y = y; a.ypart = part_y; a.n = n; a.cin = cin; a.rows = 4 * cout; a.rowsp = ceil_div(4 * cout, 16) * 16;
+    a.tconv_cout = cout; a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+    return dispatch<1, kCK1>(a, as_stream(stream));
+}
+
+extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, int mode,
+                                 const float* wpacked, const float* bias, const float* wpacked2, const float* bias2,
+                                 int set_split, float* y, int n, int cin, int cout, int h, int w,
+                                 float eps, float slope, void* stream) {
+    CINE_REQUIRE(x && wpacked && bias && y, CINE_EINVAL, "cine_conv1x1_bias: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv1x1_bias: bad sizes");
+    if (int e = check_src(x, part_x, cin, mode, np_x, "cine_conv1x1_bias")) return e;
+    CINE_REQUIRE(mode != 2, CINE_EINVAL, "cine_conv1x1_bias: mode 2 not supported");
+    const bool two = wpacked2 && bias2 && set_split < n;
+    for (int s = 0; s < (two ? 2 : 1); ++s) {     // the bias pointer is per launch: one launch per weight set
+        const int n0 = s ? set_split : 0, n1 = two ? (s ? n : set_split) : n;
+        if (n1 <= n0) continue;
+        ConvArgs a{};
+        a.s0 = Src{x + (size_t)n0 * cin * h * w, part_x ? part_x + (size_t)n0 * cin * np_x * 3 : nullptr, cin, mode, h, w, np_x};
+        a.wp0 = a.wp1 = s ? wpacked2 : wpacked; a.set_split = n1 - n0; a.bias = s ? bias2 : bias;
+        a.y = y + (size_t)n0 * cout * h * w; a.ypart = nullptr; a.n = n1 - n0; a.cin = cin; a.rows = cout;
+        a.rowsp = ceil_div(cout, 16) * 16; a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+        if (int e = dispatch<1, kCK1>(a, as_stream(stream))) return e;
+    }
     return CINE_OK;
 }
 
-extern "C" int cine_conv1x1_bias(const float* x, const float* stats_x, int mode, const float* wt, const float* bias,
-                                 float* y, int n, int cin, int cout, int h, int w, float slope, void* stream) {
-    CINE_REQUIRE(x && wt && bias && y, CINE_EINVAL, "cine_conv1x1_bias: null pointer");
-    CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv1x1_bias: bad sizes");
-    CINE_REQUIRE(mode == 0 || (mode == 1 && stats_x), CINE_EINVAL, "cine_conv1x1_bias: mode %d", mode);
-    ProfScope prof(F_CONV1, as_stream(stream));
-    hipLaunchKernelGGL(conv1x1_bias_kernel, dim3(grid1d((long)h * w, 256, 64), n), dim3(256), 0, as_stream(stream),
-                       x, stats_x, mode, wt, bias, y, cin, cout, (long)h * w, slope);
-    return check_launch("conv1x1_bias_kernel");
+extern "C" int cine_instnorm_partials(const float* x, float* part, long planes, long plane_elems, void* stream) {
+    CINE_REQUIRE(x && part && planes > 0 && plane_elems > 0, CINE_EINVAL, "cine_instnorm_partials: bad arguments");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(F_STATS, st);
+    if (plane_elems <= 8192)
+        hipLaunchKernelGGL(instnorm_partial_wave_kernel, dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, st,
+                           x, part, planes, (int)plane_elems);
+    else
+        hipLaunchKernelGGL(instnorm_partial_block_kernel, dim3((unsigned)planes), dim3(256), 0, st, x, part, plane_elems);
+    return check_launch("instnorm_partials");
 }
 
-extern "C" int cine_instnorm_stats(const float* x, float* stats, long planes, long plane_elems, float eps, void* stream) {
-    CINE_REQUIRE(x && stats && planes > 0 && plane_elems > 0, CINE_EINVAL, "cine_instnorm_stats: bad arguments");
-    return instnorm_stats(x, stats, planes, plane_elems, eps, as_stream(stream));
+extern "C" int cine_instnorm_finalize(const float* part, float* stats, long planes, int np, float eps, void* stream) {
+    CINE_REQUIRE(part && stats && planes > 0 && np > 0, CINE_EINVAL, "cine_instnorm_finalize: bad arguments");
+    ProfScope prof(F_STATS, as_stream(stream));
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)ceil_div(planes, 256L)), dim3(256), 0, as_stream(stream),
+                       part, stats, planes, np, eps);
+    return check_launch("instnorm_finalize_kernel");
 }
 
-extern "C" int cine_instnorm_lrelu_apply(const float* x, const float* stats, float* y, long planes, long plane_elems,
-                                         float slope, void* stream) {
-    CINE_REQUIRE(x && stats && y && planes > 0 && plane_elems > 0, CINE_EINVAL, "cine_instnorm_lrelu_apply: bad arguments");
+extern "C" int cine_instnorm_lrelu_apply(const float* x, const float* part, int np, float* y, long planes, long plane_elems,
+                                         float eps, float slope, void* stream) {
+    CINE_REQUIRE(x && part && y && planes > 0 && plane_elems > 0 && np > 0, CINE_EINVAL, "cine_instnorm_lrelu_apply: bad arguments");
     ProfScope prof(F_MISC, as_stream(stream));
     hipLaunchKernelGGL(instnorm_lrelu_apply_kernel, dim3(grid1d(planes * plane_elems, 256)), dim3(256), 0,
-                       as_stream(stream), x, stats, y, planes, plane_elems, slope);
+                       as_stream(stream), x, part, np, y, planes, plane_elems, eps, slope);
     return check_launch("instnorm_lrelu_apply_kernel");
 }

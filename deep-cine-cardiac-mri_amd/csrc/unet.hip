@@ -1,11 +1,15 @@
 // unet.hip -- launch sequence of one 2-D U-Net pass (reference denoisers/unet.py:73-125).
 //
-// Activations stay raw (pre-InstanceNorm) in HBM together with their per-(sample, channel)
-// {mean, rstd}; every consumer normalises + LeakyReLUs (and pools / concatenates) on load.
+// Activations stay raw (pre-InstanceNorm) in HBM together with per-tile partial statistics
+// {count, mean, M2}; every consumer merges the partials, normalises + LeakyReLUs (and pools /
+// concatenates) while staging its operands.  Two weight sets (the x-f and y-f U-Nets of one
+// cascade, varnet.py:224-226) run in the SAME launches: samples [0, n/2) use set 0, the rest set 1.
 // Workspace: one raw buffer per skip level plus three rotating scratch buffers.
 #include "common.h"
 
 using namespace cine;
+
+extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 
 namespace {
 
@@ -13,7 +17,7 @@ constexpr float kEps = 1e-5f;     // nn.InstanceNorm2d default (unet.py:161)
 constexpr float kSlope = 0.2f;    // nn.LeakyReLU(0.2)        (unet.py:162)
 
 struct Bump {
-    char* base; size_t off, cap;
+    char* base; size_t off;
     float* take(size_t floats) {
         const size_t bytes = (floats * sizeof(float) + 255) & ~size_t(255);
         float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
@@ -25,8 +29,9 @@ struct Bump {
 struct Plan {
     int P;
     int hs[8], wsz[8], ch[8];          // per level 0..P (P = bottleneck)
-    float *skip[8], *sskip[8];
-    float *scr[3], *sscr[3];
+    int np_conv[8], np_tconv[8];       // partial records per (sample, channel) of a conv / tconv output at level d
+    float *skip[8], *pskip[8];
+    float *scr[3], *pscr[3];
 };
 
 void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools) {
@@ -35,20 +40,25 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools) {
         p.hs[d] = d ? p.hs[d - 1] / 2 : h;
         p.wsz[d] = d ? p.wsz[d - 1] / 2 : w;
         p.ch[d] = chans << d;
+        p.np_conv[d] = cine_conv_stat_partials(p.ch[d], p.hs[d], p.wsz[d], 0);
     }
-    for (int d = 0; d < pools; ++d) {
-        p.skip[d] = b.take((size_t)n * p.ch[d] * p.hs[d] * p.wsz[d]);
-        p.sskip[d] = b.take((size_t)n * p.ch[d] * 2);
-    }
-    size_t big = 0, bigc = 0;
+    for (int d = 0; d < pools; ++d)    // tconv from level d+1 producing ch[d] channels on 2*hs[d+1] x 2*wsz[d+1]
+        p.np_tconv[d] = cine_conv_stat_partials(p.ch[d], p.hs[d + 1], p.wsz[d + 1], 1);
+    size_t big = 0, bigp = 0;
     for (int d = 0; d <= pools; ++d) {
         const size_t e = (size_t)p.ch[d] * p.hs[d] * p.wsz[d];
         if (e > big) big = e;
-        if ((size_t)p.ch[d] > bigc) bigc = p.ch[d];
+        size_t pe = (size_t)p.ch[d] * p.np_conv[d];
+        if (d < pools && (size_t)p.ch[d] * p.np_tconv[d] > pe) pe = (size_t)p.ch[d] * p.np_tconv[d];
+        if (pe > bigp) bigp = pe;
+    }
+    for (int d = 0; d < pools; ++d) {
+        p.skip[d] = b.take((size_t)n * p.ch[d] * p.hs[d] * p.wsz[d]);
+        p.pskip[d] = b.take((size_t)n * p.ch[d] * p.np_conv[d] * 3);
     }
     for (int i = 0; i < 3; ++i) {
         p.scr[i] = b.take((size_t)n * big);
-        p.sscr[i] = b.take((size_t)n * bigc * 2);
+        p.pscr[i] = b.take((size_t)n * bigp * 3);
     }
 }
 
@@ -57,80 +67,84 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools) {
 extern "C" size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools) {
     if (n <= 0 || h <= 0 || w <= 0 || chans <= 0 || pools <= 0 || pools > 6) return 0;
     (void)in_ch; (void)out_ch;
-    Plan p; Bump b{nullptr, 0, 0};
+    Plan p; Bump b{nullptr, 0};
     build(p, b, n, h, w, chans, pools);
     return b.off;
-}
-
-static int unet_one(const float* x, float* y, const void* const* wts, int n, int h, int w, int in_ch, int out_ch,
-                    int chans, int pools, void* ws, void* stream) {
-    Plan p; Bump b{reinterpret_cast<char*>(ws), 0, 0};
-    build(p, b, n, h, w, chans, pools);
-    int wi = 0;
-    auto W = [&](void) { return reinterpret_cast<const float*>(wts[wi++]); };
-    int e;
-    // ---- down path (unet.py:94-97) + bottleneck (:99)
-    for (int d = 0; d <= pools; ++d) {
-        const float* w1 = W(); const float* w2 = W();
-        const bool last = d == pools;
-        float* mid = p.scr[0]; float* smid = p.sscr[0];
-        float* out = last ? p.scr[1] : p.skip[d];
-        float* sout = last ? p.sscr[1] : p.sskip[d];
-        if (d == 0)
-            e = cine_conv3x3_in(x, nullptr, in_ch, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, w1, mid, smid,
-                                n, p.ch[0], h, w, kEps, kSlope, stream);
-        else
-            e = cine_conv3x3_in(p.skip[d - 1], p.sskip[d - 1], p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
-                                nullptr, nullptr, 0, 0, 0, 0, w1, mid, smid,
-                                n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-        e = cine_conv3x3_in(mid, smid, p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, w2, out, sout,
-                            n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-    }
-    // ---- up path (unet.py:102-123)
-    int cur = 1;
-    for (int u = 0; u < pools; ++u) {
-        const int d = pools - 1 - u;
-        const float* wt = W(); const float* w1 = W(); const float* w2 = W();
-        const int a = (cur + 1) % 3, c = (cur + 2) % 3;
-        // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
-        e = cine_tconv2x2_in(p.scr[cur], p.sscr[cur], 1, wt, p.scr[a], p.sscr[a], n, p.ch[d + 1], p.ch[d],
-                             p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
-        if (e) return e;
-        // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
-        e = cine_conv3x3_in(p.scr[a], p.sscr[a], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
-                            p.skip[d], p.sskip[d], p.ch[d], 1, p.hs[d], p.wsz[d], w1, p.scr[c], p.sscr[c],
-                            n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-        e = cine_conv3x3_in(p.scr[c], p.sscr[c], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, w2,
-                            p.scr[a], p.sscr[a], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-        cur = a;
-    }
-    const float* wf = W(); const float* bf = W();
-    return cine_conv1x1_bias(p.scr[cur], p.sscr[cur], 1, wf, bf, y, n, chans, out_ch, h, w, kSlope, stream);   // :69
 }
 
 extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
                                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                                    void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet2d_forward: null pointer");
-    CINE_REQUIRE(nsets >= 1 && n > 0 && n % nsets == 0, CINE_EINVAL, "cine_unet2d_forward: n=%d not divisible by nsets=%d", n, nsets);
+    CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_forward: nsets must be 1 or 2");
+    CINE_REQUIRE(n > 0 && n % nsets == 0, CINE_EINVAL, "cine_unet2d_forward: n=%d not divisible by nsets=%d", n, nsets);
     CINE_REQUIRE(h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL,
                  "cine_unet2d_forward: bad sizes");
     CINE_REQUIRE((h >> pools) >= 1 && (w >> pools) >= 1, CINE_EUNSUPPORTED,
                  "cine_unet2d_forward: %dx%d too small for %d pools", h, w, pools);
-    const int per = n / nsets;
-    const size_t need = cine_unet2d_ws_bytes(per, h, w, in_ch, out_ch, chans, pools);
+    const size_t need = cine_unet2d_ws_bytes(n, h, w, in_ch, out_ch, chans, pools);
     CINE_REQUIRE(ws_bytes >= need, CINE_EWORKSPACE, "cine_unet2d_forward: workspace %zu < %zu", ws_bytes, need);
     const int nptr = 5 * pools + 4;
-    for (int s = 0; s < nsets; ++s) {
-        for (int i = 0; i < nptr; ++i)
-            CINE_REQUIRE(weights[s * nptr + i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", s * nptr + i);
-        if (int e = unet_one(x + (size_t)s * per * in_ch * h * w, y + (size_t)s * per * out_ch * h * w,
-                             weights + s * nptr, per, h, w, in_ch, out_ch, chans, pools, ws, stream))
-            return e;
+    for (int i = 0; i < nsets * nptr; ++i)
+        CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", i);
+
+    Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
+    build(p, b, n, h, w, chans, pools);
+    const int split = n / nsets;
+    int wi = 0;
+    const float *w0, *w1;
+    auto next = [&]() {
+        w0 = reinterpret_cast<const float*>(weights[wi]);
+        w1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi]) : nullptr;
+        ++wi;
+    };
+    int e;
+    // ---- down path (unet.py:94-97) + bottleneck (:99)
+    for (int d = 0; d <= pools; ++d) {
+        const bool last = d == pools;
+        float* mid = p.scr[0]; float* pmid = p.pscr[0];
+        float* out = last ? p.scr[1] : p.skip[d];
+        float* pout = last ? p.pscr[1] : p.pskip[d];
+        next();
+        if (d == 0)
+            e = cine_conv3x3_in(x, nullptr, 0, in_ch, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
+                                mid, pmid, n, p.ch[0], h, w, kEps, kSlope, stream);
+        else
+            e = cine_conv3x3_in(p.skip[d - 1], p.pskip[d - 1], p.np_conv[d - 1], p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
+                                nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
+                                mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+        if (e) return e;
+        next();
+        e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+                            w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+        if (e) return e;
     }
-    return CINE_OK;
+    // ---- up path (unet.py:102-123)
+    int cur = 1;
+    int np_cur = p.np_conv[pools];
+    for (int u = 0; u < pools; ++u) {
+        const int d = pools - 1 - u;
+        const int a = (cur + 1) % 3, c = (cur + 2) % 3;
+        next();   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
+        e = cine_tconv2x2_in(p.scr[cur], p.pscr[cur], np_cur, 1, w0, w1, split, p.scr[a], p.pscr[a], n,
+                             p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
+        if (e) return e;
+        next();   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
+        e = cine_conv3x3_in(p.scr[a], p.pscr[a], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
+                            p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
+                            p.scr[c], p.pscr[c], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+        if (e) return e;
+        next();
+        e = cine_conv3x3_in(p.scr[c], p.pscr[c], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+                            w0, w1, split, p.scr[a], p.pscr[a], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+        if (e) return e;
+        cur = a; np_cur = p.np_conv[d];
+    }
+    // ---- final 1x1 conv + bias (unet.py:69)
+    const float* wf0 = reinterpret_cast<const float*>(weights[wi]);
+    const float* bf0 = reinterpret_cast<const float*>(weights[wi + 1]);
+    const float* wf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi]) : nullptr;
+    const float* bf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi + 1]) : nullptr;
+    return cine_conv1x1_bias(p.scr[cur], p.pscr[cur], np_cur, 1, wf0, bf0, wf1, bf1, split, y, n, chans, out_ch, h, w,
+                             kEps, kSlope, stream);
 }

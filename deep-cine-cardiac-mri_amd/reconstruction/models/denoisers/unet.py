@@ -55,7 +55,8 @@ class TransposeConvBlock(nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         if self.dims != 2:
             raise NotImplementedError("3-D TransposeConvBlock is not on the HIP path yet")
-        y, st = ops.tconv2x2_in(image, None, 0, self.layers[0].weight)
+        wt = self.layers[0].weight
+        y, st = ops.tconv2x2_in(image, None, 0, ops.pack_tconv2x2(wt), wt.shape[1])
         return ops.instnorm_lrelu_apply(y, st)
 
 

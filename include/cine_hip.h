@@ -118,52 +118,68 @@ int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, const float
  * U-Net regulariser                            reference: denoisers/unet.py
  * ------------------------------------------------------------------------------------------ */
 
-/* Repack one 3x3 conv weight (cout, cin, 3, 3) (unet.py:160,164) into the MFMA staging layout.
- * packed must hold cine_conv3x3_packed_floats(cout, cin) floats. */
+/* Weight repacking into the MFMA staging layout [chunk][tap][ck][rows padded to 16]:
+ *   conv3x3 (cout, cin, 3, 3) (unet.py:160,164); tconv (cin, cout, 2, 2) (unet.py:213-215) as a
+ *   1x1 GEMM with 4*cout rows; conv1x1 (cout, cin) (unet.py:69).  *_packed_floats sizes `packed`. */
 size_t cine_conv3x3_packed_floats(int cout, int cin);
+size_t cine_tconv2x2_packed_floats(int cin, int cout);
+size_t cine_conv1x1_packed_floats(int cout, int cin);
 int cine_pack_conv3x3(const float* w, float* packed, int cout, int cin, void* stream);
+int cine_pack_tconv2x2(const float* w, float* packed, int cin, int cout, void* stream);
+int cine_pack_conv1x1(const float* w, float* packed, int cout, int cin, void* stream);
 
-/* One ConvBlock half (unet.py:159-162): y = conv3x3(x, pad 1, no bias), plus the InstanceNorm
- * statistics of y (biased variance, eps) as stats (n, cout, 2) = {mean, rstd}.  The normalise +
- * LeakyReLU(slope) is applied by whichever kernel consumes (y, stats) next.
- * Inputs are up to two channel-concatenated sources (torch.cat, unet.py:122); source s has
- * c_s channels, extent (h_s, w_s) and mode_s:
- *   0 = use as is;  1 = apply (x - mean) * rstd then LeakyReLU on load (stats_s (n, c_s, 2));
- *   2 = mode 1 followed by 2x2 average pool (unet.py:97; source extent is then (2h, 2w)-ish).
- * A source smaller than (h, w) reads as zero outside its extent (the up-path zero pad,
- * unet.py:106-120).  wpacked from cine_pack_conv3x3 with cin = c0 + c1. */
-int cine_conv3x3_in(const float* x0, const float* stats0, int c0, int mode0, int h0, int w0,
-                    const float* x1, const float* stats1, int c1, int mode1, int h1, int w1,
-                    const float* wpacked, float* y, float* stats_y,
-                    int n, int cout, int h, int w, float eps, float slope, void* stream);
+/* InstanceNorm statistics travel as PARTIAL records {count, mean, M2}: a tensor (n, c, h, w) carries
+ * part (n, c, np, 3).  The conv / tconv kernels emit one record per (sample, channel, output tile)
+ * (np = cine_conv_stat_partials(cout, h, w, is_tconv), h/w = the kernel's INPUT grid for tconv);
+ * consumers merge them (Chan) into mean and rstd = 1/sqrt(M2/count + eps): biased variance, as
+ * nn.InstanceNorm2d (unet.py:161,165,216). */
+int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 
-/* TransposeConvBlock (unet.py:212-217): y = conv_transpose2d(act(x), k 2, s 2, no bias) and the
- * InstanceNorm statistics of y.  wt is the torch layout (cin, cout, 2, 2).  x mode as above (0|1). */
-int cine_tconv2x2_in(const float* x, const float* stats_x, int mode, const float* wt,
-                     float* y, float* stats_y, int n, int cin, int cout, int h, int w,
+/* One ConvBlock half (unet.py:159-162): y = conv3x3(X, pad 1, no bias) and the partial statistics of y.
+ * The normalise + LeakyReLU(slope) of y is applied by whichever kernel consumes (y, part_y) next.
+ * X = channel concat (torch.cat, unet.py:122) of up to two sources; source s has c_s channels,
+ * extent (h_s, w_s), np_s partial records and mode_s:
+ *   0 = use as is;  1 = InstanceNorm + LeakyReLU on load;
+ *   2 = mode 1 followed by 2x2 average pool (unet.py:97; the source extent is then ~(2h, 2w)).
+ * A source smaller than (h, w) reads as zero outside its extent (up-path zero pad, unet.py:106-120).
+ * wpacked2 != NULL: samples >= set_split use wpacked2 (two weight sets in one launch).
+ * part_y may be NULL (no statistics). */
+int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                    const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1,
+                    const float* wpacked, const float* wpacked2, int set_split,
+                    float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+
+/* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)
+ * and the partial statistics of y.  x mode 0|1 as above. */
+int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, int mode,
+                     const float* wpacked, const float* wpacked2, int set_split,
+                     float* y, float* part_y, int n, int cin, int cout, int h, int w,
                      float eps, float slope, void* stream);
 
-/* final 1x1 conv with bias (unet.py:69): wt (cout, cin), bias (cout). x mode as above (0|1). */
-int cine_conv1x1_bias(const float* x, const float* stats_x, int mode, const float* wt, const float* bias,
-                      float* y, int n, int cin, int cout, int h, int w, float slope, void* stream);
+/* final 1x1 conv with bias (unet.py:69).  x mode 0|1 as above. */
+int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, int mode,
+                      const float* wpacked, const float* bias, const float* wpacked2, const float* bias2,
+                      int set_split, float* y, int n, int cin, int cout, int h, int w,
+                      float eps, float slope, void* stream);
 
-/* InstanceNorm2d statistics (unet.py:161,165,216): stats (n*c, 2) = {mean, 1/sqrt(var_biased + eps)}. */
-int cine_instnorm_stats(const float* x, float* stats, long planes, long plane_elems, float eps, void* stream);
-
-/* materialise act(x) = LeakyReLU((x - mean) * rstd) (debug / block-level parity). */
-int cine_instnorm_lrelu_apply(const float* x, const float* stats, float* y, long planes, long plane_elems,
-                              float slope, void* stream);
+/* Stand-alone statistics of `planes` planes of plane_elems floats: part (planes, 1, 3). */
+int cine_instnorm_partials(const float* x, float* part, long planes, long plane_elems, void* stream);
+/* merge np partials per plane into stats (planes, 2) = {mean, rstd}. */
+int cine_instnorm_finalize(const float* part, float* stats, long planes, int np, float eps, void* stream);
+/* materialise act(x) = LeakyReLU((x - mean) * rstd) (block-level parity / debugging). */
+int cine_instnorm_lrelu_apply(const float* x, const float* part, int np, float* y, long planes, long plane_elems,
+                              float eps, float slope, void* stream);
 
 /* Whole 2-D U-Net (unet.py:73-125) on n planes (n, in_ch, h, w) -> (n, out_ch, h, w).
  * `weights` is a HOST array of device pointers in this order:
  *   for d in 0..pools-1: down[d].conv1 (packed), down[d].conv2 (packed)
  *   bottleneck conv1 (packed), conv2 (packed)
- *   for u in 0..pools-1: tconv[u] (torch layout), up[u].conv1 (packed), up[u].conv2 (packed)
- *   final 1x1 weight (out_ch, chans), final bias (out_ch)
+ *   for u in 0..pools-1: tconv[u] (packed), up[u].conv1 (packed), up[u].conv2 (packed)
+ *   final 1x1 weight (packed), final bias (out_ch)
  * i.e. 2*pools + 2 + 3*pools + 2 pointers.
- * `nsets` > 1 runs nsets independent weight sets over consecutive groups of n/nsets planes in
- * the same launches (the xf and yf U-Nets of one cascade, varnet.py:224-226); `weights` then
- * holds nsets such arrays back to back. */
+ * `nsets` == 2 runs two weight sets over the two halves of the n planes in the SAME launches
+ * (the xf and yf U-Nets of one cascade, varnet.py:224-226); `weights` then holds two such arrays
+ * back to back. */
 size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
 int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,

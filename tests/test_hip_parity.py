@@ -189,38 +189,70 @@ def test_norm_unet_vs_reference_golden(golden, dev):
                                           (128, 64, 52, 4), (64, 32, 104, 8), (32, 16, 208, 16),
                                           (8, 8, 208, 208), (5, 10, 25, 25), (18, 36, 13, 7), (2, 8, 1, 1)])
 def test_conv3x3_shapes_vs_torch(dev, cin, cout, h, w):
-    """Every cfg-2 layer shape plus odd ones, against torch's fp32 conv on the CPU."""
+    """Every cfg-2 layer shape plus odd ones, against torch's fp32 conv on the CPU; the fused
+    InstanceNorm partial statistics are merged and compared with the exact mean / rstd."""
     from cine_hip import ops
     import torch.nn.functional as F
     n = 3
     x = rnd(cin * 7 + h, n, cin, h, w); wt = rnd(cout, cout, cin, 3, 3) / (3 * cin ** 0.5)
-    y, st = ops.conv3x3_in([(x.to(dev), None, 0)], ops.pack_conv3x3(wt.to(dev)), cout, h, w)
+    y, part = ops.conv3x3_in([(x.to(dev), None, 0)], ops.pack_conv3x3(wt.to(dev)), cout, h, w)
     ref = F.conv2d(x, wt, padding=1)
     assert rel_err(y.cpu(), ref) < OP_TOL
-    if h * w > 1:
-        assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3))) < 1e-4
-        rstd = 1 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)
-        assert rel_err(st[..., 1].cpu(), rstd) < 1e-4
+    assert float(part[..., 0].sum(dim=2).min()) == h * w and float(part[..., 0].sum(dim=2).max()) == h * w
+    st = ops.instnorm_finalize(part)
+    assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3))) < 1e-4
+    rstd = 1 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert rel_err(st[..., 1].cpu(), rstd) < 1e-4
+
+
+def test_conv3x3_two_weight_sets_in_one_launch(dev):
+    from cine_hip import ops
+    import torch.nn.functional as F
+    x = rnd(1, 6, 16, 52, 16); wa = rnd(2, 16, 16, 3, 3) / 12; wb = rnd(3, 16, 16, 3, 3) / 12
+    y, _ = ops.conv3x3_in([(x.to(dev), None, 0)], ops.pack_conv3x3(wa.to(dev)), 16, 52, 16,
+                          wpacked2=ops.pack_conv3x3(wb.to(dev)), set_split=4)
+    ref = torch.cat([F.conv2d(x[:4], wa, padding=1), F.conv2d(x[4:], wb, padding=1)])
+    assert rel_err(y.cpu(), ref) < OP_TOL
 
 
 def test_conv3x3_fused_sources_vs_torch(dev):
     """norm+LReLU on load, pooled source, concat of two sources with a short `up` extent."""
     from cine_hip import ops
     import torch.nn.functional as F
-    n, c, h, w = 2, 8, 13, 10
-    skip = rnd(1, n, c, h, w); up = rnd(2, n, c, 12, 10)            # up is one row short -> zero pad
-    wt = rnd(3, 16, 2 * c, 3, 3) / 12
     act = lambda t: F.leaky_relu(F.instance_norm(t, eps=1e-5), 0.2)
-    s_skip, s_up = ops.instnorm_stats(skip.to(dev)), ops.instnorm_stats(up.to(dev))
-    y, _ = ops.conv3x3_in([(up.to(dev), s_up, 1), (skip.to(dev), s_skip, 1)], ops.pack_conv3x3(wt.to(dev)), 16, h, w)
-    ref = F.conv2d(torch.cat([F.pad(act(up), [0, 0, 0, 1]), act(skip)], 1), wt, padding=1)
+    for (n, c, h, w, uh) in ((2, 8, 13, 10, 12), (2, 16, 52, 16, 52), (3, 8, 26, 8, 26)):
+        skip = rnd(1, n, c, h, w); up = rnd(2, n, c, uh, w)           # uh < h -> zero pad row
+        wt = rnd(3, 16, 2 * c, 3, 3) / 12
+        p_skip, p_up = ops.instnorm_partials(skip.to(dev)), ops.instnorm_partials(up.to(dev))
+        y, _ = ops.conv3x3_in([(up.to(dev), p_up, 1), (skip.to(dev), p_skip, 1)], ops.pack_conv3x3(wt.to(dev)), 16, h, w)
+        ref = F.conv2d(torch.cat([F.pad(act(up), [0, 0, 0, h - uh]), act(skip)], 1), wt, padding=1)
+        assert rel_err(y.cpu(), ref) < BLOCK_TOL
+    for (n, c, H2, W2) in ((2, 8, 26, 20), (2, 16, 104, 16), (2, 8, 27, 21), (2, 64, 8, 4)):
+        big = rnd(4, n, c, H2, W2)
+        p_big = ops.instnorm_partials(big.to(dev))
+        wt2 = rnd(5, 16, c, 3, 3) / 8
+        y, _ = ops.conv3x3_in([(big.to(dev), p_big, 2)], ops.pack_conv3x3(wt2.to(dev)), 16, H2 // 2, W2 // 2)
+        ref = F.conv2d(F.avg_pool2d(act(big), 2), wt2, padding=1)
+        assert rel_err(y.cpu(), ref) < BLOCK_TOL
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(128, 64, 26, 2), (64, 32, 52, 4), (32, 16, 104, 8), (8, 4, 6, 5), (16, 8, 26, 26)])
+def test_tconv_and_conv1x1_vs_torch(dev, cin, cout, h, w):
+    from cine_hip import ops
+    import torch.nn.functional as F
+    n = 3
+    x = rnd(cin + h, n, cin, h, w); wt = rnd(cout, cin, cout, 2, 2) / cin ** 0.5
+    act = lambda t: F.leaky_relu(F.instance_norm(t, eps=1e-5), 0.2)
+    px = ops.instnorm_partials(x.to(dev))
+    y, part = ops.tconv2x2_in(x.to(dev), px, 1, ops.pack_tconv2x2(wt.to(dev)), cout)
+    ref = F.conv_transpose2d(act(x), wt, stride=2)
     assert rel_err(y.cpu(), ref) < BLOCK_TOL
-    big = rnd(4, n, c, 26, 20)
-    s_big = ops.instnorm_stats(big.to(dev))
-    wt2 = rnd(5, 16, c, 3, 3) / 8
-    y, _ = ops.conv3x3_in([(big.to(dev), s_big, 2)], ops.pack_conv3x3(wt2.to(dev)), 16, 13, 10)
-    ref = F.conv2d(F.avg_pool2d(act(big), 2), wt2, padding=1)
-    assert rel_err(y.cpu(), ref) < BLOCK_TOL
+    st = ops.instnorm_finalize(part)
+    assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3))) < 1e-4
+    assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)) < 1e-4
+    w1 = rnd(7, 2, cin, 1, 1) / cin ** 0.5; b1 = rnd(8, 2)
+    y1 = ops.conv1x1_bias(x.to(dev), px, 1, ops.pack_conv1x1(w1.to(dev)), b1.to(dev))
+    assert rel_err(y1.cpu(), F.conv2d(act(x), w1, b1)) < BLOCK_TOL
 
 
 # ------------------------------------------------------------------ blocks and models

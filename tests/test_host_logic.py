@@ -30,6 +30,9 @@ def test_argument_validation_without_gpu():
     assert b"null" in L.cine_last_error()
     assert L.cine_conv3x3_packed_floats(16, 2) == 1 * 9 * 8 * 16
     assert L.cine_conv3x3_packed_floats(10, 12) == 2 * 9 * 8 * 16
+    assert L.cine_tconv2x2_packed_floats(32, 16) == 2 * 16 * 64
+    assert L.cine_conv_stat_partials(16, 208, 16, 0) == 4 and L.cine_conv_stat_partials(32, 104, 8, 0) == 1
+    assert L.cine_conv_stat_partials(16, 104, 8, 1) == 16
     assert L.cine_unet2d_ws_bytes(4, 16, 16, 2, 2, 4, 2) > 0
     assert L.cine_unet2d_ws_bytes(4, 16, 16, 2, 2, 4, 0) == 0
     assert L.cine_xfyf_ws_bytes(1, 15, 200, 200) == 15 * 200 * 200 * 8
