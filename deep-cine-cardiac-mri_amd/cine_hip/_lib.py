@@ -30,6 +30,9 @@ _SIGS = {
     "cine_fft1c": (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
     "cine_sens_reduce": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_sens_expand_dc": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_kspace_to_hybrid": (c_int, [P, P, c_long, c_int, c_int, P]),
+    "cine_hybrid_reduce": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_expand_dc_hybrid": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_sens_prologue": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_rss_normalise": (c_int, [P, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, P]),

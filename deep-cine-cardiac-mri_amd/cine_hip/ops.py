@@ -108,6 +108,47 @@ def sens_expand_dc(img: torch.Tensor, sens: torch.Tensor, kref: Optional[torch.T
     return out
 
 
+def kspace_to_hybrid(k: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Centered column IFFT (first half of ifft2c): k-space -> hybrid space (image along h, k along w)."""
+    _pair(k)
+    k = _dev(k, "k-space")
+    h, w = k.shape[-3], k.shape[-2]
+    if out is None:
+        out = torch.empty_like(k)
+    check(lib().cine_kspace_to_hybrid(k.data_ptr(), out.data_ptr(), k.numel() // (h * w * 2), h, w, _stream()),
+          "cine_kspace_to_hybrid")
+    return out
+
+
+def hybrid_reduce(hyb: torch.Tensor, sens: torch.Tensor, magnitude: bool = False) -> torch.Tensor:
+    """Second half of sens_reduce (reference varnet.py:187-194) on hybrid-space data."""
+    hyb = _dev(hyb, "hybrid k-space"); sens = _dev(sens, "sens_maps")
+    b, t, c, h, w, _ = hyb.shape
+    if sens.shape != (b, 1, c, h, w, 2):
+        raise ValueError(f"sens_maps shape {tuple(sens.shape)} does not match {tuple(hyb.shape)}")
+    out = torch.empty((b, t, h, w) if magnitude else (b, t, 1, h, w, 2), device=hyb.device, dtype=hyb.dtype)
+    check(lib().cine_hybrid_reduce(hyb.data_ptr(), sens.data_ptr(), out.data_ptr(), b, t, c, h, w, int(magnitude),
+                                   _stream()), "cine_hybrid_reduce")
+    return out
+
+
+def expand_dc_hybrid(img: torch.Tensor, sens: torch.Tensor, kref: torch.Tensor, mask: torch.Tensor,
+                     lambda_reg: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sens_expand + soft DC (reference varnet.py:181-185, 281-282) followed by the column IFFT that the
+    next cascade's sens_reduce starts with, without writing the k-space in between."""
+    img = _dev(img, "image"); sens = _dev(sens, "sens_maps"); kref = _dev(kref, "ref_kspace")
+    mask = _dev(mask, "mask", torch.uint8); lambda_reg = _dev(lambda_reg.detach(), "lambda_reg")
+    b, t, c, h, w, _ = kref.shape
+    if img.numel() != b * t * h * w * 2 or sens.shape != (b, 1, c, h, w, 2) or mask.numel() != b * t * h:
+        raise ValueError("expand_dc_hybrid: shape mismatch")
+    if out is None:
+        out = torch.empty_like(kref)
+    check(lib().cine_expand_dc_hybrid(img.data_ptr(), sens.data_ptr(), kref.data_ptr(), mask.data_ptr(),
+                                      lambda_reg.data_ptr(), out.data_ptr(), b, t, c, h, w, 0, _stream()),
+          "cine_expand_dc_hybrid")
+    return out
+
+
 def sens_prologue(masked_kspace: torch.Tensor, row_lo: int, row_hi: int) -> torch.Tensor:
     """reference varnet.py:71-74: ifft2c(mask_center(mean_t(k)))."""
     k = _dev(masked_kspace, "masked_kspace")

@@ -118,15 +118,11 @@ struct Fft200 {
     // position of frequency (or, for PN input, of the k-th input) in the tile
     CINE_HD static int pos_of(int k) { return 20 * (k % 10) + k / 10; }
 
-    // Strided radix-10 over positions {20 j + c}, j = 0..9, for column c.
-    // TW_AFTER: multiply output j by W200^(c j) (NP first stage);
-    // TW_BEFORE: multiply input j by W200^(c j) (PN second stage).
+    // Register-level radix-10 for column c (= n2 in the NP flavour, = output column in PN):
+    // TW_BEFORE multiplies input j by W200^(c j), TW_AFTER multiplies output j by W200^(c j);
+    // either way the ortho scale 1/sqrt(200) rides along.  tw = forward table (conjugated for DIR < 0).
     template <int DIR, bool TW_BEFORE, bool TW_AFTER>
-    CINE_HD static void stage_r10(cf* tile, int LP, int item, int lines, const cf* tw) {
-        const int line = item % lines, c = item / lines;
-        cf v[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = tile[(20 * j + c) * LP + line];
+    CINE_HD static void r10_regs(cf (&v)[10], int c, const cf* tw) {
         if (TW_BEFORE) {
 #pragma unroll
             for (int j = 1; j < 10; ++j) {
@@ -144,6 +140,16 @@ struct Fft200 {
             }
             v[0] = cscale(v[0], 0.070710678118654752f);
         }
+    }
+
+    // Strided radix-10 over positions {20 j + c}, j = 0..9, for column c, in place on the tile.
+    template <int DIR, bool TW_BEFORE, bool TW_AFTER>
+    CINE_HD static void stage_r10(cf* tile, int LP, int item, int lines, const cf* tw) {
+        const int line = item % lines, c = item / lines;
+        cf v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = tile[(20 * j + c) * LP + line];
+        r10_regs<DIR, TW_BEFORE, TW_AFTER>(v, c, tw);
 #pragma unroll
         for (int j = 0; j < 10; ++j) tile[(20 * j + c) * LP + line] = v[j];
     }

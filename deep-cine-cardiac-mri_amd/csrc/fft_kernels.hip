@@ -242,6 +242,225 @@ __global__ void row_pass_kernel(RowArgs a) {
     }
 }
 
+// ================================================================== N = 200 fast passes
+// First butterfly stage straight from global memory into registers, last stage straight back:
+// ONE LDS exchange per transform (the generic kernels above need three passes over the tile).
+// 32 lines per workgroup, 320 threads: 640 radix-10 items (2 per thread), 320 radix-20 items.
+constexpr int kLP200c = 32;     // column passes: lanes run over lines, contiguous LDS rows
+constexpr int kLP200r = 33;     // row passes: lanes run over points, odd stride spreads banks
+
+__device__ __forceinline__ int wrap200(int x) { return x >= 200 ? x - 200 : (x < 0 ? x + 200 : x); }
+
+// Column pass along h (H == 200).  DIR forward/inverse, optional DC on the centered rows, and with
+// INV_AFTER the inverse transform of the blended column right away (k-space -> DC -> hybrid space
+// without the k-space ever leaving the CU):
+//   global -> r10 -> LDS -> r20 [-> DC -> r20^-1 -> LDS -> r10^-1] -> global
+template <int DIR, int POST, bool INV_AFTER>
+__global__ __launch_bounds__(kThreads200) void col200_kernel(ColArgs a) {
+    constexpr int LP = kLP200c;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf* t = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * kLines200;
+    const long img = blockIdx.y;
+    const cf* in = a.in + img * 200 * a.W;
+    cf* out = a.out + img * 200 * a.W;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int item = tid + r * kThreads200;
+        const int line = item & 31, c = item >> 5;
+        const int col = w0 + line;
+        cf v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int g = wrap200(20 * j + c - 100);            // x'[n] = x[(n - s_in) mod N], s_in = 100
+            v[j] = col < a.W ? in[(long)g * a.W + col] : mk(0.f, 0.f);
+        }
+        Fft200::r10_regs<DIR, false, true>(v, c, TW200);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
+    }
+    __syncthreads();
+    {
+        const int line = tid & 31, g = tid >> 5;
+        const int col = w0 + line;
+        cf v[20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) v[j] = t[(20 * g + j) * LP + line];
+        dft20<DIR>(v);                                          // v[k2] = X'[g + 10 k2] -> centered row (k + 100) % 200
+        if (POST != POST_NONE && col < a.W) {
+            const uint8_t* mrow = a.mask + (img / a.coils) * 200;
+            if (POST == POST_DC) {
+                const float vv = softplus1(*a.lam);
+                const cf* kref = a.kref + img * 200 * a.W;
+#pragma unroll
+                for (int k2 = 0; k2 < 20; ++k2) {
+                    const int i = wrap200(g + 10 * k2 + 100);
+                    if (mrow[i]) {
+                        const cf rr = kref[(long)i * a.W + col];
+                        v[k2] = mk((v[k2].x + vv * rr.x) / (1.f + vv), (v[k2].y + vv * rr.y) / (1.f + vv));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < 20; ++k2)
+                    if (!mrow[wrap200(g + 10 * k2 + 100)]) v[k2] = mk(0.f, 0.f);
+            }
+        }
+        if (!INV_AFTER) {
+            if (col < a.W) {
+#pragma unroll
+                for (int k2 = 0; k2 < 20; ++k2) out[(long)wrap200(g + 10 * k2 + 100) * a.W + col] = v[k2];
+            }
+            return;
+        }
+        dft20<-DIR>(v);                                         // PN flavour, stage A on the same registers
+#pragma unroll
+        for (int j = 0; j < 20; ++j) t[(20 * g + j) * LP + line] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int item = tid + r * kThreads200;
+        const int line = item & 31, c = item >> 5;
+        const int col = w0 + line;
+        cf v[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = t[(20 * j + c) * LP + line];
+        Fft200::r10_regs<-DIR, true, false>(v, c, TW200);
+        if (col < a.W) {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) out[(long)wrap200(20 * j + c + 100) * a.W + col] = v[j];
+        }
+    }
+}
+
+// Row pass along w (W == 200), inverse, fused with conj(S) multiply + coil sum (+ magnitude):
+//   global -> r10^-1 -> LDS -> r20^-1 -> LDS -> sum_c conj(S) x -> global
+template <int POST>
+__global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
+    constexpr int LP = kLP200r;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf* t = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int bt = blockIdx.y, b = bt / a.T;
+    const int h0 = blockIdx.x * a.rpw;
+    const long HW = (long)a.H * 200;
+    cf acc[kMaxOut];
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) acc[o] = mk(0.f, 0.f);
+    for (int c0 = 0; c0 < a.C; c0 += a.cc) {
+        const int nc = min(a.cc, a.C - c0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int item = tid + r * kThreads200;
+            const int c = item % 20, line = item / 20;
+            const int cl = line / a.rpw, rr = line - cl * a.rpw;
+            const int h = h0 + rr;
+            const bool ok = cl < nc && h < a.H;
+            const cf* src = a.in + ((long)bt * a.C + c0 + cl) * HW + (long)h * 200;
+            cf v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = ok ? src[wrap200(20 * j + c - 100)] : mk(0.f, 0.f);
+            Fft200::r10_regs<-1, false, true>(v, c, TW200);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
+        }
+        __syncthreads();
+        {
+            const int line = tid & 31, g = tid >> 5;
+            cf v[20];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) v[j] = t[(20 * g + j) * LP + line];
+            dft20<-1>(v);
+#pragma unroll
+            for (int j = 0; j < 20; ++j) t[(20 * g + j) * LP + line] = v[j];     // pos 20 g + k2 <-> k = g + 10 k2
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            const int e = tid + o * kThreads200;
+            if (e >= a.rpw * 200) break;
+            const int rr = e / 200, i = e - rr * 200;
+            const int h = h0 + rr;
+            if (h >= a.H) continue;
+            const int k = wrap200(i - 100);
+            const int p = Fft200::pos_of(k) * LP;
+            cf s_acc = acc[o];
+            for (int cl = 0; cl < nc; ++cl) {
+                const cf x = t[p + cl * a.rpw + rr];
+                const cf s = a.sens[((long)b * a.C + c0 + cl) * HW + (long)h * 200 + i];
+                const cf m = cmulc(x, s);
+                s_acc.x += m.x; s_acc.y += m.y;
+            }
+            acc[o] = s_acc;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) {
+        const int e = tid + o * kThreads200;
+        if (e >= a.rpw * 200) break;
+        const int rr = e / 200, i = e - rr * 200;
+        const int h = h0 + rr;
+        if (h >= a.H) continue;
+        if (POST == RPOST_REDUCE_ABS)
+            a.out_abs[(long)bt * HW + (long)h * 200 + i] = sqrtf(acc[o].x * acc[o].x + acc[o].y * acc[o].y);
+        else
+            a.out[(long)bt * HW + (long)h * 200 + i] = acc[o];
+    }
+}
+
+// Row pass along w (W == 200), forward, fused with the sensitivity multiply:
+//   S x (L2-resident reads) -> r20 -> LDS -> r10 -> global, natural order out (160-byte runs)
+__global__ __launch_bounds__(kThreads200) void row200_expand_kernel(RowArgs a) {
+    constexpr int LP = kLP200r;
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf* t = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int bt = blockIdx.y, b = bt / a.T;
+    const int h0 = blockIdx.x * a.rpw;
+    const long HW = (long)a.H * 200;
+    for (int c0 = 0; c0 < a.C; c0 += a.cc) {
+        const int nc = min(a.cc, a.C - c0);
+        {
+            const int g = tid % 10, line = tid / 10;
+            const int cl = line / a.rpw, rr = line - cl * a.rpw;
+            const int h = h0 + rr;
+            const bool ok = cl < nc && h < a.H;
+            const cf* sp = a.sens + ((long)b * a.C + c0 + cl) * HW + (long)h * 200;
+            const cf* xp = a.img + (long)bt * HW + (long)h * 200;
+            cf v[20];
+#pragma unroll
+            for (int j = 0; j < 20; ++j) {
+                const int gi = wrap200(10 * j + g - 100);
+                v[j] = ok ? cmul(xp[gi], sp[gi]) : mk(0.f, 0.f);
+            }
+            dft20<1>(v);
+#pragma unroll
+            for (int j = 0; j < 20; ++j) t[(20 * g + j) * LP + line] = v[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int item = tid + r * kThreads200;
+            const int c = item % 20, line = item / 20;
+            const int cl = line / a.rpw, rr = line - cl * a.rpw;
+            const int h = h0 + rr;
+            cf v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = t[(20 * j + c) * LP + line];
+            Fft200::r10_regs<1, true, false>(v, c, TW200);
+            if (cl < nc && h < a.H) {
+                cf* dst = a.out + ((long)bt * a.C + c0 + cl) * HW + (long)h * 200;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) dst[wrap200(20 * j + c + 100)] = v[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static size_t lds_bytes(bool f200, int n, int lines) {
     const size_t tile = (size_t)n * (lines + 1) * sizeof(cf);
@@ -255,19 +474,21 @@ static int check_n(int n, const char* what) {
     return CINE_OK;
 }
 
-template <int POST>
+template <int POST, bool INV_AFTER = false>
 static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st) {
     if (nimg == 0) return CINE_OK;
     const bool f200 = a.H == 200;
     const int lines = f200 ? kLines200 : kLinesGen;
     dim3 grid(ceil_div(a.W, lines), (unsigned)nimg);
     CINE_REQUIRE(nimg <= 65535, CINE_EUNSUPPORTED, "column pass: %ld images > 65535", nimg);
-    const size_t lds = lds_bytes(f200, a.H, lines);
     ProfScope prof(F_FFT_COL, st);
     if (f200) {
-        if (inverse) hipLaunchKernelGGL((col_pass_kernel<true, -1, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
-        else hipLaunchKernelGGL((col_pass_kernel<true, 1, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
+        const size_t lds = (size_t)200 * kLP200c * sizeof(cf);
+        if (inverse) hipLaunchKernelGGL((col200_kernel<-1, POST, INV_AFTER>), grid, dim3(kThreads200), lds, st, a);
+        else hipLaunchKernelGGL((col200_kernel<1, POST, INV_AFTER>), grid, dim3(kThreads200), lds, st, a);
     } else {
+        static_assert(!INV_AFTER || true, "");
+        const size_t lds = lds_bytes(false, a.H, lines);
         if (inverse) hipLaunchKernelGGL((col_pass_kernel<false, -1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
         else hipLaunchKernelGGL((col_pass_kernel<false, 1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
     }
@@ -281,7 +502,11 @@ static int launch_row(RowArgs a, dim3 grid, bool inverse, hipStream_t st) {
     const int lines = f200 ? kLines200 : kLinesGen;
     const size_t lds = lds_bytes(f200, a.W, lines);
     ProfScope prof(F_FFT_ROW, st);
-    if (f200) {
+    if (f200 && PRE == PRE_SMUL && POST == RPOST_NONE && !inverse) {
+        hipLaunchKernelGGL(row200_expand_kernel, grid, dim3(kThreads200), (size_t)200 * kLP200r * sizeof(cf), st, a);
+    } else if (f200 && PRE == PRE_NONE && POST != RPOST_NONE && inverse) {
+        hipLaunchKernelGGL((row200_reduce_kernel<POST>), grid, dim3(kThreads200), (size_t)200 * kLP200r * sizeof(cf), st, a);
+    } else if (f200) {
         if (inverse) hipLaunchKernelGGL((row_pass_kernel<true, -1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
         else hipLaunchKernelGGL((row_pass_kernel<true, 1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
     } else {
@@ -347,45 +572,59 @@ extern "C" int cine_fft1c(const float* in, float* out, long nlines, int n, int i
                       as_stream(stream));
 }
 
-extern "C" int cine_sens_reduce(const float* k, const float* sens, float* out, float* tmp,
-                                int b, int t, int c, int h, int w, int magnitude, void* stream) {
-    CINE_REQUIRE(k && sens && out && tmp, CINE_EINVAL, "cine_sens_reduce: null pointer");
-    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_reduce: bad sizes");
-    if (int e = check_n(h, "cine_sens_reduce(h)")) return e;
-    if (int e = check_n(w, "cine_sens_reduce(w)")) return e;
+// hybrid space = image along h, k-space along w: what a centered column IFFT of k-space gives.
+extern "C" int cine_kspace_to_hybrid(const float* k, float* hyb, long nimg, int h, int w, void* stream) {
+    CINE_REQUIRE(k && hyb, CINE_EINVAL, "cine_kspace_to_hybrid: null pointer");
+    CINE_REQUIRE(nimg >= 0 && h > 0 && w > 0, CINE_EINVAL, "cine_kspace_to_hybrid: bad sizes");
+    if (int e = check_n(h, "cine_kspace_to_hybrid(h)")) return e;
     hipStream_t st = as_stream(stream);
-    const long nimg = (long)b * t * c;
     for (long i0 = 0; i0 < nimg; i0 += 32768) {
         const long ni = (nimg - i0) < 32768 ? (nimg - i0) : 32768;
         ColArgs ca{};
         ca.in = reinterpret_cast<const cf*>(k) + i0 * h * w;
-        ca.out = reinterpret_cast<cf*>(tmp) + i0 * h * w;
+        ca.out = reinterpret_cast<cf*>(hyb) + i0 * h * w;
         ca.H = h; ca.W = w; ca.s_in = (h + 1) / 2; ca.s_out = h / 2; ca.coils = 1;
         if (int e = launch_col<POST_NONE>(ca, ni, true, st)) return e;
     }
+    return CINE_OK;
+}
+
+extern "C" int cine_hybrid_reduce(const float* hyb, const float* sens, float* out,
+                                  int b, int t, int c, int h, int w, int magnitude, void* stream) {
+    CINE_REQUIRE(hyb && sens && out, CINE_EINVAL, "cine_hybrid_reduce: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_hybrid_reduce: bad sizes");
+    if (int e = check_n(w, "cine_hybrid_reduce(w)")) return e;
     RowArgs r{};
-    r.in = reinterpret_cast<const cf*>(tmp);
+    r.in = reinterpret_cast<const cf*>(hyb);
     r.out = reinterpret_cast<cf*>(out); r.out_abs = out;
     r.W = w; r.s_in = (w + 1) / 2; r.s_out = w / 2;
     r.sens = reinterpret_cast<const cf*>(sens);
     r.T = t; r.C = c; r.H = h;
     coil_tiling(c, w, r.rpw, r.cc);
-    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_sens_reduce: b*t > 65535");
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_hybrid_reduce: b*t > 65535");
     dim3 grid(ceil_div(h, r.rpw), b * t);
-    return magnitude ? launch_row<PRE_NONE, RPOST_REDUCE_ABS>(r, grid, true, st)
-                     : launch_row<PRE_NONE, RPOST_REDUCE>(r, grid, true, st);
+    return magnitude ? launch_row<PRE_NONE, RPOST_REDUCE_ABS>(r, grid, true, as_stream(stream))
+                     : launch_row<PRE_NONE, RPOST_REDUCE>(r, grid, true, as_stream(stream));
 }
 
-extern "C" int cine_sens_expand_dc(const float* img, const float* sens, const float* kref, const uint8_t* mask,
-                                   const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
-                                   int hard_mask, void* stream) {
-    CINE_REQUIRE(img && sens && out, CINE_EINVAL, "cine_sens_expand_dc: null pointer");
-    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_expand_dc: bad sizes");
-    CINE_REQUIRE(!hard_mask || mask, CINE_EINVAL, "cine_sens_expand_dc: hard_mask needs mask");
-    CINE_REQUIRE(!kref || hard_mask || (mask && lambda_dev), CINE_EINVAL,
-                 "cine_sens_expand_dc: soft DC needs mask and lambda_dev");
-    if (int e = check_n(h, "cine_sens_expand_dc(h)")) return e;
-    if (int e = check_n(w, "cine_sens_expand_dc(w)")) return e;
+extern "C" int cine_sens_reduce(const float* k, const float* sens, float* out, float* tmp,
+                                int b, int t, int c, int h, int w, int magnitude, void* stream) {
+    CINE_REQUIRE(k && sens && out && tmp, CINE_EINVAL, "cine_sens_reduce: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_reduce: bad sizes");
+    if (int e = cine_kspace_to_hybrid(k, tmp, (long)b * t * c, h, w, stream)) return e;
+    return cine_hybrid_reduce(tmp, sens, out, b, t, c, h, w, magnitude, stream);
+}
+
+// shared by cine_sens_expand_dc (to_hybrid = false) and cine_expand_dc_hybrid (to_hybrid = true)
+static int expand_dc(const float* img, const float* sens, const float* kref, const uint8_t* mask,
+                     const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
+                     int hard_mask, bool to_hybrid, void* stream, const char* what) {
+    CINE_REQUIRE(img && sens && out, CINE_EINVAL, "%s: null pointer", what);
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0 && c <= 32768, CINE_EINVAL, "%s: bad sizes", what);
+    CINE_REQUIRE(!hard_mask || mask, CINE_EINVAL, "%s: hard_mask needs mask", what);
+    CINE_REQUIRE(!kref || hard_mask || (mask && lambda_dev), CINE_EINVAL, "%s: soft DC needs mask and lambda_dev", what);
+    if (int e = check_n(h, what)) return e;
+    if (int e = check_n(w, what)) return e;
     hipStream_t st = as_stream(stream);
     RowArgs r{};
     r.out = reinterpret_cast<cf*>(out);
@@ -394,11 +633,11 @@ extern "C" int cine_sens_expand_dc(const float* img, const float* sens, const fl
     r.img = reinterpret_cast<const cf*>(img);
     r.T = t; r.C = c; r.H = h;
     coil_tiling(c, w, r.rpw, r.cc);
-    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_sens_expand_dc: b*t > 65535");
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "%s: b*t > 65535", what);
     if (int e = launch_row<PRE_SMUL, RPOST_NONE>(r, dim3(ceil_div(h, r.rpw), b * t), false, st)) return e;
     const long nimg = (long)b * t * c;
-    for (long i0 = 0; i0 < nimg; i0 += 32768 / c * c) {
-        const long step = 32768 / c * c;
+    const long step = 32768 / c * c;
+    for (long i0 = 0; i0 < nimg; i0 += step) {
         const long ni = (nimg - i0) < step ? (nimg - i0) : step;
         ColArgs ca{};
         ca.in = reinterpret_cast<const cf*>(out) + i0 * h * w;
@@ -408,10 +647,34 @@ extern "C" int cine_sens_expand_dc(const float* img, const float* sens, const fl
         ca.mask = mask ? mask + (i0 / c) * h : nullptr;
         ca.lam = lambda_dev;
         int e;
+        if (to_hybrid && h == 200) {
+            // forward column FFT -> DC -> inverse column FFT in one kernel
+            if (hard_mask) e = launch_col<POST_HARD, true>(ca, ni, false, st);
+            else if (kref) e = launch_col<POST_DC, true>(ca, ni, false, st);
+            else e = launch_col<POST_NONE, true>(ca, ni, false, st);
+            if (e) return e;
+            continue;
+        }
         if (hard_mask) e = launch_col<POST_HARD>(ca, ni, false, st);
         else if (kref) e = launch_col<POST_DC>(ca, ni, false, st);
         else e = launch_col<POST_NONE>(ca, ni, false, st);
         if (e) return e;
+        if (to_hybrid) {
+            ColArgs ci = ca; ci.kref = nullptr; ci.mask = nullptr;
+            if ((e = launch_col<POST_NONE>(ci, ni, true, st))) return e;
+        }
     }
     return CINE_OK;
+}
+
+extern "C" int cine_sens_expand_dc(const float* img, const float* sens, const float* kref, const uint8_t* mask,
+                                   const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
+                                   int hard_mask, void* stream) {
+    return expand_dc(img, sens, kref, mask, lambda_dev, out, b, t, c, h, w, hard_mask, false, stream, "cine_sens_expand_dc");
+}
+
+extern "C" int cine_expand_dc_hybrid(const float* img, const float* sens, const float* kref, const uint8_t* mask,
+                                     const float* lambda_dev, float* hyb, int b, int t, int c, int h, int w,
+                                     int hard_mask, void* stream) {
+    return expand_dc(img, sens, kref, mask, lambda_dev, hyb, b, t, c, h, w, hard_mask, true, stream, "cine_expand_dc_hybrid");
 }

@@ -125,8 +125,11 @@ class VarNet(nn.Module):
         read-back of the mask (needed inside hipGraph capture)."""
         if sens_maps is None:
             sens_maps = self.sens_net(masked_kspace, mask, acs)
-        k = masked_kspace
-        for i, cascade in enumerate(self.cascades):
-            k = cascade(k, masked_kspace, mask, sens_maps, _destroy_current=i > 0)
-        owned = len(self.cascades) > 0
-        return ops.sens_reduce(k, sens_maps, magnitude=True, destroy_input=owned)
+        # Cascade chain in hybrid space (image along h, k-space along w): the k-space between two
+        # cascades (reference varnet.py:147-148) is consumed only by the next sens_reduce, so the DC
+        # kernel hands over its column-IFFT'd tile instead of writing k-space to HBM.
+        hyb = ops.kspace_to_hybrid(masked_kspace)
+        for cascade in self.cascades:
+            image = ops.hybrid_reduce(hyb, sens_maps)
+            ops.expand_dc_hybrid(cascade.regularise(image), sens_maps, masked_kspace, mask, cascade.lambda_reg, out=hyb)
+        return ops.hybrid_reduce(hyb, sens_maps, magnitude=True)

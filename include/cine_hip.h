@@ -74,6 +74,21 @@ int cine_sens_expand_dc(const float* img, const float* sens, const float* kref, 
                         const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
                         int hard_mask, void* stream);
 
+/* The same two operators split at "hybrid space" (image along h, k-space along w), so that a
+ * cascade chain never writes k-space to HBM: the next cascade's sens_reduce (varnet.py:253) starts
+ * with the column IFFT of exactly the tile the DC (varnet.py:281-282) just produced.
+ *   cine_kspace_to_hybrid : centered column IFFT of nimg k-space images (first half of ifft2c)
+ *   cine_hybrid_reduce    : row IFFT + conj(S) multiply + coil sum (second half of sens_reduce)
+ *   cine_expand_dc_hybrid : sens_expand + DC as cine_sens_expand_dc, then the column IFFT, in one pass
+ * cine_sens_reduce(k) == cine_hybrid_reduce(cine_kspace_to_hybrid(k)); and
+ * cine_expand_dc_hybrid(...) == cine_kspace_to_hybrid(cine_sens_expand_dc(...)). hyb may alias k. */
+int cine_kspace_to_hybrid(const float* k, float* hyb, long nimg, int h, int w, void* stream);
+int cine_hybrid_reduce(const float* hyb, const float* sens, float* out,
+                       int b, int t, int c, int h, int w, int magnitude, void* stream);
+int cine_expand_dc_hybrid(const float* img, const float* sens, const float* kref, const uint8_t* mask,
+                          const float* lambda_dev, float* hyb, int b, int t, int c, int h, int w,
+                          int hard_mask, void* stream);
+
 /* SensitivityModel prologue (varnet.py:62-74): mean over frames, keep rows [row_lo, row_hi) of
  * dim h (transforms.mask_center, data/transforms.py:95-108), ifft2c.  k (b,t,c,h,w,2) -> out (b,c,h,w,2). */
 int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,

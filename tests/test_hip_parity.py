@@ -141,6 +141,28 @@ def test_coil_ops_full_size_vs_oracle(dev):
     assert abs(float(lhs - rhs)) / abs(float(lhs)) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(5, 3, 24, 20), (3, 15, 200, 200), (2, 4, 200, 24), (2, 5, 24, 200)])
+def test_hybrid_space_chain_equals_kspace_chain(dev, shape):
+    """kspace_to_hybrid / hybrid_reduce / expand_dc_hybrid against the k-space operators they split."""
+    from cine_hip import ops
+    t, c, h, w = shape
+    g = torch.Generator().manual_seed(h * w)
+    k = torch.randn(1, t, c, h, w, 2, generator=g).to(dev)
+    sens = torch.randn(1, 1, c, h, w, 2, generator=g).to(dev)
+    mask = (torch.rand(1, t, 1, h, 1, 1, generator=g) > 0.7).byte().to(dev)
+    lam = torch.tensor([0.3]).to(dev)
+    hyb = ops.kspace_to_hybrid(k)
+    img = ops.sens_reduce(k, sens)
+    assert rel_err(ops.hybrid_reduce(hyb, sens).cpu(), img.cpu()) < OP_TOL
+    assert rel_err(ops.hybrid_reduce(hyb, sens, magnitude=True).cpu(), ops.sens_reduce(k, sens, magnitude=True).cpu()) < OP_TOL
+    knew = ops.sens_expand_dc(img, sens, k, mask, lam)
+    hyb2 = ops.expand_dc_hybrid(img, sens, k, mask, lam)
+    assert rel_err(hyb2.cpu(), ops.kspace_to_hybrid(knew).cpu()) < OP_TOL
+    # in place on an existing hybrid buffer
+    ops.expand_dc_hybrid(img, sens, k, mask, lam, out=hyb)
+    assert torch.equal(hyb, hyb2)
+
+
 def test_sens_prologue_and_rss(dev):
     from cine_hip import ops
     from oracle import centered_fft as cf, complex_ops as co
