@@ -13,6 +13,24 @@
 #include "common.h"
 #include "fft_core.h"
 
+// Diagnostic builds only (tools/fft_stamps.hip defines CINE_STAMPS): per-phase s_memtime stamps
+// of workgroup-lane 0 into a side buffer.  In the product build the macro is empty.
+#ifdef CINE_STAMPS
+__device__ unsigned long long g_cine_stamps[1 << 20];
+#define CINE_STAMP(slot)                                                                          \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0) {                                                                   \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            g_cine_stamps[((blockIdx.y * gridDim.x + blockIdx.x) % (1 << 16)) * 16 + (slot)] = t_; \
+        }                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define CINE_STAMP(slot) do { } while (0)
+#endif
+
 namespace cine {
 
 __device__ const float2 TW200[200] = {
@@ -246,8 +264,10 @@ __global__ void row_pass_kernel(RowArgs a) {
 // First butterfly stage straight from global memory into registers, last stage straight back:
 // ONE LDS exchange per transform (the generic kernels above need three passes over the tile).
 // 32 lines per workgroup, 320 threads: 640 radix-10 items (2 per thread), 320 radix-20 items.
-constexpr int kLP200c = 32;     // column passes: lanes run over lines, contiguous LDS rows
-constexpr int kLP200r = 33;     // row passes: lanes run over points, odd stride spreads banks
+constexpr int kFL = 16;                 // lines per workgroup of the fast passes (small tiles -> 5-6 workgroups per CU)
+constexpr int kFT = 10 * kFL;           // threads: one radix-20 item each, two radix-10 items each
+constexpr int kLP200c = kFL;            // column passes: lanes run over lines, contiguous LDS rows
+constexpr int kLP200r = kFL + 1;        // row passes: lanes run over points, odd stride spreads banks
 
 __device__ __forceinline__ int wrap200(int x) { return x >= 200 ? x - 200 : (x < 0 ? x + 200 : x); }
 
@@ -256,73 +276,91 @@ __device__ __forceinline__ int wrap200(int x) { return x >= 200 ? x - 200 : (x <
 // without the k-space ever leaving the CU):
 //   global -> r10 -> LDS -> r20 [-> DC -> r20^-1 -> LDS -> r10^-1] -> global
 template <int DIR, int POST, bool INV_AFTER>
-__global__ __launch_bounds__(kThreads200) void col200_kernel(ColArgs a) {
+__global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
     constexpr int LP = kLP200c;
     extern __shared__ __align__(16) unsigned char smem[];
     cf* t = reinterpret_cast<cf*>(smem);
     const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * kLines200;
+    const int w0 = blockIdx.x * kFL;
     const long img = blockIdx.y;
     const cf* in = a.in + img * 200 * a.W;
     cf* out = a.out + img * 200 * a.W;
+    CINE_STAMP(0);
+    // DC operands of the rows this thread will own after the radix-20 stage (k = g + 10 k2, centered
+    // row (k + 100) % 200).  Fetched FIRST so their latency overlaps the stage-1 stream instead of
+    // adding two dependent round trips behind the LDS exchange.  Unsampled rows read kref[0]
+    // (one cached line): no branches, no HBM traffic for the rows the mask drops.
+    unsigned mbits = 0;
+    cf rr[20];
+    if (POST != POST_NONE) {
+        const int g2 = tid / kFL;
+        const uint8_t* mrow = a.mask + (img / a.coils) * 200;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int item = tid + r * kThreads200;
-        const int line = item & 31, c = item >> 5;
-        const int col = w0 + line;
-        cf v[10];
+        for (int k2 = 0; k2 < 20; ++k2) mbits |= (mrow[wrap200(g2 + 10 * k2 + 100)] ? 1u : 0u) << k2;
+        if (POST == POST_DC) {
+            const cf* kref = a.kref + img * 200 * a.W;
+            const int colc = min(w0 + tid % kFL, a.W - 1);
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int g = wrap200(20 * j + c - 100);            // x'[n] = x[(n - s_in) mod N], s_in = 100
-            v[j] = col < a.W ? in[(long)g * a.W + col] : mk(0.f, 0.f);
+            for (int k2 = 0; k2 < 20; ++k2) {
+                const int off = ((mbits >> k2) & 1u) ? wrap200(g2 + 10 * k2 + 100) * a.W + colc : 0;
+                rr[k2] = kref[off];
+            }
         }
+    }
+#pragma unroll 1
+    for (int r = 0; r < 2; ++r) {
+        const int item = tid + r * kFT;
+        const int line = item % kFL, c = item / kFL;
+        const int col = w0 + line;
+        const int colc = min(col, a.W - 1);                     // clamped: lanes past the edge load a valid
+        cf v[10];                                               // column and are never stored (no branches)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) v[j] = in[wrap200(20 * j + c - 100) * a.W + colc];   // x'[n] = x[(n - 100) mod N]
         Fft200::r10_regs<DIR, false, true>(v, c, TW200);
 #pragma unroll
         for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
+        CINE_STAMP(1 + r);
     }
     __syncthreads();
+    CINE_STAMP(3);
     {
-        const int line = tid & 31, g = tid >> 5;
+        const int line = tid % kFL, g = tid / kFL;
         const int col = w0 + line;
         cf v[20];
 #pragma unroll
         for (int j = 0; j < 20; ++j) v[j] = t[(20 * g + j) * LP + line];
         dft20<DIR>(v);                                          // v[k2] = X'[g + 10 k2] -> centered row (k + 100) % 200
-        if (POST != POST_NONE && col < a.W) {
-            const uint8_t* mrow = a.mask + (img / a.coils) * 200;
-            if (POST == POST_DC) {
-                const float vv = softplus1(*a.lam);
-                const cf* kref = a.kref + img * 200 * a.W;
+        CINE_STAMP(4);
+        if (POST == POST_DC) {
+            const float vv = softplus1(*a.lam), inv = 1.0f / (1.f + vv);
 #pragma unroll
-                for (int k2 = 0; k2 < 20; ++k2) {
-                    const int i = wrap200(g + 10 * k2 + 100);
-                    if (mrow[i]) {
-                        const cf rr = kref[(long)i * a.W + col];
-                        v[k2] = mk((v[k2].x + vv * rr.x) / (1.f + vv), (v[k2].y + vv * rr.y) / (1.f + vv));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k2 = 0; k2 < 20; ++k2)
-                    if (!mrow[wrap200(g + 10 * k2 + 100)]) v[k2] = mk(0.f, 0.f);
+            for (int k2 = 0; k2 < 20; ++k2) {
+                const cf b = mk((v[k2].x + vv * rr[k2].x) * inv, (v[k2].y + vv * rr[k2].y) * inv);
+                v[k2] = ((mbits >> k2) & 1u) ? b : v[k2];
             }
+        } else if (POST == POST_HARD) {
+#pragma unroll
+            for (int k2 = 0; k2 < 20; ++k2) v[k2] = ((mbits >> k2) & 1u) ? v[k2] : mk(0.f, 0.f);
         }
         if (!INV_AFTER) {
             if (col < a.W) {
 #pragma unroll
-                for (int k2 = 0; k2 < 20; ++k2) out[(long)wrap200(g + 10 * k2 + 100) * a.W + col] = v[k2];
+                for (int k2 = 0; k2 < 20; ++k2) out[wrap200(g + 10 * k2 + 100) * a.W + col] = v[k2];
             }
             return;
         }
+        CINE_STAMP(5);
         dft20<-DIR>(v);                                         // PN flavour, stage A on the same registers
 #pragma unroll
         for (int j = 0; j < 20; ++j) t[(20 * g + j) * LP + line] = v[j];
+        CINE_STAMP(6);
     }
     __syncthreads();
-#pragma unroll
+    CINE_STAMP(7);
+#pragma unroll 1
     for (int r = 0; r < 2; ++r) {
-        const int item = tid + r * kThreads200;
-        const int line = item & 31, c = item >> 5;
+        const int item = tid + r * kFT;
+        const int line = item % kFL, c = item / kFL;
         const int col = w0 + line;
         cf v[10];
 #pragma unroll
@@ -330,15 +368,16 @@ __global__ __launch_bounds__(kThreads200) void col200_kernel(ColArgs a) {
         Fft200::r10_regs<-DIR, true, false>(v, c, TW200);
         if (col < a.W) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) out[(long)wrap200(20 * j + c + 100) * a.W + col] = v[j];
+            for (int j = 0; j < 10; ++j) out[wrap200(20 * j + c + 100) * a.W + col] = v[j];
         }
+        CINE_STAMP(8 + r);
     }
 }
 
 // Row pass along w (W == 200), inverse, fused with conj(S) multiply + coil sum (+ magnitude):
 //   global -> r10^-1 -> LDS -> r20^-1 -> LDS -> sum_c conj(S) x -> global
 template <int POST>
-__global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
+__global__ __launch_bounds__(kFT, 3) void row200_reduce_kernel(RowArgs a) {
     constexpr int LP = kLP200r;
     extern __shared__ __align__(16) unsigned char smem[];
     cf* t = reinterpret_cast<cf*>(smem);
@@ -351,24 +390,33 @@ __global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
     for (int o = 0; o < kMaxOut; ++o) acc[o] = mk(0.f, 0.f);
     for (int c0 = 0; c0 < a.C; c0 += a.cc) {
         const int nc = min(a.cc, a.C - c0);
+        // sensitivities of this thread's first output pixel, fetched up front (up to kSPre coils)
+        constexpr int kSPre = 16;
+        cf spre[kSPre];
+        {
+            const int rr0 = tid / 200, i0 = tid - rr0 * 200;
+            const cf* sb = a.sens + ((long)b * a.C + c0) * HW + (long)min(h0 + rr0, a.H - 1) * 200 + i0;
 #pragma unroll
+            for (int u = 0; u < kSPre; ++u) spre[u] = sb[(long)min(u, nc - 1) * HW];
+        }
+#pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const int item = tid + r * kThreads200;
+            const int item = tid + r * kFT;
             const int c = item % 20, line = item / 20;
             const int cl = line / a.rpw, rr = line - cl * a.rpw;
             const int h = h0 + rr;
-            const bool ok = cl < nc && h < a.H;
-            const cf* src = a.in + ((long)bt * a.C + c0 + cl) * HW + (long)h * 200;
+            // lines past the coil chunk / image edge read a clamped (valid) row; their results are never used
+            const cf* src = a.in + ((long)bt * a.C + c0 + min(cl, nc - 1)) * HW + (long)min(h, a.H - 1) * 200;
             cf v[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = ok ? src[wrap200(20 * j + c - 100)] : mk(0.f, 0.f);
+            for (int j = 0; j < 10; ++j) v[j] = src[wrap200(20 * j + c - 100)];
             Fft200::r10_regs<-1, false, true>(v, c, TW200);
 #pragma unroll
             for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
         }
         __syncthreads();
         {
-            const int line = tid & 31, g = tid >> 5;
+            const int line = tid % kFL, g = tid / kFL;
             cf v[20];
 #pragma unroll
             for (int j = 0; j < 20; ++j) v[j] = t[(20 * g + j) * LP + line];
@@ -379,7 +427,7 @@ __global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
         __syncthreads();
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) {
-            const int e = tid + o * kThreads200;
+            const int e = tid + o * kFT;
             if (e >= a.rpw * 200) break;
             const int rr = e / 200, i = e - rr * 200;
             const int h = h0 + rr;
@@ -387,11 +435,29 @@ __global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
             const int k = wrap200(i - 100);
             const int p = Fft200::pos_of(k) * LP;
             cf s_acc = acc[o];
-            for (int cl = 0; cl < nc; ++cl) {
-                const cf x = t[p + cl * a.rpw + rr];
-                const cf s = a.sens[((long)b * a.C + c0 + cl) * HW + (long)h * 200 + i];
-                const cf m = cmulc(x, s);
-                s_acc.x += m.x; s_acc.y += m.y;
+            const cf* sbase = a.sens + ((long)b * a.C + c0) * HW + (long)h * 200 + i;
+            int cg0 = 0;
+            if (o == 0) {                                   // first output: sensitivities already in registers
+#pragma unroll
+                for (int u = 0; u < kSPre; ++u) {
+                    const cf m = cmulc(t[p + min(u, nc - 1) * a.rpw + rr], spre[u]);
+                    if (u < nc) { s_acc.x += m.x; s_acc.y += m.y; }
+                }
+                cg0 = kSPre;
+            }
+            for (int cg = cg0; cg < nc; cg += 5) {
+                cf sv[5], xv[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int cl = min(cg + u, nc - 1);
+                    sv[u] = sbase[(long)cl * HW];
+                    xv[u] = t[p + cl * a.rpw + rr];
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const cf m = cmulc(xv[u], sv[u]);
+                    if (cg + u < nc) { s_acc.x += m.x; s_acc.y += m.y; }
+                }
             }
             acc[o] = s_acc;
         }
@@ -399,7 +465,7 @@ __global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
     }
 #pragma unroll
     for (int o = 0; o < kMaxOut; ++o) {
-        const int e = tid + o * kThreads200;
+        const int e = tid + o * kFT;
         if (e >= a.rpw * 200) break;
         const int rr = e / 200, i = e - rr * 200;
         const int h = h0 + rr;
@@ -413,7 +479,7 @@ __global__ __launch_bounds__(kThreads200) void row200_reduce_kernel(RowArgs a) {
 
 // Row pass along w (W == 200), forward, fused with the sensitivity multiply:
 //   S x (L2-resident reads) -> r20 -> LDS -> r10 -> global, natural order out (160-byte runs)
-__global__ __launch_bounds__(kThreads200) void row200_expand_kernel(RowArgs a) {
+__global__ __launch_bounds__(kFT, 3) void row200_expand_kernel(RowArgs a) {
     constexpr int LP = kLP200r;
     extern __shared__ __align__(16) unsigned char smem[];
     cf* t = reinterpret_cast<cf*>(smem);
@@ -427,23 +493,25 @@ __global__ __launch_bounds__(kThreads200) void row200_expand_kernel(RowArgs a) {
             const int g = tid % 10, line = tid / 10;
             const int cl = line / a.rpw, rr = line - cl * a.rpw;
             const int h = h0 + rr;
-            const bool ok = cl < nc && h < a.H;
-            const cf* sp = a.sens + ((long)b * a.C + c0 + cl) * HW + (long)h * 200;
-            const cf* xp = a.img + (long)bt * HW + (long)h * 200;
-            cf v[20];
+            const int hc = min(h, a.H - 1);                     // clamped: out-of-range lines are never stored
+            const cf* sp = a.sens + ((long)b * a.C + c0 + min(cl, nc - 1)) * HW + (long)hc * 200;
+            const cf* xp = a.img + (long)bt * HW + (long)hc * 200;
+            cf xs[20], ss[20], v[20];
 #pragma unroll
             for (int j = 0; j < 20; ++j) {
                 const int gi = wrap200(10 * j + g - 100);
-                v[j] = ok ? cmul(xp[gi], sp[gi]) : mk(0.f, 0.f);
+                xs[j] = xp[gi]; ss[j] = sp[gi];
             }
+#pragma unroll
+            for (int j = 0; j < 20; ++j) v[j] = cmul(xs[j], ss[j]);
             dft20<1>(v);
 #pragma unroll
             for (int j = 0; j < 20; ++j) t[(20 * g + j) * LP + line] = v[j];
         }
         __syncthreads();
-#pragma unroll
+#pragma unroll 1
         for (int r = 0; r < 2; ++r) {
-            const int item = tid + r * kThreads200;
+            const int item = tid + r * kFT;
             const int c = item % 20, line = item / 20;
             const int cl = line / a.rpw, rr = line - cl * a.rpw;
             const int h = h0 + rr;
@@ -478,14 +546,14 @@ template <int POST, bool INV_AFTER = false>
 static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st) {
     if (nimg == 0) return CINE_OK;
     const bool f200 = a.H == 200;
-    const int lines = f200 ? kLines200 : kLinesGen;
+    const int lines = f200 ? kFL : kLinesGen;
     dim3 grid(ceil_div(a.W, lines), (unsigned)nimg);
     CINE_REQUIRE(nimg <= 65535, CINE_EUNSUPPORTED, "column pass: %ld images > 65535", nimg);
     ProfScope prof(F_FFT_COL, st);
     if (f200) {
         const size_t lds = (size_t)200 * kLP200c * sizeof(cf);
-        if (inverse) hipLaunchKernelGGL((col200_kernel<-1, POST, INV_AFTER>), grid, dim3(kThreads200), lds, st, a);
-        else hipLaunchKernelGGL((col200_kernel<1, POST, INV_AFTER>), grid, dim3(kThreads200), lds, st, a);
+        if (inverse) hipLaunchKernelGGL((col200_kernel<-1, POST, INV_AFTER>), grid, dim3(kFT), lds, st, a);
+        else hipLaunchKernelGGL((col200_kernel<1, POST, INV_AFTER>), grid, dim3(kFT), lds, st, a);
     } else {
         static_assert(!INV_AFTER || true, "");
         const size_t lds = lds_bytes(false, a.H, lines);
@@ -503,9 +571,9 @@ static int launch_row(RowArgs a, dim3 grid, bool inverse, hipStream_t st) {
     const size_t lds = lds_bytes(f200, a.W, lines);
     ProfScope prof(F_FFT_ROW, st);
     if (f200 && PRE == PRE_SMUL && POST == RPOST_NONE && !inverse) {
-        hipLaunchKernelGGL(row200_expand_kernel, grid, dim3(kThreads200), (size_t)200 * kLP200r * sizeof(cf), st, a);
+        hipLaunchKernelGGL(row200_expand_kernel, grid, dim3(kFT), (size_t)200 * kLP200r * sizeof(cf), st, a);
     } else if (f200 && PRE == PRE_NONE && POST != RPOST_NONE && inverse) {
-        hipLaunchKernelGGL((row200_reduce_kernel<POST>), grid, dim3(kThreads200), (size_t)200 * kLP200r * sizeof(cf), st, a);
+        hipLaunchKernelGGL((row200_reduce_kernel<POST>), grid, dim3(kFT), (size_t)200 * kLP200r * sizeof(cf), st, a);
     } else if (f200) {
         if (inverse) hipLaunchKernelGGL((row_pass_kernel<true, -1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
         else hipLaunchKernelGGL((row_pass_kernel<true, 1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
@@ -519,8 +587,8 @@ static int launch_row(RowArgs a, dim3 grid, bool inverse, hipStream_t st) {
 // rows per workgroup / coils per chunk for the coil-mode row pass
 static void coil_tiling(int C, int W, int& rpw, int& cc) {
     const bool f200 = W == 200;
-    const int lines = f200 ? kLines200 : kLinesGen;
-    const int nt = f200 ? kThreads200 : kThreadsGen;
+    const int lines = f200 ? kFL : kLinesGen;
+    const int nt = f200 ? kFT : kThreadsGen;
     cc = C < lines ? C : lines;
     rpw = lines / cc;
     while (rpw > 1 && (long)rpw * W > (long)kMaxOut * nt) --rpw;
