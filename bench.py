@@ -170,8 +170,8 @@ def main():
             holder["o"] = forward()
         result = lambda: holder["o"]                                  # noqa: E731
 
-    outs = torch.empty((args.steps,) + tuple(out.shape[1:]), device=dev)
-    gathered = torch.empty((world * args.steps,) + tuple(out.shape[1:]), device=dev) if world > 1 else None
+    from cine_hip import shard
+    outs = torch.empty((args.steps,) + tuple(out.shape[1:]), device=dev)   # this rank's slices r, r+N, r+2N, ...
 
     for _ in range(args.warmup):
         step()
@@ -183,8 +183,8 @@ def main():
     for i in range(args.steps):
         step()
         outs[i].copy_(result()[0])
-    if world > 1:
-        dist.all_gather_into_tensor(gathered, outs)                   # volume assembly over xGMI
+    volume = shard.assemble_volume(outs, world * args.steps)          # one all-gather over xGMI (no-op at N=1)
+    assert volume.shape[0] == world * args.steps
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
