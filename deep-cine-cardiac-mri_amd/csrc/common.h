@@ -5,6 +5,38 @@
 #include <cstdio>
 #include "../../include/cine_hip.h"
 
+// Diagnostic builds only (tools/*_stamps.hip define CINE_STAMPS): per-phase s_memtime stamps
+// of workgroup-lane 0 into a side buffer.  In the product build the macro is empty.
+#ifdef CINE_STAMPS
+__device__ unsigned long long g_cine_stamps[1 << 20];
+#define CINE_STAMP(slot)                                                                          \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0) {                                                                   \
+            unsigned long long t_;                                                                \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
+            g_cine_stamps[(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % (1 << 16)) * 16 + (slot)] = t_; \
+        }                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+// wall-clock (100 MHz s_memrealtime) stamp + hardware id (XCC, SE, CU) of the workgroup
+#define CINE_STAMP_RT(slot)                                                                       \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        if (threadIdx.x == 0) {                                                                   \
+            unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                             \
+            unsigned hw_ = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));            \
+            unsigned xcc_ = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));           \
+            unsigned long long* p_ = &g_cine_stamps[(((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % (1 << 16)) * 16]; \
+            p_[(slot)] = t_; p_[15] = ((unsigned long long)xcc_ << 32) | hw_;                      \
+        }                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define CINE_STAMP(slot) do { } while (0)
+#define CINE_STAMP_RT(slot) do { } while (0)
+#endif
+
 namespace cine {
 
 void set_error(const char* fmt, ...);   // api.cpp (thread-local buffer)

@@ -67,7 +67,11 @@ struct ConvCfg {
     static constexpr int RPF = 16 / TW;            // rows per fragment
     static constexpr int NF = WN * MT;             // fragments per workgroup
     static constexpr int TH = NF * RPF;            // tile rows
-    static constexpr int ROWS = TH + 2 * HALO, COLS = TW + 2 * HALO;
+    static constexpr int ROWS = TH + 2 * HALO;
+    // LDS row: [0, TW) interior, then (3x3 only) right halo at TW and left halo at COLS-1, i.e. image
+    // column x lives at (x + COLS) % COLS.  COLS is a multiple of the staging piece so interior
+    // pieces are 16-byte aligned (ds_write_b128).
+    static constexpr int COLS = HALO ? (TW >= 4 ? TW + 4 : TW + 2) : TW;
     static constexpr int PS = ((ROWS * COLS + 31) / 32) * 32 + 16;   // plane stride == 16 (mod 32)
     static constexpr int COT = 16 * CT * WM;
     static constexpr int COTP = (COT % 32 == 0) ? COT + 16 : COT;
@@ -77,7 +81,11 @@ struct ConvCfg {
     static constexpr int NPT = (NPIECE + NT - 1) / NT;
     static constexpr int IN_FLOATS = CK * PS;
     static constexpr int W_FLOATS = TAPS * CK * COTP;
-    static constexpr int RED_FLOATS = WN * COT + COT;
+    static constexpr int RED_FLOATS = 3 * WN * COT;
+    // waves per SIMD to ask the register allocator for (= workgroups per CU for 256-thread groups):
+    // 4 (<= 128 VGPR+AGPR) when the accumulator tile is <= 64 registers, else 3 (<= 168)
+    static constexpr int MINW_ACC = (4 * CT * MT <= 64) ? 4 : 3;
+    static constexpr int MINW = (4 * NPT > 36) ? MINW_ACC - 1 : MINW_ACC;   // big staging batches need room
     static_assert(RED_FLOATS <= IN_FLOATS, "reduction scratch must fit in the input tile");
     static size_t lds_bytes(int cin) { return (size_t)(IN_FLOATS + W_FLOATS + 2 * cin) * sizeof(float); }
 };
@@ -101,7 +109,7 @@ template <> struct Piece<4> { typedef float4 T; };
 template <> struct Piece<2> { typedef float2 T; };
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_kernel(ConvArgs a) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     constexpr int HALO = C::HALO, PW = C::PW;
     typedef typename Piece<PW>::T piece_t;
@@ -120,9 +128,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
     const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
     const int q = lane & 15, kk = lane >> 4;
     const int qr = q / TW, qc = q % TW;
-    const int base_in = kk * C::PS + (wn * MT * C::RPF + qr) * C::COLS + qc;
+    // A operand (pixels x k): lane = pixel q of the fragment, channel kk of the k-step; one base per dx
+    int base_in[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+        base_in[dx] = kk * C::PS + (wn * MT * C::RPF + qr) * C::COLS + (HALO ? (qc + dx - 1 + C::COLS) % C::COLS : qc);
+    // B operand (k x rows): lane = output row q of the 16-row tile, channel kk
     const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
 
+    CINE_STAMP_RT(9);
+    CINE_STAMP(0);
     // ---- prologue: merged InstanceNorm stats of every input channel; zero the tile once
     for (int ci = tid; ci < a.cin; ci += C::NT) {
         const bool first = ci < a.s0.c;
@@ -132,16 +147,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
         if (s.mode != 0) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
         st_lds[2 * ci] = mr.x; st_lds[2 * ci + 1] = mr.y;
     }
-    for (int e = tid; e < C::IN_FLOATS; e += C::NT) in_lds[e] = 0.f;
+    if (HALO) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
+        for (int e = tid; e < CK * C::ROWS * 2; e += C::NT) {
+            const int ck = e / (C::ROWS * 2), rem = e % (C::ROWS * 2);
+            in_lds[ck * C::PS + (rem >> 1) * C::COLS + ((rem & 1) ? C::COLS - 1 : TW)] = 0.f;
+        }
+    }
 
-    f32x4 acc[CT][MT];
+    f32x4 acc[CT][MT];   // acc[ct][f][j] = out[row 16*ct + q][pixel 4*kk + j of fragment f]
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    CINE_STAMP(1);
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         __syncthreads();
+        if (chunk == 0) CINE_STAMP(2);
         // ---- weight slab [tap][ck][COT] from the packed layout [chunk][tap][ck][rowsp]
         {
             const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
@@ -179,12 +201,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                     const int row = rem / C::PR, j = rem % C::PR;
                     const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
                     const float* r = reinterpret_cast<const float*>(&raw[i]);
-                    float* dst = in_lds + ck * C::PS + row * C::COLS + HALO + PW * j;
+                    piece_t o;
+                    float* ov = reinterpret_cast<float*>(&o);
 #pragma unroll
                     for (int u = 0; u < PW; ++u) {
-                        float v = s.mode == 0 ? r[u] : act(r[u], mean, rstd, a.slope);
-                        dst[u] = ok[i] ? v : 0.f;
+                        const float v = s.mode == 0 ? r[u] : act(r[u], mean, rstd, a.slope);
+                        ov[u] = ok[i] ? v : 0.f;
                     }
+                    *reinterpret_cast<piece_t*>(in_lds + ck * C::PS + row * C::COLS + PW * j) = o;
                 }
             } else {
                 // pooled source (extent 2H x 2W): 2*PW floats from each of two rows per piece
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                     const int row = rem / C::PR, j = rem % C::PR;
                     const int gy = r0 - HALO + row, gx = c0 + PW * j;
                     const bool ok = ci0 + ck < a.cin && gy >= 0 && 2 * gy + 1 < s.h && gx < a.W;
-                    float* dst = in_lds + ck * C::PS + row * C::COLS + HALO + PW * j;
+                    float* dst = in_lds + ck * C::PS + row * C::COLS + PW * j;
                     if (ok) {
                         const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
                         const float* src = s.x + (((long)n * s.c + cl0 + ck) * s.h + 2 * gy) * s.w + 2 * gx;
@@ -225,17 +249,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                     float v = 0.f;
                     if (ci0 + ck < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                         v = fetch_scalar(s, n, cl0 + ck, gy, gx, st_lds[2 * (ci0 + ck)], st_lds[2 * (ci0 + ck) + 1], a.slope);
-                    in_lds[ck * C::PS + row * C::COLS + (side ? TW + 1 : 0)] = v;
+                    in_lds[ck * C::PS + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
                 }
             }
         } else {
             // ---- generic scalar staging (odd widths, mixed-source chunks, narrow `up` extents)
-            for (int e = tid; e < CK * C::ROWS * C::COLS; e += C::NT) {
-                const int ck = e / (C::ROWS * C::COLS);
-                const int rem = e - ck * (C::ROWS * C::COLS);
-                const int row = rem / C::COLS, col = rem - row * C::COLS;
+            constexpr int XC = TW + 2 * HALO;               // image columns c0-HALO .. c0+TW-1+HALO
+            for (int e = tid; e < CK * C::ROWS * XC; e += C::NT) {
+                const int ck = e / (C::ROWS * XC);
+                const int rem = e - ck * (C::ROWS * XC);
+                const int row = rem / XC, xcol = rem - row * XC;
+                const int col = (xcol - HALO + C::COLS) % C::COLS;
                 const int ci = ci0 + ck;
-                const int gy = r0 - HALO + row, gx = c0 - HALO + col;
+                const int gy = r0 - HALO + row, gx = c0 - HALO + xcol;
                 float v = 0.f;
                 if (ci < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                     const bool f0 = ci < a.s0.c;
@@ -244,117 +270,171 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
                 in_lds[ck * C::PS + row * C::COLS + col] = v;
             }
         }
+        if (chunk == 0) CINE_STAMP(3);
         __syncthreads();
-        // ---- MFMA sweep
+        if (chunk == 0) CINE_STAMP(4);
+        // ---- MFMA sweep: TAPS * CK/4 operand groups, software-pipelined one group ahead.  The
+        // scheduling barriers keep the compiler from hoisting every group's ds_reads to the top
+        // (which costs > 100 extra VGPRs and with them half the occupancy).
+        {
+            constexpr int NG = TAPS * (CK / 4);
+            float af[2][CT], bf[2][MT];
+            auto load_group = [&](int g, float (&wa)[CT], float (&xa)[MT]) {
+                const int tap = g / (CK / 4), ks = g % (CK / 4);
+                const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+                for (int ct = 0; ct < CT; ++ct) wa[ct] = w_lds[base_w + (tap * CK + 4 * ks) * C::COTP + 16 * ct];
 #pragma unroll
-            for (int ks = 0; ks < CK / 4; ++ks) {
-                float af[CT], bf[MT];
+                for (int f = 0; f < MT; ++f) xa[f] = in_lds[base_in[dx] + (4 * ks) * C::PS + (f * C::RPF + dy) * C::COLS];
+            };
+            load_group(0, af[0], bf[0]);
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) af[ct] = w_lds[base_w + (tap * CK + 4 * ks) * C::COTP + 16 * ct];
-#pragma unroll
-                for (int f = 0; f < MT; ++f)
-                    bf[f] = in_lds[base_in + (4 * ks) * C::PS + (f * C::RPF + dy) * C::COLS + dx];
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-                    for (int f = 0; f < MT; ++f)
-                        acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ct], bf[f], acc[ct][f], 0, 0, 0);
+                    for (int f = 0; f < MT; ++f)   // M = pixels (bf), N = output rows (af)
+                        acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g & 1][f], af[g & 1][ct], acc[ct][f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (chunk == 0) CINE_STAMP(5);
     }
 
-    // ---- epilogue.  Lane holds rows m = co0 + 16*(wm*CT+ct) + 4*kk + j, pixel q of fragment f.
-    unsigned vmask = 0;                             // which of my fragments' pixels are inside the image
-#pragma unroll
-    for (int f = 0; f < MT; ++f) {
-        const int gy = r0 + (wn * MT + f) * C::RPF + qr, gx = c0 + qc;
-        if (gy < a.H && gx < a.W) vmask |= 1u << f;
-    }
+    CINE_STAMP(6);
+    // ---- epilogue.  Lane holds output row m = co0 + 16*(wm*CT+ct) + q at pixels 4*kk .. 4*kk+3 of
+    // fragment f (4 consecutive pixels of one image row when TW >= 4).
+    constexpr int PPR = TW >= 4 ? 4 : TW;             // consecutive pixels per image row held by a lane
+    const int pr0 = (4 * kk) / TW, pc0 = (4 * kk) % TW;
+    const int gx0 = c0 + pc0;
     if (a.bias) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int ct = 0; ct < CT; ++ct) {
+            const int m = co0 + 16 * (wm * CT + ct) + q;
+            const float bv = m < a.rows ? a.bias[m] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = co0 + 16 * (wm * CT + ct) + 4 * kk + j;
-                const float bv = m < a.rows ? a.bias[m] : 0.f;
+            for (int f = 0; f < MT; ++f)
 #pragma unroll
-                for (int f = 0; f < MT; ++f) acc[ct][f][j] += bv;
-            }
+                for (int j = 0; j < 4; ++j) acc[ct][f][j] += bv;
+        }
     }
+    // validity of my 4 pixels per fragment: bit (4 f + j)
+    unsigned long long vmask = 0;
+#pragma unroll
+    for (int f = 0; f < MT; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = 4 * kk + j;
+            const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+            if (gy < a.H && gx < a.W) vmask |= 1ull << (4 * f + j);
+        }
     if (a.ypart) {
-        __syncthreads();                            // everyone is done reading in_lds
-        float* red = in_lds;                        // [WN][COT]
-        float* meanl = in_lds + WN * C::COT;        // [COT]
-        const float cnt = (float)(min(C::TH, a.H - r0) * min(TW, a.W - c0));
-        float mrow[CT][4];
+        // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass
+        // per WAVE in registers (sum -> wave mean -> squared deviations), the WN wave records are merged
+        // with Chan's formula by one thread per row.
+        const int rows_w = min(max(a.H - (r0 + wn * MT * C::RPF), 0), MT * C::RPF);
+        const float cnt_w = (float)(rows_w * min(TW, a.W - c0));
+        float mean_w[CT], m2_w[CT];
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int ct = 0; ct < CT; ++ct) {
+            float sacc = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int f = 0; f < MT; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc += ((vmask >> (4 * f + j)) & 1ull) ? acc[ct][f][j] : 0.f;
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            mean_w[ct] = cnt_w > 0.f ? sacc / cnt_w : 0.f;
+            float qacc = 0.f;
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float sacc = 0.f;
-#pragma unroll
-                    for (int f = 0; f < MT; ++f) {
-                        float v = acc[ct][f][j];
-                        if (pass) { v -= mrow[ct][j]; v *= v; }
-                        sacc += ((vmask >> f) & 1u) ? v : 0.f;
-                    }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 16);
-                    if (q == 0) red[wn * C::COT + 16 * (wm * CT + ct) + 4 * kk + j] = sacc;
+                    const float d = acc[ct][f][j] - mean_w[ct];
+                    qacc += ((vmask >> (4 * f + j)) & 1ull) ? d * d : 0.f;
                 }
-            __syncthreads();
-            if (tid < C::COT) {
-                float tot = 0.f;
+            qacc += __shfl_xor(qacc, 16, 64);
+            qacc += __shfl_xor(qacc, 32, 64);
+            m2_w[ct] = qacc;
+        }
+        __syncthreads();                            // everyone is done reading in_lds
+        float* red = in_lds;                        // [WN][COT][3]
+        if (kk == 0) {
 #pragma unroll
-                for (int w = 0; w < WN; ++w) tot += red[w * C::COT + tid];
-                const int m = co0 + tid;
-                if (pass == 0) {
-                    meanl[tid] = tot / cnt;
-                } else if (m < a.rows) {
-                    long slot;
-                    if (a.tconv_cout > 0) {
-                        const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
-                        slot = ((long)n * a.tconv_cout + co) * (a.tiles * 4) + tile * 4 + ab;
-                    } else {
-                        slot = ((long)n * a.rows + m) * a.tiles + tile;
-                    }
-                    float* o = a.ypart + slot * 3;
-                    o[0] = cnt; o[1] = meanl[tid]; o[2] = tot;
-                }
+            for (int ct = 0; ct < CT; ++ct) {
+                float* o = red + (wn * C::COT + 16 * (wm * CT + ct) + q) * 3;
+                o[0] = cnt_w; o[1] = mean_w[ct]; o[2] = m2_w[ct];
             }
-            __syncthreads();
-            if (pass == 0) {
+        }
+        __syncthreads();
+        if (tid < C::COT && co0 + tid < a.rows) {
+            const int m = co0 + tid;
+            float cnt = 0.f, mean = 0.f;
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
+            for (int w = 0; w < WN; ++w) { const float* r = red + (w * C::COT + tid) * 3; cnt += r[0]; mean += r[0] * r[1]; }
+            mean /= cnt;
+            float m2 = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mrow[ct][j] = meanl[16 * (wm * CT + ct) + 4 * kk + j];
+            for (int w = 0; w < WN; ++w) {
+                const float* r = red + (w * C::COT + tid) * 3;
+                const float d = r[1] - mean;
+                m2 += r[2] + r[0] * d * d;
+            }
+            long slot;
+            if (a.tconv_cout > 0) {
+                const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
+                slot = ((long)n * a.tconv_cout + co) * (a.tiles * 4) + tile * 4 + ab;
+            } else {
+                slot = ((long)n * a.rows + m) * a.tiles + tile;
+            }
+            float* o = a.ypart + slot * 3;
+            o[0] = cnt; o[1] = mean; o[2] = m2;
+        }
+    }
+    CINE_STAMP(7);
+    // ---- store raw output: PPR consecutive pixels of one row per (ct, f [, half])
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = co0 + 16 * (wm * CT + ct) + q;
+        if (m >= a.rows) continue;
+        if (a.tconv_cout > 0) {
+            const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
+            float* yb = a.y + ((long)n * a.tconv_cout + co) * (2 * a.H) * (2 * a.W);
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!((vmask >> (4 * f + j)) & 1ull)) continue;
+                    const int p = 4 * kk + j;
+                    const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+                    yb[(long)(2 * gy + (ab >> 1)) * (2 * a.W) + 2 * gx + (ab & 1)] = acc[ct][f][j];
+                }
+            continue;
+        }
+        float* yb = a.y + ((long)n * a.rows + m) * a.H * a.W;
+        const bool vec = (a.W % PPR) == 0;            // rows stay 16-byte (8-byte) aligned
+#pragma unroll
+        for (int f = 0; f < MT; ++f) {
+#pragma unroll
+            for (int hrow = 0; hrow < 4 / PPR; ++hrow) {
+                const int gy = r0 + (wn * MT + f) * C::RPF + pr0 + hrow;
+                const int j0 = hrow * PPR;
+                if (!((vmask >> (4 * f + j0)) & 1ull)) continue;
+                float* dst = yb + (long)gy * a.W + gx0;
+                if (vec) {
+                    if (PPR == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+                    else *reinterpret_cast<float2*>(dst) = make_float2(acc[ct][f][j0], acc[ct][f][j0 + 1]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PPR; ++u)
+                        if ((vmask >> (4 * f + j0 + u)) & 1ull) dst[u] = acc[ct][f][j0 + u];
+                }
             }
         }
     }
-    // ---- store raw output
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int f = 0; f < MT; ++f) {
-            if (!((vmask >> f) & 1u)) continue;
-            const int gy = r0 + (wn * MT + f) * C::RPF + qr, gx = c0 + qc;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = co0 + 16 * (wm * CT + ct) + 4 * kk + j;
-                if (m >= a.rows) continue;
-                if (a.tconv_cout > 0) {
-                    const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
-                    a.y[(((long)n * a.tconv_cout + co) * (2 * a.H) + 2 * gy + (ab >> 1)) * (2 * a.W) + 2 * gx + (ab & 1)] = acc[ct][f][j];
-                } else {
-                    a.y[(((long)n * a.rows + m) * a.H + gy) * a.W + gx] = acc[ct][f][j];
-                }
-            }
-        }
+    CINE_STAMP(8);
+    CINE_STAMP_RT(10);
 }
 
 // ---------------------------------------------------------------- weight packing

@@ -13,24 +13,6 @@
 #include "common.h"
 #include "fft_core.h"
 
-// Diagnostic builds only (tools/fft_stamps.hip defines CINE_STAMPS): per-phase s_memtime stamps
-// of workgroup-lane 0 into a side buffer.  In the product build the macro is empty.
-#ifdef CINE_STAMPS
-__device__ unsigned long long g_cine_stamps[1 << 20];
-#define CINE_STAMP(slot)                                                                          \
-    do {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        if (threadIdx.x == 0) {                                                                   \
-            unsigned long long t_;                                                                \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");             \
-            g_cine_stamps[((blockIdx.y * gridDim.x + blockIdx.x) % (1 << 16)) * 16 + (slot)] = t_; \
-        }                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    } while (0)
-#else
-#define CINE_STAMP(slot) do { } while (0)
-#endif
-
 namespace cine {
 
 __device__ const float2 TW200[200] = {
