@@ -6,7 +6,9 @@
 One "step" = one full forward of BASELINE.json configs[1] on one synthetic cine slice
 already resident in HBM: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, R=4
 (sens-map network + 6 x [sens_reduce, x-f/y-f U-Nets, sens_expand + soft DC] + final
-magnitude), fp32 end to end through the hand-written HIP kernels.
+magnitude), fp32 end to end through the hand-written HIP kernels.  Slices are independent, so a GPU
+keeps `--inflight` (default 3) of them in flight, each replaying its own hipGraph on its own stream:
+their memory-bound and MFMA-bound phases interleave.  K steps = K slices in total.
 
 N > 1: launched by torch.distributed.run, one process per GPU (RCCL = backend "nccl").
 Slices are independent, so ranks shard them with no data-path collective (weak scaling:
@@ -73,6 +75,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="independent slices in flight per GPU, each on its own HIP stream (its own hipGraph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=2)
     return ap.parse_args()
@@ -134,55 +138,66 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from cine_hip import synth
+    from cine_hip import synth, shard
+    S = max(1, min(args.inflight, args.steps))
     ex = synth.make_cine_slice(CFG["frames"], CFG["coils"], CFG["h"], CFG["w"], accel=CFG["accel"], seed=rank)
     mk, mask = ex["masked_kspace"].to(dev), ex["mask"].to(dev)
     net = build_model(dev)
     acs = net.sens_net.acs_window(mask)          # host read-back of the 1-D mask, outside capture
+    # every in-flight slice has its own input copy, stream and (when captured) graph; weights are shared
+    mks = [mk] + [mk.clone() for _ in range(S - 1)]
 
-    def forward():
-        return net(mk, mask, acs=acs)
+    def forward(i=0):
+        return net(mks[i], mask, acs=acs)
 
     out = forward()                               # also packs the weights
     torch.cuda.synchronize()
 
-    graph = None
-    if not args.no_graph:
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    graphs, gouts = [], []
+    use_graph = not args.no_graph
+    if use_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                forward()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                gout = forward()
-            step = graph.replay
-            result = lambda: gout                                     # noqa: E731
+            for i in range(S):
+                with torch.cuda.stream(streams[i]):
+                    forward(i)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=streams[i]):
+                    o = forward(i)
+                graphs.append(g); gouts.append(o)
         except Exception as e:                                        # pragma: no cover
             if rank == 0:
                 print(f"# hipGraph capture failed ({e}); running eagerly", file=sys.stderr)
-            graph = None
-    if graph is None:
-        holder = {}
+            use_graph = False
+    torch.cuda.synchronize()
 
-        def step():
-            holder["o"] = forward()
-        result = lambda: holder["o"]                                  # noqa: E731
-
-    from cine_hip import shard
     outs = torch.empty((args.steps,) + tuple(out.shape[1:]), device=dev)   # this rank's slices r, r+N, r+2N, ...
 
-    for _ in range(args.warmup):
-        step()
+    def run(nsteps, keep):
+        """nsteps slices, round-robin over the S streams; each stream is an in-order queue."""
+        for k in range(nsteps):
+            i = k % S
+            with torch.cuda.stream(streams[i]):
+                o = gouts[i] if use_graph else None
+                if use_graph:
+                    graphs[i].replay()
+                else:
+                    o = forward(i)
+                if keep:
+                    outs[k].copy_(o[0])
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+    run(args.warmup, False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step()
-        outs[i].copy_(result()[0])
+    run(args.steps, True)
     volume = shard.assemble_volume(outs, world * args.steps)          # one all-gather over xGMI (no-op at N=1)
     assert volume.shape[0] == world * args.steps
     torch.cuda.synchronize()
@@ -221,7 +236,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, "
                                "R=4 Gaussian-density Cartesian mask, sens net 8ch/3 pools, U-Net 16ch/3 pools; "
                                "one slice per step, seeded random-init weights",
-                   "launch": "hipGraph replay" if graph is not None else "eager",
+                   "launch": ("hipGraph replay" if use_graph else "eager") + f", {S} independent slices in flight on {S} HIP streams",
                    "parallelism": f"slice-sharded x{world}, one all-gather for volume assembly"},
         "roofline": roofline, "roofline_fft_dc": roof_fft,
         "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items()},
