@@ -35,10 +35,10 @@ _SIGS = {
     "cine_expand_dc_hybrid": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_sens_prologue": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_rss_normalise": (c_int, [P, c_int, c_int, c_int, c_int, P]),
-    "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, P]),
+    "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_unpack": (c_int, [P, P, P, c_int, c_int, c_int, P]),
     "cine_xfyf_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "cine_xfyf_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_xfyf_pack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_xfyf_unpack": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_conv3x3_packed_floats": (c_size_t, [c_int, c_int]),
     "cine_tconv2x2_packed_floats": (c_size_t, [c_int, c_int]),
@@ -59,6 +59,9 @@ _SIGS = {
     "cine_unet2d_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_complex_abs": (c_int, [P, P, c_long, P]),
+    "cine_dot_ws_bytes": (c_size_t, []),
+    "cine_dot": (c_int, [P, P, c_long, P, P, P]),
+    "cine_axpby_dev": (c_int, [P, P, P, c_long, P, P, P, c_float, P]),
     "cine_profile_begin": (c_int, []),
     "cine_profile_end": (c_int, [P, P, c_int]),
     "cine_profile_families": (c_int, []),

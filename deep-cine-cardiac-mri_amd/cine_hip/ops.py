@@ -149,6 +149,21 @@ def expand_dc_hybrid(img: torch.Tensor, sens: torch.Tensor, kref: torch.Tensor, 
     return out
 
 
+def expand_mask_hybrid(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Hybrid-space image of M A x: sens_expand, hard mask (reference cinenet.py:126-129), column IFFT."""
+    img = _dev(img, "image"); sens = _dev(sens, "sens_maps"); mask = _dev(mask, "mask", torch.uint8)
+    b, _, c, h, w, _ = sens.shape
+    t = img.shape[1]
+    if img.numel() != b * t * h * w * 2 or mask.numel() != b * t * h:
+        raise ValueError("expand_mask_hybrid: shape mismatch")
+    if out is None:
+        out = torch.empty((b, t, c, h, w, 2), device=img.device, dtype=img.dtype)
+    check(lib().cine_expand_dc_hybrid(img.data_ptr(), sens.data_ptr(), None, mask.data_ptr(), None,
+                                      out.data_ptr(), b, t, c, h, w, 1, _stream()), "cine_expand_dc_hybrid")
+    return out
+
+
 def sens_prologue(masked_kspace: torch.Tensor, row_lo: int, row_hi: int) -> torch.Tensor:
     """reference varnet.py:71-74: ifft2c(mask_center(mean_t(k)))."""
     k = _dev(masked_kspace, "masked_kspace")
@@ -176,52 +191,87 @@ def complex_abs(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------ CG vector ops (device-side scalars)
+_dot_ws = {}
+
+
+def dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch.dot(a.flatten(), b.flatten()) into a 1-element device tensor (reference cinenet.py:148,155,163)."""
+    a = _dev(a, "dot lhs"); b = _dev(b, "dot rhs")
+    if a.numel() != b.numel():
+        raise ValueError("dot: size mismatch")
+    if out is None:
+        out = torch.empty(1, device=a.device, dtype=a.dtype)
+    key = (a.device, torch.cuda.current_stream().cuda_stream)
+    ws = _dot_ws.get(key)
+    if ws is None:
+        ws = _dot_ws[key] = torch.empty(lib().cine_dot_ws_bytes(), device=a.device, dtype=torch.uint8)
+    check(lib().cine_dot(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "cine_dot")
+    return out
+
+
+def axpby_dev(a: torch.Tensor, b: torch.Tensor, num: Optional[torch.Tensor] = None, den: Optional[torch.Tensor] = None,
+              lambda_reg: Optional[torch.Tensor] = None, sign: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a + sign * s * b, s = num/den (device scalars) or softplus(lambda_reg)."""
+    a = _dev(a, "axpby a"); b = _dev(b, "axpby b")
+    if out is None:
+        out = torch.empty_like(a)
+    lam = None if lambda_reg is None else _dev(lambda_reg.detach(), "lambda_reg")
+    check(lib().cine_axpby_dev(out.data_ptr(), a.data_ptr(), b.data_ptr(), a.numel(), _p(num), _p(den), _p(lam),
+                               float(sign), _stream()), "cine_axpby_dev")
+    return out
+
+
 # ------------------------------------------------------------------ NormUnet halves / rotations
 def pad16(n: int) -> int:
     return ((n - 1) | 15) + 1
 
 
-def normunet_pack(x: torch.Tensor):
-    """(n,h,w,2) -> planes (n,2,hp,wp), stats (n,2,2); reference norm_unet.py:48-86."""
+def normunet_pack(x: torch.Tensor, norm: bool = True):
+    """(n,h,w,2) -> planes (n,2,hp,wp), stats (n,2,2); reference norm_unet.py:48-86.
+    norm=False: plain (re, im) -> 2-channel repack, no normalisation / padding (cinenet.py:242), stats None."""
     x = _dev(x, "normunet_pack input")
     n, h, w, _ = x.shape
-    planes = torch.empty((n, 2, pad16(h), pad16(w)), device=x.device, dtype=x.dtype)
-    stats = torch.empty((n, 2, 2), device=x.device, dtype=x.dtype)
-    check(lib().cine_normunet_pack(x.data_ptr(), planes.data_ptr(), stats.data_ptr(), n, h, w, _stream()),
+    hp, wp = (pad16(h), pad16(w)) if norm else (h, w)
+    planes = torch.empty((n, 2, hp, wp), device=x.device, dtype=x.dtype)
+    stats = torch.empty((n, 2, 2), device=x.device, dtype=x.dtype) if norm else None
+    check(lib().cine_normunet_pack(x.data_ptr(), planes.data_ptr(), _p(stats), n, h, w, int(norm), _stream()),
           "cine_normunet_pack")
     return planes, stats
 
 
-def normunet_unpack(planes: torch.Tensor, stats: torch.Tensor, h: int, w: int) -> torch.Tensor:
-    """reference norm_unet.py:88-96, 71-74, 53-57."""
-    planes = _dev(planes, "planes"); stats = _dev(stats, "stats")
+def normunet_unpack(planes: torch.Tensor, stats: Optional[torch.Tensor], h: int, w: int) -> torch.Tensor:
+    """reference norm_unet.py:88-96, 71-74, 53-57 (stats None: inverse of the plain repack)."""
+    planes = _dev(planes, "planes")
     n = planes.shape[0]
     y = torch.empty((n, h, w, 2), device=planes.device, dtype=planes.dtype)
-    check(lib().cine_normunet_unpack(planes.data_ptr(), stats.data_ptr(), y.data_ptr(), n, h, w, _stream()),
+    check(lib().cine_normunet_unpack(planes.data_ptr(), _p(stats), y.data_ptr(), n, h, w, _stream()),
           "cine_normunet_unpack")
     return y
 
 
-def xfyf_pack(img: torch.Tensor, xf: bool):
-    """reference varnet.py:202-217 + NormUnet front halves. img (b,t,h,w,2)."""
+def xfyf_pack(img: torch.Tensor, xf: bool, norm: bool = True):
+    """reference varnet.py:202-217 + NormUnet front halves (norm=True), or cinenet.py:181-195 (norm=False:
+    plain unpadded planes, stats None).  img (b,t,h,w,2)."""
     _pair(img)
     img = _dev(img, "image")
     b, t, h, w, _ = img.shape
     dev, dt = img.device, img.dtype
-    if pad16(w) == pad16(h):
+    pd = pad16 if norm else (lambda v: v)
+    if pd(w) == pd(h):
         # one allocation so equal-sized x-f / y-f plane sets can go through the U-Net launches together
-        joint = torch.empty((b * h + b * w, 2, pad16(w), pad16(t)), device=dev, dtype=dt)
+        joint = torch.empty((b * h + b * w, 2, pd(w), pd(t)), device=dev, dtype=dt)
         pxf, pyf = joint[:b * h], joint[b * h:]
     else:
-        pxf = torch.empty((b * h, 2, pad16(w), pad16(t)), device=dev, dtype=dt)
-        pyf = torch.empty((b * w, 2, pad16(h), pad16(t)), device=dev, dtype=dt)
-    sxf = torch.empty((b * h, 2, 2), device=dev, dtype=dt)
-    syf = torch.empty((b * w, 2, 2), device=dev, dtype=dt)
+        pxf = torch.empty((b * h, 2, pd(w), pd(t)), device=dev, dtype=dt)
+        pyf = torch.empty((b * w, 2, pd(h), pd(t)), device=dev, dtype=dt)
+    sxf = torch.empty((b * h, 2, 2), device=dev, dtype=dt) if norm else None
+    syf = torch.empty((b * w, 2, 2), device=dev, dtype=dt) if norm else None
     mean = torch.empty((b, h, w, 2), device=dev, dtype=dt)
     nbytes = lib().cine_xfyf_ws_bytes(b, t, h, w)
     ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    check(lib().cine_xfyf_pack(img.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), sxf.data_ptr(), syf.data_ptr(),
-                               mean.data_ptr(), b, t, h, w, int(xf), ws.data_ptr(), nbytes, _stream()),
+    check(lib().cine_xfyf_pack(img.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), _p(sxf), _p(syf),
+                               mean.data_ptr(), b, t, h, w, int(xf), int(norm), ws.data_ptr(), nbytes, _stream()),
           "cine_xfyf_pack")
     return pxf, pyf, sxf, syf, mean
 
@@ -229,8 +279,8 @@ def xfyf_pack(img: torch.Tensor, xf: bool):
 def xfyf_unpack(pxf, pyf, sxf, syf, mean, b: int, t: int, h: int, w: int, xf: bool) -> torch.Tensor:
     """reference varnet.py:229-241 + NormUnet back halves -> (b,t,1,h,w,2)."""
     out = torch.empty((b, t, 1, h, w, 2), device=pxf.device, dtype=pxf.dtype)
-    check(lib().cine_xfyf_unpack(_dev(pxf, "pxf").data_ptr(), _dev(pyf, "pyf").data_ptr(), sxf.data_ptr(),
-                                 syf.data_ptr(), mean.data_ptr(), out.data_ptr(), b, t, h, w, int(xf), _stream()),
+    check(lib().cine_xfyf_unpack(_dev(pxf, "pxf").data_ptr(), _dev(pyf, "pyf").data_ptr(), _p(sxf),
+                                 _p(syf), mean.data_ptr(), out.data_ptr(), b, t, h, w, int(xf), _stream()),
           "cine_xfyf_unpack")
     return out
 

@@ -33,6 +33,7 @@ struct PackArgs {
     const float* x; float* planes; float* stats;
     int n, I, J, Ip, Jp, pad_i, pad_j;
     int ninner; long s_outer, s_inner, si, sj;
+    int norm;                     // 0: plain re/im planes (CineNet / XPDNet feed a bare Unet), 1: NormUnet group norm
 };
 
 __global__ void normunet_pack_kernel(PackArgs a) {
@@ -40,6 +41,18 @@ __global__ void normunet_pack_kernel(PackArgs a) {
     const int n = blockIdx.x;
     const float* src = a.x + (long)(n / a.ninner) * a.s_outer + (long)(n % a.ninner) * a.s_inner;
     const int cnt = a.I * a.J;
+    if (!a.norm) {
+        float* pr0 = a.planes + (long)n * 2 * a.Ip * a.Jp;
+        float* pi0 = pr0 + (long)a.Ip * a.Jp;
+        for (int e = threadIdx.x; e < a.Ip * a.Jp; e += blockDim.x) {
+            const int ip = e / a.Jp, jp = e - ip * a.Jp;
+            const int i = ip - a.pad_i, j = jp - a.pad_j;
+            float2 v = make_float2(0.f, 0.f);
+            if (i >= 0 && i < a.I && j >= 0 && j < a.J) v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+            pr0[e] = v.x; pi0[e] = v.y;
+        }
+        return;
+    }
     // pass 1: means (norm_unet.py:64)
     float sr = 0.f, si_ = 0.f;
     for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
@@ -80,8 +93,8 @@ __global__ void normunet_pack_kernel(PackArgs a) {
 __global__ void normunet_unpack_kernel(const float* planes, const float* stats, float* y,
                                        int I, int J, int Ip, int Jp, int pad_i, int pad_j) {
     const int n = blockIdx.y;
-    const float* st = stats + (long)n * 4;
-    const float mr = st[0], sdr = st[1], mi = st[2], sdi = st[3];
+    float mr = 0.f, sdr = 1.f, mi = 0.f, sdi = 1.f;
+    if (stats) { const float* st = stats + (long)n * 4; mr = st[0]; sdr = st[1]; mi = st[2]; sdi = st[3]; }
     const float* pr = planes + (long)n * 2 * Ip * Jp;
     const float* pi = pr + (long)Ip * Jp;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < I * J; e += gridDim.x * blockDim.x) {
@@ -173,8 +186,8 @@ __global__ void xfyf_unpack_kernel(UnpackArgs a) {
     // xf plane sample n = b*H + h: (2, Wp, Tp), element [ch][w + pad_w][t + pad_t]
     // yf plane sample n = b*W + w: (2, Hp, Tp), element [ch][h + pad_h][t + pad_t]
     const long nxf = (long)b * H + h;
-    const float* sx = a.sxf + nxf * 4;
-    const float xmr = sx[0], xsr = sx[1], xmi = sx[2], xsi = sx[3];
+    float xmr = 0.f, xsr = 1.f, xmi = 0.f, xsi = 1.f;
+    if (a.sxf) { const float* sx = a.sxf + nxf * 4; xmr = sx[0]; xsr = sx[1]; xmi = sx[2]; xsi = sx[3]; }
     const float* pxr = a.pxf + nxf * 2 * a.Wp * a.Tp;
     const float* pxi = pxr + (long)a.Wp * a.Tp;
     for (int e = threadIdx.x; e < np * T; e += blockDim.x) {
@@ -183,11 +196,12 @@ __global__ void xfyf_unpack_kernel(UnpackArgs a) {
         const int qx = (w + a.pad_w) * a.Tp + t + a.pad_t;
         const float xr = pxr[qx] * xsr + xmr, xi = pxi[qx] * xsi + xmi;      // norm_unet.py:71-74
         const long nyf = (long)b * W + w;
-        const float* sy = a.syf + nyf * 4;
+        float ymr = 0.f, ysr = 1.f, ymi = 0.f, ysi = 1.f;
+        if (a.syf) { const float* sy = a.syf + nyf * 4; ymr = sy[0]; ysr = sy[1]; ymi = sy[2]; ysi = sy[3]; }
         const float* pyr = a.pyf + nyf * 2 * a.Hp * a.Tp;
         const float* pyi = pyr + (long)a.Hp * a.Tp;
         const int qy = (h + a.pad_h) * a.Tp + t + a.pad_t;
-        const float yr = pyr[qy] * sy[1] + sy[0], yi = pyi[qy] * sy[3] + sy[2];
+        const float yr = pyr[qy] * ysr + ymr, yi = pyi[qy] * ysi + ymi;
         buf[t * kPix + p] = mk(0.5f * (xr + yr), 0.5f * (xi + yi));          // varnet.py:232
     }
     __syncthreads();
@@ -274,17 +288,17 @@ static unsigned grid_for(long n, int threads, long cap = 4096) {
 
 using namespace cine;
 
-static void pad_split(int n, int& np, int& lo) {
-    np = cine_pad16(n);
-    lo = (np - n) / 2;            // floor on the left/top, ceil on the right/bottom (norm_unet.py:82-83)
+static void pad_split(int n, int& np, int& lo, bool norm = true) {
+    np = norm ? cine_pad16(n) : n;    // plain planes are not padded (cinenet.py:194-195, 242)
+    lo = (np - n) / 2;                // floor on the left/top, ceil on the right/bottom (norm_unet.py:82-83)
 }
 
-extern "C" int cine_normunet_pack(const float* x, float* planes, float* stats, int n, int h, int w, void* stream) {
-    CINE_REQUIRE(x && planes && stats, CINE_EINVAL, "cine_normunet_pack: null pointer");
+extern "C" int cine_normunet_pack(const float* x, float* planes, float* stats, int n, int h, int w, int norm, void* stream) {
+    CINE_REQUIRE(x && planes && (stats || !norm), CINE_EINVAL, "cine_normunet_pack: null pointer");
     CINE_REQUIRE(n > 0 && h > 0 && w > 0 && (long)h * w > 1, CINE_EINVAL, "cine_normunet_pack: bad sizes");
     PackArgs a{};
-    a.x = x; a.planes = planes; a.stats = stats; a.n = n; a.I = h; a.J = w;
-    pad_split(h, a.Ip, a.pad_i); pad_split(w, a.Jp, a.pad_j);
+    a.x = x; a.planes = planes; a.stats = stats; a.n = n; a.I = h; a.J = w; a.norm = norm != 0;
+    pad_split(h, a.Ip, a.pad_i, a.norm); pad_split(w, a.Jp, a.pad_j, a.norm);
     a.ninner = 1; a.s_outer = (long)h * w * 2; a.s_inner = 0; a.si = (long)w * 2; a.sj = 2;
     ProfScope prof(F_PACK, as_stream(stream));
     hipLaunchKernelGGL(normunet_pack_kernel, dim3(n), dim3(256), 0, as_stream(stream), a);
@@ -292,10 +306,10 @@ extern "C" int cine_normunet_pack(const float* x, float* planes, float* stats, i
 }
 
 extern "C" int cine_normunet_unpack(const float* planes, const float* stats, float* y, int n, int h, int w, void* stream) {
-    CINE_REQUIRE(planes && stats && y, CINE_EINVAL, "cine_normunet_unpack: null pointer");
+    CINE_REQUIRE(planes && y, CINE_EINVAL, "cine_normunet_unpack: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && h > 0 && w > 0, CINE_EINVAL, "cine_normunet_unpack: bad sizes");
     int hp, ph, wp, pw;
-    pad_split(h, hp, ph); pad_split(w, wp, pw);
+    pad_split(h, hp, ph, stats != nullptr); pad_split(w, wp, pw, stats != nullptr);
     ProfScope prof(F_PACK, as_stream(stream));
     hipLaunchKernelGGL(normunet_unpack_kernel, dim3(grid_for((long)h * w, 256, 64), n), dim3(256), 0, as_stream(stream),
                        planes, stats, y, h, w, hp, wp, ph, pw);
@@ -307,8 +321,8 @@ extern "C" size_t cine_xfyf_ws_bytes(int b, int t, int h, int w) {
 }
 
 extern "C" int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_yf, float* stats_xf, float* stats_yf,
-                              float* mean_img, int b, int t, int h, int w, int xf, void* ws, size_t ws_bytes, void* stream) {
-    CINE_REQUIRE(img && planes_xf && planes_yf && stats_xf && stats_yf && mean_img && ws, CINE_EINVAL,
+                              float* mean_img, int b, int t, int h, int w, int xf, int norm, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(img && planes_xf && planes_yf && mean_img && ws && (!norm || (stats_xf && stats_yf)), CINE_EINVAL,
                  "cine_xfyf_pack: null pointer");
     CINE_REQUIRE(b > 0 && t > 1 && h > 0 && w > 0, CINE_EINVAL, "cine_xfyf_pack: bad sizes");
     CINE_REQUIRE(t <= 64, CINE_EUNSUPPORTED, "cine_xfyf_pack: %d frames > 64", t);
@@ -324,15 +338,15 @@ extern "C" int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_
     // xf planes: sample (b, h), rows = w, cols = t          (varnet.py:216)
     PackArgs a{};
     a.x = reinterpret_cast<const float*>(X); a.planes = planes_xf; a.stats = stats_xf;
-    a.n = b * h; a.I = w; a.J = t;
-    pad_split(w, a.Ip, a.pad_i); pad_split(t, a.Jp, a.pad_j);
+    a.n = b * h; a.I = w; a.J = t; a.norm = norm != 0;
+    pad_split(w, a.Ip, a.pad_i, a.norm); pad_split(t, a.Jp, a.pad_j, a.norm);
     a.ninner = h; a.s_outer = HW * t * 2; a.s_inner = (long)w * t * 2; a.si = (long)t * 2; a.sj = 2;
     hipLaunchKernelGGL(normunet_pack_kernel, dim3(a.n), dim3(256), 0, st, a);
     if (int e = check_launch("normunet_pack_kernel(xf)")) return e;
     // yf planes: sample (b, w), rows = h, cols = t          (varnet.py:217)
     a.planes = planes_yf; a.stats = stats_yf;
     a.n = b * w; a.I = h; a.J = t;
-    pad_split(h, a.Ip, a.pad_i); pad_split(t, a.Jp, a.pad_j);
+    pad_split(h, a.Ip, a.pad_i, a.norm); pad_split(t, a.Jp, a.pad_j, a.norm);
     a.ninner = w; a.s_outer = HW * t * 2; a.s_inner = (long)t * 2; a.si = (long)w * t * 2; a.sj = 2;
     hipLaunchKernelGGL(normunet_pack_kernel, dim3(a.n), dim3(256), 0, st, a);
     return check_launch("normunet_pack_kernel(yf)");
@@ -341,7 +355,7 @@ extern "C" int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_
 extern "C" int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, const float* stats_xf,
                                 const float* stats_yf, const float* mean_img, float* out,
                                 int b, int t, int h, int w, int xf, void* stream) {
-    CINE_REQUIRE(planes_xf && planes_yf && stats_xf && stats_yf && mean_img && out, CINE_EINVAL,
+    CINE_REQUIRE(planes_xf && planes_yf && mean_img && out && ((stats_xf != nullptr) == (stats_yf != nullptr)), CINE_EINVAL,
                  "cine_xfyf_unpack: null pointer");
     CINE_REQUIRE(b > 0 && t > 1 && t <= 64 && h > 0 && w > 0 && h <= 65535 && b <= 65535, CINE_EINVAL,
                  "cine_xfyf_unpack: bad sizes");
@@ -349,7 +363,8 @@ extern "C" int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, 
     a.pxf = planes_xf; a.pyf = planes_yf; a.sxf = stats_xf; a.syf = stats_yf;
     a.mean_img = reinterpret_cast<const cf*>(mean_img); a.out = reinterpret_cast<cf*>(out);
     a.T = t; a.H = h; a.W = w; a.xf = xf;
-    pad_split(t, a.Tp, a.pad_t); pad_split(h, a.Hp, a.pad_h); pad_split(w, a.Wp, a.pad_w);
+    const bool nrm = stats_xf != nullptr;     // plain planes (no stats) are unpadded
+    pad_split(t, a.Tp, a.pad_t, nrm); pad_split(h, a.Hp, a.pad_h, nrm); pad_split(w, a.Wp, a.pad_w, nrm);
     const size_t lds = ((size_t)t * kPix + t) * sizeof(cf);
     ProfScope prof(F_PACK, as_stream(stream));
     hipLaunchKernelGGL(xfyf_unpack_kernel, dim3(ceil_div(w, kPix), h, b), dim3(256), lds, as_stream(stream), a);
@@ -383,4 +398,53 @@ extern "C" int cine_complex_abs(const float* x, float* y, long n, void* stream) 
     hipLaunchKernelGGL(complex_abs_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const cf*>(x), y, n);
     return check_launch("complex_abs_kernel");
+}
+
+// ---------------------------------------------------------------- CG vector ops (cinenet.py:136-171)
+// Scalars stay in device memory (the reference pulls them to the host with .item(), :159-169).
+namespace cine {
+constexpr int kDotBlocks = 256;
+__global__ void dot_partial_kernel(const float* a, const float* b, long n, float* part) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += a[i] * b[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ void dot_final_kernel(const float* part, int np, float* out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *out = s;
+}
+// out = a + sign * (num / den) * b      (den == nullptr -> 1; num == nullptr -> softplus(*lam))
+__global__ void axpby_dev_kernel(float* out, const float* a, const float* b, long n, const float* num, const float* den,
+                                 const float* lam, float sign) {
+    float s;
+    if (num) s = den ? *num / *den : *num;
+    else { const float l = *lam; s = l > 20.f ? l : log1pf(expf(l)); }
+    s *= sign;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + s * b[i];
+}
+}  // namespace cine
+
+extern "C" size_t cine_dot_ws_bytes(void) { return kDotBlocks * sizeof(float); }
+
+extern "C" int cine_dot(const float* a, const float* b, long n, float* out_dev, void* ws, void* stream) {
+    CINE_REQUIRE(a && b && out_dev && ws && n > 0, CINE_EINVAL, "cine_dot: bad arguments");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(kDotBlocks), dim3(256), 0, st, a, b, n, reinterpret_cast<float*>(ws));
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<const float*>(ws), kDotBlocks, out_dev);
+    return check_launch("cine_dot");
+}
+
+extern "C" int cine_axpby_dev(float* out, const float* a, const float* b, long n, const float* num_dev, const float* den_dev,
+                              const float* lambda_dev, float sign, void* stream) {
+    CINE_REQUIRE(out && a && b && n > 0 && (num_dev || lambda_dev), CINE_EINVAL, "cine_axpby_dev: bad arguments");
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(axpby_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, as_stream(stream), out, a, b, n,
+                       num_dev, den_dev, lambda_dev, sign);
+    return check_launch("axpby_dev_kernel");
 }

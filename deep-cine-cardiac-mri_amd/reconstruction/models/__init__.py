@@ -1,3 +1,4 @@
 from .varnet import SensitivityModel, VarNet, VarNetBlock
+from .cinenet import CineNet, CineNetBlock
 
-__all__ = ["SensitivityModel", "VarNet", "VarNetBlock"]
+__all__ = ["SensitivityModel", "VarNet", "VarNetBlock", "CineNet", "CineNetBlock"]

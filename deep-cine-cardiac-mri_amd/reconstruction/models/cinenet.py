@@ -1,0 +1,126 @@
+"""CineNet on the MI355X kernels: U-Net regulariser + conjugate-gradient data consistency.
+
+Drop-in for the reference's models/cinenet.py (CineNet :14, CineNetBlock :77): same constructor,
+``forward(masked_kspace, mask, sens_maps)`` signature and state-dict keys.  The normal operator
+A^H M A (HOperator :121-133) is one row-FFT kernel, one fused column FFT -> hard mask -> column IFFT
+kernel and one row-IFFT + coil-sum kernel; the CG scalars (alpha, beta, :159-169) stay in device
+memory, so the solve has no host synchronisation and can be captured in a hipGraph.
+Inference only; GPU tensors only.  ``dynamic_type='3D'`` needs the Conv3d path (not on HIP yet).
+"""
+import math
+
+import torch
+from torch import nn
+
+from cine_hip import ops
+from .denoisers.unet import Unet
+
+
+class CineNetBlock(nn.Module):
+    def __init__(self, model: nn.Module, CG_iters: int, dynamic_type: str, weight_sharing: bool):
+        super().__init__()
+        self.model = model
+        self.CG_iters = CG_iters
+        self.dynamic_type = dynamic_type
+        self.weight_sharing = weight_sharing
+        self.Softplus = nn.Softplus(1.)
+        self.lambda_reg = nn.Parameter(torch.full((1,), math.log(math.e - 1.0)))
+        self._uw = None
+
+    def sens_expand(self, x, sens_maps):
+        return ops.sens_expand_dc(x, sens_maps)
+
+    def sens_reduce(self, x, sens_maps):
+        return ops.sens_reduce(x, sens_maps)
+
+    def HOperator(self, x, mask, sens_maps, _hyb=None):
+        """A^H M A x + softplus(lambda) x  (reference cinenet.py:121-133)."""
+        hyb = ops.expand_mask_hybrid(x, sens_maps, mask, out=_hyb)
+        return ops.axpby_dev(ops.hybrid_reduce(hyb, sens_maps), x, lambda_reg=self.lambda_reg)
+
+    def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int):
+        """Hx = b with exactly CG_iters iterations (reference cinenet.py:136-171)."""
+        bsz, t, _, h, w, _ = x.shape
+        hyb = torch.empty((bsz, t, sens_maps.shape[2], h, w, 2), device=x.device, dtype=x.dtype)
+        r = ops.axpby_dev(b, self.HOperator(x, mask, sens_maps, hyb), num=_one(x), sign=-1.0)
+        p = r.clone()
+        rr_old = ops.dot(r, r)
+        x = x.clone()
+        for _ in range(CG_iters):
+            d = self.HOperator(p, mask, sens_maps, hyb)
+            pd = ops.dot(p, d)
+            ops.axpby_dev(x, p, num=rr_old, den=pd, out=x)                  # x += alpha p
+            ops.axpby_dev(r, d, num=rr_old, den=pd, sign=-1.0, out=r)       # r -= alpha d
+            rr_new = ops.dot(r, r)
+            ops.axpby_dev(r, p, num=rr_new, den=rr_old, out=p)              # p = r + beta p
+            rr_old = rr_new
+        return x
+
+    def _xfyf_weights(self):
+        if self._uw is None:
+            nets = [self.model, self.model] if self.weight_sharing else [self.model[0], self.model[1]]
+            self._uw = (ops.UnetWeights(nets), ops.UnetWeights([nets[0]]), ops.UnetWeights([nets[1]]))
+        return self._uw
+
+    def xfyf_transform(self, image_combined):
+        """(b, t, h, w, 2) -> (b, t, 1, h, w, 2); planes go to the bare U-Nets unnormalised and unpadded."""
+        b, t, h, w, _ = image_combined.shape
+        xf = self.dynamic_type == 'XF'
+        pxf, pyf, _, _, mean = ops.xfyf_pack(image_combined, xf, norm=False)
+        both, wx, wy = self._xfyf_weights()
+        if pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr():
+            joint = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+            out = ops.unet2d_forward(joint, both)
+            oxf, oyf = out[:pxf.shape[0]], out[pxf.shape[0]:]
+        else:
+            oxf, oyf = ops.unet2d_forward(pxf, wx), ops.unet2d_forward(pyf, wy)
+        return ops.xfyf_unpack(oxf, oyf, None, None, mean, b, t, h, w, xf)
+
+    def regularise(self, image_pred):
+        b, t, c, h, w, ch = image_pred.shape
+        if self.dynamic_type in ['XF', 'XT']:
+            return self.xfyf_transform(image_pred.squeeze(2))
+        if self.dynamic_type == '2D':
+            planes, _ = ops.normunet_pack(image_pred.reshape(b * t, h, w, 2), norm=False)
+            return ops.normunet_unpack(self.model(planes), None, h, w).view(b, t, 1, h, w, 2)
+        if self.dynamic_type == '3D':
+            raise NotImplementedError("CineNet dynamic_type='3D' (Conv3d U-Net) is not on the HIP path yet")
+        raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
+
+    def forward(self, image_pred, image_ref, mask, sens_maps):
+        model_out = self.regularise(image_pred)
+        rhs = ops.axpby_dev(image_ref, model_out, lambda_reg=self.lambda_reg)       # x_ref + v x_reg
+        return self.ConjGrad(model_out, rhs, mask, sens_maps, self.CG_iters)
+
+
+_ones = {}
+
+
+def _one(like: torch.Tensor) -> torch.Tensor:
+    t = _ones.get(like.device)
+    if t is None:
+        t = _ones[like.device] = torch.ones(1, device=like.device, dtype=torch.float32)
+    return t
+
+
+class CineNet(nn.Module):
+    def __init__(self, num_cascades: int = 12, CG_iters: int = 4, chans: int = 18, pools: int = 4,
+                 dynamic_type: str = 'XF', weight_sharing: bool = False):
+        super().__init__()
+        if dynamic_type in ['XF', 'XT']:
+            self.model = Unet(chans, pools, dims=2) if weight_sharing else \
+                nn.ModuleList([Unet(chans, pools, dims=2), Unet(chans, pools, dims=2)])
+        elif dynamic_type == '3D':
+            self.model = Unet(chans, pools, dims=3)
+        else:
+            self.model = Unet(chans, pools, dims=2)
+        self.cascades = nn.ModuleList(
+            [CineNetBlock(self.model, CG_iters, dynamic_type, weight_sharing) for _ in range(num_cascades)])
+
+    @torch.no_grad()
+    def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        image_pred = ops.sens_reduce(masked_kspace, sens_maps)
+        image_ref = image_pred.clone()
+        for cascade in self.cascades:
+            image_pred = cascade(image_pred, image_ref, mask, sens_maps)
+        return ops.complex_abs(image_pred.squeeze(2))

@@ -107,10 +107,13 @@ int cine_pad16(int n);
 
 /* NormUnet front half on `n` complex images (n, h, w, 2): complex_to_chan_dim (:48-51), group
  * norm with unbiased std (:59-69), zero pad to x16 (:76-86).
- * planes (n, 2, hp, wp) fp32; stats (n, 2, 2) = {mean, std} per (sample, re|im). */
-int cine_normunet_pack(const float* x, float* planes, float* stats, int n, int h, int w, void* stream);
+ * planes (n, 2, hp, wp) fp32; stats (n, 2, 2) = {mean, std} per (sample, re|im).
+ * norm == 0: just the (re, im) -> 2-channel repack with no normalisation and no padding, planes
+ * (n, 2, h, w) -- the layout CineNet feeds its bare Unet (cinenet.py:242). */
+int cine_normunet_pack(const float* x, float* planes, float* stats, int n, int h, int w, int norm, void* stream);
 
-/* NormUnet back half (:88-96 unpad, :71-74 unnorm, :53-57 chan_complex_to_last_dim). */
+/* NormUnet back half (:88-96 unpad, :71-74 unnorm, :53-57 chan_complex_to_last_dim).
+ * stats == NULL: inverse of the norm == 0 repack (cinenet.py:243-244). */
 int cine_normunet_unpack(const float* planes, const float* stats, float* y, int n, int h, int w, void* stream);
 
 /* VarNetBlock.xfyf_transform front half (varnet.py:202-217) + both NormUnet front halves:
@@ -121,10 +124,12 @@ int cine_normunet_unpack(const float* planes, const float* stats, float* y, int 
  * ws: cine_xfyf_ws_bytes(b, t, h, w). */
 size_t cine_xfyf_ws_bytes(int b, int t, int h, int w);
 int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_yf, float* stats_xf, float* stats_yf,
-                   float* mean_img, int b, int t, int h, int w, int xf, void* ws, size_t ws_bytes, void* stream);
+                   float* mean_img, int b, int t, int h, int w, int xf, int norm, void* ws, size_t ws_bytes, void* stream);
 
-/* back half (varnet.py:229-241): unpad + unnorm both planes, un-rotate, average, inverse
- * temporal DFT, add the temporal mean.  out (b, t, 1, h, w, 2). */
+/* norm == 0 gives CineNet's variant (cinenet.py:181-195): same rotation, planes (b*h, 2, w, t) /
+ * (b*w, 2, h, t) unnormalised and unpadded; stats may then be NULL (also in cine_xfyf_unpack).
+ * back half (varnet.py:229-241 / cinenet.py:206-219): unpad + unnorm both planes, un-rotate, average,
+ * inverse temporal DFT, add the temporal mean.  out (b, t, 1, h, w, 2). */
 int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, const float* stats_xf,
                      const float* stats_yf, const float* mean_img, float* out,
                      int b, int t, int h, int w, int xf, void* stream);
@@ -199,6 +204,19 @@ size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chan
 int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                         void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conjugate-gradient vector ops                reference: reconstruction/models/cinenet.py:136-171
+ * ------------------------------------------------------------------------------------------ */
+/* *out_dev = sum_i a[i] * b[i] over n floats (torch.dot on the flattened (re, im) pairs, :148,155,163);
+ * deterministic two-stage reduction; ws holds cine_dot_ws_bytes(). */
+size_t cine_dot_ws_bytes(void);
+int cine_dot(const float* a, const float* b, long n, float* out_dev, void* ws, void* stream);
+/* out = a + sign * s * b with s read from DEVICE memory: s = *num_dev / *den_dev (den_dev NULL -> 1), or
+ * s = softplus(*lambda_dev) when num_dev is NULL.  Covers x + alpha p, r - alpha d, r + beta p (:159-169),
+ * the rhs x_ref + v x_reg (:255-257) and H's "+ v x" (:133) without the reference's .item() host syncs. */
+int cine_axpby_dev(float* out, const float* a, const float* b, long n, const float* num_dev, const float* den_dev,
+                   const float* lambda_dev, float sign, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * small element-wise helpers                   reference: reconstruction/utils/math.py

@@ -215,7 +215,37 @@ def g_varnet_cfg1():
          data_seed=0, weight_seed=1)
 
 
-GENERATORS = dict(ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def g_cinenet():
+    """CineNet blocks + whole models (reference models/cinenet.py), tiny shape."""
+    t, c, h, w = 5, 3, 24, 20
+    a = {}
+    k = rnd(61, 1, t, c, h, w, 2)
+    mask = tiny_mask(t, h)
+    sens = rnd(62, 1, 1, c, h, w, 2) * 0.5
+    mk = k * mask
+    a.update(masked_kspace=mk, mask=mask, sens=sens)
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("3D", "3D", False),
+                         ("XFws", "XF", True)):
+        net = RM.CineNet(2, 3, 4, 2, dyn, ws).eval()
+        synth.fill_parameters_(net, 63)
+        for i, cas in enumerate(net.cascades):
+            cas.lambda_reg.fill_(0.1 + 0.4 * i)
+        a.update(sd_np(net, f"{tag}::sd::"))
+        a[f"{tag}_out"] = net(mk, mask, sens)
+        if tag == "XF":
+            blk = net.cascades[0]
+            img = blk.sens_reduce(mk, sens)
+            a["img"] = img
+            a["H_img"] = blk.HOperator(img, mask, sens)
+            a["xfyf"] = blk.xfyf_transform(img.squeeze(2))
+            rhs = img + 0.7 * a["xfyf"]
+            a["cg_rhs"] = rhs
+            a["cg_out"] = blk.ConjGrad(a["xfyf"], rhs, mask, sens, 3)
+            a["block_out"] = blk(img, img, mask, sens)
+    save("cinenet", **a)
+
+
+GENERATORS = dict(cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1)
 

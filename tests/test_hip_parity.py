@@ -360,3 +360,57 @@ def test_varnet_cfg2_vs_reference_golden(golden, dev):
     tgt = ex["target"][0, :, ::4, ::4].numpy()
     d_ssim = abs(evaluate.ssim(tgt, got[0].numpy()) - evaluate.ssim(tgt, ref[0].numpy()))
     assert d_ssim < 1e-4
+
+
+# ------------------------------------------------------------------ CineNet
+def test_cg_vector_ops(dev):
+    from cine_hip import ops
+    a, b = rnd(1, 3, 7, 200, 2), rnd(2, 3, 7, 200, 2)
+    d = ops.dot(a.to(dev), b.to(dev))
+    assert abs(float(d) - float(torch.dot(a.flatten().double(), b.flatten().double()))) < 1e-3
+    num, den = torch.tensor([3.0], device=dev), torch.tensor([4.0], device=dev)
+    assert rel_err(ops.axpby_dev(a.to(dev), b.to(dev), num=num, den=den, sign=-1.0).cpu(), a - 0.75 * b) < 1e-6
+    lam = torch.tensor([0.3])
+    assert rel_err(ops.axpby_dev(a.to(dev), b.to(dev), lambda_reg=lam.to(dev)).cpu(),
+                   a + torch.nn.functional.softplus(lam) * b) < 1e-6
+
+
+def test_cinenet_block_vs_reference_golden(golden, dev):
+    import reconstruction.models as M
+    g = golden("cinenet")
+    net = M.CineNet(2, 3, 4, 2, "XF")
+    net.load_state_dict(state_dict_from(g, "XF::sd::"), strict=True)
+    net.to(dev).eval()
+    blk = net.cascades[0]
+    mk, sens, mask = cuda(g["masked_kspace"], dev), cuda(g["sens"], dev), cuda(g["mask"], dev)
+    img = cuda(g["img"], dev)
+    assert rel_err(blk.HOperator(img, mask, sens).cpu(), g["H_img"]) < OP_TOL
+    assert rel_err(blk.xfyf_transform(img.squeeze(2)).cpu(), g["xfyf"]) < BLOCK_TOL
+    out = blk.ConjGrad(cuda(g["xfyf"], dev), cuda(g["cg_rhs"], dev), mask, sens, 3)
+    assert rel_err(out.cpu(), g["cg_out"]) < BLOCK_TOL
+    assert rel_err(blk(img, img, mask, sens).cpu(), g["block_out"]) < MODEL_TOL
+
+
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+def test_cinenet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
+    import reconstruction.models as M
+    g = golden("cinenet")
+    net = M.CineNet(2, 3, 4, 2, dyn, ws)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net.to(dev).eval()
+    out = net(cuda(g["masked_kspace"], dev), cuda(g["mask"], dev), cuda(g["sens"], dev))
+    assert rel_err(out.cpu(), g[f"{tag}_out"]) < MODEL_TOL
+
+
+def test_cinenet_full_size_2d_vs_oracle(dev):
+    """CineNet 2D, 2 cascades, CG 6, 15 coils x 15 frames x 200x200 (script widths) against the CPU oracle."""
+    import reconstruction.models as M
+    from oracle import cinenet_ref as C
+    from cine_hip import synth
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=6, seed=2)
+    hip = M.CineNet(2, 6, 16, 3, "2D").eval(); synth.fill_parameters_(hip, 3)
+    ref = C.CineNet(2, 6, 16, 3, "2D").eval(); ref.load_state_dict(hip.state_dict(), strict=True)
+    with torch.no_grad():
+        want = ref(ex["masked_kspace"], ex["mask"], ex["sens_maps"])
+    got = hip.to(dev)(ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["sens_maps"].to(dev)).cpu()
+    assert rel_err(got, want) < MODEL_TOL

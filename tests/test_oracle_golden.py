@@ -125,3 +125,32 @@ def test_varnet_tiny(golden, tag, dyn, ws):
         out = net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"]))
     assert out.shape == g[f"{tag}_out"].shape
     assert rel_err(out, g[f"{tag}_out"]) < 1e-4
+
+
+# ------------------------------------------------------------------ CineNet
+def test_cinenet_block_pieces(golden):
+    from oracle import cinenet_ref as C
+    g = golden("cinenet")
+    net = C.CineNet(2, 3, 4, 2, "XF").eval()
+    net.load_state_dict(state_dict_from(g, "XF::sd::"), strict=True)
+    blk = net.cascades[0]
+    mk, sens, mask = (torch.from_numpy(g[n]) for n in ("masked_kspace", "sens", "mask"))
+    with torch.no_grad():
+        img = blk.sens_reduce(mk, sens)
+        assert rel_err(img, g["img"]) < OP_TOL
+        assert rel_err(blk.HOperator(img, mask, sens), g["H_img"]) < OP_TOL
+        assert rel_err(blk.xfyf_transform(img.squeeze(2)), g["xfyf"]) < 2e-5
+        assert rel_err(blk.ConjGrad(torch.from_numpy(g["xfyf"]), torch.from_numpy(g["cg_rhs"]), mask, sens, 3), g["cg_out"]) < 2e-5
+        assert rel_err(blk(img, img, mask, sens), g["block_out"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False),
+                                        ("3D", "3D", False), ("XFws", "XF", True)])
+def test_cinenet_tiny(golden, tag, dyn, ws):
+    from oracle import cinenet_ref as C
+    g = golden("cinenet")
+    net = C.CineNet(2, 3, 4, 2, dyn, ws).eval()
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["sens"]))
+    assert rel_err(out, g[f"{tag}_out"]) < 1e-4
