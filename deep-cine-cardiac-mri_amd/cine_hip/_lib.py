@@ -49,6 +49,10 @@ _SIGS = {
     "cine_conv_stat_partials": (c_int, [c_int, c_int, c_int, c_int]),
     "cine_conv3x3_in": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int,
                                 P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_conv3x3_ex": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                P, P, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_mwcnn_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
+    "cine_mwcnn_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_tconv2x2_in": (c_int, [P, P, c_int, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_float, P]),
     "cine_conv1x1_bias": (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
@@ -59,6 +63,14 @@ _SIGS = {
     "cine_unet2d_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_complex_abs": (c_int, [P, P, c_long, P]),
+    "cine_mwcnn_pad": (c_int, [c_int, c_int, P, P]),
+    "cine_xpd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cine_xpd_pack": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_xpd_unpack": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_chanlast_to_planes": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_planes_to_chanlast": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_extract_complex": (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
+    "cine_repeat_complex": (c_int, [P, P, c_long, c_int, P]),
     "cine_dot_ws_bytes": (c_size_t, []),
     "cine_dot": (c_int, [P, P, c_long, P, P, P]),
     "cine_axpby_dev": (c_int, [P, P, P, c_long, P, P, P, c_float, P]),

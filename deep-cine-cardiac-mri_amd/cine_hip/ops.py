@@ -453,3 +453,131 @@ def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[to
                                     weights.out_ch, weights.chans, weights.pools, workspace.data_ptr(),
                                     workspace.numel(), _stream()), "cine_unet2d_forward")
     return y
+
+
+# ------------------------------------------------------------------ MWCNN / XPDNet plumbing
+def mwcnn_pad(size: int, n_scales: int):
+    """(padded, left, right) of reference utils/padding.py:26-47 for one dimension."""
+    l, r = ctypes.c_int(), ctypes.c_int()
+    padded = lib().cine_mwcnn_pad(int(size), int(n_scales), ctypes.byref(l), ctypes.byref(r))
+    return padded, l.value, r.value
+
+
+class MwcnnWeights:
+    """Packed 3x3 weights of one reference MWCNN in the order cine_mwcnn_forward expects."""
+
+    def __init__(self, net: torch.nn.Module):
+        self.net = net
+        self._key = None
+        self._keep = []
+        self._ptrs = None
+        self.nf = (ctypes.c_int * net.n_scales)(*net.n_filters_per_scale)
+        self.nc = (ctypes.c_int * net.n_scales)(*net.n_convs_per_scale)
+
+    def _params(self):
+        n = self.net
+        seq = [("c3", n.first_convs[0].layers[0].weight)]
+        for blocks in n.conv_blocks_per_scale:
+            for blk in blocks:
+                seq.append(("c3", blk.layers[0].weight))
+        seq += [("c3", n.first_convs[-1].weight), ("raw", n.first_convs[-1].bias)]
+        return seq
+
+    def pointers(self):
+        params = self._params()
+        key = tuple((p.data_ptr(), p._version) for _, p in params)
+        if key != self._key:
+            keep = [(_dev(p.detach(), "mwcnn bias") if kind == "raw" else _pack(kind, p)) for kind, p in params]
+            self._keep, self._key = keep, key
+            self._ptrs = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        return self._ptrs
+
+
+def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights) -> torch.Tensor:
+    """reference denoisers/mwcnn.py:135-179 on (n, in_ch, h, w), h and w multiples of 2^n_scales."""
+    x = _dev(x, "mwcnn input")
+    net = w.net
+    n, cin, h, wd = x.shape
+    if cin != net.in_chans:
+        raise ValueError(f"mwcnn input has {cin} channels, expected {net.in_chans}")
+    need = lib().cine_mwcnn_ws_bytes(n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters)
+    ws = torch.empty(max(need, 1), device=x.device, dtype=torch.uint8)
+    y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
+    check(lib().cine_mwcnn_forward(x.data_ptr(), y.data_ptr(), w.pointers(), n, h, wd, cin, net.out_chans, net.n_scales,
+                                   w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res),
+                                   ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward")
+    return y
+
+
+def xpd_pack(buf: torch.Tensor, extra: torch.Tensor, n_primal: int, n_scales: int, xf: bool):
+    """reference xpdnet.py:424-474: buffer (b,t,1,h,w,2n) + backward-op image -> padded x-f / y-f planes + mean."""
+    buf = _dev(buf, "image buffer"); extra = _dev(extra, "backward-op image")
+    b, t, _, h, w, ch = buf.shape
+    if ch != 2 * n_primal:
+        raise ValueError("image buffer channel count")
+    nc = n_primal + 1
+    tp, wp, hp = mwcnn_pad(t, n_scales)[0], mwcnn_pad(w, n_scales)[0], mwcnn_pad(h, n_scales)[0]
+    pxf = torch.empty((b * h, 2 * nc, wp, tp), device=buf.device, dtype=buf.dtype)
+    pyf = torch.empty((b * w, 2 * nc, hp, tp), device=buf.device, dtype=buf.dtype)
+    mean = torch.empty((b, h, w, nc, 2), device=buf.device, dtype=buf.dtype)
+    nbytes = lib().cine_xpd_ws_bytes(b, t, h, w, n_primal)
+    ws = torch.empty(nbytes, device=buf.device, dtype=torch.uint8)
+    check(lib().cine_xpd_pack(buf.data_ptr(), extra.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), mean.data_ptr(),
+                              b, t, h, w, n_primal, n_scales, int(xf), ws.data_ptr(), nbytes, _stream()), "cine_xpd_pack")
+    return pxf, pyf, mean
+
+
+def xpd_unpack(oxf, oyf, mean, b, t, h, w, n_primal, n_scales, xf) -> torch.Tensor:
+    """reference xpdnet.py:485-509 -> new image buffer (b,t,1,h,w,2n)."""
+    out = torch.empty((b, t, 1, h, w, 2 * n_primal), device=oxf.device, dtype=oxf.dtype)
+    check(lib().cine_xpd_unpack(_dev(oxf, "oxf").data_ptr(), _dev(oyf, "oyf").data_ptr(), mean.data_ptr(), out.data_ptr(),
+                                b, t, h, w, n_primal, n_scales, int(xf), _stream()), "cine_xpd_unpack")
+    return out
+
+
+def chanlast_to_planes(x: torch.Tensor, n_scales: int = 0) -> torch.Tensor:
+    """(n, h, w, c) -> (n, c, pad(h), pad(w)) zero padded per utils/padding.py (n_scales = 0: no padding)."""
+    x = _dev(x, "channel-last tensor")
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, mwcnn_pad(h, n_scales)[0], mwcnn_pad(w, n_scales)[0]), device=x.device, dtype=x.dtype)
+    check(lib().cine_chanlast_to_planes(x.data_ptr(), out.data_ptr(), n, c, h, w, n_scales, _stream()), "cine_chanlast_to_planes")
+    return out
+
+
+def planes_to_chanlast(p: torch.Tensor, h: int, w: int, n_scales: int = 0) -> torch.Tensor:
+    p = _dev(p, "planes")
+    n, c = p.shape[:2]
+    out = torch.empty((n, h, w, c), device=p.device, dtype=p.dtype)
+    check(lib().cine_planes_to_chanlast(p.data_ptr(), out.data_ptr(), n, c, h, w, n_scales, _stream()), "cine_planes_to_chanlast")
+    return out
+
+
+def extract_complex(buf: torch.Tensor, c_re: int, c_im: int) -> torch.Tensor:
+    """(..., C) real buffer -> (..., 2) complex image from channels (c_re, c_im) (reference xpdnet.py:128,161,321-326)."""
+    buf = _dev(buf, "buffer")
+    out = torch.empty(buf.shape[:-1] + (2,), device=buf.device, dtype=buf.dtype)
+    check(lib().cine_extract_complex(buf.data_ptr(), out.data_ptr(), buf.numel() // buf.shape[-1], buf.shape[-1], c_re, c_im,
+                                     _stream()), "cine_extract_complex")
+    return out
+
+
+def repeat_complex(img: torch.Tensor, n: int) -> torch.Tensor:
+    """torch.repeat_interleave(img, n, dim=-1) of a (..., 2) image (reference xpdnet.py:306-307)."""
+    img = _dev(img, "image")
+    out = torch.empty(img.shape[:-1] + (2 * n,), device=img.device, dtype=img.dtype)
+    check(lib().cine_repeat_complex(img.data_ptr(), out.data_ptr(), img.numel() // 2, n, _stream()), "cine_repeat_complex")
+    return out
+
+
+def expand_resid_hybrid(img: torch.Tensor, sens: torch.Tensor, kref: torch.Tensor, mask: torch.Tensor,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Hybrid-space image of M (A x) - k_ref: XPDNet's K step with the measurement residual
+    (reference xpdnet.py:128-131, 295-298), ready for hybrid_reduce (the masked backward operator :161-167)."""
+    img = _dev(img, "image"); sens = _dev(sens, "sens_maps"); kref = _dev(kref, "ref_kspace")
+    mask = _dev(mask, "mask", torch.uint8)
+    b, t, c, h, w, _ = kref.shape
+    if out is None:
+        out = torch.empty_like(kref)
+    check(lib().cine_expand_dc_hybrid(img.data_ptr(), sens.data_ptr(), kref.data_ptr(), mask.data_ptr(), None,
+                                      out.data_ptr(), b, t, c, h, w, 2, _stream()), "cine_expand_dc_hybrid")
+    return out

@@ -47,8 +47,13 @@ __device__ __forceinline__ float act(float x, float mean, float rstd, float slop
 
 struct Src {
     const float* x; const float* part;   // raw activations (n, c, h, w); partial stats (n, c, np, 3)
-    int c, mode, h, w, np;               // mode 0 as-is, 1 norm+LReLU, 2 norm+LReLU+avgpool2
+    int c, mode, h, w, np;               // mode 0 as-is, 1 norm+LReLU, 2 norm+LReLU+avgpool2,
+                                         // 3 Haar DWT of act(x): 4c channels at (h/2, w/2)   (mwcnn.py:224-236)
+                                         // 4 Haar IWT of act(x): c/4 channels at (2h, 2w)    (mwcnn.py:252-261)
+    int act;                             // modes 3/4: 1 = x is raw (normalise + LReLU first), 0 = use as is
 };
+// input channels a source contributes after its on-load transform
+__host__ __device__ inline int src_cin(const Src& s) { return s.mode == 3 ? 4 * s.c : (s.mode == 4 ? s.c / 4 : s.c); }
 struct ConvArgs {
     Src s0, s1;
     const float* wp0; const float* wp1; int set_split;   // samples >= set_split use wp1
@@ -56,6 +61,8 @@ struct ConvArgs {
     float* y; float* ypart;
     int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout for tconv), padded to 16
     int tconv_cout;                      // > 0: transpose-conv store mapping with this many channels
+    int add_src1;                        // 1: source 1 is ADDED to source 0 channel-wise (MWCNN skips, mwcnn.py:164,172)
+                                         //    instead of concatenated
     float slope, eps;
     int tiles_w, tiles, nchunks, fast;
 };
@@ -87,12 +94,47 @@ struct ConvCfg {
     static constexpr int MINW_ACC = (4 * CT * MT <= 64) ? 4 : 3;
     static constexpr int MINW = (4 * NPT > 36) ? MINW_ACC - 1 : MINW_ACC;   // big staging batches need room
     static_assert(RED_FLOATS <= IN_FLOATS, "reduction scratch must fit in the input tile");
-    static size_t lds_bytes(int cin) { return (size_t)(IN_FLOATS + W_FLOATS + 2 * cin) * sizeof(float); }
+    static size_t lds_bytes(int src_chans) { return (size_t)(IN_FLOATS + W_FLOATS + 2 * src_chans) * sizeof(float); }
 };
 
-// scalar (any shape) fetch of one transformed input value
-__device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int gy, int gx, float mean, float rstd, float slope) {
+// scalar (any shape) fetch of one transformed input value; st = {mean, rstd} table of THIS source's channels
+__device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int gy, int gx, const float* st, float slope) {
+    if (s.mode == 3) {                               // DWT: band = cl / c, source channel = cl % c
+        const int band = cl / s.c, c = cl - band * s.c;
+        if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;
+        const float* p = s.x + (((long)n * s.c + c) * s.h + 2 * gy) * s.w + 2 * gx;
+        float x1 = p[0], x3 = p[1], x2 = p[s.w], x4 = p[s.w + 1];          // x1 even/even, x2 odd row, x3 odd col
+        if (s.act) {
+            const float m = st[2 * c], r = st[2 * c + 1];
+            x1 = act(x1, m, r, slope); x2 = act(x2, m, r, slope); x3 = act(x3, m, r, slope); x4 = act(x4, m, r, slope);
+        }
+        x1 *= 0.5f; x2 *= 0.5f; x3 *= 0.5f; x4 *= 0.5f;
+        switch (band) {
+            case 0: return x1 + x2 + x3 + x4;        // LL
+            case 1: return -x1 - x2 + x3 + x4;       // HL
+            case 2: return -x1 + x2 - x3 + x4;       // LH
+            default: return x1 - x2 - x3 + x4;       // HH
+        }
+    }
+    if (s.mode == 4) {                               // IWT: channel cl from source channels cl + k * c/4
+        const int cq = s.c / 4, sy = gy >> 1, sx = gx >> 1;
+        if (sy >= s.h || sx >= s.w) return 0.f;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cl + k * cq;
+            float t = s.x[(((long)n * s.c + c) * s.h + sy) * s.w + sx];
+            if (s.act) t = act(t, st[2 * c], st[2 * c + 1], slope);
+            v[k] = 0.5f * t;
+        }
+        const int ry = gy & 1, rx = gx & 1;
+        if (!ry && !rx) return v[0] - v[1] - v[2] + v[3];
+        if (ry && !rx) return v[0] - v[1] + v[2] - v[3];
+        if (!ry && rx) return v[0] + v[1] - v[2] - v[3];
+        return v[0] + v[1] + v[2] + v[3];
+    }
     const long plane = (long)n * s.c + cl;
+    const float mean = st[2 * cl], rstd = st[2 * cl + 1];
     if (s.mode == 2) {
         if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;
         const float* p = s.x + (plane * s.h + 2 * gy) * s.w + 2 * gx;
@@ -139,12 +181,14 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     CINE_STAMP_RT(9);
     CINE_STAMP(0);
     // ---- prologue: merged InstanceNorm stats of every input channel; zero the tile once
-    for (int ci = tid; ci < a.cin; ci += C::NT) {
+    // table layout: source 0's channels, then source 1's (for modes 0/1/2 that is the concat channel order)
+    for (int ci = tid; ci < a.s0.c + a.s1.c; ci += C::NT) {
         const bool first = ci < a.s0.c;
         const Src& s = first ? a.s0 : a.s1;
         const int cl = first ? ci : ci - a.s0.c;
         float2 mr = make_float2(0.f, 1.f);
-        if (s.mode != 0) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+        const bool need = (s.mode == 1 || s.mode == 2) || (s.mode >= 3 && s.act);
+        if (need) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
         st_lds[2 * ci] = mr.x; st_lds[2 * ci + 1] = mr.y;
     }
     if (HALO) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                     const int gy = r0 - 1 + row, gx = side ? c0 + TW : c0 - 1;
                     float v = 0.f;
                     if (ci0 + ck < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                        v = fetch_scalar(s, n, cl0 + ck, gy, gx, st_lds[2 * (ci0 + ck)], st_lds[2 * (ci0 + ck) + 1], a.slope);
+                        v = fetch_scalar(s, n, cl0 + ck, gy, gx, st_lds + (first ? 0 : 2 * a.s0.c), a.slope);
                     in_lds[ck * C::PS + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
                 }
             }
@@ -264,8 +308,14 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                 const int gy = r0 - HALO + row, gx = c0 - HALO + xcol;
                 float v = 0.f;
                 if (ci < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    const bool f0 = ci < a.s0.c;
-                    v = fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? ci : ci - a.s0.c, gy, gx, st_lds[2 * ci], st_lds[2 * ci + 1], a.slope);
+                    const int c0n = src_cin(a.s0);
+                    if (a.add_src1) {
+                        v = fetch_scalar(a.s0, n, ci, gy, gx, st_lds, a.slope) +
+                            fetch_scalar(a.s1, n, ci, gy, gx, st_lds + 2 * a.s0.c, a.slope);
+                    } else {
+                        const bool f0 = ci < c0n;
+                        v = fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? ci : ci - c0n, gy, gx, st_lds + (f0 ? 0 : 2 * a.s0.c), a.slope);
+                    }
                 }
                 in_lds[ck * C::PS + row * C::COLS + col] = v;
             }
@@ -539,7 +589,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     std::call_once(once, [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    const size_t lds = C::lds_bytes(a.cin);
+    const size_t lds = C::lds_bytes(a.s0.c + a.s1.c);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv: %d input channels need %zu bytes of LDS", a.cin, lds);
     a.tiles_w = ceil_div(a.W, TW);
     a.tiles = a.tiles_w * ceil_div(a.H, C::TH);
@@ -547,10 +597,11 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     const int PW = C::PW;
     auto src_ok = [&](const Src& s) {
         if (s.c == 0) return true;
+        if (s.mode >= 3) return false;
         if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0;
         return s.w == a.W && s.h <= a.H;
     };
-    a.fast = (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
+    a.fast = !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     ProfScope prof(TAPS == 9 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1), st);
@@ -647,19 +698,51 @@ static int check_src(const float* x, const float* part, int c, int mode, int np,
     return CINE_OK;
 }
 
+static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                        const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                        const float* wpacked, const float* wpacked2, int set_split, const float* bias,
+                        float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+
 extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                                const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1,
                                const float* wpacked, const float* wpacked2, int set_split,
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
+    return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, 0, wpacked, wpacked2, set_split,
+                        nullptr, y, part_y, n, cout, h, w, eps, slope, stream);
+}
+
+extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                               const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                               const float* wpacked, const float* bias,
+                               float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
+    return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, add_src1, wpacked, nullptr, 0,
+                        bias, y, part_y, n, cout, h, w, eps, slope, stream);
+}
+
+// mode encoding of the extended entry: low 3 bits = mode (0..4), bit 3 set = source is raw and gets
+// InstanceNorm + LeakyReLU before the wavelet transform (modes 3/4)
+static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                        const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                        const float* wpacked, const float* wpacked2, int set_split, const float* bias,
+                        float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3x3_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3x3_in: bad sizes");
-    if (int e = check_src(x0, part0, c0, mode0, np0, "cine_conv3x3_in(src0)")) return e;
-    if (int e = check_src(x1, part1, c1, mode1, np1, "cine_conv3x3_in(src1)")) return e;
+    const int act0 = (mode0 >> 3) & 1, act1 = (mode1 >> 3) & 1;
+    mode0 &= 7; mode1 &= 7;
+    CINE_REQUIRE(mode0 <= 4 && mode1 <= 4, CINE_EINVAL, "cine_conv3x3_in: bad mode");
+    CINE_REQUIRE(mode0 != 4 || c0 % 4 == 0, CINE_EINVAL, "cine_conv3x3_in: IWT source needs 4k channels");
+    if (int e = check_src(x0, part0, c0, (mode0 >= 3 ? act0 : mode0), np0, "cine_conv3x3_in(src0)")) return e;
+    if (int e = check_src(x1, part1, c1, (mode1 >= 3 ? act1 : mode1), np1, "cine_conv3x3_in(src1)")) return e;
     ConvArgs a{};
-    a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0};
-    a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1};
+    a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, act0};
+    a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, act1};
+    a.add_src1 = add_src1 && c1 > 0;
+    a.bias = bias;
+    if (a.add_src1) CINE_REQUIRE(src_cin(a.s0) == src_cin(a.s1), CINE_EINVAL, "cine_conv3x3_in: added sources differ in channels");
     a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
-    a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
+    a.y = y; a.ypart = part_y; a.n = n;
+    a.cin = a.add_src1 ? src_cin(a.s0) : src_cin(a.s0) + src_cin(a.s1);
+    a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK3);
     return dispatch<9, kCK3>(a, as_stream(stream));
 }
@@ -673,7 +756,7 @@ extern "C" int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, i
     if (int e = check_src(x, part_x, cin, mode, np_x, "cine_tconv2x2_in")) return e;
     CINE_REQUIRE(mode != 2, CINE_EINVAL, "cine_tconv2x2_in: mode 2 not supported");
     ConvArgs a{};
-    a.s0 = Src{x, part_x, cin, mode, h, w, np_x};
+    a.s0 = Src{x, part_x, cin, mode, h, w, np_x, 0};
     a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = cin; a.rows = 4 * cout; a.rowsp = ceil_div(4 * cout, 16) * 16;
     a.tconv_cout = cout; a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
@@ -693,7 +776,7 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
         const int n0 = s ? set_split : 0, n1 = two ? (s ? n : set_split) : n;
         if (n1 <= n0) continue;
         ConvArgs a{};
-        a.s0 = Src{x + (size_t)n0 * cin * h * w, part_x ? part_x + (size_t)n0 * cin * np_x * 3 : nullptr, cin, mode, h, w, np_x};
+        a.s0 = Src{x + (size_t)n0 * cin * h * w, part_x ? part_x + (size_t)n0 * cin * np_x * 3 : nullptr, cin, mode, h, w, np_x, 0};
         a.wp0 = a.wp1 = s ? wpacked2 : wpacked; a.set_split = n1 - n0; a.bias = s ? bias2 : bias;
         a.y = y + (size_t)n0 * cout * h * w; a.ypart = nullptr; a.n = n1 - n0; a.cin = cin; a.rows = cout;
         a.rowsp = ceil_div(cout, 16) * 16; a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);

@@ -24,7 +24,7 @@ constexpr int kLinesGen = 8, kThreadsGen = 256;
 constexpr int kMaxGenericN = 400;
 constexpr int kMaxOut = 4;                          // reduce outputs per thread
 
-enum { POST_NONE = 0, POST_DC = 1, POST_HARD = 2 };
+enum { POST_NONE = 0, POST_DC = 1, POST_HARD = 2, POST_RESID = 3 };   // RESID: mask ? k - kref : 0 (xpdnet.py:128-131,295-298)
 enum { PRE_NONE = 0, PRE_SMUL = 1 };
 enum { RPOST_NONE = 0, RPOST_REDUCE = 1, RPOST_REDUCE_ABS = 2 };
 
@@ -102,7 +102,7 @@ __global__ void col_pass_kernel(ColArgs a) {
     float v = 0.f, inv1v = 1.f;
     if (POST == POST_DC) { v = softplus1(*a.lam); }
     const uint8_t* mrow = (POST != POST_NONE) ? a.mask + (img / a.coils) * H : nullptr;
-    const cf* kref = (POST == POST_DC) ? a.kref + img * H * a.W : nullptr;
+    const cf* kref = (POST == POST_DC || POST == POST_RESID) ? a.kref + img * H * a.W : nullptr;
     for (int e = tid; e < H * LINES; e += nt) {
         const int i = e / LINES, l = e % LINES, col = w0 + l;
         if (col >= a.W) continue;
@@ -115,6 +115,8 @@ __global__ void col_pass_kernel(ColArgs a) {
             }
         } else if (POST == POST_HARD) {
             if (!mrow[i]) val = mk(0.f, 0.f);
+        } else if (POST == POST_RESID) {
+            val = mrow[i] ? csub(val, kref[(long)i * a.W + col]) : mk(0.f, 0.f);
         }
         out[(long)i * a.W + col] = val;
     }
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         const uint8_t* mrow = a.mask + (img / a.coils) * 200;
 #pragma unroll
         for (int k2 = 0; k2 < 20; ++k2) mbits |= (mrow[wrap200(g2 + 10 * k2 + 100)] ? 1u : 0u) << k2;
-        if (POST == POST_DC) {
+        if (POST == POST_DC || POST == POST_RESID) {
             const cf* kref = a.kref + img * 200 * a.W;
             const int colc = min(w0 + tid % kFL, a.W - 1);
 #pragma unroll
@@ -323,6 +325,9 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         } else if (POST == POST_HARD) {
 #pragma unroll
             for (int k2 = 0; k2 < 20; ++k2) v[k2] = ((mbits >> k2) & 1u) ? v[k2] : mk(0.f, 0.f);
+        } else if (POST == POST_RESID) {
+#pragma unroll
+            for (int k2 = 0; k2 < 20; ++k2) v[k2] = ((mbits >> k2) & 1u) ? csub(v[k2], rr[k2]) : mk(0.f, 0.f);
         }
         if (!INV_AFTER) {
             if (col < a.W) {
@@ -672,6 +677,7 @@ static int expand_dc(const float* img, const float* sens, const float* kref, con
     CINE_REQUIRE(img && sens && out, CINE_EINVAL, "%s: null pointer", what);
     CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0 && c <= 32768, CINE_EINVAL, "%s: bad sizes", what);
     CINE_REQUIRE(!hard_mask || mask, CINE_EINVAL, "%s: hard_mask needs mask", what);
+    CINE_REQUIRE(hard_mask >= 0 && hard_mask <= 2 && (hard_mask != 2 || kref), CINE_EINVAL, "%s: hard_mask %d", what, hard_mask);
     CINE_REQUIRE(!kref || hard_mask || (mask && lambda_dev), CINE_EINVAL, "%s: soft DC needs mask and lambda_dev", what);
     if (int e = check_n(h, what)) return e;
     if (int e = check_n(w, what)) return e;
@@ -699,13 +705,15 @@ static int expand_dc(const float* img, const float* sens, const float* kref, con
         int e;
         if (to_hybrid && h == 200) {
             // forward column FFT -> DC -> inverse column FFT in one kernel
-            if (hard_mask) e = launch_col<POST_HARD, true>(ca, ni, false, st);
+            if (hard_mask == 2) e = launch_col<POST_RESID, true>(ca, ni, false, st);
+            else if (hard_mask) e = launch_col<POST_HARD, true>(ca, ni, false, st);
             else if (kref) e = launch_col<POST_DC, true>(ca, ni, false, st);
             else e = launch_col<POST_NONE, true>(ca, ni, false, st);
             if (e) return e;
             continue;
         }
-        if (hard_mask) e = launch_col<POST_HARD>(ca, ni, false, st);
+        if (hard_mask == 2) e = launch_col<POST_RESID>(ca, ni, false, st);
+        else if (hard_mask) e = launch_col<POST_HARD>(ca, ni, false, st);
         else if (kref) e = launch_col<POST_DC>(ca, ni, false, st);
         else e = launch_col<POST_NONE>(ca, ni, false, st);
         if (e) return e;

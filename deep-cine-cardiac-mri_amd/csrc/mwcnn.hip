@@ -1,0 +1,162 @@
+// mwcnn.hip -- launch sequence of one multi-level wavelet CNN pass (reference denoisers/mwcnn.py:135-179).
+//
+// Same storage discipline as unet.hip: every feature map is kept RAW with its InstanceNorm partial
+// statistics; normalise + LeakyReLU, the Haar DWT that replaces pooling (mwcnn.py:216-236), the Haar IWT
+// that replaces up-sampling (:240-263) and the additive skips (:164,172) are applied while the next conv
+// stages its operands.  Only the default topology of the reference is handled on this path
+// (n_first_convs = 1, res = False -- what XPDNet builds, xpdnet.py:251-262); anything else is rejected.
+#include "common.h"
+
+using namespace cine;
+
+extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
+extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                               const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                               const float* wpacked, const float* bias,
+                               float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+
+namespace {
+constexpr float kEps = 1e-5f, kSlope = 0.2f;
+constexpr int kMaxScales = 6, kMaxConvs = 8;
+enum { M_PLAIN = 0, M_ACT = 1, M_DWT_ACT = 3 | 8, M_IWT_ACT = 4 | 8 };
+
+struct Bump {
+    char* base; size_t off;
+    float* take(size_t floats) {
+        const size_t bytes = (floats * sizeof(float) + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+struct Feat { float* x; float* part; int c, h, w, np; };
+
+struct Plan {
+    int S, first, out_ch, in_ch;
+    int nf[kMaxScales], nc[kMaxScales];
+    Feat first_feat, skip[kMaxScales], scr[3];
+};
+
+// channel plan of mwcnn.py:110-132
+void chans(const Plan& p, int s, int i, int& ci, int& co) {
+    ci = co = p.nf[s];
+    if (i == 0) ci = 4 * (s == 0 ? p.first : p.nf[s - 1]);
+    if (i == 2 * p.nc[s] - 1) co = s == 0 ? (4 * p.first > 4 * p.out_ch ? 4 * p.first : 4 * p.out_ch) : 4 * p.nf[s - 1];
+}
+
+Feat alloc(Bump& b, int n, int c, int h, int w) {
+    Feat f; f.c = c; f.h = h; f.w = w; f.np = cine_conv_stat_partials(c, h, w, 0);
+    f.x = b.take((size_t)n * c * h * w); f.part = b.take((size_t)n * c * f.np * 3);
+    return f;
+}
+
+void build(Plan& p, Bump& b, int n, int h, int w) {
+    p.first_feat = alloc(b, n, p.first, h, w);
+    size_t big = 0, bigc = 0; int bigh = 0, bigw = 0;
+    for (int s = 0; s < p.S; ++s) {
+        const int hs = h >> (s + 1), ws = w >> (s + 1);
+        p.skip[s] = alloc(b, n, p.nf[s], hs, ws);
+        for (int i = 0; i < 2 * p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            const size_t e = (size_t)co * hs * ws;
+            if (e > big) { big = e; }
+            if ((size_t)co > bigc) bigc = co;
+            if (hs > bigh) { bigh = hs; bigw = ws; }
+        }
+    }
+    const int npmax = cine_conv_stat_partials(16, bigh, bigw, 0);      // most tiles per plane occur at the finest scale
+    for (int i = 0; i < 3; ++i) {
+        p.scr[i].x = b.take((size_t)n * big);
+        p.scr[i].part = b.take((size_t)n * bigc * (npmax > 0 ? npmax : 1) * 3 * 4);
+    }
+}
+
+int check_topology(int n_scales, const int* nf, const int* nc, int n_first_convs, int res) {
+    CINE_REQUIRE(n_scales >= 1 && n_scales <= kMaxScales, CINE_EUNSUPPORTED, "cine_mwcnn: n_scales %d", n_scales);
+    CINE_REQUIRE(n_first_convs == 1 && !res, CINE_EUNSUPPORTED,
+                 "cine_mwcnn: only n_first_convs = 1, res = False (the XPDNet topology) is on the HIP path");
+    for (int s = 0; s < n_scales; ++s)
+        CINE_REQUIRE(nf[s] > 0 && nc[s] >= 1 && 2 * nc[s] <= kMaxConvs, CINE_EUNSUPPORTED, "cine_mwcnn: scale %d plan", s);
+    return CINE_OK;
+}
+}  // namespace
+
+extern "C" size_t cine_mwcnn_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
+                                      const int* n_convs, int first_filters) {
+    if (n <= 0 || h <= 0 || w <= 0 || n_scales < 1 || n_scales > kMaxScales || !n_filters || !n_convs) return 0;
+    Plan p{}; p.S = n_scales; p.first = first_filters; p.out_ch = out_ch; p.in_ch = in_ch;
+    for (int s = 0; s < n_scales; ++s) { p.nf[s] = n_filters[s]; p.nc[s] = n_convs[s]; }
+    Bump b{nullptr, 0};
+    build(p, b, n, h, w);
+    return b.off;
+}
+
+// weights (host array of device pointers): first_convs[0] (packed 3x3), then for every scale s and conv i
+// conv_blocks_per_scale[s][i] (packed 3x3), then first_convs[1] weight (packed 3x3) and its bias.
+extern "C" int cine_mwcnn_forward(const float* x, float* y, const void* const* weights, int n, int h, int w,
+                                  int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                                  int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(x && y && weights && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_forward: null pointer");
+    CINE_REQUIRE(n > 0 && h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && first_filters > 0, CINE_EINVAL, "cine_mwcnn_forward: bad sizes");
+    if (int e = check_topology(n_scales, n_filters, n_convs, n_first_convs, res)) return e;
+    CINE_REQUIRE(h % (1 << n_scales) == 0 && w % (1 << n_scales) == 0, CINE_EINVAL,
+                 "cine_mwcnn_forward: %dx%d is not a multiple of 2^%d (pad_for_mwcnn first)", h, w, n_scales);
+    const size_t need = cine_mwcnn_ws_bytes(n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters);
+    CINE_REQUIRE(ws_bytes >= need, CINE_EWORKSPACE, "cine_mwcnn_forward: workspace %zu < %zu", ws_bytes, need);
+    Plan p{}; p.S = n_scales; p.first = first_filters; p.out_ch = out_ch; p.in_ch = in_ch;
+    for (int s = 0; s < n_scales; ++s) { p.nf[s] = n_filters[s]; p.nc[s] = n_convs[s]; }
+    Bump b{reinterpret_cast<char*>(ws), 0};
+    build(p, b, n, h, w);
+    // pointer index of conv_blocks_per_scale[s][i] in module order (after first_convs[0])
+    int woff[kMaxScales + 1]; woff[0] = 1;
+    for (int s = 0; s < p.S; ++s) woff[s + 1] = woff[s] + 2 * p.nc[s];
+    auto WB = [&](int s, int i) { return reinterpret_cast<const float*>(weights[woff[s] + i]); };
+    for (int i = 0; i < woff[p.S] + 2; ++i) CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_mwcnn_forward: weights[%d] is null", i);
+    auto conv = [&](const Feat& s0, int mode0, const Feat* s1, int mode1, int add, const float* wp, const float* bias,
+                    float* yo, float* po, int cout, int ho, int wo) {
+        return cine_conv3x3_ex(s0.x, s0.part, s0.np, s0.c, mode0, s0.h, s0.w,
+                               s1 ? s1->x : nullptr, s1 ? s1->part : nullptr, s1 ? s1->np : 0, s1 ? s1->c : 0, mode1,
+                               s1 ? s1->h : 0, s1 ? s1->w : 0, add, wp, bias, yo, po, n, cout, ho, wo, kEps, kSlope, stream);
+    };
+    int e;
+    // first conv block (mwcnn.py:143-146): in_ch -> first filters at full resolution
+    Feat in{const_cast<float*>(x), nullptr, in_ch, h, w, 0};
+    if ((e = conv(in, M_PLAIN, nullptr, 0, 0, reinterpret_cast<const float*>(weights[0]), nullptr, p.first_feat.x,
+                  p.first_feat.part, p.first, h, w))) return e;
+    // ---- analysis path (:148-154): DWT on load, n_convs blocks per scale
+    Feat cur = p.first_feat;
+    int scr_i = 0;
+    for (int s = 0; s < p.S; ++s) {
+        const int hs = h >> (s + 1), wsz = w >> (s + 1);
+        for (int i = 0; i < p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            const bool last = i == p.nc[s] - 1;
+            Feat out = last ? p.skip[s] : p.scr[scr_i];
+            out.c = co; out.h = hs; out.w = wsz; out.np = cine_conv_stat_partials(co, hs, wsz, 0);
+            if ((e = conv(cur, i == 0 ? M_DWT_ACT : M_ACT, nullptr, 0, 0, WB(s, i), nullptr, out.x, out.part, co, hs, wsz))) return e;
+            if (!last) scr_i = (scr_i + 1) % 3;
+            cur = out;
+        }
+    }
+    // ---- synthesis path (:156-168)
+    for (int s = p.S - 1; s >= 0; --s) {
+        const int hs = h >> (s + 1), wsz = w >> (s + 1);
+        for (int i = p.nc[s]; i < 2 * p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            Feat out = p.scr[scr_i];
+            out.c = co; out.h = hs; out.w = wsz; out.np = cine_conv_stat_partials(co, hs, wsz, 0);
+            if (i == p.nc[s] && s != p.S - 1)   // IWT of the coarser scale + this scale's last analysis feature
+                e = conv(cur, M_IWT_ACT, &p.skip[s], M_ACT, 1, WB(s, i), nullptr, out.x, out.part, co, hs, wsz);
+            else
+                e = conv(cur, M_ACT, nullptr, 0, 0, WB(s, i), nullptr, out.x, out.part, co, hs, wsz);
+            if (e) return e;
+            scr_i = (scr_i + 1) % 3;
+            cur = out;
+        }
+    }
+    // ---- final IWT + first feature, last conv with bias and no norm (:170-174, 77-83)
+    const float* wl = reinterpret_cast<const float*>(weights[woff[p.S]]);
+    const float* bl = reinterpret_cast<const float*>(weights[woff[p.S] + 1]);
+    return conv(cur, M_IWT_ACT, &p.first_feat, M_ACT, 1, wl, bl, y, nullptr, out_ch, h, w);
+}

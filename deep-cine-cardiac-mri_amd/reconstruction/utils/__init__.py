@@ -3,8 +3,9 @@ from .fftc import fft1c, ifft1c, fft2c, ifft2c, fftshift, ifftshift, roll
 from .math import (complex_abs, complex_abs_sq, complex_conj, complex_mul,
                    complex_to_real_multi_ch, real_to_complex_multi_ch, tensor_to_complex_np)
 from .coil_combine import rss, rss_complex
+from .padding import pad_for_mwcnn, unpad_from_mwcnn
 
 __all__ = ["fft1c", "ifft1c", "fft2c", "ifft2c", "fftshift", "ifftshift", "roll",
            "complex_abs", "complex_abs_sq", "complex_conj", "complex_mul",
            "complex_to_real_multi_ch", "real_to_complex_multi_ch", "tensor_to_complex_np",
-           "rss", "rss_complex"]
+           "rss", "rss_complex", "pad_for_mwcnn", "unpad_from_mwcnn"]

@@ -69,7 +69,9 @@ int cine_sens_reduce(const float* k, const float* sens, float* out, float* tmp,
  * img (b, t, 1, h, w, 2); kref (b, t, c, h, w, 2); mask uint8 (b, t, 1, h, 1, 1);
  * lambda_dev points to ONE float in device memory (cascades.N.lambda_reg).
  * kref == NULL  => plain sens_expand (no blend; mask / lambda_dev ignored).
- * hard_mask != 0 => out = mask ? kth : 0  (CineNet HOperator, cinenet.py:121-133; kref ignored). */
+ * hard_mask == 1 => out = mask ? kth : 0  (CineNet HOperator, cinenet.py:121-133; kref ignored).
+ * hard_mask == 2 => out = mask ? kth - kref : 0  (XPDNet measurement residual of the masked forward
+ *                   operator, xpdnet.py:128-131, 295-298). */
 int cine_sens_expand_dc(const float* img, const float* sens, const float* kref, const uint8_t* mask,
                         const float* lambda_dev, float* out, int b, int t, int c, int h, int w,
                         int hard_mask, void* stream);
@@ -169,6 +171,17 @@ int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mo
                     const float* wpacked, const float* wpacked2, int set_split,
                     float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
+/* Extended form used by the wavelet CNN (denoisers/mwcnn.py): source modes additionally take
+ *   3 = Haar DWT of the source (mwcnn.py:224-236): 4 c_s channels [LL, HL, LH, HH] at (h_s/2, w_s/2)
+ *   4 = Haar IWT of the source (mwcnn.py:252-261): c_s/4 channels at (2 h_s, 2 w_s)
+ * with bit 3 (| 8) set when the source is raw and must be InstanceNorm + LeakyReLU'd first;
+ * add_src1 != 0 ADDS source 1 to source 0 channel-wise (the MWCNN skips, :164,172) instead of
+ * concatenating; bias (cout) may be NULL. */
+int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                    const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                    const float* wpacked, const float* bias,
+                    float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+
 /* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)
  * and the partial statistics of y.  x mode 0|1 as above. */
 int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, int mode,
@@ -204,6 +217,41 @@ size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chan
 int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                         void* ws, size_t ws_bytes, void* stream);
+
+/* Whole MWCNN (denoisers/mwcnn.py:135-179) on n planes (n, in_ch, h, w) -> (n, out_ch, h, w); h, w
+ * multiples of 2^n_scales (utils/padding.py pads before the call).  Handles the topology XPDNet builds
+ * (n_first_convs = 1, res = False, xpdnet.py:251-262); others return CINE_EUNSUPPORTED.
+ * `weights` (host array of device pointers, all 3x3 packed with cine_pack_conv3x3):
+ *   first_convs[0]; conv_blocks_per_scale[s][i] for s, i in module order; first_convs[1] weight, bias. */
+size_t cine_mwcnn_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
+                           const int* n_convs, int first_filters);
+int cine_mwcnn_forward(const float* x, float* y, const void* const* weights, int n, int h, int w,
+                       int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                       int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * XPDNet primal-buffer plumbing                reference: models/xpdnet.py:301-326, 406-509
+ * ------------------------------------------------------------------------------------------ */
+/* utils/padding.py:26-47 for one dimension: returns the padded size (multiple of 2^n_scales); odd sizes
+ * get the extra element on the left. */
+int cine_mwcnn_pad(int size, int n_scales, int* left, int* right);
+/* I-step front half (:424-471): buf (b,t,1,h,w,2n) + backward-op image `extra` (b,t,1,h,w,2) as complex
+ * channel n, temporal mean subtract, (xf) ifftshift(fft(fftshift(.))) over t, rotation into
+ * planes_xf (b*h, 2(n+1), pad(w), pad(t)) / planes_yf (b*w, 2(n+1), pad(h), pad(t)); mean (b,h,w,n+1,2). */
+size_t cine_xpd_ws_bytes(int b, int t, int h, int w, int n_primal);
+int cine_xpd_pack(const float* buf, const float* extra, float* planes_xf, float* planes_yf, float* mean,
+                  int b, int t, int h, int w, int n_primal, int n_scales, int xf, void* ws, size_t ws_bytes, void* stream);
+/* I-step back half (:485-509) on the MWCNN outputs (2n channels): unpad, un-rotate, average, inverse
+ * temporal transform, add the temporal mean of channels 0..n-1.  out (b,t,1,h,w,2n). */
+int cine_xpd_unpack(const float* planes_xf, const float* planes_yf, const float* mean, float* out,
+                    int b, int t, int h, int w, int n_primal, int n_scales, int xf, void* stream);
+/* 2-D mode repacks (:442-444): channel-last (n, h, w, c) <-> zero-padded planes (n, c, pad(h), pad(w)). */
+int cine_chanlast_to_planes(const float* x, float* planes, int n, int c, int h, int w, int n_scales, void* stream);
+int cine_planes_to_chanlast(const float* planes, float* y, int n, int c, int h, int w, int n_scales, void* stream);
+/* complex image from channels (c_re, c_im) of a channel-last buffer (:128, :161, :321-326); and
+ * repeat_interleave of a complex image into an n-fold buffer (:306-307). */
+int cine_extract_complex(const float* buf, float* out, long npix, int c, int c_re, int c_im, void* stream);
+int cine_repeat_complex(const float* img, float* buf, long npix, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conjugate-gradient vector ops                reference: reconstruction/models/cinenet.py:136-171

@@ -24,8 +24,15 @@ def load_golden(name):
 
 
 def state_dict_from(g, prefix):
-    """Collect 'prefix<key>' arrays of a golden file into a torch state_dict."""
-    return {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix)}
+    """Collect 'prefix<key>' arrays of a golden file into a torch state_dict (expanding the alias table
+    of tensors the reference registers under several names)."""
+    import json
+    sd = {k[len(prefix):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix) and not k.endswith("__alias__")}
+    table = g.get(prefix + "__alias__")
+    if table is not None:
+        for k, canon in json.loads(bytes(table).decode()).items():
+            sd[k] = sd[canon]
+    return sd
 
 
 def rnd(seed, *shape):

@@ -31,6 +31,7 @@ sys.path.insert(0, REF)
 import reconstruction.utils as RU            # noqa: E402
 import reconstruction.models as RM           # noqa: E402
 from reconstruction.models.denoisers import unet as r_unet, norm_unet as r_norm_unet  # noqa: E402
+from reconstruction.models.denoisers import mwcnn as r_mwcnn                          # noqa: E402
 from reconstruction.data import subsample as r_sub, transforms as r_tf                 # noqa: E402
 
 sys.path.insert(0, os.path.join(ROOT, "deep-cine-cardiac-mri_amd"))
@@ -45,7 +46,19 @@ def rnd(seed, *shape):
 
 
 def sd_np(module, prefix="sd::"):
-    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+    """State dict as arrays; tensors registered under several names (the aliased cascades.N.model.* /
+    cascades.M.image_net.* entries) are stored once, the other names go into a JSON alias table."""
+    import json
+    out, first, alias = {}, {}, {}
+    for k, v in module.state_dict().items():
+        key = (v.data_ptr(), tuple(v.shape))
+        if key in first:
+            alias[k] = first[key]
+        else:
+            first[key] = k
+            out[prefix + k] = v.detach().cpu().numpy()
+    out[prefix + "__alias__"] = np.frombuffer(json.dumps(alias).encode(), dtype=np.uint8)
+    return out
 
 
 def save(name, **arrays):
@@ -245,7 +258,40 @@ def g_cinenet():
     save("cinenet", **a)
 
 
-GENERATORS = dict(cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def g_xpdnet():
+    """DWT / IWT / pad_for_mwcnn / MWCNN / XPDNet (reference denoisers/mwcnn.py, utils/padding.py, models/xpdnet.py)."""
+    a = {}
+    x = rnd(71, 2, 3, 8, 6)
+    a.update(dwt_x=x, dwt_y=r_mwcnn.DWT()(x), iwt_y=r_mwcnn.IWT()(r_mwcnn.DWT()(x)))
+    for tag, shape in (("p1", (2, 3, 20, 5)), ("p2", (1, 2, 15, 9)), ("p3", (1, 1, 16, 8))):
+        x = rnd(72, *shape)
+        y, pads = RU.pad_for_mwcnn(x, 3)
+        a[f"{tag}_x"] = x; a[f"{tag}_y"] = y; a[f"{tag}_pads"] = np.array([int(p) for p in pads])
+        a[f"{tag}_back"] = RU.unpad_from_mwcnn(y, pads)
+    mw = r_mwcnn.MWCNN(in_chans=6, out_chans=4, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1],
+                       first_conv_n_filters=8).eval()
+    synth.fill_parameters_(mw, 73, keep=())
+    x = rnd(73, 3, 6, 16, 8)
+    a.update(sd_np(mw, "mw::")); a.update(mw_x=x, mw_y=mw(x))
+    t, c, h, w = 5, 3, 24, 20
+    k = rnd(74, 1, t, c, h, w, 2)
+    mask = tiny_mask(t, h)
+    mk = k * mask
+    a.update(masked_kspace=mk, mask=mask)
+    kw = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
+              n_convs_per_scale=[1, 1], first_conv_n_filters=8, n_primal=2)
+    for tag, dyn, ws, po in (("XF", "XF", False, True), ("XT", "XT", False, True), ("2D", "2D", False, True),
+                             ("XFws", "XF", True, True), ("XFdual", "XF", False, False)):
+        net = RM.XPDNet(dynamic_type=dyn, weight_sharing=ws, primal_only=po, **kw).eval()
+        synth.fill_parameters_(net, 75, keep=())
+        a.update(sd_np(net, f"{tag}::sd::"))
+        a[f"{tag}_out"] = net(mk, mask)
+        if tag == "XF":
+            a["sens_out"] = net.sens_net(mk, mask)
+    save("xpdnet", **a)
+
+
+GENERATORS = dict(xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1)
 

@@ -414,3 +414,78 @@ def test_cinenet_full_size_2d_vs_oracle(dev):
         want = ref(ex["masked_kspace"], ex["mask"], ex["sens_maps"])
     got = hip.to(dev)(ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["sens_maps"].to(dev)).cpu()
     assert rel_err(got, want) < MODEL_TOL
+
+
+# ------------------------------------------------------------------ MWCNN / XPDNet
+def test_mwcnn_vs_reference_golden(golden, dev):
+    from reconstruction.models.denoisers import MWCNN
+    g = golden("xpdnet")
+    mw = MWCNN(in_chans=6, out_chans=4, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1],
+               first_conv_n_filters=8)
+    mw.load_state_dict(state_dict_from(g, "mw::"), strict=True)
+    mw.to(dev).eval()
+    assert rel_err(mw(cuda(g["mw_x"], dev)).cpu(), g["mw_y"]) < BLOCK_TOL
+
+
+def test_mwcnn_default_topology_vs_oracle(dev):
+    """The 3-scale default XPDNet builds (12 -> 10 channels) on cfg-3 sized planes 200 x 16."""
+    from reconstruction.models.denoisers import MWCNN
+    from oracle import xpdnet_ref as X
+    from cine_hip import synth
+    hip = MWCNN(in_chans=12, out_chans=10).eval(); synth.fill_parameters_(hip, 5, keep=())
+    ref = X.MWCNN(in_chans=12, out_chans=10).eval(); ref.load_state_dict(hip.state_dict(), strict=True)
+    x = rnd(9, 3, 12, 200, 16)
+    with torch.no_grad():
+        want = ref(x)
+    assert rel_err(hip.to(dev)(x.to(dev)).cpu(), want) < BLOCK_TOL
+
+
+def test_xpd_buffer_pack_unpack_vs_oracle(dev):
+    from cine_hip import ops
+    from oracle import xpdnet_ref as X, centered_fft as cf, complex_ops as co
+    b, t, h, w, n, ns = 1, 5, 12, 10, 2, 2
+    buf = rnd(1, b, t, 1, h, w, 2 * n); extra = rnd(2, b, t, 1, h, w, 2)
+    for xf in (True, False):
+        pxf, pyf, mean = ops.xpd_pack(buf.to(dev), extra.to(dev), n, ns, xf)
+        ib = co.complex_to_real_multi_ch(torch.cat([co.real_to_complex_multi_ch(buf, n), co.real_to_complex_multi_ch(extra, 1)], -1)).squeeze(2)
+        m = ib.mean(dim=1, keepdim=True)
+        x = ib - m
+        if xf:
+            x = co.complex_to_real_multi_ch(cf.xpd_temporal_fft(co.real_to_complex_multi_ch(x, n + 1), dim=1))
+        rxf, _ = X.pad_for_mwcnn(x.permute(0, 2, 4, 3, 1).reshape(b * h, 2 * (n + 1), w, t), ns)
+        ryf, _ = X.pad_for_mwcnn(x.permute(0, 3, 4, 2, 1).reshape(b * w, 2 * (n + 1), h, t), ns)
+        assert rel_err(pxf.cpu(), rxf) < OP_TOL and rel_err(pyf.cpu(), ryf) < OP_TOL
+        # back half on synthetic "network outputs"
+        oxf = rnd(3, b * h, 2 * n, *rxf.shape[2:]); oyf = rnd(4, b * w, 2 * n, *ryf.shape[2:])
+        got = ops.xpd_unpack(oxf.to(dev), oyf.to(dev), mean, b, t, h, w, n, ns, xf)
+        _, padx = X.pad_for_mwcnn(torch.zeros(1, 1, w, t), ns); _, pady = X.pad_for_mwcnn(torch.zeros(1, 1, h, t), ns)
+        a_ = X.unpad_from_mwcnn(oxf, padx).reshape(b, h, 1, 2 * n, w, t).permute(0, 5, 2, 1, 4, 3)
+        b_ = X.unpad_from_mwcnn(oyf, pady).reshape(b, w, 1, 2 * n, h, t).permute(0, 5, 2, 4, 1, 3)
+        out = 0.5 * (a_ + b_)
+        if xf:
+            out = co.complex_to_real_multi_ch(cf.xpd_temporal_ifft(co.real_to_complex_multi_ch(out, n), dim=1))
+        mm = m.unsqueeze(2)
+        want = out + torch.cat([mm[..., :n], mm[..., n + 1:-1]], dim=-1)
+        assert rel_err(got.cpu(), want) < OP_TOL
+
+
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+def test_xpdnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
+    import reconstruction.models as M
+    g = golden("xpdnet")
+    net = M.XPDNet(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
+                   n_convs_per_scale=[1, 1], first_conv_n_filters=8, n_primal=2, dynamic_type=dyn, weight_sharing=ws)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net.to(dev).eval()
+    mk, mask = cuda(g["masked_kspace"], dev), cuda(g["mask"], dev)
+    if tag == "XF":
+        assert rel_err(net.sens_net(mk, mask).cpu(), g["sens_out"]) < BLOCK_TOL
+    out = net(mk, mask)
+    assert rel_err(out.cpu(), g[f"{tag}_out"]) < MODEL_TOL
+    assert torch.equal(mk.cpu(), torch.from_numpy(g["masked_kspace"]))
+
+
+def test_xpdnet_dual_not_silently_wrong():
+    import reconstruction.models as M
+    with pytest.raises(NotImplementedError):
+        M.XPDNet(num_cascades=1, primal_only=False)

@@ -154,3 +154,42 @@ def test_cinenet_tiny(golden, tag, dyn, ws):
     with torch.no_grad():
         out = net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"]), torch.from_numpy(g["sens"]))
     assert rel_err(out, g[f"{tag}_out"]) < 1e-4
+
+
+# ------------------------------------------------------------------ XPDNet / MWCNN
+def test_wavelets_and_mwcnn_padding(golden):
+    from oracle import xpdnet_ref as X
+    g = golden("xpdnet")
+    x = torch.from_numpy(g["dwt_x"])
+    assert rel_err(X.DWT()(x), g["dwt_y"]) < 1e-6
+    assert rel_err(X.IWT()(X.DWT()(x)), g["iwt_y"]) < 1e-6 and rel_err(X.IWT()(X.DWT()(x)), x) < 1e-6
+    for tag in ("p1", "p2", "p3"):
+        y, pads = X.pad_for_mwcnn(torch.from_numpy(g[f"{tag}_x"]), 3)
+        assert list(pads) == list(g[f"{tag}_pads"]) and np.array_equal(y.numpy(), g[f"{tag}_y"])
+        assert np.array_equal(X.unpad_from_mwcnn(y, pads).numpy(), g[f"{tag}_back"])
+
+
+def test_mwcnn(golden):
+    from oracle import xpdnet_ref as X
+    g = golden("xpdnet")
+    mw = X.MWCNN(in_chans=6, out_chans=4, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1],
+                 first_conv_n_filters=8).eval()
+    mw.load_state_dict(state_dict_from(g, "mw::"), strict=True)
+    with torch.no_grad():
+        assert rel_err(mw(torch.from_numpy(g["mw_x"])), g["mw_y"]) < 2e-5
+
+
+@pytest.mark.parametrize("tag,dyn,ws,po", [("XF", "XF", False, True), ("XT", "XT", False, True), ("2D", "2D", False, True),
+                                           ("XFws", "XF", True, True), ("XFdual", "XF", False, False)])
+def test_xpdnet_tiny(golden, tag, dyn, ws, po):
+    from oracle import xpdnet_ref as X
+    g = golden("xpdnet")
+    net = X.XPDNet(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
+                   n_convs_per_scale=[1, 1], first_conv_n_filters=8, n_primal=2, dynamic_type=dyn,
+                   weight_sharing=ws, primal_only=po).eval()
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    with torch.no_grad():
+        out = net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"]))
+        if tag == "XF":
+            assert rel_err(net.sens_net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"])), g["sens_out"]) < 2e-5
+    assert rel_err(out, g[f"{tag}_out"]) < 1e-4
