@@ -58,6 +58,7 @@ struct ConvArgs {
     Src s0, s1;
     const float* wp0; const float* wp1; int set_split;   // samples >= set_split use wp1
     const float* bias;
+    const float* addend; int relu;       // epilogue: y = [relu](conv + bias + addend), addend shaped like y
     float* y; float* ypart;
     int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout for tconv), padded to 16
     int tconv_cout;                      // > 0: transpose-conv store mapping with this many channels
@@ -379,6 +380,25 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
             const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
             if (gy < a.H && gx < a.W) vmask |= 1ull << (4 * f + j);
         }
+    if (a.addend || a.relu) {          // CRNN cells: sum with a precomputed term, then ReLU (recurrent_varnet.py:172-178)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int m = co0 + 16 * (wm * CT + ct) + q;
+            if (m >= a.rows) continue;
+            const float* ab = a.addend ? a.addend + ((long)n * a.rows + m) * a.H * a.W : nullptr;
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!((vmask >> (4 * f + j)) & 1ull)) continue;
+                    const int p = 4 * kk + j;
+                    const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+                    float v = acc[ct][f][j];
+                    if (ab) v += ab[(long)gy * a.W + gx];
+                    acc[ct][f][j] = a.relu ? fmaxf(v, 0.f) : v;
+                }
+        }
+    }
     if (a.ypart) {
         // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass
         // per WAVE in registers (sum -> wave mean -> squared deviations), the WN wave records are merged
@@ -701,6 +721,7 @@ static int check_src(const float* x, const float* part, int c, int mode, int np,
 static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
+                        const float* addend, int relu,
                         float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
@@ -708,15 +729,15 @@ extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int
                                const float* wpacked, const float* wpacked2, int set_split,
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, 0, wpacked, wpacked2, set_split,
-                        nullptr, y, part_y, n, cout, h, w, eps, slope, stream);
+                        nullptr, nullptr, 0, y, part_y, n, cout, h, w, eps, slope, stream);
 }
 
 extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                                const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
-                               const float* wpacked, const float* bias,
+                               const float* wpacked, const float* bias, const float* addend, int relu,
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, add_src1, wpacked, nullptr, 0,
-                        bias, y, part_y, n, cout, h, w, eps, slope, stream);
+                        bias, addend, relu, y, part_y, n, cout, h, w, eps, slope, stream);
 }
 
 // mode encoding of the extended entry: low 3 bits = mode (0..4), bit 3 set = source is raw and gets
@@ -724,6 +745,7 @@ extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int
 static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
+                        const float* addend, int relu,
                         float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3x3_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3x3_in: bad sizes");
@@ -737,7 +759,7 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
     a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, act0};
     a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, act1};
     a.add_src1 = add_src1 && c1 > 0;
-    a.bias = bias;
+    a.bias = bias; a.addend = addend; a.relu = relu;
     if (a.add_src1) CINE_REQUIRE(src_cin(a.s0) == src_cin(a.s1), CINE_EINVAL, "cine_conv3x3_in: added sources differ in channels");
     a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
     a.y = y; a.ypart = part_y; a.n = n;

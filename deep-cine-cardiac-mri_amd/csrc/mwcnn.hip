@@ -12,7 +12,7 @@ using namespace cine;
 extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                                const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
-                               const float* wpacked, const float* bias,
+                               const float* wpacked, const float* bias, const float* addend, int relu,
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 namespace {
@@ -117,7 +117,7 @@ extern "C" int cine_mwcnn_forward(const float* x, float* y, const void* const* w
                     float* yo, float* po, int cout, int ho, int wo) {
         return cine_conv3x3_ex(s0.x, s0.part, s0.np, s0.c, mode0, s0.h, s0.w,
                                s1 ? s1->x : nullptr, s1 ? s1->part : nullptr, s1 ? s1->np : 0, s1 ? s1->c : 0, mode1,
-                               s1 ? s1->h : 0, s1 ? s1->w : 0, add, wp, bias, yo, po, n, cout, ho, wo, kEps, kSlope, stream);
+                               s1 ? s1->h : 0, s1 ? s1->w : 0, add, wp, bias, nullptr, 0, yo, po, n, cout, ho, wo, kEps, kSlope, stream);
     };
     int e;
     // first conv block (mwcnn.py:143-146): in_ch -> first filters at full resolution

@@ -1,0 +1,38 @@
+"""CineNet_RNN on the MI355X kernels (drop-in for the reference's models/recurrent_cinenet.py:12-187)."""
+import math
+
+import torch
+from torch import nn
+
+from cine_hip import ops
+from .cinenet import CineNetBlock
+from .recurrent_common import BCRNNlayer, CRNNBody, CRNNcell  # noqa: F401
+
+
+class CineNet_RNN(CRNNBody):
+    def __init__(self, num_cascades: int = 10, CG_iters: int = 4, chans: int = 64):
+        super().__init__()
+        self.num_cascades, self.CG_iters, self.chans = num_cascades, CG_iters, chans
+        self._make_body(2, chans, 2)
+        self.Softplus = nn.Softplus(1.)
+        self.lambda_reg = nn.Parameter(torch.full((1,), math.log(math.e - 1.0)))
+
+    # the normal operator and CG are CineNet's (reference recurrent_cinenet.py:75-125 == cinenet.py:121-171)
+    HOperator = CineNetBlock.HOperator
+    ConjGrad = CineNetBlock.ConjGrad
+
+    @torch.no_grad()
+    def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        b, t, _, h, w, _ = ref_kspace.shape
+        if b != 1:
+            raise NotImplementedError("the CRNN models assume batch 1, like the reference")
+        x_ref = ops.sens_reduce(ref_kspace, sens_maps)
+        img = x_ref
+        state = self.zero_state(t, b, h, w, img)
+        for _ in range(self.num_cascades):
+            planes, _ = ops.normunet_pack(img.view(t, h, w, 2), norm=False)
+            out, state = self.body(planes.view(t, 1, 2, h, w), state, planes)
+            x = ops.normunet_unpack(out, None, h, w).view(1, t, 1, h, w, 2)
+            rhs = ops.axpby_dev(x_ref, x, lambda_reg=self.lambda_reg)
+            img = self.ConjGrad(x, rhs, mask, sens_maps, self.CG_iters)
+        return ops.complex_abs(img.squeeze(2))

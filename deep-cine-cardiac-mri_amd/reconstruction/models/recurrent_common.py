@@ -1,0 +1,124 @@
+"""Shared body of the three convolutional-RNN hybrids on the MI355X conv kernel.
+
+The reference repeats ``CRNNcell`` / ``BCRNNlayer`` verbatim in recurrent_varnet.py:153-259,
+recurrent_cinenet.py and recurrent_xpdnet.py; here they are stated once (parameter holders with the same
+attribute names) and re-exported by the three model files.
+
+A cell update h = ReLU(i2h(x_t) + h2h(h) + ih2ih(h_iter_t)) (:172-178) is evaluated as
+  P_t = conv3x3([h_iter_t, x_t]; [W_ih2ih | W_i2h]) + (b_i2h + b_h2h + b_ih2ih)     all frames in one launch
+  h_t = ReLU(conv3x3(h_{t-1}; W_h2h) + P_t)                                           the serial chain
+so only the genuinely sequential h2h convolution sits on the critical path; every "conv_x(a) + conv_h(b)"
+pair of the body (:122-134) is one convolution over the concatenated inputs.  Sums, biases and ReLU ride in
+the MFMA kernel's epilogue.
+"""
+import torch
+from torch import nn
+
+from cine_hip import ops
+
+
+class CRNNcell(nn.Module):
+    def __init__(self, input_size: int, hidden_size: int, kernel_size: int):
+        super().__init__()
+        self.i2h = nn.Conv2d(input_size, hidden_size, kernel_size, padding=kernel_size // 2)
+        self.h2h = nn.Conv2d(hidden_size, hidden_size, kernel_size, padding=kernel_size // 2)
+        self.ih2ih = nn.Conv2d(hidden_size, hidden_size, kernel_size, padding=kernel_size // 2)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, input, hidden_iteration, hidden):
+        c = self.h2h.out_channels
+        w = ops.pack_conv3x3(torch.cat([self.ih2ih.weight, self.i2h.weight], dim=1))
+        p = ops.conv3x3_sum([hidden_iteration, input], w, (self.i2h.bias + self.h2h.bias + self.ih2ih.bias).detach(), c)
+        return ops.conv3x3_sum([hidden], ops.pack_conv3x3(self.h2h.weight), None, c, addend=p, relu=True)
+
+
+class BCRNNlayer(nn.Module):
+    def __init__(self, input_size: int, hidden_size: int, kernel_size: int):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.CRNN_model = CRNNcell(input_size, hidden_size, kernel_size)
+        self._key = None
+
+    def _packed(self):
+        cell = self.CRNN_model
+        params = (cell.i2h.weight, cell.h2h.weight, cell.ih2ih.weight, cell.i2h.bias, cell.h2h.bias, cell.ih2ih.bias)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key != self._key:
+            self._w_in = ops.pack_conv3x3(torch.cat([cell.ih2ih.weight, cell.i2h.weight], dim=1))
+            self._w_hh = ops.pack_conv3x3(cell.h2h.weight)
+            self._bias = (cell.i2h.bias + cell.h2h.bias + cell.ih2ih.bias).detach().contiguous()
+            self._key = key
+        return self._w_in, self._w_hh, self._bias
+
+    def forward(self, input: torch.Tensor, hidden_iteration: torch.Tensor) -> torch.Tensor:
+        """input (t, b, ch, h, w), hidden_iteration (t, b, hidden, h, w) -> (t, b, hidden, h, w)."""
+        t, b, ch, h, w = input.shape
+        c = self.hidden_size
+        w_in, w_hh, bias = self._packed()
+        p = ops.conv3x3_sum([hidden_iteration.reshape(t * b, c, h, w), input.reshape(t * b, ch, h, w)], w_in, bias, c)
+        p = p.view(t, b, c, h, w)
+        zero = torch.zeros((b, c, h, w), device=p.device, dtype=p.dtype)       # hid_init (:236)
+        out = torch.empty_like(p)
+        hid = zero
+        for i in range(t):                                                      # forward pass over time (:241-245)
+            hid = ops.conv3x3_sum([hid], w_hh, None, c, addend=p[i], relu=True)
+            out[i].copy_(hid)
+        hid = zero
+        for i in range(t - 1, -1, -1):                                          # backward pass, same cell (:247-252)
+            hid = ops.conv3x3_sum([hid], w_hh, None, c, addend=p[i], relu=True)
+            ops.axpby_dev(out[i], hid, num=_one(hid), out=out[i])               # output_f + output_b (:254)
+        return out
+
+
+_ones = {}
+
+
+def _one(like: torch.Tensor) -> torch.Tensor:
+    t = _ones.get(like.device)
+    if t is None:
+        t = _ones[like.device] = torch.ones(1, device=like.device, dtype=torch.float32)
+    return t
+
+
+class CRNNBody(nn.Module):
+    """BCRNN + three (conv_x + conv_h -> ReLU) layers + conv4 (reference recurrent_varnet.py:48-63, 116-136)."""
+
+    def _make_body(self, in_ch: int, chans: int, out_ch: int):
+        self.bcrnn = BCRNNlayer(input_size=in_ch, hidden_size=chans, kernel_size=3)
+        for k in (1, 2, 3):
+            setattr(self, f"conv{k}_x", nn.Conv2d(chans, chans, 3, padding=3 // 2))
+            setattr(self, f"conv{k}_h", nn.Conv2d(chans, chans, 3, padding=3 // 2))
+        self.conv4_x = nn.Conv2d(chans, out_ch, 3, padding=3 // 2)
+        self.relu = nn.ReLU(inplace=True)
+        self._body_key = None
+
+    def _body_packed(self):
+        convs = [getattr(self, f"conv{k}_{s}") for k in (1, 2, 3) for s in ("x", "h")] + [self.conv4_x]
+        key = tuple((p.data_ptr(), p._version) for c in convs for p in (c.weight, c.bias))
+        if key != self._body_key:
+            self._pairs = []
+            for k in (1, 2, 3):
+                cx, chh = getattr(self, f"conv{k}_x"), getattr(self, f"conv{k}_h")
+                self._pairs.append((ops.pack_conv3x3(torch.cat([cx.weight, chh.weight], dim=1)),
+                                    (cx.bias + chh.bias).detach().contiguous()))
+            self._w4 = ops.pack_conv3x3(self.conv4_x.weight)
+            self._b4 = self.conv4_x.bias.detach().contiguous()
+            self._body_key = key
+        return self._pairs, self._w4, self._b4
+
+    def zero_state(self, t: int, b: int, h: int, w: int, like: torch.Tensor):
+        return [torch.zeros(t * b, self.chans, h, w, device=like.device, dtype=like.dtype) for _ in range(4)]
+
+    def body(self, x: torch.Tensor, state, residual: torch.Tensor):
+        """x (t, b, ch, h, w); state [x0..x3] of the previous cascade; returns (residual + conv4(x3), new state)."""
+        t, b, _, h, w = x.shape
+        c = self.chans
+        pairs, w4, b4 = self._body_packed()
+        x0 = self.bcrnn(x, state[0].view(t, b, c, h, w)).view(t * b, c, h, w)
+        feats = [x0]
+        cur = x0
+        for k in range(3):
+            cur = ops.conv3x3_sum([cur, state[k + 1]], pairs[k][0], pairs[k][1], c, relu=True)
+            feats.append(cur)
+        out = ops.conv3x3_sum([cur], w4, b4, self.conv4_x.out_channels, addend=residual)
+        return out, feats

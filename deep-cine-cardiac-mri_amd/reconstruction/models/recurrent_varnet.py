@@ -1,0 +1,36 @@
+"""VarNet_RNN on the MI355X kernels (drop-in for the reference's models/recurrent_varnet.py:13-150)."""
+import math
+
+import torch
+from torch import nn
+
+from cine_hip import ops
+from .recurrent_common import BCRNNlayer, CRNNBody, CRNNcell  # noqa: F401  (re-exported like the reference)
+from .varnet import SensitivityModel
+
+
+class VarNet_RNN(CRNNBody):
+    def __init__(self, num_cascades: int = 12, sens_chans: int = 8, sens_pools: int = 4, chans: int = 18):
+        super().__init__()
+        self.num_cascades, self.chans = num_cascades, chans
+        self.sens_net = SensitivityModel(sens_chans, sens_pools)
+        self._make_body(2, chans, 2)
+        self.Softplus = nn.Softplus(1.)
+        self.lambda_reg = nn.Parameter(torch.full((1,), math.log(math.e - 1.0)))
+
+    @torch.no_grad()
+    def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
+        sens_maps = self.sens_net(ref_kspace, mask, acs)
+        b, t, _, h, w, _ = ref_kspace.shape
+        if b != 1:
+            raise NotImplementedError("the CRNN models assume batch 1, like the reference (recurrent_varnet.py:110-113)")
+        hyb = ops.kspace_to_hybrid(ref_kspace)
+        img = ops.hybrid_reduce(hyb, sens_maps)                                   # (1, t, 1, h, w, 2)
+        state = self.zero_state(t, b, h, w, img)
+        for _ in range(self.num_cascades):
+            planes, _ = ops.normunet_pack(img.view(t, h, w, 2), norm=False)      # (t, 2, h, w)
+            out, state = self.body(planes.view(t, 1, 2, h, w), state, planes)
+            new_img = ops.normunet_unpack(out, None, h, w).view(1, t, 1, h, w, 2)
+            ops.expand_dc_hybrid(new_img, sens_maps, ref_kspace, mask, self.lambda_reg, out=hyb)   # :80-90
+            img = ops.hybrid_reduce(hyb, sens_maps)
+        return ops.complex_abs(img.squeeze(2))

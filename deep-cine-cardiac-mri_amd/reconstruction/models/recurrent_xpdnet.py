@@ -1,0 +1,48 @@
+"""XPDNet_RNN on the MI355X kernels (drop-in for the reference's models/recurrent_xpdnet.py:14-240)."""
+import torch
+from torch import nn
+
+from cine_hip import ops
+from .recurrent_common import BCRNNlayer, CRNNBody, CRNNcell  # noqa: F401
+from .xpdnet import BackwardOperator, ForwardOperator, SensitivityModel
+
+
+class XPDNet_RNN(CRNNBody):
+    def __init__(self, num_cascades: int = 12, sens_chans: int = 8, sens_pools: int = 4, chans: int = 18,
+                 primal_only: bool = True, n_primal: int = 5, n_dual: int = 1):
+        super().__init__()
+        if not primal_only:
+            raise NotImplementedError("XPDNet_RNN(primal_only=False) needs KSpaceCNN (Conv3d), which is not on the HIP path")
+        self.num_cascades, self.chans = num_cascades, chans
+        self.i_buffer_mode, self.k_buffer_mode = True, False
+        self.i_buffer_size, self.k_buffer_size = n_primal, 1
+        self.backward_op = BackwardOperator(masked=False)
+        self.forward_op = ForwardOperator(masked=True)
+        self.sens_net = SensitivityModel(sens_chans, sens_pools)
+        self._make_body(2 * (n_primal + 1), chans, 2 * n_primal)
+        self.kspace_net = [self.measurements_residual for _ in range(num_cascades)]
+
+    @staticmethod
+    def measurements_residual(concat_kspace: torch.Tensor) -> torch.Tensor:
+        return concat_kspace[..., [0, 2]] - concat_kspace[..., [1, 3]]
+
+    @torch.no_grad()
+    def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
+        n = self.i_buffer_size
+        b, t, _, h, w, _ = ref_kspace.shape
+        if b != 1:
+            raise NotImplementedError("the CRNN models assume batch 1, like the reference")
+        sens_maps = self.sens_net(ref_kspace, mask, acs)
+        image_buffer = ops.repeat_complex(ops.sens_reduce(ref_kspace, sens_maps), n)       # (1, t, 1, h, w, 2n)
+        hyb = torch.empty_like(ref_kspace)
+        state = self.zero_state(t, b, h, w, image_buffer)
+        keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]                  # channels [:n] and [n+1:-1]
+        for _ in range(self.num_cascades):
+            x0 = ops.extract_complex(image_buffer, 0, n)
+            ops.expand_resid_hybrid(x0, sens_maps, ref_kspace, mask, out=hyb)               # K step (:110-140)
+            bwd = ops.hybrid_reduce(hyb, sens_maps)                                         # masked backward op (:142-163)
+            cat = torch.cat([image_buffer[..., :n], bwd[..., :1], image_buffer[..., n:], bwd[..., 1:]], dim=-1)
+            planes = ops.chanlast_to_planes(cat.view(t, h, w, 2 * (n + 1)))                 # (t, 2(n+1), h, w)
+            out, state = self.body(planes.view(t, 1, 2 * (n + 1), h, w), state, planes[:, keep].contiguous())
+            image_buffer = ops.planes_to_chanlast(out, h, w).view(1, t, 1, h, w, 2 * n)
+        return ops.complex_abs(ops.extract_complex(image_buffer, 0, n).squeeze(2))

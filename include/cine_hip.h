@@ -176,10 +176,13 @@ int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mo
  *   4 = Haar IWT of the source (mwcnn.py:252-261): c_s/4 channels at (2 h_s, 2 w_s)
  * with bit 3 (| 8) set when the source is raw and must be InstanceNorm + LeakyReLU'd first;
  * add_src1 != 0 ADDS source 1 to source 0 channel-wise (the MWCNN skips, :164,172) instead of
- * concatenating; bias (cout) may be NULL. */
+ * concatenating; bias (cout) may be NULL.
+ * Epilogue for the convolutional-RNN cells (models/recurrent_varnet.py:153-200): y = conv + bias + addend,
+ * then ReLU when relu != 0; addend (n, cout, h, w) may be NULL.  A sum of convolutions of different inputs
+ * (i2h + h2h + ih2ih, :172-178) is one convolution over the concatenated inputs with concatenated weights. */
 int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                     const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
-                    const float* wpacked, const float* bias,
+                    const float* wpacked, const float* bias, const float* addend, int relu,
                     float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 /* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)

@@ -291,7 +291,25 @@ def g_xpdnet():
     save("xpdnet", **a)
 
 
-GENERATORS = dict(xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def g_rnn():
+    """VarNet_RNN / CineNet_RNN / XPDNet_RNN (reference models/recurrent_*.py), tiny shape."""
+    t, c, h, w = 5, 3, 24, 20
+    a = {}
+    k = rnd(81, 1, t, c, h, w, 2)
+    mask = tiny_mask(t, h)
+    sens = rnd(82, 1, 1, c, h, w, 2) * 0.5
+    mk = k * mask
+    a.update(masked_kspace=mk, mask=mask, sens=sens)
+    net = RM.VarNet_RNN(3, 4, 2, 6).eval(); synth.fill_parameters_(net, 83); net.lambda_reg.fill_(0.4)
+    a.update(sd_np(net, "varnet_rnn::sd::")); a["varnet_rnn_out"] = net(mk, mask)
+    net = RM.CineNet_RNN(3, 3, 6).eval(); synth.fill_parameters_(net, 84); net.lambda_reg.fill_(0.4)
+    a.update(sd_np(net, "cinenet_rnn::sd::")); a["cinenet_rnn_out"] = net(mk, mask, sens)
+    net = RM.XPDNet_RNN(3, 4, 2, 6, True, 2, 1).eval(); synth.fill_parameters_(net, 85, keep=())
+    a.update(sd_np(net, "xpdnet_rnn::sd::")); a["xpdnet_rnn_out"] = net(mk, mask)
+    save("rnn", **a)
+
+
+GENERATORS = dict(rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1)
 

@@ -489,3 +489,30 @@ def test_xpdnet_dual_not_silently_wrong():
     import reconstruction.models as M
     with pytest.raises(NotImplementedError):
         M.XPDNet(num_cascades=1, primal_only=False)
+
+
+# ------------------------------------------------------------------ convolutional-RNN hybrids
+def test_conv3x3_sum_epilogue_vs_torch(dev):
+    """Sum of two biased convolutions + addend + ReLU as one launch (the CRNN cell update)."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    a, b = rnd(1, 2, 16, 24, 20), rnd(2, 2, 2, 24, 20)
+    wa, wb = rnd(3, 16, 16, 3, 3) / 12, rnd(4, 16, 2, 3, 3) / 4
+    ba, bb, add = rnd(5, 16), rnd(6, 16), rnd(7, 2, 16, 24, 20)
+    w = ops.pack_conv3x3(torch.cat([wa, wb], 1).to(dev))
+    y = ops.conv3x3_sum([a.to(dev), b.to(dev)], w, (ba + bb).to(dev), 16, addend=add.to(dev), relu=True)
+    ref = F.relu(F.conv2d(a, wa, ba, padding=1) + F.conv2d(b, wb, bb, padding=1) + add)
+    assert rel_err(y.cpu(), ref) < OP_TOL
+
+
+def test_rnn_models_vs_reference_golden(golden, dev):
+    import reconstruction.models as M
+    g = golden("rnn")
+    mk, mask, sens = cuda(g["masked_kspace"], dev), cuda(g["mask"], dev), cuda(g["sens"], dev)
+    net = M.VarNet_RNN(3, 4, 2, 6); net.load_state_dict(state_dict_from(g, "varnet_rnn::sd::"), strict=True)
+    assert rel_err(net.to(dev).eval()(mk, mask).cpu(), g["varnet_rnn_out"]) < MODEL_TOL
+    net = M.CineNet_RNN(3, 3, 6); net.load_state_dict(state_dict_from(g, "cinenet_rnn::sd::"), strict=True)
+    assert rel_err(net.to(dev).eval()(mk, mask, sens).cpu(), g["cinenet_rnn_out"]) < MODEL_TOL
+    net = M.XPDNet_RNN(3, 4, 2, 6, True, 2, 1); net.load_state_dict(state_dict_from(g, "xpdnet_rnn::sd::"), strict=True)
+    assert rel_err(net.to(dev).eval()(mk, mask).cpu(), g["xpdnet_rnn_out"]) < MODEL_TOL
+    assert torch.equal(mk.cpu(), torch.from_numpy(g["masked_kspace"]))

@@ -193,3 +193,17 @@ def test_xpdnet_tiny(golden, tag, dyn, ws, po):
         if tag == "XF":
             assert rel_err(net.sens_net(torch.from_numpy(g["masked_kspace"]), torch.from_numpy(g["mask"])), g["sens_out"]) < 2e-5
     assert rel_err(out, g[f"{tag}_out"]) < 1e-4
+
+
+# ------------------------------------------------------------------ CRNN hybrids
+def test_rnn_models(golden):
+    from oracle import recurrent_ref as R
+    g = golden("rnn")
+    mk, mask, sens = (torch.from_numpy(g[n]) for n in ("masked_kspace", "mask", "sens"))
+    with torch.no_grad():
+        net = R.VarNet_RNN(3, 4, 2, 6).eval(); net.load_state_dict(state_dict_from(g, "varnet_rnn::sd::"), strict=True)
+        assert rel_err(net(mk, mask), g["varnet_rnn_out"]) < 1e-4
+        net = R.CineNet_RNN(3, 3, 6).eval(); net.load_state_dict(state_dict_from(g, "cinenet_rnn::sd::"), strict=True)
+        assert rel_err(net(mk, mask, sens), g["cinenet_rnn_out"]) < 1e-4
+        net = R.XPDNet_RNN(3, 4, 2, 6, True, 2, 1).eval(); net.load_state_dict(state_dict_from(g, "xpdnet_rnn::sd::"), strict=True)
+        assert rel_err(net(mk, mask), g["xpdnet_rnn_out"]) < 1e-4
