@@ -63,6 +63,20 @@ _SIGS = {
     "cine_unet2d_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_complex_abs": (c_int, [P, P, c_long, P]),
+    "cine_conv3d_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_tconv3d_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_pack_conv3d": (c_int, [P, P, c_int, c_int, P]),
+    "cine_pack_tconv3d": (c_int, [P, P, c_int, c_int, P]),
+    "cine_conv_stat_partials3d": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "cine_conv3d_in": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                               P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_tconv3d_in": (c_int, [P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_conv1x1x1_bias": (c_int, [P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_instnorm_merge": (c_int, [P, P, c_long, c_int, P]),
+    "cine_unet3d_ws_bytes": (c_size_t, [c_int] * 8),
+    "cine_unet3d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_normunet3d_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_normunet3d_unpack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_mwcnn_pad": (c_int, [c_int, c_int, P, P]),
     "cine_xpd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "cine_xpd_pack": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

@@ -301,6 +301,18 @@ def _pack(kind: str, w: torch.Tensor) -> torch.Tensor:
             raise ValueError("pack_tconv2x2 expects a (cin, cout, 2, 2) weight")
         out = torch.empty(L.cine_tconv2x2_packed_floats(cin, cout), device=w.device, dtype=w.dtype)
         check(L.cine_pack_tconv2x2(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "cine_pack_tconv2x2")
+    elif kind == "c27":
+        cout, cin = w.shape[:2]
+        if tuple(w.shape[2:]) != (3, 3, 3):
+            raise ValueError("pack_conv3d expects a (cout, cin, 3, 3, 3) weight")
+        out = torch.empty(L.cine_conv3d_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_conv3d(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv3d")
+    elif kind == "tc3":
+        cin, cout = w.shape[:2]
+        if tuple(w.shape[2:]) != (2, 2, 2):
+            raise ValueError("pack_tconv3d expects a (cin, cout, 2, 2, 2) weight")
+        out = torch.empty(L.cine_tconv3d_packed_floats(cin, cout), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_tconv3d(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "cine_pack_tconv3d")
     elif kind == "c1":
         cout, cin = w.shape[0], w.shape[1]
         out = torch.empty(L.cine_conv1x1_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
@@ -411,12 +423,13 @@ class UnetWeights:
         out = []
         for u in self.unets:
             seq = []
+            k3, kt = ("c3", "tc") if getattr(u, "dims", 2) == 2 else ("c27", "tc3")
             for blk in list(u.down_sample_layers) + [u.conv]:
-                seq += [("c3", blk.layers[0].weight), ("c3", blk.layers[4].weight)]
+                seq += [(k3, blk.layers[0].weight), (k3, blk.layers[4].weight)]
             for i, (tc, uc) in enumerate(zip(u.up_transpose_conv, u.up_conv)):
                 last = i == len(u.up_conv) - 1
                 blk = uc[0] if last else uc
-                seq += [("tc", tc.layers[0].weight), ("c3", blk.layers[0].weight), ("c3", blk.layers[4].weight)]
+                seq += [(kt, tc.layers[0].weight), (k3, blk.layers[0].weight), (k3, blk.layers[4].weight)]
             fin = u.up_conv[-1][1]
             seq += [("c1", fin.weight), ("raw", fin.bias)]
             out.append(seq)
@@ -597,4 +610,42 @@ def conv3x3_sum(srcs: Sequence, wpacked: torch.Tensor, bias: Optional[torch.Tens
                                 _p(x1), None, 0, 0 if x1 is None else x1.shape[1], 0, h, w, 0,
                                 wpacked.data_ptr(), _p(bias), _p(addend), int(relu),
                                 y.data_ptr(), None, n, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3x3_ex")
+    return y
+
+
+# ------------------------------------------------------------------ 3-D U-Net path (dynamic_type '3D')
+def normunet3d_pack(x: torch.Tensor, norm: bool = True):
+    """(n, t, h, w, 2) -> planes (n, 2, Tp, Hp, Wp) [+ stats (n, 2, 2)]; reference norm_unet.py:149-189."""
+    x = _dev(x, "normunet3d_pack input")
+    n, t, h, w, _ = x.shape
+    pd = pad16 if norm else (lambda v: v)
+    planes = torch.empty((n, 2, pd(t), pd(h), pd(w)), device=x.device, dtype=x.dtype)
+    stats = torch.empty((n, 2, 2), device=x.device, dtype=x.dtype) if norm else None
+    check(lib().cine_normunet3d_pack(x.data_ptr(), planes.data_ptr(), _p(stats), n, t, h, w, int(norm), _stream()),
+          "cine_normunet3d_pack")
+    return planes, stats
+
+
+def normunet3d_unpack(planes: torch.Tensor, stats: Optional[torch.Tensor], t: int, h: int, w: int) -> torch.Tensor:
+    planes = _dev(planes, "planes")
+    n = planes.shape[0]
+    y = torch.empty((n, t, h, w, 2), device=planes.device, dtype=planes.dtype)
+    check(lib().cine_normunet3d_unpack(planes.data_ptr(), _p(stats), y.data_ptr(), n, t, h, w, _stream()),
+          "cine_normunet3d_unpack")
+    return y
+
+
+def unet3d_forward(x: torch.Tensor, weights: UnetWeights) -> torch.Tensor:
+    """reference denoisers/unet.py:73-125 with dims = 3 on (n, in_ch, d, h, w) volumes."""
+    x = _dev(x, "unet3d input")
+    n, cin, d, h, w = x.shape
+    if len(weights.unets) != 1:
+        raise ValueError("unet3d_forward takes one weight set")
+    need = lib().cine_unet3d_ws_bytes(n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools)
+    if need == 0:
+        raise CineHipError("cine_unet3d_ws_bytes rejected the shape")
+    ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+    y = torch.empty((n, weights.out_ch, d, h, w), device=x.device, dtype=x.dtype)
+    check(lib().cine_unet3d_forward(x.data_ptr(), y.data_ptr(), weights.pointers(), n, d, h, w, cin, weights.out_ch,
+                                    weights.chans, weights.pools, ws.data_ptr(), ws.numel(), _stream()), "cine_unet3d_forward")
     return y

@@ -3,8 +3,10 @@
 // One implicit-GEMM kernel on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, the
 // same numerics class as the reference's fp32 convolutions) serves
 //   TAPS = 9 : conv3x3, pad 1, no bias             (unet.py:160,164)
-//   TAPS = 1 : conv-transpose k2 s2 as a 1x1 GEMM with 4*cout rows (unet.py:212-215),
+//   TAPS = 1 : conv-transpose k2 s2 as a 1x1 GEMM with 4*cout (8*cout in 3-D) rows (unet.py:212-215),
 //              and the final 1x1 conv + bias         (unet.py:69)
+//   TAPS = 27: conv3x3x3 over (depth, h, w) volumes  (unet.py:48-49, dims = 3): one workgroup works on one
+//              depth slice and stages the three input slices z-1, z, z+1
 //     D[row][pixel] += W[row][(tap, cin)] * X[(tap, cin)][pixel]
 //   M = 16 output rows, N = 16 pixels (one "fragment" = 16/TW rows x TW columns), K = 4 input
 //   channels of one tap.
@@ -51,6 +53,7 @@ struct Src {
                                          // 3 Haar DWT of act(x): 4c channels at (h/2, w/2)   (mwcnn.py:224-236)
                                          // 4 Haar IWT of act(x): c/4 channels at (2h, 2w)    (mwcnn.py:252-261)
     int act;                             // modes 3/4: 1 = x is raw (normalise + LReLU first), 0 = use as is
+    int d;                               // depth of the source volume (1 for 2-D planes)
 };
 // input channels a source contributes after its on-load transform
 __host__ __device__ inline int src_cin(const Src& s) { return s.mode == 3 ? 4 * s.c : (s.mode == 4 ? s.c / 4 : s.c); }
@@ -60,7 +63,9 @@ struct ConvArgs {
     const float* bias;
     const float* addend; int relu;       // epilogue: y = [relu](conv + bias + addend), addend shaped like y
     float* y; float* ypart;
-    int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout for tconv), padded to 16
+    int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout / 8*cout for tconv), padded to 16
+    int D, tiles_hw;                     // output depth (1 in 2-D); tiles per depth slice
+    int vol;                             // 1: 3-D entry point (a depth-1 volume is still a volume: 8-way transpose conv)
     int tconv_cout;                      // > 0: transpose-conv store mapping with this many channels
     int add_src1;                        // 1: source 1 is ADDED to source 0 channel-wise (MWCNN skips, mwcnn.py:164,172)
                                          //    instead of concatenated
@@ -71,7 +76,8 @@ struct ConvArgs {
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
 struct ConvCfg {
     static constexpr int NT = 64 * WM * WN;
-    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int HALO = TAPS == 1 ? 0 : 1;
+    static constexpr int ZP = TAPS == 27 ? 3 : 1;  // input depth slices held in LDS
     static constexpr int RPF = 16 / TW;            // rows per fragment
     static constexpr int NF = WN * MT;             // fragments per workgroup
     static constexpr int TH = NF * RPF;            // tile rows
@@ -80,7 +86,8 @@ struct ConvCfg {
     // column x lives at (x + COLS) % COLS.  COLS is a multiple of the staging piece so interior
     // pieces are 16-byte aligned (ds_write_b128).
     static constexpr int COLS = HALO ? (TW >= 4 ? TW + 4 : TW + 2) : TW;
-    static constexpr int PS = ((ROWS * COLS + 31) / 32) * 32 + 16;   // plane stride == 16 (mod 32)
+    static constexpr int ZS = ROWS * COLS;         // stride between the depth slices of one channel
+    static constexpr int PS = ((ZP * ROWS * COLS + 31) / 32) * 32 + 16;   // channel stride == 16 (mod 32)
     static constexpr int COT = 16 * CT * WM;
     static constexpr int COTP = (COT % 32 == 0) ? COT + 16 : COT;
     static constexpr int PW = TW >= 4 ? 4 : TW;    // floats per staging piece
@@ -99,13 +106,13 @@ struct ConvCfg {
 };
 
 // scalar (any shape) fetch of one transformed input value; st = {mean, rstd} table of THIS source's channels
-__device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int gy, int gx, const float* st, float slope) {
+__device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int gz, int gy, int gx, const float* st, float slope) {
     if (s.mode == 3) {                               // DWT: band = cl / c, source channel = cl % c
         const int band = cl / s.c, c = cl - band * s.c;
         if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;
         const float* p = s.x + (((long)n * s.c + c) * s.h + 2 * gy) * s.w + 2 * gx;
         float x1 = p[0], x3 = p[1], x2 = p[s.w], x4 = p[s.w + 1];          // x1 even/even, x2 odd row, x3 odd col
-        if (s.act) {
+        if (s.act & 1) {
             const float m = st[2 * c], r = st[2 * c + 1];
             x1 = act(x1, m, r, slope); x2 = act(x2, m, r, slope); x3 = act(x3, m, r, slope); x4 = act(x4, m, r, slope);
         }
@@ -125,7 +132,7 @@ __device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int g
         for (int k = 0; k < 4; ++k) {
             const int c = cl + k * cq;
             float t = s.x[(((long)n * s.c + c) * s.h + sy) * s.w + sx];
-            if (s.act) t = act(t, st[2 * c], st[2 * c + 1], slope);
+            if (s.act & 1) t = act(t, st[2 * c], st[2 * c + 1], slope);
             v[k] = 0.5f * t;
         }
         const int ry = gy & 1, rx = gx & 1;
@@ -138,12 +145,23 @@ __device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int g
     const float mean = st[2 * cl], rstd = st[2 * cl + 1];
     if (s.mode == 2) {
         if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;
+        if (s.act & 2) {                             // volume source: avg_pool3d 2x2x2 (unet.py:88,97)
+            if (2 * gz + 1 >= s.d) return 0.f;
+            float acc8 = 0.f;
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const float* p = s.x + ((plane * s.d + 2 * gz + dz) * s.h + 2 * gy) * s.w + 2 * gx;
+                acc8 += act(p[0], mean, rstd, slope) + act(p[1], mean, rstd, slope) +
+                        act(p[s.w], mean, rstd, slope) + act(p[s.w + 1], mean, rstd, slope);
+            }
+            return 0.125f * acc8;
+        }
         const float* p = s.x + (plane * s.h + 2 * gy) * s.w + 2 * gx;
         return 0.25f * (act(p[0], mean, rstd, slope) + act(p[1], mean, rstd, slope) +
                         act(p[s.w], mean, rstd, slope) + act(p[s.w + 1], mean, rstd, slope));
     }
-    if (gy >= s.h || gx >= s.w) return 0.f;
-    const float v = s.x[(plane * s.h + gy) * s.w + gx];
+    if (gz >= s.d || gy >= s.h || gx >= s.w) return 0.f;
+    const float v = s.x[((plane * s.d + gz) * s.h + gy) * s.w + gx];
     return s.mode == 0 ? v : act(v, mean, rstd, slope);
 }
 
@@ -163,8 +181,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x;
-    const int ty = tile / a.tiles_w, tx = tile % a.tiles_w;
+    const int tile = blockIdx.x;                      // (depth slice, tile row, tile column)
+    const int z0 = tile / a.tiles_hw, t2 = tile - z0 * a.tiles_hw;
+    const int ty = t2 / a.tiles_w, tx = t2 % a.tiles_w;
     const int r0 = ty * C::TH, c0 = tx * TW;
     const int co0 = blockIdx.y * C::COT;
     const int n = blockIdx.z;
@@ -188,13 +207,13 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         const Src& s = first ? a.s0 : a.s1;
         const int cl = first ? ci : ci - a.s0.c;
         float2 mr = make_float2(0.f, 1.f);
-        const bool need = (s.mode == 1 || s.mode == 2) || (s.mode >= 3 && s.act);
+        const bool need = (s.mode == 1 || s.mode == 2) || (s.mode >= 3 && (s.act & 1));
         if (need) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
         st_lds[2 * ci] = mr.x; st_lds[2 * ci + 1] = mr.y;
     }
     if (HALO) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
-        for (int e = tid; e < CK * C::ROWS * 2; e += C::NT) {
-            const int ck = e / (C::ROWS * 2), rem = e % (C::ROWS * 2);
+        for (int e = tid; e < CK * C::ZP * C::ROWS * 2; e += C::NT) {
+            const int ck = e / (C::ZP * C::ROWS * 2), rem = e % (C::ZP * C::ROWS * 2);
             in_lds[ck * C::PS + (rem >> 1) * C::COLS + ((rem & 1) ? C::COLS - 1 : TW)] = 0.f;
         }
     }
@@ -293,32 +312,33 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                     const int gy = r0 - 1 + row, gx = side ? c0 + TW : c0 - 1;
                     float v = 0.f;
                     if (ci0 + ck < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                        v = fetch_scalar(s, n, cl0 + ck, gy, gx, st_lds + (first ? 0 : 2 * a.s0.c), a.slope);
+                        v = fetch_scalar(s, n, cl0 + ck, 0, gy, gx, st_lds + (first ? 0 : 2 * a.s0.c), a.slope);
                     in_lds[ck * C::PS + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
                 }
             }
         } else {
             // ---- generic scalar staging (odd widths, mixed-source chunks, narrow `up` extents)
             constexpr int XC = TW + 2 * HALO;               // image columns c0-HALO .. c0+TW-1+HALO
-            for (int e = tid; e < CK * C::ROWS * XC; e += C::NT) {
-                const int ck = e / (C::ROWS * XC);
-                const int rem = e - ck * (C::ROWS * XC);
-                const int row = rem / XC, xcol = rem - row * XC;
+            for (int e = tid; e < CK * C::ZP * C::ROWS * XC; e += C::NT) {
+                const int ck = e / (C::ZP * C::ROWS * XC);
+                const int rem = e - ck * (C::ZP * C::ROWS * XC);
+                const int zp = rem / (C::ROWS * XC), rem2 = rem - zp * (C::ROWS * XC);
+                const int row = rem2 / XC, xcol = rem2 - row * XC;
                 const int col = (xcol - HALO + C::COLS) % C::COLS;
                 const int ci = ci0 + ck;
-                const int gy = r0 - HALO + row, gx = c0 - HALO + xcol;
+                const int gz = z0 + zp - (C::ZP == 3 ? 1 : 0), gy = r0 - HALO + row, gx = c0 - HALO + xcol;
                 float v = 0.f;
-                if (ci < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                if (ci < a.cin && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                     const int c0n = src_cin(a.s0);
                     if (a.add_src1) {
-                        v = fetch_scalar(a.s0, n, ci, gy, gx, st_lds, a.slope) +
-                            fetch_scalar(a.s1, n, ci, gy, gx, st_lds + 2 * a.s0.c, a.slope);
+                        v = fetch_scalar(a.s0, n, ci, gz, gy, gx, st_lds, a.slope) +
+                            fetch_scalar(a.s1, n, ci, gz, gy, gx, st_lds + 2 * a.s0.c, a.slope);
                     } else {
                         const bool f0 = ci < c0n;
-                        v = fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? ci : ci - c0n, gy, gx, st_lds + (f0 ? 0 : 2 * a.s0.c), a.slope);
+                        v = fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? ci : ci - c0n, gz, gy, gx, st_lds + (f0 ? 0 : 2 * a.s0.c), a.slope);
                     }
                 }
-                in_lds[ck * C::PS + row * C::COLS + col] = v;
+                in_lds[ck * C::PS + zp * C::ZS + row * C::COLS + col] = v;
             }
         }
         if (chunk == 0) CINE_STAMP(3);
@@ -332,11 +352,13 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
             float af[2][CT], bf[2][MT];
             auto load_group = [&](int g, float (&wa)[CT], float (&xa)[MT]) {
                 const int tap = g / (CK / 4), ks = g % (CK / 4);
-                const int dy = TAPS == 9 ? tap / 3 : 0, dx = TAPS == 9 ? tap % 3 : 0;
+                const int dz = TAPS == 27 ? tap / 9 : 0;
+                const int dy = TAPS == 1 ? 0 : (tap / 3) % 3, dx = TAPS == 1 ? 0 : tap % 3;
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) wa[ct] = w_lds[base_w + (tap * CK + 4 * ks) * C::COTP + 16 * ct];
 #pragma unroll
-                for (int f = 0; f < MT; ++f) xa[f] = in_lds[base_in[dx] + (4 * ks) * C::PS + (f * C::RPF + dy) * C::COLS];
+                for (int f = 0; f < MT; ++f)
+                    xa[f] = in_lds[base_in[dx] + (4 * ks) * C::PS + dz * C::ZS + (f * C::RPF + dy) * C::COLS];
             };
             load_group(0, af[0], bf[0]);
 #pragma unroll
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         for (int ct = 0; ct < CT; ++ct) {
             const int m = co0 + 16 * (wm * CT + ct) + q;
             if (m >= a.rows) continue;
-            const float* ab = a.addend ? a.addend + ((long)n * a.rows + m) * a.H * a.W : nullptr;
+            const float* ab = a.addend ? a.addend + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W : nullptr;
 #pragma unroll
             for (int f = 0; f < MT; ++f)
 #pragma unroll
@@ -453,8 +475,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
             }
             long slot;
             if (a.tconv_cout > 0) {
+                const int nsub = a.vol ? 8 : 4;         // sub-positions of the k2 s2 transpose conv
                 const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
-                slot = ((long)n * a.tconv_cout + co) * (a.tiles * 4) + tile * 4 + ab;
+                slot = ((long)n * a.tconv_cout + co) * (a.tiles * nsub) + tile * nsub + ab;
             } else {
                 slot = ((long)n * a.rows + m) * a.tiles + tile;
             }
@@ -470,7 +493,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         if (m >= a.rows) continue;
         if (a.tconv_cout > 0) {
             const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
-            float* yb = a.y + ((long)n * a.tconv_cout + co) * (2 * a.H) * (2 * a.W);
+            // 2-D: ab = 2a + b -> (2y+a, 2x+b); 3-D: ab = 4a + 2b + c -> (2z+a, 2y+b, 2x+c)
+            const int sz = a.vol ? (ab >> 2) : 0, ab2 = a.vol ? (ab & 3) : ab;
+            float* yb = a.y + (((long)n * a.tconv_cout + co) * (a.vol ? 2 * a.D : 1) + (a.vol ? 2 * z0 + sz : 0)) * (2 * a.H) * (2 * a.W);
 #pragma unroll
             for (int f = 0; f < MT; ++f)
 #pragma unroll
@@ -478,12 +503,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                     if (!((vmask >> (4 * f + j)) & 1ull)) continue;
                     const int p = 4 * kk + j;
                     const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
-                    yb[(long)(2 * gy + (ab >> 1)) * (2 * a.W) + 2 * gx + (ab & 1)] = acc[ct][f][j];
+                    yb[(long)(2 * gy + (ab2 >> 1)) * (2 * a.W) + 2 * gx + (ab2 & 1)] = acc[ct][f][j];
                 }
             continue;
         }
-        float* yb = a.y + ((long)n * a.rows + m) * a.H * a.W;
-        const bool vec = (a.W % PPR) == 0;            // rows stay 16-byte (8-byte) aligned
+        float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W;
+        const bool vec = (a.W % PPR) == 0 && ((long)a.H * a.W) % PPR == 0;   // rows stay 16-byte (8-byte) aligned
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
 #pragma unroll
@@ -525,6 +550,8 @@ __global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout
         if (m < rows && ci < cin) {
             if (kind == 0) v = w[((long)m * cin + ci) * 9 + tap];
             else if (kind == 1) { const int ab = m / cout, co = m % cout; v = w[((long)ci * cout + co) * 4 + ab]; }
+            else if (kind == 3) v = w[((long)m * cin + ci) * 27 + tap];                                   // conv3d
+            else if (kind == 4) { const int ab = m / cout, co = m % cout; v = w[((long)ci * cout + co) * 8 + ab]; }   // tconv3d
             else v = w[(long)m * cin + ci];
         }
         p[e] = v;
@@ -600,6 +627,7 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
 // ---------------------------------------------------------------- host dispatch
 constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
 constexpr int kCK1 = 16;    // 1x1 / tconv
+constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel live in LDS
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
 static int launch_cfg(ConvArgs a, hipStream_t st) {
@@ -612,7 +640,8 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     const size_t lds = C::lds_bytes(a.s0.c + a.s1.c);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv: %d input channels need %zu bytes of LDS", a.cin, lds);
     a.tiles_w = ceil_div(a.W, TW);
-    a.tiles = a.tiles_w * ceil_div(a.H, C::TH);
+    a.tiles_hw = a.tiles_w * ceil_div(a.H, C::TH);
+    a.tiles = a.tiles_hw * a.D;
     // vectorised staging preconditions (see kernel): widths multiple of the piece, one source per chunk
     const int PW = C::PW;
     auto src_ok = [&](const Src& s) {
@@ -621,10 +650,10 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
         if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0;
         return s.w == a.W && s.h <= a.H;
     };
-    a.fast = !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
+    a.fast = !a.vol && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
-    ProfScope prof(TAPS == 9 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1), st);
+    ProfScope prof(TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1), st);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, a);
     return check_launch("conv_mfma_kernel");
 }
@@ -647,7 +676,7 @@ static int dispatch(const ConvArgs& a, hipStream_t st) {
 }
 
 // tiles per sample of the configuration dispatch() picks (must mirror dispatch_tw)
-int tiles_for(int rowsp, int h, int w) {
+int tiles_for(int rowsp, int h, int w, int d = 1) {
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
     int nf;
@@ -655,7 +684,7 @@ int tiles_for(int rowsp, int h, int w) {
     else if (rowsp <= 64 || frags > 8) nf = 13;
     else nf = 4;
     const int TH = nf * 16 / TW;
-    return ceil_div(w, TW) * ceil_div(h, TH);
+    return ceil_div(w, TW) * ceil_div(h, TH) * d;
 }
 
 static unsigned grid1d(long n, int threads, long cap = 8192) {
@@ -676,6 +705,13 @@ extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv) {
     return tiles_for(rowsp, h, w) * (is_tconv ? 4 : 1);
 }
 
+extern "C" int cine_conv_stat_partials3d(int cout, int d, int h, int w, int is_tconv) {
+    if (cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
+    const int rows = is_tconv ? 8 * cout : cout;
+    const int rowsp = ceil_div(rows, 16) * 16;
+    return tiles_for(rowsp, h, w, d) * (is_tconv ? 8 : 1);
+}
+
 static size_t packed_floats(int rows, int cin, int taps, int ck) {
     return (size_t)ceil_div(cin, ck) * taps * ck * (ceil_div(rows, 16) * 16);
 }
@@ -691,7 +727,8 @@ extern "C" size_t cine_conv1x1_packed_floats(int cout, int cin) {
 
 static int pack(const float* w, float* packed, int kind, int cout, int cin, void* stream, const char* what) {
     CINE_REQUIRE(w && packed && cout > 0 && cin > 0, CINE_EINVAL, "%s: bad arguments", what);
-    const int rows = kind == 1 ? 4 * cout : cout, taps = kind == 0 ? 9 : 1, ck = kind == 0 ? kCK3 : kCK1;
+    const int rows = kind == 1 ? 4 * cout : (kind == 4 ? 8 * cout : cout);
+    const int taps = kind == 0 ? 9 : (kind == 3 ? 27 : 1), ck = kind == 0 ? kCK3 : (kind == 3 ? kCK27 : kCK1);
     const int rowsp = ceil_div(rows, 16) * 16, nchunks = ceil_div(cin, ck);
     const long total = (long)nchunks * taps * ck * rowsp;
     ProfScope prof(F_MISC, as_stream(stream));
@@ -707,6 +744,18 @@ extern "C" int cine_pack_tconv2x2(const float* w, float* packed, int cin, int co
 }
 extern "C" int cine_pack_conv1x1(const float* w, float* packed, int cout, int cin, void* stream) {
     return pack(w, packed, 2, cout, cin, stream, "cine_pack_conv1x1");
+}
+extern "C" size_t cine_conv3d_packed_floats(int cout, int cin) {
+    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(cout, cin, 27, kCK27);
+}
+extern "C" size_t cine_tconv3d_packed_floats(int cin, int cout) {
+    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(8 * cout, cin, 1, kCK1);
+}
+extern "C" int cine_pack_conv3d(const float* w, float* packed, int cout, int cin, void* stream) {
+    return pack(w, packed, 3, cout, cin, stream, "cine_pack_conv3d");
+}
+extern "C" int cine_pack_tconv3d(const float* w, float* packed, int cin, int cout, void* stream) {
+    return pack(w, packed, 4, cout, cin, stream, "cine_pack_tconv3d");
 }
 
 static int check_src(const float* x, const float* part, int c, int mode, int np, const char* what) {
@@ -756,8 +805,8 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
     if (int e = check_src(x0, part0, c0, (mode0 >= 3 ? act0 : mode0), np0, "cine_conv3x3_in(src0)")) return e;
     if (int e = check_src(x1, part1, c1, (mode1 >= 3 ? act1 : mode1), np1, "cine_conv3x3_in(src1)")) return e;
     ConvArgs a{};
-    a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, act0};
-    a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, act1};
+    a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, act0, 1};
+    a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, act1, 1};
     a.add_src1 = add_src1 && c1 > 0;
     a.bias = bias; a.addend = addend; a.relu = relu;
     if (a.add_src1) CINE_REQUIRE(src_cin(a.s0) == src_cin(a.s1), CINE_EINVAL, "cine_conv3x3_in: added sources differ in channels");
@@ -765,7 +814,7 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
     a.y = y; a.ypart = part_y; a.n = n;
     a.cin = a.add_src1 ? src_cin(a.s0) : src_cin(a.s0) + src_cin(a.s1);
     a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
-    a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK3);
+    a.H = h; a.W = w; a.D = 1; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK3);
     return dispatch<9, kCK3>(a, as_stream(stream));
 }
 
@@ -778,10 +827,10 @@ extern "C" int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, i
     if (int e = check_src(x, part_x, cin, mode, np_x, "cine_tconv2x2_in")) return e;
     CINE_REQUIRE(mode != 2, CINE_EINVAL, "cine_tconv2x2_in: mode 2 not supported");
     ConvArgs a{};
-    a.s0 = Src{x, part_x, cin, mode, h, w, np_x, 0};
+    a.s0 = Src{x, part_x, cin, mode, h, w, np_x, 0, 1};
     a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = cin; a.rows = 4 * cout; a.rowsp = ceil_div(4 * cout, 16) * 16;
-    a.tconv_cout = cout; a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+    a.tconv_cout = cout; a.H = h; a.W = w; a.D = 1; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
     return dispatch<1, kCK1>(a, as_stream(stream));
 }
 
@@ -798,10 +847,10 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
         const int n0 = s ? set_split : 0, n1 = two ? (s ? n : set_split) : n;
         if (n1 <= n0) continue;
         ConvArgs a{};
-        a.s0 = Src{x + (size_t)n0 * cin * h * w, part_x ? part_x + (size_t)n0 * cin * np_x * 3 : nullptr, cin, mode, h, w, np_x, 0};
+        a.s0 = Src{x + (size_t)n0 * cin * h * w, part_x ? part_x + (size_t)n0 * cin * np_x * 3 : nullptr, cin, mode, h, w, np_x, 0, 1};
         a.wp0 = a.wp1 = s ? wpacked2 : wpacked; a.set_split = n1 - n0; a.bias = s ? bias2 : bias;
         a.y = y + (size_t)n0 * cout * h * w; a.ypart = nullptr; a.n = n1 - n0; a.cin = cin; a.rows = cout;
-        a.rowsp = ceil_div(cout, 16) * 16; a.H = h; a.W = w; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+        a.rowsp = ceil_div(cout, 16) * 16; a.H = h; a.W = w; a.D = 1; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
         if (int e = dispatch<1, kCK1>(a, as_stream(stream))) return e;
     }
     return CINE_OK;
@@ -834,4 +883,77 @@ extern "C" int cine_instnorm_lrelu_apply(const float* x, const float* part, int 
     hipLaunchKernelGGL(instnorm_lrelu_apply_kernel, dim3(grid1d(planes * plane_elems, 256)), dim3(256), 0,
                        as_stream(stream), x, part, np, y, planes, plane_elems, eps, slope);
     return check_launch("instnorm_lrelu_apply_kernel");
+}
+
+// ---------------------------------------------------------------- 3-D entry points (unet.py dims = 3)
+extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int c0, int mode0, int d0, int h0, int w0,
+                              const float* x1, const float* part1, int np1, int c1, int mode1, int d1, int h1, int w1,
+                              const float* wpacked, const float* bias, const float* addend, int relu,
+                              float* y, float* part_y, int n, int cout, int d, int h, int w, float eps, float slope, void* stream) {
+    CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3d_in: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && d > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3d_in: bad sizes");
+    CINE_REQUIRE(mode0 >= 0 && mode0 <= 2 && mode1 >= 0 && mode1 <= 2, CINE_EINVAL, "cine_conv3d_in: modes 0..2 only");
+    if (int e = check_src(x0, part0, c0, mode0, np0, "cine_conv3d_in(src0)")) return e;
+    if (int e = check_src(x1, part1, c1, mode1, np1, "cine_conv3d_in(src1)")) return e;
+    ConvArgs a{};
+    a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, 2, d0};          // act bit 1 marks a volume source
+    a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, 2, d1 > 0 ? d1 : 1};
+    a.vol = 1;
+    a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = bias; a.addend = addend; a.relu = relu;
+    a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
+    a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK27);
+    return dispatch<27, kCK27>(a, as_stream(stream));
+}
+
+extern "C" int cine_tconv3d_in(const float* x, const float* part_x, int np_x, int mode, const float* wpacked,
+                               float* y, float* part_y, int n, int cin, int cout, int d, int h, int w,
+                               float eps, float slope, void* stream) {
+    CINE_REQUIRE(x && wpacked && y, CINE_EINVAL, "cine_tconv3d_in: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_tconv3d_in: bad sizes");
+    CINE_REQUIRE(mode == 0 || mode == 1, CINE_EINVAL, "cine_tconv3d_in: mode %d", mode);
+    if (int e = check_src(x, part_x, cin, mode, np_x, "cine_tconv3d_in")) return e;
+    ConvArgs a{};
+    a.s0 = Src{x, part_x, cin, mode, h, w, np_x, 2, d};
+    a.vol = 1;
+    a.wp0 = a.wp1 = wpacked; a.set_split = n;
+    a.y = y; a.ypart = part_y; a.n = n; a.cin = cin; a.rows = 8 * cout; a.rowsp = ceil_div(8 * cout, 16) * 16;
+    a.tconv_cout = cout; a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+    return dispatch<1, kCK1>(a, as_stream(stream));
+}
+
+extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x, int mode, const float* wpacked,
+                                   const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
+                                   float eps, float slope, void* stream) {
+    CINE_REQUIRE(x && wpacked && bias && y, CINE_EINVAL, "cine_conv1x1x1_bias: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv1x1x1_bias: bad sizes");
+    CINE_REQUIRE(mode == 0 || mode == 1, CINE_EINVAL, "cine_conv1x1x1_bias: mode %d", mode);
+    if (int e = check_src(x, part_x, cin, mode, np_x, "cine_conv1x1x1_bias")) return e;
+    ConvArgs a{};
+    a.s0 = Src{x, part_x, cin, mode, h, w, np_x, 2, d};
+    a.vol = 1;
+    a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = bias;
+    a.y = y; a.n = n; a.cin = cin; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
+    a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+    return dispatch<1, kCK1>(a, as_stream(stream));
+}
+
+// np partial records per plane -> ONE record per plane (volumes emit one record per tile and depth slice; merging
+// them once keeps the consumers' prologue short)
+__global__ void instnorm_merge_kernel(const float* part, float* out, long planes, int np) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes) return;
+    const float* p = part + i * np * 3;
+    float cnt = 0.f, mean = 0.f;
+    for (int k = 0; k < np; ++k) { cnt += p[3 * k]; mean += p[3 * k] * p[3 * k + 1]; }
+    mean /= cnt;
+    float m2 = 0.f;
+    for (int k = 0; k < np; ++k) { const float dlt = p[3 * k + 1] - mean; m2 += p[3 * k + 2] + p[3 * k] * dlt * dlt; }
+    out[3 * i] = cnt; out[3 * i + 1] = mean; out[3 * i + 2] = m2;
+}
+extern "C" int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream) {
+    CINE_REQUIRE(part && out && planes > 0 && np > 0, CINE_EINVAL, "cine_instnorm_merge: bad arguments");
+    ProfScope prof(F_STATS, as_stream(stream));
+    hipLaunchKernelGGL(instnorm_merge_kernel, dim3((unsigned)ceil_div(planes, 256L)), dim3(256), 0, as_stream(stream),
+                       part, out, planes, np);
+    return check_launch("instnorm_merge_kernel");
 }

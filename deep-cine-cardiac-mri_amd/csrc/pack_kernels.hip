@@ -448,3 +448,80 @@ extern "C" int cine_axpby_dev(float* out, const float* a, const float* b, long n
                        num_dev, den_dev, lambda_dev, sign);
     return check_launch("axpby_dev_kernel");
 }
+
+// ---------------------------------------------------------------- NormUnet3D front / back halves (norm_unet.py:149-219)
+namespace cine {
+// one workgroup per sample: x (n, T, H, W, 2) -> planes (n, 2, Tp, Hp, Wp), stats (n, 2, 2)
+__global__ void normunet3d_pack_kernel(const float* x, float* planes, float* stats, int T, int H, int W,
+                                       int Tp, int Hp, int Wp, int pt, int ph, int pw, int norm) {
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    const long cnt = (long)T * H * W;
+    const float2* src = reinterpret_cast<const float2*>(x) + (long)n * cnt;
+    float mr = 0.f, mi = 0.f, sdr = 1.f, sdi = 1.f;
+    if (norm) {
+        float sr = 0.f, si_ = 0.f;
+        for (long e = threadIdx.x; e < cnt; e += blockDim.x) { const float2 v = src[e]; sr += v.x; si_ += v.y; }
+        mr = block_sum(sr, red) / cnt; mi = block_sum(si_, red) / cnt;
+        float qr = 0.f, qi = 0.f;
+        for (long e = threadIdx.x; e < cnt; e += blockDim.x) {
+            const float2 v = src[e];
+            qr += (v.x - mr) * (v.x - mr); qi += (v.y - mi) * (v.y - mi);
+        }
+        sdr = sqrtf(block_sum(qr, red) / (cnt - 1)); sdi = sqrtf(block_sum(qi, red) / (cnt - 1));   // unbiased (:166)
+        if (threadIdx.x == 0) { float* st = stats + (long)n * 4; st[0] = mr; st[1] = sdr; st[2] = mi; st[3] = sdi; }
+    }
+    const long pcnt = (long)Tp * Hp * Wp;
+    float* pr = planes + (long)n * 2 * pcnt;
+    float* pi = pr + pcnt;
+    for (long e = threadIdx.x; e < pcnt; e += blockDim.x) {
+        const int wp = (int)(e % Wp); const long r = e / Wp;
+        const int hp = (int)(r % Hp), tp = (int)(r / Hp);
+        const int t = tp - pt, h = hp - ph, w = wp - pw;
+        float vr = 0.f, vi = 0.f;
+        if (t >= 0 && t < T && h >= 0 && h < H && w >= 0 && w < W) {
+            const float2 v = src[((long)t * H + h) * W + w];
+            vr = (v.x - mr) / sdr; vi = (v.y - mi) / sdi;
+        }
+        pr[e] = vr; pi[e] = vi;
+    }
+}
+__global__ void normunet3d_unpack_kernel(const float* planes, const float* stats, float* y, int T, int H, int W,
+                                         int Tp, int Hp, int Wp, int pt, int ph, int pw) {
+    const int n = blockIdx.y;
+    float mr = 0.f, sdr = 1.f, mi = 0.f, sdi = 1.f;
+    if (stats) { const float* st = stats + (long)n * 4; mr = st[0]; sdr = st[1]; mi = st[2]; sdi = st[3]; }
+    const long cnt = (long)T * H * W, pcnt = (long)Tp * Hp * Wp;
+    const float* pr = planes + (long)n * 2 * pcnt;
+    const float* pi = pr + pcnt;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(e % W); const long r = e / W;
+        const int h = (int)(r % H), t = (int)(r / H);
+        const long q = ((long)(t + pt) * Hp + h + ph) * Wp + w + pw;
+        reinterpret_cast<float2*>(y)[(long)n * cnt + e] = make_float2(pr[q] * sdr + mr, pi[q] * sdi + mi);
+    }
+}
+}  // namespace cine
+
+extern "C" int cine_normunet3d_pack(const float* x, float* planes, float* stats, int n, int t, int h, int w, int norm, void* stream) {
+    CINE_REQUIRE(x && planes && (stats || !norm), CINE_EINVAL, "cine_normunet3d_pack: null pointer");
+    CINE_REQUIRE(n > 0 && t > 0 && h > 0 && w > 0 && (long)t * h * w > 1, CINE_EINVAL, "cine_normunet3d_pack: bad sizes");
+    int tp, pt, hp, ph, wp, pw;
+    pad_split(t, tp, pt, norm != 0); pad_split(h, hp, ph, norm != 0); pad_split(w, wp, pw, norm != 0);
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(normunet3d_pack_kernel, dim3(n), dim3(1024), 0, as_stream(stream), x, planes, stats, t, h, w,
+                       tp, hp, wp, pt, ph, pw, norm);
+    return check_launch("normunet3d_pack_kernel");
+}
+
+extern "C" int cine_normunet3d_unpack(const float* planes, const float* stats, float* y, int n, int t, int h, int w, void* stream) {
+    CINE_REQUIRE(planes && y, CINE_EINVAL, "cine_normunet3d_unpack: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && t > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_normunet3d_unpack: bad sizes");
+    int tp, pt, hp, ph, wp, pw;
+    const bool nrm = stats != nullptr;
+    pad_split(t, tp, pt, nrm); pad_split(h, hp, ph, nrm); pad_split(w, wp, pw, nrm);
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(normunet3d_unpack_kernel, dim3(grid_for((long)t * h * w, 256, 1024), n), dim3(256), 0, as_stream(stream),
+                       planes, stats, y, t, h, w, tp, hp, wp, pt, ph, pw);
+    return check_launch("normunet3d_unpack_kernel");
+}

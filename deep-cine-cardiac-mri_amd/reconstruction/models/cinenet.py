@@ -5,7 +5,7 @@ Drop-in for the reference's models/cinenet.py (CineNet :14, CineNetBlock :77): s
 A^H M A (HOperator :121-133) is one row-FFT kernel, one fused column FFT -> hard mask -> column IFFT
 kernel and one row-IFFT + coil-sum kernel; the CG scalars (alpha, beta, :159-169) stay in device
 memory, so the solve has no host synchronisation and can be captured in a hipGraph.
-Inference only; GPU tensors only.  ``dynamic_type='3D'`` needs the Conv3d path (not on HIP yet).
+Inference only; GPU tensors only.
 """
 import math
 
@@ -84,7 +84,9 @@ class CineNetBlock(nn.Module):
             planes, _ = ops.normunet_pack(image_pred.reshape(b * t, h, w, 2), norm=False)
             return ops.normunet_unpack(self.model(planes), None, h, w).view(b, t, 1, h, w, 2)
         if self.dynamic_type == '3D':
-            raise NotImplementedError("CineNet dynamic_type='3D' (Conv3d U-Net) is not on the HIP path yet")
+            # (b, t, 1, h, w, 2) -> (b, 2, t, h, w) volumes for the bare 3-D Unet and back (reference cinenet.py:251-253)
+            planes, _ = ops.normunet3d_pack(image_pred.reshape(b, t, h, w, 2), norm=False)
+            return ops.normunet3d_unpack(self.model(planes), None, t, h, w).view(b, t, 1, h, w, 2)
         raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
 
     def forward(self, image_pred, image_ref, mask, sens_maps):

@@ -28,7 +28,7 @@ class NormUnet(nn.Module):
 
 
 class NormUnet3D(nn.Module):
-    """Parameter-compatible holder; the Conv3d path is not implemented on HIP yet."""
+    """NormUnet over (t, h, w) volumes: group norm, pad all three dims to x16, Conv3d U-Net, unpad, un-normalise."""
 
     def __init__(self, chans: int, num_pools: int, in_chans: int = 2, out_chans: int = 2, drop_prob: float = 0.0):
         super().__init__()
@@ -38,4 +38,9 @@ class NormUnet3D(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.shape[-1] == 2:
             raise ValueError("Last dimension must be 2 for complex.")
-        raise NotImplementedError("NormUnet3D (Conv3d U-Net) is not on the HIP path yet")
+        b, c, t, h, w, _ = x.shape
+        if c != 1:
+            raise NotImplementedError("HIP NormUnet3D handles one complex channel per sample (all reference call sites)")
+        planes, stats = ops.normunet3d_pack(x.reshape(b, t, h, w, 2))
+        planes = self.unet(planes)
+        return ops.normunet3d_unpack(planes, stats, t, h, w).view(b, 1, t, h, w, 2)

@@ -89,8 +89,8 @@ class Unet(nn.Module):
         return self._hip_weights
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        if self.dims != 2:
-            raise NotImplementedError("3-D U-Net (Conv3d) is not on the HIP path yet")
         if self.training and self.drop_prob > 0:
             raise NotImplementedError("dropout > 0 in training mode is not supported by the HIP path")
+        if self.dims == 3:
+            return ops.unet3d_forward(image, self.hip_weights())
         return ops.unet2d_forward(image, self.hip_weights())

@@ -221,6 +221,38 @@ int cine_unet2d_forward(const float* x, float* y, const void* const* weights, in
                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                         void* ws, size_t ws_bytes, void* stream);
 
+/* ---- 3-D variants (reference unet.py with dims = 3, norm_unet.py:117-219; VarNet / CineNet dynamic_type '3D') ----
+ * Volumes are (n, c, d, h, w).  Conv3d 3x3x3 pad 1 (unet.py:48-49), ConvTranspose3d k2 s2 as a GEMM with 8*cout rows,
+ * 1x1x1 conv + bias; on-load modes 0 / 1 / 2 (2 = avg_pool3d 2x2x2), concat of two sources, up-path zero pad, bias /
+ * addend / ReLU epilogue as in 2-D.  A volume emits cine_conv_stat_partials3d() statistics records per (sample,
+ * channel); cine_instnorm_merge folds np records into one. */
+size_t cine_conv3d_packed_floats(int cout, int cin);
+size_t cine_tconv3d_packed_floats(int cin, int cout);
+int cine_pack_conv3d(const float* w, float* packed, int cout, int cin, void* stream);     /* (cout, cin, 3, 3, 3) */
+int cine_pack_tconv3d(const float* w, float* packed, int cin, int cout, void* stream);    /* (cin, cout, 2, 2, 2) */
+int cine_conv_stat_partials3d(int cout, int d, int h, int w, int is_tconv);
+int cine_conv3d_in(const float* x0, const float* part0, int np0, int c0, int mode0, int d0, int h0, int w0,
+                   const float* x1, const float* part1, int np1, int c1, int mode1, int d1, int h1, int w1,
+                   const float* wpacked, const float* bias, const float* addend, int relu,
+                   float* y, float* part_y, int n, int cout, int d, int h, int w, float eps, float slope, void* stream);
+int cine_tconv3d_in(const float* x, const float* part_x, int np_x, int mode, const float* wpacked,
+                    float* y, float* part_y, int n, int cin, int cout, int d, int h, int w,
+                    float eps, float slope, void* stream);
+int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x, int mode, const float* wpacked,
+                        const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
+                        float eps, float slope, void* stream);
+int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream);
+/* Whole 3-D U-Net (unet.py:73-125, dims = 3); weights ordered as for cine_unet2d_forward (one set), packed with
+ * cine_pack_conv3d / cine_pack_tconv3d / cine_pack_conv1x1. */
+size_t cine_unet3d_ws_bytes(int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools);
+int cine_unet3d_forward(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
+                        int in_ch, int out_ch, int chans, int pools, void* ws, size_t ws_bytes, void* stream);
+/* NormUnet3D front / back halves (norm_unet.py:149-219): x (n, t, h, w, 2) -> planes (n, 2, pad16(t), pad16(h),
+ * pad16(w)) with group norm (unbiased std) and stats (n, 2, 2); norm == 0 / stats == NULL: plain unpadded repack
+ * (CineNet's bare 3-D Unet, cinenet.py:251-253). */
+int cine_normunet3d_pack(const float* x, float* planes, float* stats, int n, int t, int h, int w, int norm, void* stream);
+int cine_normunet3d_unpack(const float* planes, const float* stats, float* y, int n, int t, int h, int w, void* stream);
+
 /* Whole MWCNN (denoisers/mwcnn.py:135-179) on n planes (n, in_ch, h, w) -> (n, out_ch, h, w); h, w
  * multiples of 2^n_scales (utils/padding.py pads before the call).  Handles the topology XPDNet builds
  * (n_first_convs = 1, res = False, xpdnet.py:251-262); others return CINE_EUNSUPPORTED.

@@ -278,7 +278,7 @@ def test_tconv_and_conv1x1_vs_torch(dev, cin, cout, h, w):
 
 
 # ------------------------------------------------------------------ blocks and models
-@pytest.mark.parametrize("dyn", ["XF", "XT", "2D"])
+@pytest.mark.parametrize("dyn", ["XF", "XT", "2D", "3D"])
 def test_varnet_block_vs_reference_golden(golden, dev, dyn):
     import reconstruction.models as M
     g = golden("varnet_block")
@@ -304,7 +304,8 @@ def test_sensitivity_model_vs_reference_golden(golden, dev):
     assert rel_err(out.cpu(), g["sens_out"]) < BLOCK_TOL
 
 
-@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("3D", "3D", False),
+                                        ("XFws", "XF", True)])
 def test_varnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
     import reconstruction.models as M
     g = golden("varnet_tiny")
@@ -316,15 +317,6 @@ def test_varnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
     assert out.shape == g[f"{tag}_out"].shape
     assert rel_err(out.cpu(), g[f"{tag}_out"]) < MODEL_TOL
     assert torch.equal(mk.cpu(), torch.from_numpy(g["masked_kspace"]))     # caller's input not mutated
-
-
-def test_varnet_3d_not_silently_wrong(dev):
-    import reconstruction.models as M
-    net = M.VarNet(1, 4, 2, 4, 2, "3D").to(dev).eval()
-    k = torch.zeros(1, 5, 3, 24, 20, 2, device=dev)
-    m = torch.zeros(1, 5, 1, 24, 1, 1, dtype=torch.uint8, device=dev); m[:, :, :, 10:14] = 1
-    with pytest.raises(NotImplementedError):
-        net(k, m)
 
 
 def test_varnet_cfg1_vs_reference_golden(golden, dev):
@@ -391,7 +383,8 @@ def test_cinenet_block_vs_reference_golden(golden, dev):
     assert rel_err(blk(img, img, mask, sens).cpu(), g["block_out"]) < MODEL_TOL
 
 
-@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("3D", "3D", False),
+                                        ("XFws", "XF", True)])
 def test_cinenet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
     import reconstruction.models as M
     g = golden("cinenet")
@@ -516,3 +509,46 @@ def test_rnn_models_vs_reference_golden(golden, dev):
     net = M.XPDNet_RNN(3, 4, 2, 6, True, 2, 1); net.load_state_dict(state_dict_from(g, "xpdnet_rnn::sd::"), strict=True)
     assert rel_err(net.to(dev).eval()(mk, mask).cpu(), g["xpdnet_rnn_out"]) < MODEL_TOL
     assert torch.equal(mk.cpu(), torch.from_numpy(g["masked_kspace"]))
+
+
+# ------------------------------------------------------------------ 3-D path
+@pytest.mark.parametrize("cin,cout,d,h,w", [(2, 16, 5, 24, 20), (16, 16, 15, 40, 32), (32, 64, 3, 13, 9), (64, 128, 1, 6, 5), (5, 7, 4, 9, 11)])
+def test_conv3d_vs_torch(dev, cin, cout, d, h, w):
+    from cine_hip import ops, _lib
+    import torch.nn.functional as F
+    n = 2
+    x = rnd(cin + d, n, cin, d, h, w); wt = rnd(cout, cout, cin, 3, 3, 3) / (5 * cin ** 0.5)
+    L = _lib.lib()
+    wp = ops._pack("c27", wt.to(dev))
+    y = torch.empty((n, cout, d, h, w), device=dev)
+    npart = L.cine_conv_stat_partials3d(cout, d, h, w, 0)
+    part = torch.empty((n, cout, npart, 3), device=dev)
+    xd = x.to(dev)
+    _lib.check(L.cine_conv3d_in(xd.data_ptr(), None, 0, cin, 0, d, h, w, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(), None, None, 0,
+                                y.data_ptr(), part.data_ptr(), n, cout, d, h, w, 1e-5, 0.2, torch.cuda.current_stream().cuda_stream))
+    ref = F.conv3d(x, wt, padding=1)
+    assert rel_err(y.cpu(), ref) < OP_TOL
+    st = ops.instnorm_finalize(part)
+    assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3, 4))) < 1e-4
+    assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3, 4), unbiased=False) + 1e-5)) < 1e-4
+
+
+def test_unet3d_and_normunet3d_vs_reference_golden(golden, dev):
+    from reconstruction.models.denoisers import NormUnet3D
+    g = golden("unet")
+    nu3 = NormUnet3D(4, 2); nu3.load_state_dict(state_dict_from(g, "nu3::"), strict=True); nu3.to(dev).eval()
+    assert rel_err(nu3(cuda(g["nu3_x"], dev)).cpu(), g["nu3_y"]) < BLOCK_TOL
+
+
+def test_cinenet_3d_cfg4_shape_vs_oracle(dev):
+    """BASELINE configs[3] shape: 3-D CineNet (1 cascade for test time), CG 6, 15 coils x 15 frames x 200x200, R=6."""
+    import reconstruction.models as M
+    from oracle import cinenet_ref as C
+    from cine_hip import synth
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=6, seed=4)
+    hip = M.CineNet(1, 6, 16, 3, "3D").eval(); synth.fill_parameters_(hip, 7)
+    ref = C.CineNet(1, 6, 16, 3, "3D").eval(); ref.load_state_dict(hip.state_dict(), strict=True)
+    with torch.no_grad():
+        want = ref(ex["masked_kspace"], ex["mask"], ex["sens_maps"])
+    got = hip.to(dev)(ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["sens_maps"].to(dev)).cpu()
+    assert rel_err(got, want) < MODEL_TOL
