@@ -649,3 +649,17 @@ def unet3d_forward(x: torch.Tensor, weights: UnetWeights) -> torch.Tensor:
     check(lib().cine_unet3d_forward(x.data_ptr(), y.data_ptr(), weights.pointers(), n, d, h, w, cin, weights.out_ch,
                                     weights.chans, weights.pools, ws.data_ptr(), ws.numel(), _stream()), "cine_unet3d_forward")
     return y
+
+
+def conv3d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
+    """Conv3d(3x3x3, 'same') + bias (+ ReLU) on (n, c, d, h, w) (reference denoisers/kspace_net.py:33-46)."""
+    x = _dev(x, "conv3d input")
+    n, cin, d, h, w = x.shape
+    cout = weight.shape[0]
+    wp = _pack("c27", weight)
+    bias = _dev(bias.detach(), "conv3d bias")
+    y = torch.empty((n, cout, d, h, w), device=x.device, dtype=x.dtype)
+    check(lib().cine_conv3d_in(x.data_ptr(), None, 0, cin, 0, d, h, w, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(),
+                               bias.data_ptr(), None, int(relu), y.data_ptr(), None, n, cout, d, h, w,
+                               IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3d_in")
+    return y

@@ -3,6 +3,7 @@ import torch
 from torch import nn
 
 from cine_hip import ops
+from .denoisers.kspace_net import KSpaceCNN
 from .recurrent_common import BCRNNlayer, CRNNBody, CRNNcell  # noqa: F401
 from .xpdnet import BackwardOperator, ForwardOperator, SensitivityModel
 
@@ -11,16 +12,18 @@ class XPDNet_RNN(CRNNBody):
     def __init__(self, num_cascades: int = 12, sens_chans: int = 8, sens_pools: int = 4, chans: int = 18,
                  primal_only: bool = True, n_primal: int = 5, n_dual: int = 1):
         super().__init__()
-        if not primal_only:
-            raise NotImplementedError("XPDNet_RNN(primal_only=False) needs KSpaceCNN (Conv3d), which is not on the HIP path")
         self.num_cascades, self.chans = num_cascades, chans
-        self.i_buffer_mode, self.k_buffer_mode = True, False
-        self.i_buffer_size, self.k_buffer_size = n_primal, 1
+        self.i_buffer_mode, self.k_buffer_mode = True, not primal_only
+        self.i_buffer_size, self.k_buffer_size = n_primal, 1 if primal_only else n_dual
         self.backward_op = BackwardOperator(masked=False)
         self.forward_op = ForwardOperator(masked=True)
         self.sens_net = SensitivityModel(sens_chans, sens_pools)
         self._make_body(2 * (n_primal + 1), chans, 2 * n_primal)
-        self.kspace_net = [self.measurements_residual for _ in range(num_cascades)]
+        if not primal_only:
+            self.kspace_net = nn.ModuleList([KSpaceCNN(in_chans=2 * (n_dual + 2), out_chans=2 * n_dual, n_convs=3,
+                                                       n_filters=16) for _ in range(num_cascades)])
+        else:
+            self.kspace_net = [self.measurements_residual for _ in range(num_cascades)]
 
     @staticmethod
     def measurements_residual(concat_kspace: torch.Tensor) -> torch.Tensor:
@@ -37,10 +40,19 @@ class XPDNet_RNN(CRNNBody):
         hyb = torch.empty_like(ref_kspace)
         state = self.zero_state(t, b, h, w, image_buffer)
         keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]                  # channels [:n] and [n+1:-1]
-        for _ in range(self.num_cascades):
+        nd = self.k_buffer_size
+        kbuf = ops.repeat_complex(ref_kspace, nd) if self.k_buffer_mode else None
+        for i in range(self.num_cascades):
             x0 = ops.extract_complex(image_buffer, 0, n)
-            ops.expand_resid_hybrid(x0, sens_maps, ref_kspace, mask, out=hyb)               # K step (:110-140)
-            bwd = ops.hybrid_reduce(hyb, sens_maps)                                         # masked backward op (:142-163)
+            if self.k_buffer_mode:                                                          # dual buffer + KSpaceCNN
+                fwd = ops.sens_expand_dc(x0, sens_maps, None, mask, None, hard_mask=True)
+                cat_k = torch.cat([kbuf[..., :nd], fwd[..., :1], ref_kspace[..., :1],
+                                   kbuf[..., nd:], fwd[..., 1:], ref_kspace[..., 1:]], dim=-1)
+                kbuf = self.kspace_net[i](cat_k).contiguous()
+                bwd = ops.sens_reduce(ops.extract_complex(kbuf, 0, nd) * mask + 0.0, sens_maps)
+            else:
+                ops.expand_resid_hybrid(x0, sens_maps, ref_kspace, mask, out=hyb)           # K step (:110-140)
+                bwd = ops.hybrid_reduce(hyb, sens_maps)                                     # masked backward op (:142-163)
             cat = torch.cat([image_buffer[..., :n], bwd[..., :1], image_buffer[..., n:], bwd[..., 1:]], dim=-1)
             planes = ops.chanlast_to_planes(cat.view(t, h, w, 2 * (n + 1)))                 # (t, 2(n+1), h, w)
             out, state = self.body(planes.view(t, 1, 2 * (n + 1), h, w), state, planes[:, keep].contiguous())

@@ -7,8 +7,8 @@ and state-dict keys (``sens_net.unet_model.*``, ``image_net.N[.{0,1}].*`` and th
   K step : S x0 -> row FFT; column FFT -> hard mask -> minus k_ref -> column IFFT (one kernel, hybrid space)
   I step : row IFFT + conj(S) + coil sum; buffer pack (temporal mean / XPDNet's own temporal transform /
            x-f, y-f rotation / left-heavy zero pad); two MWCNNs; unpack
-and never materialises the k-space buffer.  ``primal_only=False`` (KSpaceCNN, Conv3d) is not on the HIP
-path.  Inference only; GPU tensors only.
+and never materialises the k-space buffer.  ``primal_only=False`` adds the KSpaceCNN dual update (Conv3d on the MFMA kernel) and materialises
+the k-space buffer.  Inference only; GPU tensors only.
 """
 from typing import Dict, List, Union
 
@@ -18,6 +18,7 @@ from torch import nn
 from cine_hip import ops
 from .denoisers.unet import Unet
 from .denoisers.mwcnn import MWCNN
+from .denoisers.kspace_net import KSpaceCNN
 from .varnet import SensitivityModel as _VarnetSens
 
 
@@ -115,8 +116,10 @@ class XPDNet(nn.Module):
         self.sens_net = SensitivityModel(sens_chans, sens_pools)
         self.backward_op = BackwardOperator(masked=False)
         if not primal_only:
-            raise NotImplementedError("XPDNet(primal_only=False) needs KSpaceCNN (Conv3d), which is not on the HIP path")
-        self.kspace_net = [self.measurements_residual for _ in range(num_cascades)]
+            self.kspace_net = nn.ModuleList([KSpaceCNN(in_chans=2 * (n_dual + 2), out_chans=2 * n_dual, n_convs=3,
+                                                       n_filters=16) for _ in range(num_cascades)])
+        else:
+            self.kspace_net = [self.measurements_residual for _ in range(num_cascades)]
         kw = dict(in_chans=2 * (n_primal + 1), out_chans=2 * n_primal, dims=2, n_scales=n_scales,
                   n_filters_per_scale=n_filters_per_scale, n_convs_per_scale=n_convs_per_scale,
                   n_first_convs=n_first_convs, first_conv_n_filters=first_conv_n_filters, res=res)
@@ -140,9 +143,20 @@ class XPDNet(nn.Module):
         image = ops.sens_reduce(masked_kspace, sens_maps)                       # unmasked backward op (:303)
         image_buffer = ops.repeat_complex(image, n)                             # (:307)
         hyb = torch.empty_like(masked_kspace)
+        nd = self.k_buffer_size
+        kbuf = ops.repeat_complex(masked_kspace, nd) if self.k_buffer_mode else None          # (:306)
         for i_domain in range(1, len(self.domain_sequence), 2):                 # each 'K' then 'I' pair (:310-319)
             x0 = ops.extract_complex(image_buffer, 0, n)                        # channel 0 of the buffer (:128)
-            ops.expand_resid_hybrid(x0, sens_maps, masked_kspace, mask, out=hyb)    # K: M A x0 - k_ref
-            backward_img = ops.hybrid_reduce(hyb, sens_maps)                    # I: masked backward op
+            if self.k_buffer_mode:
+                # dual buffer: the k-space net needs the whole k-space, so it is materialised (:385-403)
+                fwd = ops.sens_expand_dc(x0, sens_maps, None, mask, None, hard_mask=True)
+                cat = torch.cat([kbuf[..., :nd], fwd[..., :1], masked_kspace[..., :1],
+                                 kbuf[..., nd:], fwd[..., 1:], masked_kspace[..., 1:]], dim=-1)
+                kbuf = self.kspace_net[i_domain // 2](cat).contiguous()
+                k0 = ops.extract_complex(kbuf, 0, nd) * mask + 0.0              # masked backward op (:161-167)
+                backward_img = ops.sens_reduce(k0, sens_maps)
+            else:
+                ops.expand_resid_hybrid(x0, sens_maps, masked_kspace, mask, out=hyb)    # K: M A x0 - k_ref
+                backward_img = ops.hybrid_reduce(hyb, sens_maps)                # I: masked backward op
             image_buffer = self.cascades[i_domain].regularise(i_domain, image_buffer, backward_img)
         return ops.complex_abs(ops.extract_complex(image_buffer, 0, n).squeeze(2))      # (:321-326)

@@ -462,12 +462,14 @@ def test_xpd_buffer_pack_unpack_vs_oracle(dev):
         assert rel_err(got.cpu(), want) < OP_TOL
 
 
-@pytest.mark.parametrize("tag,dyn,ws", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
-def test_xpdnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
+@pytest.mark.parametrize("tag,dyn,ws,po", [("XF", "XF", False, True), ("XT", "XT", False, True), ("2D", "2D", False, True),
+                                           ("XFws", "XF", True, True), ("XFdual", "XF", False, False)])
+def test_xpdnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws, po):
     import reconstruction.models as M
     g = golden("xpdnet")
     net = M.XPDNet(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
-                   n_convs_per_scale=[1, 1], first_conv_n_filters=8, n_primal=2, dynamic_type=dyn, weight_sharing=ws)
+                   n_convs_per_scale=[1, 1], first_conv_n_filters=8, n_primal=2, dynamic_type=dyn, weight_sharing=ws,
+                   primal_only=po)
     net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
     net.to(dev).eval()
     mk, mask = cuda(g["masked_kspace"], dev), cuda(g["mask"], dev)
@@ -478,10 +480,16 @@ def test_xpdnet_tiny_vs_reference_golden(golden, dev, tag, dyn, ws):
     assert torch.equal(mk.cpu(), torch.from_numpy(g["masked_kspace"]))
 
 
-def test_xpdnet_dual_not_silently_wrong():
+def test_xpdnet_rnn_dual_vs_oracle(dev):
     import reconstruction.models as M
-    with pytest.raises(NotImplementedError):
-        M.XPDNet(num_cascades=1, primal_only=False)
+    from oracle import recurrent_ref as R
+    from cine_hip import synth
+    ex = synth.make_cine_slice(5, 3, 24, 20, accel=4, center_lines=4, seed=3)
+    hip = M.XPDNet_RNN(2, 4, 2, 6, False, 2, 1).eval(); synth.fill_parameters_(hip, 9, keep=())
+    ref = R.XPDNet_RNN(2, 4, 2, 6, False, 2, 1).eval(); ref.load_state_dict(hip.state_dict(), strict=True)
+    with torch.no_grad():
+        want = ref(ex["masked_kspace"], ex["mask"])
+    assert rel_err(hip.to(dev)(ex["masked_kspace"].to(dev), ex["mask"].to(dev)).cpu(), want) < MODEL_TOL
 
 
 # ------------------------------------------------------------------ convolutional-RNN hybrids
