@@ -22,6 +22,7 @@
 //              {count, mean, M2} (exact two-pass in registers; consumers merge them with Chan's
 //              formula -- deterministic, no atomics), bias for the 1x1 conv.
 #include <mutex>
+#include <type_traits>
 #include "common.h"
 
 namespace cine {
@@ -42,9 +43,11 @@ __device__ __forceinline__ float2 merge_partials(const float* p, int np, float e
     return make_float2(mean, 1.0f / sqrtf(m2 / cnt + eps));
 }
 
-__device__ __forceinline__ float act(float x, float mean, float rstd, float slope) {
-    const float v = (x - mean) * rstd;
-    return v > 0.f ? v : v * slope;
+// InstanceNorm + LeakyReLU of one raw value: scale = rstd, shift = -mean * rstd (the x * alpha + beta form of
+// ATen's batch-norm transform); 0 <= slope <= 1 so that leaky_relu(v) == max(v, v * slope)
+__device__ __forceinline__ float act(float x, float scale, float shift, float slope) {
+    const float v = fmaf(x, scale, shift);
+    return fmaxf(v, v * slope);
 }
 
 struct Src {
@@ -94,18 +97,30 @@ struct ConvCfg {
     static constexpr int PR = TW / PW;             // pieces per row
     static constexpr int NPIECE = CK * ROWS * PR;
     static constexpr int NPT = (NPIECE + NT - 1) / NT;
+    // staging map of the vectorised path: a thread owns one (row, piece) slot of the tile -- KR of them when
+    // there are more slots than threads -- in channels g, g + G, ...: slot arithmetic happens once, the
+    // pieces of a thread differ by compile-time strides
+    static constexpr int RP = ROWS * PR;
+    static constexpr int KR = (RP + NT - 1) / NT;
+    static constexpr int gsel() { int g = 1; while (2 * g <= CK && 2 * g * RP <= NT) g *= 2; return g; }
+    static constexpr int G = gsel();
+    static constexpr int NCI = CK / G, NPF = KR * NCI;
     static constexpr int IN_FLOATS = CK * PS;
     static constexpr int W_FLOATS = TAPS * CK * COTP;
     static constexpr int RED_FLOATS = 3 * WN * COT;
-    // waves per SIMD to ask the register allocator for (= workgroups per CU for 256-thread groups):
-    // 4 (<= 128 VGPR+AGPR) when the accumulator tile is <= 64 registers, else 3 (<= 168)
-    static constexpr int MINW_ACC = (4 * CT * MT <= 64) ? 4 : 3;
-    static constexpr int MINW = (4 * NPT > 36) ? MINW_ACC - 1 : MINW_ACC;   // big staging batches need room
+#ifndef CINE_REG_OVH
+#define CINE_REG_OVH 48
+#endif
+    // waves per SIMD to ask the register allocator for (= workgroups per CU for 256-thread groups), from an
+    // estimate of the live registers: accumulators + two operand groups + the chunk prefetched during the sweep
+    static constexpr int NWT = (TAPS * CK * (COT / 4) + NT - 1) / NT;   // weight float4 per thread and chunk
+    static constexpr int REGS = 4 * CT * MT + 2 * (CT + MT) + PW * NPF + 4 * NWT + CINE_REG_OVH;
+    static constexpr int MINW = REGS <= 128 ? 4 : (REGS <= 168 ? 3 : 2);
     static_assert(RED_FLOATS <= IN_FLOATS, "reduction scratch must fit in the input tile");
     static size_t lds_bytes(int src_chans) { return (size_t)(IN_FLOATS + W_FLOATS + 2 * src_chans) * sizeof(float); }
 };
 
-// scalar (any shape) fetch of one transformed input value; st = {mean, rstd} table of THIS source's channels
+// scalar (any shape) fetch of one transformed input value; st = {scale, shift} table (see act()) of THIS source's channels
 __device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int gz, int gy, int gx, const float* st, float slope) {
     if (s.mode == 3) {                               // DWT: band = cl / c, source channel = cl % c
         const int band = cl / s.c, c = cl - band * s.c;
@@ -142,7 +157,7 @@ __device__ __forceinline__ float fetch_scalar(const Src& s, int n, int cl, int g
         return v[0] + v[1] + v[2] + v[3];
     }
     const long plane = (long)n * s.c + cl;
-    const float mean = st[2 * cl], rstd = st[2 * cl + 1];
+    const float mean = st[2 * cl], rstd = st[2 * cl + 1];   // positional: {scale, shift}
     if (s.mode == 2) {
         if (2 * gy + 1 >= s.h || 2 * gx + 1 >= s.w) return 0.f;
         if (s.act & 2) {                             // volume source: avg_pool3d 2x2x2 (unet.py:88,97)
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     extern __shared__ __align__(16) float smem_f[];
     float* in_lds = smem_f;
     float* w_lds = smem_f + C::IN_FLOATS;
-    float* st_lds = w_lds + C::W_FLOATS;            // {mean, rstd} per input channel
+    float* st_lds = w_lds + C::W_FLOATS;            // {scale, shift} per input channel (see act())
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -200,6 +215,53 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
 
     CINE_STAMP_RT(9);
     CINE_STAMP(0);
+    // ---- chunk pipeline.  issue(c) puts the global loads of chunk c (weight slab + raw input pieces) in
+    // flight into registers; commit(c) applies the on-load transform and writes them to LDS.  issue(c+1)
+    // is placed before the MFMA sweep of chunk c, so the memory latency of the next chunk hides under it.
+    constexpr int NWT = C::NWT;
+    float4 wraw[NWT];
+    constexpr int KR = C::KR, G = C::G, NCI = C::NCI;
+    piece_t xraw[C::NPF];
+    const int sg = KR == 1 ? tid / C::RP : 0;         // my channel group of the staging map (a slot if < G)
+    const int srp = KR == 1 ? tid - sg * C::RP : tid; // my (row, piece) slot
+    const int sgc = G == 1 ? 0 : min(sg, G - 1);
+    auto chunk_src = [&](int chunk, int& cl0) -> const Src& {
+        const int ci0 = chunk * CK;
+        const bool first = ci0 < a.s0.c;
+        cl0 = first ? ci0 : ci0 - a.s0.c;
+        return first ? a.s0 : a.s1;
+    };
+    auto issue = [&](int chunk) {
+        const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int e = tid + i * C::NT;
+            const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
+            const bool v = e < TAPS * CK * (C::COT / 4) && co0 + c4 < a.rowsp;
+            wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wsrc);
+        }
+        int cl0;
+        const Src& s = chunk_src(chunk, cl0);
+        if (a.fast && s.mode != 2) {
+            const char* sb = reinterpret_cast<const char*>(s.x + ((long)n * s.c + cl0) * s.h * a.W);
+            const unsigned cstride = (unsigned)(s.h * a.W) * 4u;        // bytes between channels
+            const int cmax = s.c - 1 - cl0;                              // last channel of this source, chunk-relative
+#pragma unroll
+            for (int k = 0; k < KR; ++k) {
+                const int rp = srp + k * C::NT, row = rp / C::PR, j = rp % C::PR;
+                const int gy = min(max(r0 - HALO + row, 0), s.h - 1), gx = min(c0 + PW * j, a.W - PW);
+                const unsigned voff = (unsigned)(gy * a.W + gx) * 4u;
+#pragma unroll
+                for (int i = 0; i < NCI; ++i) {
+                    const int ck = min(sgc + i * G, cmax);              // uniform when G == 1
+                    xraw[k * NCI + i] = *reinterpret_cast<const piece_t*>(sb + (size_t)((unsigned)ck * cstride) + voff);
+                }
+            }
+        }
+    };
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+
     // ---- prologue: merged InstanceNorm stats of every input channel; zero the tile once
     // table layout: source 0's channels, then source 1's (for modes 0/1/2 that is the concat channel order)
     for (int ci = tid; ci < a.s0.c + a.s1.c; ci += C::NT) {
@@ -209,7 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         float2 mr = make_float2(0.f, 1.f);
         const bool need = (s.mode == 1 || s.mode == 2) || (s.mode >= 3 && (s.act & 1));
         if (need) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
-        st_lds[2 * ci] = mr.x; st_lds[2 * ci + 1] = mr.y;
+        st_lds[2 * ci] = mr.y; st_lds[2 * ci + 1] = -mr.x * mr.y;      // {scale, shift} of act()
     }
     if (HALO) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
         for (int e = tid; e < CK * C::ZP * C::ROWS * 2; e += C::NT) {
@@ -226,53 +288,59 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
 
     CINE_STAMP(1);
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        __syncthreads();
+        __syncthreads();                              // stats table ready / previous sweep done with LDS
         if (chunk == 0) CINE_STAMP(2);
-        // ---- weight slab [tap][ck][COT] from the packed layout [chunk][tap][ck][rowsp]
-        {
-            const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
-            for (int e = tid; e < TAPS * CK * (C::COT / 4); e += C::NT) {
-                const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (co0 + c4 < a.rowsp) v = *reinterpret_cast<const float4*>(wsrc + (long)row * a.rowsp + co0 + c4);
-                *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = v;
-            }
+        // ---- commit: weight slab [tap][ck][COT] (packed layout [chunk][tap][ck][rowsp])
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int e = tid + i * C::NT;
+            if (e >= TAPS * CK * (C::COT / 4)) break;
+            const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
+            *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = co0 + c4 < a.rowsp ? wraw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int ci0 = chunk * CK;
         const bool first = ci0 < a.s0.c;
-        const Src& s = first ? a.s0 : a.s1;
-        const int cl0 = first ? ci0 : ci0 - a.s0.c;
+        int cl0;
+        const Src& s = chunk_src(chunk, cl0);
         if (a.fast) {
             // ---- vectorised staging: every piece = PW consecutive floats of one (channel, row)
             if (s.mode != 2) {
-                piece_t raw[C::NPT];
-                bool ok[C::NPT];
+                const bool plain = s.mode == 0, fullchunk = ci0 + CK <= a.cin;
 #pragma unroll
-                for (int i = 0; i < C::NPT; ++i) {
-                    const int p = tid + i * C::NT;
-                    const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
-                    const int row = rem / C::PR, j = rem % C::PR;
+                for (int k = 0; k < KR; ++k) {
+                    const int rp = srp + k * C::NT, row = rp / C::PR, j = rp % C::PR;
                     const int gy = r0 - HALO + row, gx = c0 + PW * j;
-                    ok[i] = p < C::NPIECE && ci0 + ck < a.cin && gy >= 0 && gy < s.h && gx < a.W;
-                    const int gyc = min(max(gy, 0), s.h - 1), gxc = min(gx, a.W - PW), ckc = min(cl0 + ck, s.c - 1);
-                    raw[i] = *reinterpret_cast<const piece_t*>(s.x + (((long)n * s.c + ckc) * s.h + gyc) * a.W + gxc);
-                }
+                    const bool slot = rp < C::RP && sg < G;
+                    const bool rowok = gy >= 0 && gy < s.h && gx < a.W;
+                    float* lrow = in_lds + sgc * C::PS + row * C::COLS + PW * j;
+                    const float* stp = st_lds + 2 * (ci0 + sgc);
+                    // wave-uniform: every slot of this wave is inside the image and the chunk has all CK channels
+                    if (fullchunk && __builtin_amdgcn_ballot_w64(slot && !rowok) == 0) {
+                        if (slot) {
 #pragma unroll
-                for (int i = 0; i < C::NPT; ++i) {
-                    const int p = tid + i * C::NT;
-                    if (p >= C::NPIECE) break;
-                    const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
-                    const int row = rem / C::PR, j = rem % C::PR;
-                    const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
-                    const float* r = reinterpret_cast<const float*>(&raw[i]);
-                    piece_t o;
-                    float* ov = reinterpret_cast<float*>(&o);
+                            for (int i = 0; i < NCI; ++i) {
+                                piece_t o = xraw[k * NCI + i];
+                                if (!plain) {
+                                    const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                                    float* ov = reinterpret_cast<float*>(&o);
 #pragma unroll
-                    for (int u = 0; u < PW; ++u) {
-                        const float v = s.mode == 0 ? r[u] : act(r[u], mean, rstd, a.slope);
-                        ov[u] = ok[i] ? v : 0.f;
+                                    for (int u = 0; u < PW; ++u) ov[u] = act(ov[u], ss.x, ss.y, a.slope);
+                                }
+                                *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                            }
+                        }
+                    } else if (slot) {
+#pragma unroll
+                        for (int i = 0; i < NCI; ++i) {
+                            const bool ok = rowok && ci0 + sgc + i * G < a.cin;
+                            piece_t o = xraw[k * NCI + i];
+                            float* ov = reinterpret_cast<float*>(&o);
+                            const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) ov[u] = ok ? (plain ? ov[u] : act(ov[u], ss.x, ss.y, a.slope)) : 0.f;
+                            *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                        }
                     }
-                    *reinterpret_cast<piece_t*>(in_lds + ck * C::PS + row * C::COLS + PW * j) = o;
                 }
             } else {
                 // pooled source (extent 2H x 2W): 2*PW floats from each of two rows per piece
@@ -344,6 +412,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         if (chunk == 0) CINE_STAMP(3);
         __syncthreads();
         if (chunk == 0) CINE_STAMP(4);
+        if (chunk + 1 < a.nchunks) issue(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA sweep: TAPS * CK/4 operand groups, software-pipelined one group ahead.  The
         // scheduling barriers keep the compiler from hoisting every group's ds_reads to the top
         // (which costs > 100 extra VGPRs and with them half the occupancy).
@@ -392,16 +462,20 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                 for (int j = 0; j < 4; ++j) acc[ct][f][j] += bv;
         }
     }
-    // validity of my 4 pixels per fragment: bit (4 f + j)
-    unsigned long long vmask = 0;
+    // validity of my 4 pixels per fragment: bit (4 f + j); tiles inside the image skip the masking altogether
+    const bool full = r0 + C::TH <= a.H && c0 + TW <= a.W;
+    unsigned long long vmask = ~0ull;
+    if (!full) {
+        vmask = 0;
 #pragma unroll
-    for (int f = 0; f < MT; ++f)
+        for (int f = 0; f < MT; ++f)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = 4 * kk + j;
-            const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
-            if (gy < a.H && gx < a.W) vmask |= 1ull << (4 * f + j);
-        }
+            for (int j = 0; j < 4; ++j) {
+                const int p = 4 * kk + j;
+                const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+                if (gy < a.H && gx < a.W) vmask |= 1ull << (4 * f + j);
+            }
+    }
     if (a.addend || a.relu) {          // CRNN cells: sum with a precomputed term, then ReLU (recurrent_varnet.py:172-178)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -428,28 +502,32 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         const int rows_w = min(max(a.H - (r0 + wn * MT * C::RPF), 0), MT * C::RPF);
         const float cnt_w = (float)(rows_w * min(TW, a.W - c0));
         float mean_w[CT], m2_w[CT];
+        auto wave_stats = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-            float sacc = 0.f;
+            for (int ct = 0; ct < CT; ++ct) {
+                float sacc = 0.f;
 #pragma unroll
-            for (int f = 0; f < MT; ++f)
+                for (int f = 0; f < MT; ++f)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sacc += ((vmask >> (4 * f + j)) & 1ull) ? acc[ct][f][j] : 0.f;
-            sacc += __shfl_xor(sacc, 16, 64);
-            sacc += __shfl_xor(sacc, 32, 64);
-            mean_w[ct] = cnt_w > 0.f ? sacc / cnt_w : 0.f;
-            float qacc = 0.f;
+                    for (int j = 0; j < 4; ++j) sacc += (FULL || ((vmask >> (4 * f + j)) & 1ull)) ? acc[ct][f][j] : 0.f;
+                sacc += __shfl_xor(sacc, 16, 64);
+                sacc += __shfl_xor(sacc, 32, 64);
+                mean_w[ct] = cnt_w > 0.f ? sacc / cnt_w : 0.f;
+                float qacc = 0.f;
 #pragma unroll
-            for (int f = 0; f < MT; ++f)
+                for (int f = 0; f < MT; ++f)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = acc[ct][f][j] - mean_w[ct];
-                    qacc += ((vmask >> (4 * f + j)) & 1ull) ? d * d : 0.f;
-                }
-            qacc += __shfl_xor(qacc, 16, 64);
-            qacc += __shfl_xor(qacc, 32, 64);
-            m2_w[ct] = qacc;
-        }
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = acc[ct][f][j] - mean_w[ct];
+                        qacc += (FULL || ((vmask >> (4 * f + j)) & 1ull)) ? d * d : 0.f;
+                    }
+                qacc += __shfl_xor(qacc, 16, 64);
+                qacc += __shfl_xor(qacc, 32, 64);
+                m2_w[ct] = qacc;
+            }
+        };
+        if (full) wave_stats(std::true_type{}); else wave_stats(std::false_type{});
         __syncthreads();                            // everyone is done reading in_lds
         float* red = in_lds;                        // [WN][COT][3]
         if (kk == 0) {
@@ -515,7 +593,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
             for (int hrow = 0; hrow < 4 / PPR; ++hrow) {
                 const int gy = r0 + (wn * MT + f) * C::RPF + pr0 + hrow;
                 const int j0 = hrow * PPR;
-                if (!((vmask >> (4 * f + j0)) & 1ull)) continue;
+                if (!full && !((vmask >> (4 * f + j0)) & 1ull)) continue;
                 float* dst = yb + (long)gy * a.W + gx0;
                 if (vec) {
                     if (PPR == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
@@ -620,7 +698,7 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const long plane = e / pe;
         const float2 mr = merge_partials(part + plane * np * 3, np, eps);
-        y[e] = act(x[e], mr.x, mr.y, slope);
+        y[e] = act(x[e], mr.y, -mr.x * mr.y, slope);
     }
 }
 
