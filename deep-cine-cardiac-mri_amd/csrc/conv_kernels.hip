@@ -74,6 +74,7 @@ struct ConvArgs {
                                          //    instead of concatenated
     float slope, eps;
     int tiles_w, tiles, nchunks, fast;
+    int tvec;                            // transpose conv: paired 16-byte stores (W multiple of the lane's pixel run, aligned y)
 };
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
@@ -417,11 +418,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         // ---- MFMA sweep: TAPS * CK/4 operand groups, software-pipelined one group ahead.  The
         // scheduling barriers keep the compiler from hoisting every group's ds_reads to the top
         // (which costs > 100 extra VGPRs and with them half the occupancy).
-        {
-            constexpr int NG = TAPS * (CK / 4);
+        auto sweep = [&](auto ksc) {
+            constexpr int KS = decltype(ksc)::value;   // k-steps (groups of 4 input channels) of this chunk that hold data
+            constexpr int NG = TAPS * KS;
             float af[2][CT], bf[2][MT];
             auto load_group = [&](int g, float (&wa)[CT], float (&xa)[MT]) {
-                const int tap = g / (CK / 4), ks = g % (CK / 4);
+                const int tap = g / KS, ks = g % KS;
                 const int dz = TAPS == 27 ? tap / 9 : 0;
                 const int dy = TAPS == 1 ? 0 : (tap / 3) % 3, dx = TAPS == 1 ? 0 : tap % 3;
 #pragma unroll
@@ -441,7 +443,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                         acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g & 1][f], af[g & 1][ct], acc[ct][f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        sweep(std::integral_constant<int, CK / 4>{});
         if (chunk == 0) CINE_STAMP(5);
     }
 
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
             long slot;
             if (a.tconv_cout > 0) {
                 const int nsub = a.vol ? 8 : 4;         // sub-positions of the k2 s2 transpose conv
-                const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
+                const int co = (m >> 1) % a.tconv_cout, ab = 2 * ((m >> 1) / a.tconv_cout) + (m & 1);
                 slot = ((long)n * a.tconv_cout + co) * (a.tiles * nsub) + tile * nsub + ab;
             } else {
                 slot = ((long)n * a.rows + m) * a.tiles + tile;
@@ -570,19 +573,36 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
         const int m = co0 + 16 * (wm * CT + ct) + q;
         if (m >= a.rows) continue;
         if (a.tconv_cout > 0) {
-            const int co = m % a.tconv_cout, ab = m / a.tconv_cout;
-            // 2-D: ab = 2a + b -> (2y+a, 2x+b); 3-D: ab = 4a + 2b + c -> (2z+a, 2y+b, 2x+c)
-            const int sz = a.vol ? (ab >> 2) : 0, ab2 = a.vol ? (ab & 3) : ab;
+            // row m = 2*(s*cout + co) + b with b the x-parity and s = a (2-D: output row parity) or 2*az + ay (3-D):
+            // output (2z+az, 2y+ay, 2x+b)
+            const int me = m >> 1, co = me % a.tconv_cout, sub = me / a.tconv_cout;
+            const int sz = a.vol ? (sub >> 1) : 0, ay = a.vol ? (sub & 1) : sub;
             float* yb = a.y + (((long)n * a.tconv_cout + co) * (a.vol ? 2 * a.D : 1) + (a.vol ? 2 * z0 + sz : 0)) * (2 * a.H) * (2 * a.W);
+            const bool odd = q & 1;
+            if (a.tvec) {
+                // lanes q, q^1 hold the two x-parities of the same 4 pixels: swap halves so that each lane owns
+                // 4 consecutive output floats (even lane: pixels 0,1; odd lane: pixels 2,3 of the quad)
 #pragma unroll
-            for (int f = 0; f < MT; ++f)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!((vmask >> (4 * f + j)) & 1ull)) continue;
-                    const int p = 4 * kk + j;
+                for (int f = 0; f < MT; ++f) {
+                    const float s0 = odd ? acc[ct][f][0] : acc[ct][f][2], s1 = odd ? acc[ct][f][1] : acc[ct][f][3];
+                    const float t0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                    const float t1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xf, 0xf, true));
+                    const float4 o = odd ? make_float4(t0, acc[ct][f][2], t1, acc[ct][f][3]) : make_float4(acc[ct][f][0], t0, acc[ct][f][1], t1);
+                    const int p = 4 * kk + (odd ? 2 : 0);
                     const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
-                    yb[(long)(2 * gy + (ab2 >> 1)) * (2 * a.W) + 2 * gx + (ab2 & 1)] = acc[ct][f][j];
+                    if (gy < a.H && gx < a.W) *reinterpret_cast<float4*>(yb + (long)(2 * gy + ay) * (2 * a.W) + 2 * gx) = o;
                 }
+            } else {
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!((vmask >> (4 * f + j)) & 1ull)) continue;
+                        const int p = 4 * kk + j;
+                        const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+                        yb[(long)(2 * gy + ay) * (2 * a.W) + 2 * gx + (odd ? 1 : 0)] = acc[ct][f][j];
+                    }
+            }
             continue;
         }
         float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W;
@@ -612,7 +632,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
 
 // ---------------------------------------------------------------- weight packing
 // conv3x3 (cout, cin, 3, 3)        -> [chunk][tap][ck][rowsp]     rows = cout
-// tconv   (cin, cout, 2, 2)        -> [chunk][1][ck][rowsp]       rows = 4*cout, row = (2a+b)*cout + co
+// tconv   (cin, cout, 2, 2)        -> [chunk][1][ck][rowsp]       rows = 4*cout, row = 2*(a*cout + co) + b: the two x-parities
+//                                     of one output channel sit in adjacent lanes, which pair up for 16-byte stores
 // conv1x1 (cout, cin)              -> [chunk][1][ck][rowsp]       rows = cout
 __global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout, int cin, int rows, int rowsp,
                                     int taps, int ck_, int nchunks) {
@@ -627,9 +648,9 @@ __global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout
         float v = 0.f;
         if (m < rows && ci < cin) {
             if (kind == 0) v = w[((long)m * cin + ci) * 9 + tap];
-            else if (kind == 1) { const int ab = m / cout, co = m % cout; v = w[((long)ci * cout + co) * 4 + ab]; }
+            else if (kind == 1) { const int b = m & 1, co = (m >> 1) % cout, a_ = (m >> 1) / cout; v = w[((long)ci * cout + co) * 4 + 2 * a_ + b]; }
             else if (kind == 3) v = w[((long)m * cin + ci) * 27 + tap];                                   // conv3d
-            else if (kind == 4) { const int ab = m / cout, co = m % cout; v = w[((long)ci * cout + co) * 8 + ab]; }   // tconv3d
+            else if (kind == 4) { const int c_ = m & 1, co = (m >> 1) % cout, ab = (m >> 1) / cout; v = w[((long)ci * cout + co) * 8 + 2 * ab + c_]; }   // tconv3d
             else v = w[(long)m * cin + ci];
         }
         p[e] = v;
@@ -730,6 +751,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     };
     a.fast = !a.vol && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
+    a.tvec = a.tconv_cout > 0 && a.W % (TW >= 4 ? 4 : 2) == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     ProfScope prof(TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1), st);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, a);
