@@ -724,6 +724,13 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
 }
 
 // ---------------------------------------------------------------- host dispatch
+#ifndef CINE_WN16
+#define CINE_WN16 4
+#endif
+#ifndef CINE_WN32
+#define CINE_WN32 4
+#endif
+constexpr int kWN16 = CINE_WN16, kWN32 = CINE_WN32;   // waves (each 13 pixel fragments) per workgroup for <= 16 / <= 32 output rows
 constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
 constexpr int kCK1 = 16;    // 1x1 / tconv
 constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel live in LDS
@@ -761,8 +768,8 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
 template <int TW, int TAPS, int CK>
 static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * TW, 16) * ceil_div(a.W, TW);   // fragments per sample
-    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, 4, 13, TW, TAPS>(a, st);
-    if (a.rowsp <= 32) return launch_cfg<CK, 2, 1, 4, 13, TW, TAPS>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, 13, TW, TAPS>(a, st);
+    if (a.rowsp <= 32) return launch_cfg<CK, 2, 1, kWN32, 13, TW, TAPS>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<CK, 1, 4, 1, 13, TW, TAPS>(a, st);
     return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
 }
@@ -780,7 +787,8 @@ int tiles_for(int rowsp, int h, int w, int d = 1) {
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
     int nf;
-    if (rowsp <= 32) nf = 52;
+    if (rowsp <= 16) nf = 13 * kWN16;
+    else if (rowsp <= 32) nf = 13 * kWN32;
     else if (rowsp <= 64 || frags > 8) nf = 13;
     else nf = 4;
     const int TH = nf * 16 / TW;

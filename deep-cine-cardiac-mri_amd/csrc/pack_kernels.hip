@@ -3,6 +3,7 @@
 // These are the small HBM-bound byte-moving steps around the regulariser
 // (SURVEY.md K3/K4/K5/K13/K14): every tensor here is a few MB, so the kernels
 // favour simplicity; each reads/writes with the fastest-varying index on lanes.
+#include <algorithm>
 #include "common.h"
 #include "fft_core.h"
 
@@ -36,38 +37,64 @@ struct PackArgs {
     int norm;                     // 0: plain re/im planes (CineNet / XPDNet feed a bare Unet), 1: NormUnet group norm
 };
 
-__global__ void normunet_pack_kernel(PackArgs a) {
+// Two argument sets per launch (blockIdx.y): the x-f and y-f plane sets of one cascade go out together.
+struct PackArgs2 { PackArgs s[2]; };
+constexpr int kPackRegs = 16;       // plane elements a thread keeps in registers on the single-read path
+
+__global__ void normunet_pack_kernel(PackArgs2 two) {
     __shared__ float red[16];
+    const PackArgs& a = two.s[blockIdx.y];
     const int n = blockIdx.x;
+    if (n >= a.n) return;
     const float* src = a.x + (long)(n / a.ninner) * a.s_outer + (long)(n % a.ninner) * a.s_inner;
     const int cnt = a.I * a.J;
+    const int nt = blockDim.x;
+    float* pr = a.planes + (long)n * 2 * a.Ip * a.Jp;
+    float* pi = pr + (long)a.Ip * a.Jp;
     if (!a.norm) {
-        float* pr0 = a.planes + (long)n * 2 * a.Ip * a.Jp;
-        float* pi0 = pr0 + (long)a.Ip * a.Jp;
-        for (int e = threadIdx.x; e < a.Ip * a.Jp; e += blockDim.x) {
+        for (int e = threadIdx.x; e < a.Ip * a.Jp; e += nt) {
             const int ip = e / a.Jp, jp = e - ip * a.Jp;
             const int i = ip - a.pad_i, j = jp - a.pad_j;
             float2 v = make_float2(0.f, 0.f);
             if (i >= 0 && i < a.I && j >= 0 && j < a.J) v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
-            pr0[e] = v.x; pi0[e] = v.y;
+            pr[e] = v.x; pi[e] = v.y;
         }
         return;
     }
+    const bool inreg = cnt <= kPackRegs * nt;          // uniform: the whole plane fits the workgroup's registers
+    float2 keep[kPackRegs];
     // pass 1: means (norm_unet.py:64)
     float sr = 0.f, si_ = 0.f;
-    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const int i = e / a.J, j = e - i * a.J;
-        const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
-        sr += v.x; si_ += v.y;
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < kPackRegs; ++k) {
+            const int e = threadIdx.x + k * nt;
+            const int ec = min(e, cnt - 1);
+            const int i = ec / a.J, j = ec - i * a.J;
+            keep[k] = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+            if (e < cnt) { sr += keep[k].x; si_ += keep[k].y; }
+        }
+    } else {
+        for (int e = threadIdx.x; e < cnt; e += nt) {
+            const int i = e / a.J, j = e - i * a.J;
+            const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+            sr += v.x; si_ += v.y;
+        }
     }
     const float mr = block_sum(sr, red) / cnt;
     const float mi = block_sum(si_, red) / cnt;
     // pass 2: unbiased std (norm_unet.py:65, torch.std default)
     float qr = 0.f, qi = 0.f;
-    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
-        const int i = e / a.J, j = e - i * a.J;
-        const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
-        qr += (v.x - mr) * (v.x - mr); qi += (v.y - mi) * (v.y - mi);
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < kPackRegs; ++k)
+            if (threadIdx.x + k * nt < cnt) { qr += (keep[k].x - mr) * (keep[k].x - mr); qi += (keep[k].y - mi) * (keep[k].y - mi); }
+    } else {
+        for (int e = threadIdx.x; e < cnt; e += nt) {
+            const int i = e / a.J, j = e - i * a.J;
+            const float2 v = *reinterpret_cast<const float2*>(src + i * a.si + j * a.sj);
+            qr += (v.x - mr) * (v.x - mr); qi += (v.y - mi) * (v.y - mi);
+        }
     }
     const float sdr = sqrtf(block_sum(qr, red) / (cnt - 1));
     const float sdi = sqrtf(block_sum(qi, red) / (cnt - 1));
@@ -76,9 +103,27 @@ __global__ void normunet_pack_kernel(PackArgs a) {
         st[0] = mr; st[1] = sdr; st[2] = mi; st[3] = sdi;
     }
     // pass 3: (x - mean) / std into the zero-padded planes (norm_unet.py:69, 76-86)
-    float* pr = a.planes + (long)n * 2 * a.Ip * a.Jp;
-    float* pi = pr + (long)a.Ip * a.Jp;
-    for (int e = threadIdx.x; e < a.Ip * a.Jp; e += blockDim.x) {
+    if (inreg) {
+        // interior from the registers, then the zero frame
+#pragma unroll
+        for (int k = 0; k < kPackRegs; ++k) {
+            const int e = threadIdx.x + k * nt;
+            if (e < cnt) {
+                const int i = e / a.J, j = e - i * a.J;
+                const int q = (i + a.pad_i) * a.Jp + j + a.pad_j;
+                pr[q] = (keep[k].x - mr) / sdr; pi[q] = (keep[k].y - mi) / sdi;
+            }
+        }
+        if (a.Ip != a.I || a.Jp != a.J) {
+            for (int e = threadIdx.x; e < a.Ip * a.Jp; e += nt) {
+                const int ip = e / a.Jp, jp = e - ip * a.Jp;
+                const int i = ip - a.pad_i, j = jp - a.pad_j;
+                if (i < 0 || i >= a.I || j < 0 || j >= a.J) { pr[e] = 0.f; pi[e] = 0.f; }
+            }
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < a.Ip * a.Jp; e += nt) {
         const int ip = e / a.Jp, jp = e - ip * a.Jp;
         const int i = ip - a.pad_i, j = jp - a.pad_j;
         float vr = 0.f, vi = 0.f;
@@ -88,6 +133,20 @@ __global__ void normunet_pack_kernel(PackArgs a) {
         }
         pr[e] = vr; pi[e] = vi;
     }
+}
+
+// threads per workgroup: the smallest of 256 / 512 / 1024 that keeps a plane in registers, else 1024
+static int pack_threads(const PackArgs& a) {
+    const long cnt = (long)a.I * a.J;
+    for (int nt : {256, 512, 1024}) if (cnt <= (long)kPackRegs * nt) return nt;
+    return 1024;
+}
+static int launch_pack(const PackArgs& a0, const PackArgs* a1, hipStream_t st) {
+    PackArgs2 two{};
+    two.s[0] = a0; two.s[1] = a1 ? *a1 : a0;
+    const int nt = std::max(pack_threads(a0), a1 ? pack_threads(*a1) : 0);
+    hipLaunchKernelGGL(normunet_pack_kernel, dim3(std::max(a0.n, a1 ? a1->n : 0), a1 ? 2 : 1), dim3(nt), 0, st, two);
+    return check_launch("normunet_pack_kernel");
 }
 
 __global__ void normunet_unpack_kernel(const float* planes, const float* stats, float* y,
@@ -301,8 +360,7 @@ extern "C" int cine_normunet_pack(const float* x, float* planes, float* stats, i
     pad_split(h, a.Ip, a.pad_i, a.norm); pad_split(w, a.Jp, a.pad_j, a.norm);
     a.ninner = 1; a.s_outer = (long)h * w * 2; a.s_inner = 0; a.si = (long)w * 2; a.sj = 2;
     ProfScope prof(F_PACK, as_stream(stream));
-    hipLaunchKernelGGL(normunet_pack_kernel, dim3(n), dim3(256), 0, as_stream(stream), a);
-    return check_launch("normunet_pack_kernel");
+    return launch_pack(a, nullptr, as_stream(stream));
 }
 
 extern "C" int cine_normunet_unpack(const float* planes, const float* stats, float* y, int n, int h, int w, void* stream) {
@@ -341,15 +399,13 @@ extern "C" int cine_xfyf_pack(const float* img, float* planes_xf, float* planes_
     a.n = b * h; a.I = w; a.J = t; a.norm = norm != 0;
     pad_split(w, a.Ip, a.pad_i, a.norm); pad_split(t, a.Jp, a.pad_j, a.norm);
     a.ninner = h; a.s_outer = HW * t * 2; a.s_inner = (long)w * t * 2; a.si = (long)t * 2; a.sj = 2;
-    hipLaunchKernelGGL(normunet_pack_kernel, dim3(a.n), dim3(256), 0, st, a);
-    if (int e = check_launch("normunet_pack_kernel(xf)")) return e;
+    const PackArgs axf = a;
     // yf planes: sample (b, w), rows = h, cols = t          (varnet.py:217)
     a.planes = planes_yf; a.stats = stats_yf;
     a.n = b * w; a.I = h; a.J = t;
     pad_split(h, a.Ip, a.pad_i, a.norm); pad_split(t, a.Jp, a.pad_j, a.norm);
     a.ninner = w; a.s_outer = HW * t * 2; a.s_inner = (long)t * 2; a.si = (long)w * t * 2; a.sj = 2;
-    hipLaunchKernelGGL(normunet_pack_kernel, dim3(a.n), dim3(256), 0, st, a);
-    return check_launch("normunet_pack_kernel(yf)");
+    return launch_pack(axf, &a, st);
 }
 
 extern "C" int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, const float* stats_xf,
