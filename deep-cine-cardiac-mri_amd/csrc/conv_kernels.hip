@@ -630,6 +630,60 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     CINE_STAMP_RT(10);
 }
 
+// ---------------------------------------------------------------- final 1x1 conv, few output channels
+// The U-Net's last layer (unet.py:69) maps chans -> 2: no matrix-core work to speak of, one streaming read
+// of the level-0 tensor.  Lanes run over 4-pixel groups, the channel loop keeps 8 16-byte loads in flight.
+struct Conv1Args {
+    const float* x; const float* part; int np, mode;
+    const float* wp0; const float* wp1; const float* b0; const float* b1; int set_split;
+    float* y; int cin, rowsp; long hw; float eps, slope;
+};
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(Conv1Args a) {
+    extern __shared__ __align__(16) float smem_c1[];
+    float* st = smem_c1;                 // {scale, shift} per input channel
+    float* wl = smem_c1 + 2 * a.cin;     // [cin][COUT]
+    const int n = blockIdx.y, tid = threadIdx.x;
+    const bool second = n >= a.set_split;
+    const float* wp = second ? a.wp1 : a.wp0;
+    const float* bias = second ? a.b1 : a.b0;
+    for (int ci = tid; ci < a.cin; ci += 256) {
+        float2 mr = make_float2(0.f, 1.f);
+        if (a.mode == 1) mr = merge_partials(a.part + ((long)n * a.cin + ci) * a.np * 3, a.np, a.eps);
+        st[2 * ci] = mr.y; st[2 * ci + 1] = -mr.x * mr.y;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) wl[ci * COUT + co] = wp[(long)ci * a.rowsp + co];
+    }
+    __syncthreads();
+    const long g = (long)blockIdx.x * 256 + tid;            // 4-pixel group
+    if (4 * g >= a.hw) return;
+    const float* xp = a.x + (long)n * a.cin * a.hw + 4 * g;
+    float4 acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) { const float b = bias[co]; acc[co] = make_float4(b, b, b, b); }
+    constexpr int U = 8;
+    for (int c0 = 0; c0 < a.cin; c0 += U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)min(c0 + u, a.cin - 1) * a.hw);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u >= a.cin) break;
+            const float sc = st[2 * (c0 + u)], sh = st[2 * (c0 + u) + 1];
+            float4 t = v[u];
+            if (a.mode == 1) { t.x = act(t.x, sc, sh, a.slope); t.y = act(t.y, sc, sh, a.slope); t.z = act(t.z, sc, sh, a.slope); t.w = act(t.w, sc, sh, a.slope); }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float w = wl[(c0 + u) * COUT + co];
+                acc[co].x = fmaf(w, t.x, acc[co].x); acc[co].y = fmaf(w, t.y, acc[co].y);
+                acc[co].z = fmaf(w, t.z, acc[co].z); acc[co].w = fmaf(w, t.w, acc[co].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) *reinterpret_cast<float4*>(a.y + ((long)n * COUT + co) * a.hw + 4 * g) = acc[co];
+}
+
 // ---------------------------------------------------------------- weight packing
 // conv3x3 (cout, cin, 3, 3)        -> [chunk][tap][ck][rowsp]     rows = cout
 // tconv   (cin, cout, 2, 2)        -> [chunk][1][ck][rowsp]       rows = 4*cout, row = 2*(a*cout + co) + b: the two x-parities
@@ -951,6 +1005,23 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
     if (int e = check_src(x, part_x, cin, mode, np_x, "cine_conv1x1_bias")) return e;
     CINE_REQUIRE(mode != 2, CINE_EINVAL, "cine_conv1x1_bias: mode 2 not supported");
     const bool two = wpacked2 && bias2 && set_split < n;
+    const long hw = (long)h * w;
+    if (cout <= 4 && cin <= 1024 && (mode == 0 || mode == 1) && hw % 4 == 0 &&
+        reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0) {
+        Conv1Args c{x, part_x, np_x, mode, wpacked, two ? wpacked2 : wpacked, bias, two ? bias2 : bias, two ? set_split : n,
+                    y, cin, ceil_div(cout, 16) * 16, hw, eps, slope};
+        const dim3 grid((unsigned)ceil_div(hw / 4, 256L), n);
+        const size_t lds = (size_t)(2 + cout) * cin * sizeof(float);
+        hipStream_t st = as_stream(stream);
+        ProfScope prof(F_CONV1, st);
+        switch (cout) {
+            case 1: hipLaunchKernelGGL(conv1x1_stream_kernel<1>, grid, dim3(256), lds, st, c); break;
+            case 2: hipLaunchKernelGGL(conv1x1_stream_kernel<2>, grid, dim3(256), lds, st, c); break;
+            case 3: hipLaunchKernelGGL(conv1x1_stream_kernel<3>, grid, dim3(256), lds, st, c); break;
+            default: hipLaunchKernelGGL(conv1x1_stream_kernel<4>, grid, dim3(256), lds, st, c); break;
+        }
+        return check_launch("conv1x1_stream_kernel");
+    }
     for (int s = 0; s < (two ? 2 : 1); ++s) {     // the bias pointer is per launch: one launch per weight set
         const int n0 = s ? set_split : 0, n1 = two ? (s ? n : set_split) : n;
         if (n1 <= n0) continue;

@@ -272,9 +272,12 @@ def test_tconv_and_conv1x1_vs_torch(dev, cin, cout, h, w):
     st = ops.instnorm_finalize(part)
     assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3))) < 1e-4
     assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)) < 1e-4
-    w1 = rnd(7, 2, cin, 1, 1) / cin ** 0.5; b1 = rnd(8, 2)
-    y1 = ops.conv1x1_bias(x.to(dev), px, 1, ops.pack_conv1x1(w1.to(dev)), b1.to(dev))
-    assert rel_err(y1.cpu(), F.conv2d(act(x), w1, b1)) < BLOCK_TOL
+    for c1 in (2, 3, 6):       # <= 4 output channels: streaming kernel (unless h*w is odd); more: the MFMA kernel
+        w1 = rnd(7, c1, cin, 1, 1) / cin ** 0.5; b1 = rnd(8, c1)
+        y1 = ops.conv1x1_bias(x.to(dev), px, 1, ops.pack_conv1x1(w1.to(dev)), b1.to(dev))
+        assert rel_err(y1.cpu(), F.conv2d(act(x), w1, b1)) < BLOCK_TOL
+        y0 = ops.conv1x1_bias(x.to(dev), None, 0, ops.pack_conv1x1(w1.to(dev)), b1.to(dev))
+        assert rel_err(y0.cpu(), F.conv2d(x, w1, b1)) < BLOCK_TOL
 
 
 # ------------------------------------------------------------------ blocks and models
