@@ -498,6 +498,67 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
                 }
         }
     }
+    // ---- the raw output goes out first: the stores drain while the statistics below are reduced
+    // ---- store raw output: PPR consecutive pixels of one row per (ct, f [, half])
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = co0 + 16 * (wm * CT + ct) + q;
+        if (m >= a.rows) continue;
+        if (a.tconv_cout > 0) {
+            // row m = 2*(s*cout + co) + b with b the x-parity and s = a (2-D: output row parity) or 2*az + ay (3-D):
+            // output (2z+az, 2y+ay, 2x+b)
+            const int me = m >> 1, co = me % a.tconv_cout, sub = me / a.tconv_cout;
+            const int sz = a.vol ? (sub >> 1) : 0, ay = a.vol ? (sub & 1) : sub;
+            float* yb = a.y + (((long)n * a.tconv_cout + co) * (a.vol ? 2 * a.D : 1) + (a.vol ? 2 * z0 + sz : 0)) * (2 * a.H) * (2 * a.W);
+            const bool odd = q & 1;
+            if (a.tvec) {
+                // lanes q, q^1 hold the two x-parities of the same 4 pixels: swap halves so that each lane owns
+                // 4 consecutive output floats (even lane: pixels 0,1; odd lane: pixels 2,3 of the quad)
+#pragma unroll
+                for (int f = 0; f < MT; ++f) {
+                    const float s0 = odd ? acc[ct][f][0] : acc[ct][f][2], s1 = odd ? acc[ct][f][1] : acc[ct][f][3];
+                    const float t0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                    const float t1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xf, 0xf, true));
+                    const float4 o = odd ? make_float4(t0, acc[ct][f][2], t1, acc[ct][f][3]) : make_float4(acc[ct][f][0], t0, acc[ct][f][1], t1);
+                    const int p = 4 * kk + (odd ? 2 : 0);
+                    const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+                    if (gy < a.H && gx < a.W) *reinterpret_cast<float4*>(yb + (long)(2 * gy + ay) * (2 * a.W) + 2 * gx) = o;
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!((vmask >> (4 * f + j)) & 1ull)) continue;
+                        const int p = 4 * kk + j;
+                        const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
+                        yb[(long)(2 * gy + ay) * (2 * a.W) + 2 * gx + (odd ? 1 : 0)] = acc[ct][f][j];
+                    }
+            }
+            continue;
+        }
+        float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W;
+        const bool vec = (a.W % PPR) == 0 && ((long)a.H * a.W) % PPR == 0;   // rows stay 16-byte (8-byte) aligned
+#pragma unroll
+        for (int f = 0; f < MT; ++f) {
+#pragma unroll
+            for (int hrow = 0; hrow < 4 / PPR; ++hrow) {
+                const int gy = r0 + (wn * MT + f) * C::RPF + pr0 + hrow;
+                const int j0 = hrow * PPR;
+                if (!full && !((vmask >> (4 * f + j0)) & 1ull)) continue;
+                float* dst = yb + (long)gy * a.W + gx0;
+                if (vec) {
+                    if (PPR == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+                    else *reinterpret_cast<float2*>(dst) = make_float2(acc[ct][f][j0], acc[ct][f][j0 + 1]);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < PPR; ++u)
+                        if ((vmask >> (4 * f + j0 + u)) & 1ull) dst[u] = acc[ct][f][j0 + u];
+                }
+            }
+        }
+    }
+    CINE_STAMP(7);
     if (a.ypart) {
         // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass
         // per WAVE in registers (sum -> wave mean -> squared deviations), the WN wave records are merged
@@ -564,66 +625,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
             }
             float* o = a.ypart + slot * 3;
             o[0] = cnt; o[1] = mean; o[2] = m2;
-        }
-    }
-    CINE_STAMP(7);
-    // ---- store raw output: PPR consecutive pixels of one row per (ct, f [, half])
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int m = co0 + 16 * (wm * CT + ct) + q;
-        if (m >= a.rows) continue;
-        if (a.tconv_cout > 0) {
-            // row m = 2*(s*cout + co) + b with b the x-parity and s = a (2-D: output row parity) or 2*az + ay (3-D):
-            // output (2z+az, 2y+ay, 2x+b)
-            const int me = m >> 1, co = me % a.tconv_cout, sub = me / a.tconv_cout;
-            const int sz = a.vol ? (sub >> 1) : 0, ay = a.vol ? (sub & 1) : sub;
-            float* yb = a.y + (((long)n * a.tconv_cout + co) * (a.vol ? 2 * a.D : 1) + (a.vol ? 2 * z0 + sz : 0)) * (2 * a.H) * (2 * a.W);
-            const bool odd = q & 1;
-            if (a.tvec) {
-                // lanes q, q^1 hold the two x-parities of the same 4 pixels: swap halves so that each lane owns
-                // 4 consecutive output floats (even lane: pixels 0,1; odd lane: pixels 2,3 of the quad)
-#pragma unroll
-                for (int f = 0; f < MT; ++f) {
-                    const float s0 = odd ? acc[ct][f][0] : acc[ct][f][2], s1 = odd ? acc[ct][f][1] : acc[ct][f][3];
-                    const float t0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
-                    const float t1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xf, 0xf, true));
-                    const float4 o = odd ? make_float4(t0, acc[ct][f][2], t1, acc[ct][f][3]) : make_float4(acc[ct][f][0], t0, acc[ct][f][1], t1);
-                    const int p = 4 * kk + (odd ? 2 : 0);
-                    const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
-                    if (gy < a.H && gx < a.W) *reinterpret_cast<float4*>(yb + (long)(2 * gy + ay) * (2 * a.W) + 2 * gx) = o;
-                }
-            } else {
-#pragma unroll
-                for (int f = 0; f < MT; ++f)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!((vmask >> (4 * f + j)) & 1ull)) continue;
-                        const int p = 4 * kk + j;
-                        const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
-                        yb[(long)(2 * gy + ay) * (2 * a.W) + 2 * gx + (odd ? 1 : 0)] = acc[ct][f][j];
-                    }
-            }
-            continue;
-        }
-        float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W;
-        const bool vec = (a.W % PPR) == 0 && ((long)a.H * a.W) % PPR == 0;   // rows stay 16-byte (8-byte) aligned
-#pragma unroll
-        for (int f = 0; f < MT; ++f) {
-#pragma unroll
-            for (int hrow = 0; hrow < 4 / PPR; ++hrow) {
-                const int gy = r0 + (wn * MT + f) * C::RPF + pr0 + hrow;
-                const int j0 = hrow * PPR;
-                if (!full && !((vmask >> (4 * f + j0)) & 1ull)) continue;
-                float* dst = yb + (long)gy * a.W + gx0;
-                if (vec) {
-                    if (PPR == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
-                    else *reinterpret_cast<float2*>(dst) = make_float2(acc[ct][f][j0], acc[ct][f][j0 + 1]);
-                } else {
-#pragma unroll
-                    for (int u = 0; u < PPR; ++u)
-                        if ((vmask >> (4 * f + j0 + u)) & 1ull) dst[u] = acc[ct][f][j0 + u];
-                }
-            }
         }
     }
     CINE_STAMP(8);
