@@ -6,21 +6,23 @@
 int main(int argc, char** argv) {
     const int n = 400, cin = argc > 1 ? atoi(argv[1]) : 16, cout = argc > 2 ? atoi(argv[2]) : 16;
     const int h = argc > 3 ? atoi(argv[3]) : 208, w = argc > 4 ? atoi(argv[4]) : 16;
-    const size_t xe = (size_t)n * cin * h * w, ye = (size_t)n * cout * h * w;
+    const bool tconv = argc > 5 && atoi(argv[5]) == 2;     // 5th argument 2: transpose conv k2 s2 instead of conv3x3
+    const size_t xe = (size_t)n * cin * h * w, ye = (size_t)n * cout * h * w * (tconv ? 4 : 1);
     float *x, *y, *wt, *wp, *px, *py;
     hipMalloc(&x, xe * 4); hipMalloc(&y, ye * 4); hipMalloc(&wt, (size_t)cout * cin * 9 * 4);
-    const size_t pf = cine_conv3x3_packed_floats(cout, cin); hipMalloc(&wp, pf * 4);
-    const int np = cine_conv_stat_partials(cout, h, w, 0);
+    const size_t pf = tconv ? cine_tconv2x2_packed_floats(cin, cout) : cine_conv3x3_packed_floats(cout, cin); hipMalloc(&wp, pf * 4);
+    const int np = cine_conv_stat_partials(cout, h, w, tconv ? 1 : 0);
     hipMalloc(&px, (size_t)n * cin * 3 * 4); hipMalloc(&py, (size_t)n * cout * np * 3 * 4);
     std::vector<float> hx(xe); for (auto& v : hx) v = rand() / (float)RAND_MAX - .5f;
     hipMemcpy(x, hx.data(), xe * 4, hipMemcpyHostToDevice);
     hipMemcpy(wt, hx.data(), (size_t)cout * cin * 9 * 4, hipMemcpyHostToDevice);
-    cine_pack_conv3x3(wt, wp, cout, cin, nullptr);
+    if (tconv) cine_pack_tconv2x2(wt, wp, cin, cout, nullptr); else cine_pack_conv3x3(wt, wp, cout, cin, nullptr);
     cine_instnorm_partials(x, px, (long)n * cin, (long)h * w, nullptr);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
-        int rc = cine_conv3x3_in(x, px, 1, cin, 1, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, wp, nullptr, 0, y, py, n, cout, h, w, 1e-5f, 0.2f, nullptr);
+        int rc = tconv ? cine_tconv2x2_in(x, px, 1, 1, wp, nullptr, n, y, py, n, cin, cout, h, w, 1e-5f, 0.2f, nullptr)
+                       : cine_conv3x3_in(x, px, 1, cin, 1, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, wp, nullptr, 0, y, py, n, cout, h, w, 1e-5f, 0.2f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("rc=%d  launch %d: %.1f us  (%.1f TFLOP/s)\n", rc, it, ms * 1e3, 2.0 * n * h * w * 9.0 * cin * cout / (ms * 1e-3) / 1e12);
