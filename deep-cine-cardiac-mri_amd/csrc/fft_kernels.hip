@@ -254,6 +254,10 @@ constexpr int kLP200c = kFL;            // column passes: lanes run over lines, 
 constexpr int kLP200r = kFL + 1;        // row passes: lanes run over points, odd stride spreads banks
 
 __device__ __forceinline__ int wrap200(int x) { return x >= 200 ? x - 200 : (x < 0 ? x + 200 : x); }
+// (20 j + c +- 100) mod 200 for 0 <= c < 20 and (10 k + g +- 100) mod 200 for 0 <= g < 10: with j / k a compile-time
+// constant of an unrolled loop the wrap is decided at compile time (no compare + select per access)
+__device__ __forceinline__ int rot20(int j, int c) { return 20 * j + c + (j < 5 ? 100 : -100); }
+__device__ __forceinline__ int rot10(int k, int g) { return 10 * k + g + (k < 10 ? 100 : -100); }
 
 // Column pass along h (H == 200).  DIR forward/inverse, optional DC on the centered rows, and with
 // INV_AFTER the inverse transform of the blended column right away (k-space -> DC -> hybrid space
@@ -280,13 +284,13 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         const int g2 = tid / kFL;
         const uint8_t* mrow = a.mask + (img / a.coils) * 200;
 #pragma unroll
-        for (int k2 = 0; k2 < 20; ++k2) mbits |= (mrow[wrap200(g2 + 10 * k2 + 100)] ? 1u : 0u) << k2;
+        for (int k2 = 0; k2 < 20; ++k2) mbits |= (mrow[rot10(k2, g2)] ? 1u : 0u) << k2;
         if (POST == POST_DC || POST == POST_RESID) {
             const cf* kref = a.kref + img * 200 * a.W;
             const int colc = min(w0 + tid % kFL, a.W - 1);
 #pragma unroll
             for (int k2 = 0; k2 < 20; ++k2) {
-                const int off = ((mbits >> k2) & 1u) ? wrap200(g2 + 10 * k2 + 100) * a.W + colc : 0;
+                const int off = ((mbits >> k2) & 1u) ? rot10(k2, g2) * a.W + colc : 0;
                 rr[k2] = kref[off];
             }
         }
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         const int colc = min(col, a.W - 1);                     // clamped: lanes past the edge load a valid
         cf v[10];                                               // column and are never stored (no branches)
 #pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = in[wrap200(20 * j + c - 100) * a.W + colc];   // x'[n] = x[(n - 100) mod N]
+        for (int j = 0; j < 10; ++j) v[j] = in[rot20(j, c) * a.W + colc];   // x'[n] = x[(n - 100) mod N]
         Fft200::r10_regs<DIR, false, true>(v, c, TW200);
 #pragma unroll
         for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         if (!INV_AFTER) {
             if (col < a.W) {
 #pragma unroll
-                for (int k2 = 0; k2 < 20; ++k2) out[wrap200(g + 10 * k2 + 100) * a.W + col] = v[k2];
+                for (int k2 = 0; k2 < 20; ++k2) out[rot10(k2, g) * a.W + col] = v[k2];
             }
             return;
         }
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         Fft200::r10_regs<-DIR, true, false>(v, c, TW200);
         if (col < a.W) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) out[wrap200(20 * j + c + 100) * a.W + col] = v[j];
+            for (int j = 0; j < 10; ++j) out[rot20(j, c) * a.W + col] = v[j];
         }
         CINE_STAMP(8 + r);
     }
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(kFT, 3) void row200_reduce_kernel(RowArgs a) {
             const cf* src = a.in + ((long)bt * a.C + c0 + min(cl, nc - 1)) * HW + (long)min(h, a.H - 1) * 200;
             cf v[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = src[wrap200(20 * j + c - 100)];
+            for (int j = 0; j < 10; ++j) v[j] = src[rot20(j, c)];
             Fft200::r10_regs<-1, false, true>(v, c, TW200);
 #pragma unroll
             for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(kFT, 3) void row200_expand_kernel(RowArgs a) {
             cf xs[20], ss[20], v[20];
 #pragma unroll
             for (int j = 0; j < 20; ++j) {
-                const int gi = wrap200(10 * j + g - 100);
+                const int gi = rot10(j, g);
                 xs[j] = xp[gi]; ss[j] = sp[gi];
             }
 #pragma unroll
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(kFT, 3) void row200_expand_kernel(RowArgs a) {
             if (cl < nc && h < a.H) {
                 cf* dst = a.out + ((long)bt * a.C + c0 + cl) * HW + (long)h * 200;
 #pragma unroll
-                for (int j = 0; j < 10; ++j) dst[wrap200(20 * j + c + 100)] = v[j];
+                for (int j = 0; j < 10; ++j) dst[rot20(j, c)] = v[j];
             }
         }
         __syncthreads();
