@@ -80,7 +80,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1,
                     help="slices per step: one forward over a (batch, t, coil, h, w, 2) k-space batch, the reference's batch axis")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-forwards", type=int, default=2)
+    ap.add_argument("--cpu-forwards", type=int, default=1)
     return ap.parse_args()
 
 
@@ -230,10 +230,21 @@ def main():
                 "achieved": CONV3_FLOP_PER_SLICE / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "traffic": None, "launches_per_slice": conv_n, "ms_per_slice": conv_ms}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    # HBM-side bytes per launch of that kernel family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    # command, summarised by tools/pmc_traffic.py into profiles/ (PMC collection cannot run inside the bench itself)
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tr = json.load(f)["families"]
+        roofline["traffic"] = tr["conv3x3_mfma"]["hbm_MB_per_launch"] * 1e6
+        roofline["traffic_unit"] = "HBM bytes per launch (mean over the 98 launches of a slice), PMC, profiles/r01_pmc_traffic.json"
     roof_fft = {"bound": "hbm", "kernel": "col_pass_kernel + row_pass_kernel (sens_reduce x7, sens_expand+DC x6)",
                 "achieved": FFT_DC_BYTES_PER_SLICE / (fft_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": None, "ms_per_slice": fft_ms}
     roof_fft["frac"] = roof_fft["achieved"] / roof_fft["peak"]
+    if os.path.exists(tpath):
+        roof_fft["traffic"] = (tr["fft_col_pass"]["hbm_MB_per_slice"] + tr["fft_row_pass"]["hbm_MB_per_slice"]) * 1e6
+        roof_fft["traffic_unit"] = "HBM bytes per slice over all FFT passes, PMC"
 
     line = {
         "metric": "cine slices/sec, XF-VarNet R=4 15-coil 200x200x15t", "value": world * args.steps * B / dt,
@@ -254,6 +265,10 @@ def main():
         line["cpu_baseline"] = cb
         err = float((out[:1].cpu() - ref_out).abs().max() / ref_out.abs().max())
         line["parity_max_rel_err_vs_cpu_oracle"] = err
+        from reconstruction.utils import evaluate
+        tgt = ex["target"][0].numpy()
+        line["parity_d_ssim_vs_cpu_oracle"] = abs(float(evaluate.ssim(tgt, out[0].cpu().numpy())) - float(evaluate.ssim(tgt, ref_out[0].numpy())))
+        line["parity_nmse_vs_cpu_oracle"] = float(evaluate.nmse(ref_out[0].numpy(), out[0].cpu().numpy()))
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -32,6 +32,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------- statistics helpers
 // partial record = {count, mean, M2}; merged InstanceNorm stats = {mean, 1/sqrt(M2/count + eps)}
 __device__ __forceinline__ float2 merge_partials(const float* p, int np, float eps) {
+    if (np <= 8) {
+        // the usual case (a handful of tiles per plane): one round of loads, then arithmetic in registers
+        float r[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) r[i] = p[min(i, 3 * np - 1)];
+        float cnt = 0.f, mean = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i < np) { cnt += r[3 * i]; mean += r[3 * i] * r[3 * i + 1]; }
+        mean /= cnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i < np) { const float d = r[3 * i + 1] - mean; m2 += r[3 * i + 2] + r[3 * i] * d * d; }
+        return make_float2(mean, 1.0f / sqrtf(m2 / cnt + eps));
+    }
     float cnt = 0.f, mean = 0.f;
     for (int i = 0; i < np; ++i) { cnt += p[3 * i]; mean += p[3 * i] * p[3 * i + 1]; }
     mean /= cnt;
@@ -42,7 +56,6 @@ __device__ __forceinline__ float2 merge_partials(const float* p, int np, float e
     }
     return make_float2(mean, 1.0f / sqrtf(m2 / cnt + eps));
 }
-
 // InstanceNorm + LeakyReLU of one raw value: scale = rstd, shift = -mean * rstd (the x * alpha + beta form of
 // ATen's batch-norm transform); 0 <= slope <= 1 so that leaky_relu(v) == max(v, v * slope)
 __device__ __forceinline__ float act(float x, float scale, float shift, float slope) {
