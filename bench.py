@@ -226,9 +226,10 @@ def main():
     fam = {k: (v[0] / B, v[1]) for k, v in fam.items()}            # per slice
     conv_ms, conv_n = fam["conv3x3_mfma"]
     fft_ms = fam["fft_col_pass"][0] + fam["fft_row_pass"][0]
-    roofline = {"bound": "mfma", "kernel": "conv3x3_mfma_kernel (all 14 x 12 + 14 launches of one slice)",
+    roofline = {"bound": "mfma", "kernel": "cine::conv_mfma_kernel<8, CT, WM, WN, MT, TW, 9> (the 3x3 instantiations; 14 x 6 + 14 launches of one slice)",
                 "achieved": CONV3_FLOP_PER_SLICE / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "traffic": None, "launches_per_slice": conv_n, "ms_per_slice": conv_ms}
+                "unit": "TFLOP/s", "traffic": None, "launches_per_slice": conv_n, "ms_per_slice": conv_ms,
+                "avg_launch_us": conv_ms * 1e3 / max(conv_n, 1)}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     # HBM-side bytes per launch of that kernel family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
     # command, summarised by tools/pmc_traffic.py into profiles/ (PMC collection cannot run inside the bench itself)
@@ -238,7 +239,7 @@ def main():
             tr = json.load(f)["families"]
         roofline["traffic"] = tr["conv3x3_mfma"]["hbm_MB_per_launch"] * 1e6
         roofline["traffic_unit"] = "HBM bytes per launch (mean over the 98 launches of a slice), PMC, profiles/r01_pmc_traffic.json"
-    roof_fft = {"bound": "hbm", "kernel": "col_pass_kernel + row_pass_kernel (sens_reduce x7, sens_expand+DC x6)",
+    roof_fft = {"bound": "hbm", "kernel": "cine::col200_kernel + row200_reduce_kernel + row200_expand_kernel (sens_reduce x7, sens_expand+DC x6)",
                 "achieved": FFT_DC_BYTES_PER_SLICE / (fft_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "traffic": None, "ms_per_slice": fft_ms}
     roof_fft["frac"] = roof_fft["achieved"] / roof_fft["peak"]
