@@ -12,7 +12,7 @@ import re
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcine_hip.so")
+LIB_PATH = os.environ.get("CINE_HIP_LIB") or os.path.join(_HERE, "libcine_hip.so")   # override: A/B builds of the library
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "cine_hip.h"))
 
 

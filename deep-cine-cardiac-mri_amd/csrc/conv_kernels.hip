@@ -21,8 +21,11 @@
 //   epilogue : InstanceNorm statistics of THIS layer's raw output as per-tile partials
 //              {count, mean, M2} (exact two-pass in registers; consumers merge them with Chan's
 //              formula -- deterministic, no atomics), bias for the 1x1 conv.
+#include <algorithm>
+#include <memory>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 #include "common.h"
 
 namespace cine {
@@ -198,24 +201,23 @@ template <int PW> struct Piece;
 template <> struct Piece<4> { typedef float4 T; };
 template <> struct Piece<2> { typedef float2 T; };
 
+// One workgroup's share of one layer: tile `tile` (depth slice, tile row, tile column) of sample n, output-row block
+// `coblk`.  Called once per workgroup by conv_mfma_kernel and once per (layer, tile) by the plane-persistent U-Net kernel.
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
-__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, const int coblk, const int n, float* smem_f) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     constexpr int HALO = C::HALO, PW = C::PW;
     typedef typename Piece<PW>::T piece_t;
-    extern __shared__ __align__(16) float smem_f[];
     float* in_lds = smem_f;
     float* w_lds = smem_f + C::IN_FLOATS;
     float* st_lds = w_lds + C::W_FLOATS;            // {scale, shift} per input channel (see act())
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x;                      // (depth slice, tile row, tile column)
     const int z0 = tile / a.tiles_hw, t2 = tile - z0 * a.tiles_hw;
     const int ty = t2 / a.tiles_w, tx = t2 % a.tiles_w;
     const int r0 = ty * C::TH, c0 = tx * TW;
-    const int co0 = blockIdx.y * C::COT;
-    const int n = blockIdx.z;
+    const int co0 = coblk * C::COT;
     const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
     const int q = lane & 15, kk = lane >> 4;
     const int qr = q / TW, qc = q % TW;
@@ -644,6 +646,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     CINE_STAMP_RT(10);
 }
 
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_kernel(ConvArgs a) {
+    extern __shared__ __align__(16) float smem_f[];
+    conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
+}
+
 // ---------------------------------------------------------------- final 1x1 conv, few output channels
 // The U-Net's last layer (unet.py:69) maps chans -> 2: no matrix-core work to speak of, one streaming read
 // of the level-0 tensor.  Lanes run over 4-pixel groups, the channel loop keeps 8 16-byte loads in flight.
@@ -652,12 +660,12 @@ struct Conv1Args {
     const float* wp0; const float* wp1; const float* b0; const float* b1; int set_split;
     float* y; int cin, rowsp; long hw; float eps, slope;
 };
+// One sample's share of the layer: 4-pixel groups g0, g0 + gstride, ... of sample n.
 template <int COUT>
-__global__ __launch_bounds__(256) void conv1x1_stream_kernel(Conv1Args a) {
-    extern __shared__ __align__(16) float smem_c1[];
+__device__ __forceinline__ void conv1x1_tile(const Conv1Args& a, const int n, const long g0, const long gstride, float* smem_c1) {
     float* st = smem_c1;                 // {scale, shift} per input channel
     float* wl = smem_c1 + 2 * a.cin;     // [cin][COUT]
-    const int n = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const bool second = n >= a.set_split;
     const float* wp = second ? a.wp1 : a.wp0;
     const float* bias = second ? a.b1 : a.b0;
@@ -669,33 +677,112 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(Conv1Args a) {
         for (int co = 0; co < COUT; ++co) wl[ci * COUT + co] = wp[(long)ci * a.rowsp + co];
     }
     __syncthreads();
-    const long g = (long)blockIdx.x * 256 + tid;            // 4-pixel group
-    if (4 * g >= a.hw) return;
-    const float* xp = a.x + (long)n * a.cin * a.hw + 4 * g;
-    float4 acc[COUT];
+    for (long g = g0; 4 * g < a.hw; g += gstride) {
+        const float* xp = a.x + (long)n * a.cin * a.hw + 4 * g;
+        float4 acc[COUT];
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) { const float b = bias[co]; acc[co] = make_float4(b, b, b, b); }
-    constexpr int U = 8;
-    for (int c0 = 0; c0 < a.cin; c0 += U) {
-        float4 v[U];
+        for (int co = 0; co < COUT; ++co) { const float b = bias[co]; acc[co] = make_float4(b, b, b, b); }
+        constexpr int U = 8;
+        for (int c0 = 0; c0 < a.cin; c0 += U) {
+            float4 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)min(c0 + u, a.cin - 1) * a.hw);
+            for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const float4*>(xp + (long)min(c0 + u, a.cin - 1) * a.hw);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (c0 + u >= a.cin) break;
-            const float sc = st[2 * (c0 + u)], sh = st[2 * (c0 + u) + 1];
-            float4 t = v[u];
-            if (a.mode == 1) { t.x = act(t.x, sc, sh, a.slope); t.y = act(t.y, sc, sh, a.slope); t.z = act(t.z, sc, sh, a.slope); t.w = act(t.w, sc, sh, a.slope); }
+            for (int u = 0; u < U; ++u) {
+                if (c0 + u >= a.cin) break;
+                const float sc = st[2 * (c0 + u)], sh = st[2 * (c0 + u) + 1];
+                float4 t = v[u];
+                if (a.mode == 1) { t.x = act(t.x, sc, sh, a.slope); t.y = act(t.y, sc, sh, a.slope); t.z = act(t.z, sc, sh, a.slope); t.w = act(t.w, sc, sh, a.slope); }
 #pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-                const float w = wl[(c0 + u) * COUT + co];
-                acc[co].x = fmaf(w, t.x, acc[co].x); acc[co].y = fmaf(w, t.y, acc[co].y);
-                acc[co].z = fmaf(w, t.z, acc[co].z); acc[co].w = fmaf(w, t.w, acc[co].w);
+                for (int co = 0; co < COUT; ++co) {
+                    const float w = wl[(c0 + u) * COUT + co];
+                    acc[co].x = fmaf(w, t.x, acc[co].x); acc[co].y = fmaf(w, t.y, acc[co].y);
+                    acc[co].z = fmaf(w, t.z, acc[co].z); acc[co].w = fmaf(w, t.w, acc[co].w);
+                }
             }
         }
-    }
 #pragma unroll
-    for (int co = 0; co < COUT; ++co) *reinterpret_cast<float4*>(a.y + ((long)n * COUT + co) * a.hw + 4 * g) = acc[co];
+        for (int co = 0; co < COUT; ++co) *reinterpret_cast<float4*>(a.y + ((long)n * COUT + co) * a.hw + 4 * g) = acc[co];
+    }
+}
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1x1_stream_kernel(Conv1Args a) {
+    extern __shared__ __align__(16) float smem_c1[];
+    conv1x1_tile<COUT>(a, blockIdx.y, (long)blockIdx.x * 256 + threadIdx.x, a.hw, smem_c1);
+}
+
+// ---------------------------------------------------------------- plane-persistent U-Net
+// InstanceNorm is per (sample, channel) plane and nothing else in a U-Net pass couples samples, so ONE workgroup can carry
+// its sample through every layer with no grid-wide dependency: a workgroup barrier between layers is all the ordering the
+// data needs (stores and later loads of one workgroup share the CU's L1).  The caller gives every layer output its own
+// memory (sample n at n * dense size): samples are at different layers at the same time, so no buffer may change shape.  Workgroups drift apart, so the load / statistics /
+// store phases of one overlap the MFMA sweeps of its neighbour on the CU without extra streams, and the per-sample working
+// set stays in the Infinity Cache between layers.  The program is recorded from the ordinary per-layer entry points.
+constexpr int kMaxPlaneSteps = 24;
+struct PlaneStep { int cfg, ntiles, ncoblk, pad; ConvArgs a; };
+struct PlaneProgram { int nsteps, has_c1; Conv1Args c1; PlaneStep s[kMaxPlaneSteps]; };
+
+// the layer configurations a 16-channel U-Net on <= 16-wide planes uses (levels 0..3 and the three transpose convs)
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+constexpr int plane_cfg_id() {
+    if (CK == 8 && TAPS == 9) {
+        if (CT == 1 && WM == 1 && WN == 4 && MT == 13 && TW == 16) return 0;
+        if (CT == 2 && WM == 1 && WN == 4 && MT == 13 && TW == 8) return 1;
+        if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 2;
+        if (CT == 2 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 3;
+    }
+    if (CK == 16 && TAPS == 1) {
+        if (CT == 2 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 4;
+        if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 5;
+        if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 8) return 6;
+    }
+    return -1;
+}
+
+// The program lives in device memory (written by plane_program_write_kernel from its kernarg copy): indexing a by-value
+// kernel argument with the loop variable would make the compiler keep a private copy of all of it.
+__global__ void plane_program_write_kernel(PlaneProgram src, PlaneProgram* dst) {
+    const int* s = reinterpret_cast<const int*>(&src);
+    int* d = reinterpret_cast<int*>(dst);
+    for (int i = threadIdx.x; i < (int)(sizeof(PlaneProgram) / sizeof(int)); i += blockDim.x) d[i] = s[i];
+}
+
+// Every layer configuration is a real function call here (its own register allocation): inlining all seven bodies into
+// one kernel made the allocator spill hundreds of registers.  Arguments travel in VGPRs, so the uniform ones are made
+// scalar again on entry.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+__device__ __attribute__((noinline)) void conv_tile_call(const ConvArgs* a, int tile, int coblk, int n, float* smem_f) {
+    conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(*uni_ptr(a), uni(tile), uni(coblk), uni(n), smem_f);
+}
+
+__global__ __launch_bounds__(256, 2) void unet_plane_kernel(const PlaneProgram* __restrict__ prog) {
+    extern __shared__ __align__(16) float smem_f[];
+    const int n = blockIdx.x;
+    const int nsteps = prog->nsteps;
+    for (int i = 0; i < nsteps; ++i) {
+        const ConvArgs* a = &prog->s[i].a;
+        const int cfg = prog->s[i].cfg, nt = prog->s[i].ntiles, ncb = prog->s[i].ncoblk;
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int t = 0; t < nt; ++t) {
+                switch (cfg) {
+                    case 0: conv_tile_call<8, 1, 1, 4, 13, 16, 9>(a, t, cb, n, smem_f); break;
+                    case 1: conv_tile_call<8, 2, 1, 4, 13, 8, 9>(a, t, cb, n, smem_f); break;
+                    case 2: conv_tile_call<8, 1, 4, 1, 13, 4, 9>(a, t, cb, n, smem_f); break;
+                    case 3: conv_tile_call<8, 2, 4, 1, 4, 2, 9>(a, t, cb, n, smem_f); break;
+                    case 4: conv_tile_call<16, 2, 4, 1, 4, 2, 1>(a, t, cb, n, smem_f); break;
+                    case 5: conv_tile_call<16, 1, 4, 1, 13, 4, 1>(a, t, cb, n, smem_f); break;
+                    default: conv_tile_call<16, 1, 4, 1, 13, 8, 1>(a, t, cb, n, smem_f); break;
+                }
+                __syncthreads();      // the tile's stores and statistics are ordered before whatever reads them next; LDS is free again
+            }
+    }
+    if (prog->has_c1) conv1x1_tile<2>(prog->c1, n, threadIdx.x, 256, smem_f);
 }
 
 // ---------------------------------------------------------------- weight packing
@@ -791,6 +878,64 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
     }
 }
 
+// ---------------------------------------------------------------- launch recorder (plane-persistent U-Net)
+struct RecStep {
+    int cfg; ConvArgs a; dim3 grid; size_t lds; int fam;
+    int (*launch)(const RecStep&, hipStream_t);
+    bool is_c1; Conv1Args c1; int c1_cout;
+};
+struct PlaneRecorder { std::vector<RecStep> steps; };
+static thread_local PlaneRecorder* g_rec = nullptr;
+
+PlaneRecorder* plane_record_begin() { g_rec = new PlaneRecorder(); return g_rec; }
+void plane_record_abort(PlaneRecorder* r) { if (g_rec == r) g_rec = nullptr; delete r; }
+
+// Issue what was recorded: as ONE plane-persistent kernel when every step is one of its configurations and there are
+// enough samples to fill the chip, else layer by layer exactly as if nothing had been recorded.
+size_t plane_program_bytes() { return sizeof(PlaneProgram); }
+
+// Opt-in (CINE_PLANE_KERNEL=1): on cfg 2 the plane-persistent kernel matches the per-layer launches for ONE slice in flight
+// (12.5 vs 13.0 ms) but loses with three in flight (102 vs 134 slices/s): two workgroups per CU cannot hide a 17-layer
+// latency chain.  It is kept as the base for a version with more parallelism per sample.
+bool plane_kernel_enabled() {
+    static const bool on = getenv("CINE_PLANE_KERNEL") != nullptr && atoi(getenv("CINE_PLANE_KERNEL")) != 0;
+    return on;
+}
+
+int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
+    g_rec = nullptr;
+    std::unique_ptr<PlaneRecorder> own(r);
+    bool ok = plane_kernel_enabled() && prog_dev && !r->steps.empty() && r->steps.size() <= (size_t)kMaxPlaneSteps + 1;
+    int n = -1;
+    size_t lds = 0;
+    for (size_t i = 0; ok && i < r->steps.size(); ++i) {
+        const RecStep& q = r->steps[i];
+        if (q.is_c1) { ok = i + 1 == r->steps.size() && q.c1_cout == 2 && (int)q.grid.y == n; lds = std::max(lds, q.lds); continue; }
+        ok = q.cfg >= 0 && !q.a.vol && (n < 0 || (int)q.grid.z == n) && i < (size_t)kMaxPlaneSteps;
+        n = (int)q.grid.z; lds = std::max(lds, q.lds);
+    }
+    ok = ok && n >= 128;
+    if (!ok) {
+        for (const RecStep& q : r->steps) if (int e = q.launch(q, st)) return e;
+        return CINE_OK;
+    }
+    PlaneProgram pp{};
+    for (const RecStep& q : r->steps) {
+        if (q.is_c1) { pp.has_c1 = 1; pp.c1 = q.c1; continue; }
+        PlaneStep& s = pp.s[pp.nsteps++];
+        s.cfg = q.cfg; s.ntiles = (int)q.grid.x; s.ncoblk = (int)q.grid.y; s.a = q.a;
+    }
+    static std::once_flag once;
+    std::call_once(once, [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unet_plane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    ProfScope prof(F_UNET_PLANE, st);
+    PlaneProgram* dprog = reinterpret_cast<PlaneProgram*>(prog_dev);
+    hipLaunchKernelGGL(plane_program_write_kernel, dim3(1), dim3(256), 0, st, pp, dprog);
+    hipLaunchKernelGGL(unet_plane_kernel, dim3(n), dim3(256), lds, st, dprog);
+    return check_launch("unet_plane_kernel");
+}
+
 // ---------------------------------------------------------------- host dispatch
 #ifndef CINE_WN16
 #define CINE_WN16 4
@@ -828,7 +973,19 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
     a.tvec = a.tconv_cout > 0 && a.W % (TW >= 4 ? 4 : 2) == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
-    ProfScope prof(TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1), st);
+    const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
+    if (g_rec) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
+        RecStep r{};
+        r.cfg = plane_cfg_id<CK, CT, WM, WN, MT, TW, TAPS>(); r.a = a; r.grid = grid; r.lds = lds; r.fam = fam;
+        r.launch = [](const RecStep& q, hipStream_t s2) {
+            ProfScope prof(q.fam, s2);
+            hipLaunchKernelGGL((conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>), q.grid, dim3(C::NT), q.lds, s2, q.a);
+            return check_launch("conv_mfma_kernel");
+        };
+        g_rec->steps.push_back(r);
+        return CINE_OK;
+    }
+    ProfScope prof(fam, st);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, a);
     return check_launch("conv_mfma_kernel");
 }
@@ -1027,6 +1184,22 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
         const dim3 grid((unsigned)ceil_div(hw / 4, 256L), n);
         const size_t lds = (size_t)(2 + cout) * cin * sizeof(float);
         hipStream_t st = as_stream(stream);
+        if (g_rec) {
+            RecStep r{};
+            r.is_c1 = true; r.c1 = c; r.c1_cout = cout; r.grid = grid; r.lds = lds; r.fam = F_CONV1; r.cfg = -1;
+            r.launch = [](const RecStep& q, hipStream_t s2) {
+                ProfScope prof(F_CONV1, s2);
+                switch (q.c1_cout) {
+                    case 1: hipLaunchKernelGGL(conv1x1_stream_kernel<1>, q.grid, dim3(256), q.lds, s2, q.c1); break;
+                    case 2: hipLaunchKernelGGL(conv1x1_stream_kernel<2>, q.grid, dim3(256), q.lds, s2, q.c1); break;
+                    case 3: hipLaunchKernelGGL(conv1x1_stream_kernel<3>, q.grid, dim3(256), q.lds, s2, q.c1); break;
+                    default: hipLaunchKernelGGL(conv1x1_stream_kernel<4>, q.grid, dim3(256), q.lds, s2, q.c1); break;
+                }
+                return check_launch("conv1x1_stream_kernel");
+            };
+            g_rec->steps.push_back(r);
+            return CINE_OK;
+        }
         ProfScope prof(F_CONV1, st);
         switch (cout) {
             case 1: hipLaunchKernelGGL(conv1x1_stream_kernel<1>, grid, dim3(256), lds, st, c); break;

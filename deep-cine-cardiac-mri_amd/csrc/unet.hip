@@ -5,6 +5,7 @@
 // concatenates) while staging its operands.  Two weight sets (the x-f and y-f U-Nets of one
 // cascade, varnet.py:224-226) run in the SAME launches: samples [0, n/2) use set 0, the rest set 1.
 // Workspace: one raw buffer per skip level plus three rotating scratch buffers.
+#include <algorithm>
 #include "common.h"
 
 using namespace cine;
@@ -30,11 +31,20 @@ struct Plan {
     int P;
     int hs[8], wsz[8], ch[8];          // per level 0..P (P = bottleneck)
     int np_conv[8], np_tconv[8];       // partial records per (sample, channel) of a conv / tconv output at level d
-    float *skip[8], *pskip[8];
-    float *scr[3], *pscr[3];
+    float *skip[8], *pskip[8];         // ConvBlock outputs of the down path (the concat sources)
+    float *mid[8], *pmid[8];           // first conv of the down-path ConvBlock at level d (and of the bottleneck at d = P)
+    float *bott, *pbott;               // bottleneck output
+    float *up[8], *pup[8];             // transpose-conv output at level d
+    float *ca[8], *pca[8];             // up-path ConvBlock at level d: first conv ...
+    float *cb[8], *pcb[8];             // ... and second conv
+    float* prog;                       // device copy of the plane-persistent kernel's program (private layout only)
 };
 
-void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools) {
+// private == false: three rotating scratch buffers sized for the largest layer (layers are separated by kernel boundaries, so
+// a buffer may hold different shapes over time).  private == true: every layer output owns its memory, sample n of every
+// tensor sits at n * (its dense size) -- what the plane-persistent kernel needs, where the samples are at different layers
+// at the same time.
+void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools, bool priv) {
     p.P = pools;
     for (int d = 0; d <= pools; ++d) {
         p.hs[d] = d ? p.hs[d - 1] / 2 : h;
@@ -44,23 +54,46 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools) {
     }
     for (int d = 0; d < pools; ++d)    // tconv from level d+1 producing ch[d] channels on 2*hs[d+1] x 2*wsz[d+1]
         p.np_tconv[d] = cine_conv_stat_partials(p.ch[d], p.hs[d + 1], p.wsz[d + 1], 1);
+    auto elems = [&](int d) { return (size_t)n * p.ch[d] * p.hs[d] * p.wsz[d]; };
+    auto pelems = [&](int d, bool tconv) { return (size_t)n * p.ch[d] * (tconv ? p.np_tconv[d] : p.np_conv[d]) * 3; };
+    for (int d = 0; d < pools; ++d) {
+        p.skip[d] = b.take(elems(d));
+        p.pskip[d] = b.take(pelems(d, false));
+    }
+    p.prog = nullptr;
+    if (priv) {
+        p.prog = b.take((plane_program_bytes() + 3) / 4);
+        for (int d = 0; d <= pools; ++d) { p.mid[d] = b.take(elems(d)); p.pmid[d] = b.take(pelems(d, false)); }
+        p.bott = b.take(elems(pools)); p.pbott = b.take(pelems(pools, false));
+        for (int d = 0; d < pools; ++d) {
+            p.up[d] = b.take(elems(d)); p.pup[d] = b.take(pelems(d, true));
+            p.ca[d] = b.take(elems(d)); p.pca[d] = b.take(pelems(d, false));
+            p.cb[d] = b.take(elems(d)); p.pcb[d] = b.take(pelems(d, false));
+        }
+        return;
+    }
     size_t big = 0, bigp = 0;
     for (int d = 0; d <= pools; ++d) {
-        const size_t e = (size_t)p.ch[d] * p.hs[d] * p.wsz[d];
-        if (e > big) big = e;
-        size_t pe = (size_t)p.ch[d] * p.np_conv[d];
-        if (d < pools && (size_t)p.ch[d] * p.np_tconv[d] > pe) pe = (size_t)p.ch[d] * p.np_tconv[d];
-        if (pe > bigp) bigp = pe;
+        big = std::max(big, elems(d));
+        bigp = std::max(bigp, std::max(pelems(d, false), d < pools ? pelems(d, true) : (size_t)0));
     }
-    for (int d = 0; d < pools; ++d) {
-        p.skip[d] = b.take((size_t)n * p.ch[d] * p.hs[d] * p.wsz[d]);
-        p.pskip[d] = b.take((size_t)n * p.ch[d] * p.np_conv[d] * 3);
-    }
-    for (int i = 0; i < 3; ++i) {
-        p.scr[i] = b.take((size_t)n * big);
-        p.pscr[i] = b.take((size_t)n * bigp * 3);
+    float *scr[3], *pscr[3];
+    for (int i = 0; i < 3; ++i) { scr[i] = b.take(big); pscr[i] = b.take(bigp); }
+    for (int d = 0; d <= pools; ++d) { p.mid[d] = scr[0]; p.pmid[d] = pscr[0]; }
+    p.bott = scr[1]; p.pbott = pscr[1];
+    int cur = 1;
+    for (int u = 0; u < pools; ++u) {
+        const int d = pools - 1 - u;
+        const int a = (cur + 1) % 3, c = (cur + 2) % 3;
+        p.up[d] = scr[a]; p.pup[d] = pscr[a];
+        p.ca[d] = scr[c]; p.pca[d] = pscr[c];
+        p.cb[d] = scr[a]; p.pcb[d] = pscr[a];
+        cur = a;
     }
 }
+
+// samples from which the plane-persistent kernel is worth trying (conv_kernels.hip applies the same threshold)
+constexpr int kPlaneMinSamples = 128;
 
 }  // namespace
 
@@ -68,7 +101,7 @@ extern "C" size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_c
     if (n <= 0 || h <= 0 || w <= 0 || chans <= 0 || pools <= 0 || pools > 6) return 0;
     (void)in_ch; (void)out_ch;
     Plan p; Bump b{nullptr, 0};
-    build(p, b, n, h, w, chans, pools);
+    build(p, b, n, h, w, chans, pools, plane_kernel_enabled() && n >= kPlaneMinSamples);
     return b.off;
 }
 
@@ -89,8 +122,14 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
         CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", i);
 
     Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
-    build(p, b, n, h, w, chans, pools);
+    build(p, b, n, h, w, chans, pools, plane_kernel_enabled() && n >= kPlaneMinSamples);
     const int split = n / nsets;
+    // every step below reads only its own sample's data, so the launches are recorded and issued together: as one
+    // plane-persistent kernel when the layer shapes are the ones it is built for, else layer by layer (conv_kernels.hip)
+    struct Guard {
+        PlaneRecorder* r;
+        ~Guard() { if (r) plane_record_abort(r); }
+    } guard{plane_record_begin()};
     int wi = 0;
     const float *w0, *w1;
     auto next = [&]() {
@@ -102,9 +141,9 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     // ---- down path (unet.py:94-97) + bottleneck (:99)
     for (int d = 0; d <= pools; ++d) {
         const bool last = d == pools;
-        float* mid = p.scr[0]; float* pmid = p.pscr[0];
-        float* out = last ? p.scr[1] : p.skip[d];
-        float* pout = last ? p.pscr[1] : p.pskip[d];
+        float* mid = p.mid[d]; float* pmid = p.pmid[d];
+        float* out = last ? p.bott : p.skip[d];
+        float* pout = last ? p.pbott : p.pskip[d];
         next();
         if (d == 0)
             e = cine_conv3x3_in(x, nullptr, 0, in_ch, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
@@ -120,31 +159,34 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
         if (e) return e;
     }
     // ---- up path (unet.py:102-123)
-    int cur = 1;
+    const float* cur = p.bott; const float* pcur = p.pbott;
     int np_cur = p.np_conv[pools];
     for (int u = 0; u < pools; ++u) {
         const int d = pools - 1 - u;
-        const int a = (cur + 1) % 3, c = (cur + 2) % 3;
         next();   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
-        e = cine_tconv2x2_in(p.scr[cur], p.pscr[cur], np_cur, 1, w0, w1, split, p.scr[a], p.pscr[a], n,
+        e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
                              p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
         if (e) return e;
         next();   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
-        e = cine_conv3x3_in(p.scr[a], p.pscr[a], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
+        e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
                             p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
-                            p.scr[c], p.pscr[c], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+                            p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
         next();
-        e = cine_conv3x3_in(p.scr[c], p.pscr[c], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
-                            w0, w1, split, p.scr[a], p.pscr[a], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+        e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+                            w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
-        cur = a; np_cur = p.np_conv[d];
+        cur = p.cb[d]; pcur = p.pcb[d]; np_cur = p.np_conv[d];
     }
     // ---- final 1x1 conv + bias (unet.py:69)
     const float* wf0 = reinterpret_cast<const float*>(weights[wi]);
     const float* bf0 = reinterpret_cast<const float*>(weights[wi + 1]);
     const float* wf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi]) : nullptr;
     const float* bf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi + 1]) : nullptr;
-    return cine_conv1x1_bias(p.scr[cur], p.pscr[cur], np_cur, 1, wf0, bf0, wf1, bf1, split, y, n, chans, out_ch, h, w,
-                             kEps, kSlope, stream);
+    e = cine_conv1x1_bias(cur, pcur, np_cur, 1, wf0, bf0, wf1, bf1, split, y, n, chans, out_ch, h, w,
+                          kEps, kSlope, stream);
+    if (e) return e;
+    PlaneRecorder* rec = guard.r;
+    guard.r = nullptr;
+    return plane_record_end(rec, as_stream(stream), p.prog);
 }

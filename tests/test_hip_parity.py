@@ -280,6 +280,21 @@ def test_tconv_and_conv1x1_vs_torch(dev, cin, cout, h, w):
         assert rel_err(y0.cpu(), F.conv2d(x, w1, b1)) < BLOCK_TOL
 
 
+def test_plane_persistent_unet_matches_per_layer_launches(dev, tmp_path):
+    """CINE_PLANE_KERNEL=1 (one workgroup carries a sample through all layers) must reproduce the per-layer launches bit for
+    bit: same kernels' code, same order of operations.  The switch is read once per process, hence the subprocesses."""
+    import subprocess, sys, os
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "plane_debug.py")
+    env = dict(os.environ)
+    env.pop("CINE_PLANE_KERNEL", None)
+    env["TMPDIR"] = str(tmp_path)
+    a = subprocess.run([sys.executable, script, "256", "3", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and "saved reference" in a.stdout, a.stdout + a.stderr
+    env["CINE_PLANE_KERNEL"] = "1"
+    b = subprocess.run([sys.executable, script, "256", "3", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0 and "max abs diff 0.0 " in b.stdout, b.stdout + b.stderr
+
+
 # ------------------------------------------------------------------ blocks and models
 @pytest.mark.parametrize("dyn", ["XF", "XT", "2D", "3D"])
 def test_varnet_block_vs_reference_golden(golden, dev, dyn):
