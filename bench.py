@@ -261,7 +261,7 @@ def main():
         "roofline": roofline, "roofline_fft_dc": roof_fft,
         "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items()},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:        # the host-core baseline is timed on rank 0 of the 1-GPU run only
         ref_out, cb = cpu_baseline(ex, args.cpu_forwards)
         line["cpu_baseline"] = cb
         err = float((out[:1].cpu() - ref_out).abs().max() / ref_out.abs().max())
