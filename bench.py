@@ -200,7 +200,7 @@ def main():
     run(args.warmup, False)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps, True)
@@ -208,7 +208,7 @@ def main():
     assert volume.shape[0] == world * args.steps * B
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
