@@ -280,6 +280,47 @@ def test_tconv_and_conv1x1_vs_torch(dev, cin, cout, h, w):
         assert rel_err(y0.cpu(), F.conv2d(x, w1, b1)) < BLOCK_TOL
 
 
+def test_conv3x3_random_shapes_vs_torch(dev):
+    """Seeded sweep over odd / tiny / wide extents, channel counts off the chunk size, both on-load modes, pooled and concat
+    sources, two weight sets: raw output and merged statistics against torch (fp32 CPU)."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    import random
+    rng = random.Random(1234)
+    act = lambda t: F.leaky_relu(F.instance_norm(t, eps=1e-5), 0.2)
+    for case in range(40):
+        n = rng.choice([1, 2, 3, 5])
+        h, w = rng.choice([1, 2, 3, 5, 8, 13, 16, 26, 31, 52]), rng.choice([1, 2, 3, 4, 6, 8, 15, 16, 17, 33])
+        c0 = rng.choice([1, 2, 3, 8, 9, 16, 20])
+        cout = rng.choice([1, 2, 8, 16, 17, 32, 40, 64, 72])
+        kind = rng.choice(["plain", "norm", "pool", "concat"])
+        g = torch.Generator().manual_seed(case)
+        wt = torch.randn(cout, c0 + (c0 if kind == "concat" else 0), 3, 3, generator=g) / 6
+        if kind == "pool":
+            x = torch.randn(n, c0, 2 * h + rng.choice([0, 1]), 2 * w + rng.choice([0, 1]), generator=g)
+            if x.shape[3] % 2:      # the pooled source is addressed pairwise along x
+                x = x[..., :-1].contiguous()
+            ref_in = F.avg_pool2d(act(x), 2)[..., :h, :w]
+            if ref_in.shape[2] < h or ref_in.shape[3] < w:
+                continue
+            srcs = [(x.to(dev), ops.instnorm_partials(x.to(dev)), 2)]
+        elif kind == "concat":
+            x = torch.randn(n, c0, h, w, generator=g); x2 = torch.randn(n, c0, h, w, generator=g)
+            ref_in = torch.cat([act(x), act(x2)], 1)
+            srcs = [(x.to(dev), ops.instnorm_partials(x.to(dev)), 1), (x2.to(dev), ops.instnorm_partials(x2.to(dev)), 1)]
+        else:
+            x = torch.randn(n, c0, h, w, generator=g)
+            ref_in = act(x) if kind == "norm" else x
+            srcs = [(x.to(dev), ops.instnorm_partials(x.to(dev)) if kind == "norm" else None, 1 if kind == "norm" else 0)]
+        if h * w == 1 and kind != "plain":
+            continue                                  # InstanceNorm of a single pixel is degenerate in the reference too
+        y, part = ops.conv3x3_in(srcs, ops.pack_conv3x3(wt.to(dev)), cout, h, w)
+        ref = F.conv2d(ref_in, wt, padding=1)
+        assert rel_err(y.cpu(), ref) < BLOCK_TOL, (case, kind, n, c0, cout, h, w)
+        st = ops.instnorm_finalize(part).cpu()
+        assert (st[..., 0] - ref.mean(dim=(2, 3))).abs().max() < 1e-4 * max(1.0, float(ref.abs().max())), (case, kind)
+
+
 def test_plane_persistent_unet_matches_per_layer_launches(dev, tmp_path):
     """CINE_PLANE_KERNEL=1 (one workgroup carries a sample through all layers) must reproduce the per-layer launches bit for
     bit: same kernels' code, same order of operations.  The switch is read once per process, hence the subprocesses."""
