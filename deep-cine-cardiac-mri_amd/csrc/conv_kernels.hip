@@ -1103,6 +1103,12 @@ static int check_src(const float* x, const float* part, int c, int mode, int np,
     return CINE_OK;
 }
 
+// leaky_relu(v) is evaluated as max(v, v * slope), which equals the reference's (v > 0 ? v : v * slope) for 0 <= slope <= 1
+static int check_slope(float slope, const char* what) {
+    CINE_REQUIRE(slope >= 0.f && slope <= 1.f, CINE_EINVAL, "%s: LeakyReLU slope %g outside [0, 1]", what, (double)slope);
+    return CINE_OK;
+}
+
 static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
@@ -1133,6 +1139,7 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
                         const float* addend, int relu,
                         float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3x3_in: null pointer");
+    if (int e = check_slope(slope, "cine_conv3x3_in")) return e;
     CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3x3_in: bad sizes");
     const int act0 = (mode0 >> 3) & 1, act1 = (mode1 >> 3) & 1;
     mode0 &= 7; mode1 &= 7;
@@ -1158,6 +1165,7 @@ extern "C" int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, i
                                 const float* wpacked, const float* wpacked2, int set_split,
                                 float* y, float* part_y, int n, int cin, int cout, int h, int w,
                                 float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "conv entry point")) return e;
     CINE_REQUIRE(x && wpacked && y, CINE_EINVAL, "cine_tconv2x2_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_tconv2x2_in: bad sizes");
     if (int e = check_src(x, part_x, cin, mode, np_x, "cine_tconv2x2_in")) return e;
@@ -1174,6 +1182,7 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
                                  const float* wpacked, const float* bias, const float* wpacked2, const float* bias2,
                                  int set_split, float* y, int n, int cin, int cout, int h, int w,
                                  float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "conv entry point")) return e;
     CINE_REQUIRE(x && wpacked && bias && y, CINE_EINVAL, "cine_conv1x1_bias: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv1x1_bias: bad sizes");
     if (int e = check_src(x, part_x, cin, mode, np_x, "cine_conv1x1_bias")) return e;
@@ -1247,6 +1256,7 @@ extern "C" int cine_instnorm_finalize(const float* part, float* stats, long plan
 
 extern "C" int cine_instnorm_lrelu_apply(const float* x, const float* part, int np, float* y, long planes, long plane_elems,
                                          float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "conv entry point")) return e;
     CINE_REQUIRE(x && part && y && planes > 0 && plane_elems > 0 && np > 0, CINE_EINVAL, "cine_instnorm_lrelu_apply: bad arguments");
     ProfScope prof(F_MISC, as_stream(stream));
     hipLaunchKernelGGL(instnorm_lrelu_apply_kernel, dim3(grid1d(planes * plane_elems, 256)), dim3(256), 0,
@@ -1259,6 +1269,7 @@ extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int 
                               const float* x1, const float* part1, int np1, int c1, int mode1, int d1, int h1, int w1,
                               const float* wpacked, const float* bias, const float* addend, int relu,
                               float* y, float* part_y, int n, int cout, int d, int h, int w, float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "conv entry point")) return e;
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3d_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && d > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3d_in: bad sizes");
     CINE_REQUIRE(mode0 >= 0 && mode0 <= 2 && mode1 >= 0 && mode1 <= 2, CINE_EINVAL, "cine_conv3d_in: modes 0..2 only");
@@ -1277,6 +1288,7 @@ extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int 
 extern "C" int cine_tconv3d_in(const float* x, const float* part_x, int np_x, int mode, const float* wpacked,
                                float* y, float* part_y, int n, int cin, int cout, int d, int h, int w,
                                float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "conv entry point")) return e;
     CINE_REQUIRE(x && wpacked && y, CINE_EINVAL, "cine_tconv3d_in: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_tconv3d_in: bad sizes");
     CINE_REQUIRE(mode == 0 || mode == 1, CINE_EINVAL, "cine_tconv3d_in: mode %d", mode);
@@ -1293,6 +1305,7 @@ extern "C" int cine_tconv3d_in(const float* x, const float* part_x, int np_x, in
 extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x, int mode, const float* wpacked,
                                    const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
                                    float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "conv entry point")) return e;
     CINE_REQUIRE(x && wpacked && bias && y, CINE_EINVAL, "cine_conv1x1x1_bias: null pointer");
     CINE_REQUIRE(n > 0 && n <= 65535 && cin > 0 && cout > 0 && d > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv1x1x1_bias: bad sizes");
     CINE_REQUIRE(mode == 0 || mode == 1, CINE_EINVAL, "cine_conv1x1x1_bias: mode %d", mode);

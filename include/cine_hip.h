@@ -158,7 +158,8 @@ int cine_pack_conv1x1(const float* w, float* packed, int cout, int cin, void* st
 int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 
 /* One ConvBlock half (unet.py:159-162): y = conv3x3(X, pad 1, no bias) and the partial statistics of y.
- * The normalise + LeakyReLU(slope) of y is applied by whichever kernel consumes (y, part_y) next.
+ * The normalise + LeakyReLU(slope) of y is applied by whichever kernel consumes (y, part_y) next; 0 <= slope <= 1
+ * (leaky_relu is evaluated as max(v, v * slope); other slopes are rejected with CINE_EINVAL).
  * X = channel concat (torch.cat, unet.py:122) of up to two sources; source s has c_s channels,
  * extent (h_s, w_s), np_s partial records and mode_s:
  *   0 = use as is;  1 = InstanceNorm + LeakyReLU on load;

@@ -31,6 +31,9 @@ def test_argument_validation_without_gpu():
     assert L.cine_conv3x3_packed_floats(16, 2) == 1 * 9 * 8 * 16
     assert L.cine_conv3x3_packed_floats(10, 12) == 2 * 9 * 8 * 16
     assert L.cine_tconv2x2_packed_floats(32, 16) == 2 * 16 * 64
+    # LeakyReLU slopes outside [0, 1] are rejected before anything is launched (act() evaluates max(v, v * slope))
+    assert L.cine_tconv2x2_in(None, None, 0, 0, None, None, 0, None, None, 1, 1, 1, 2, 2, 1e-5, 1.5, None) == -1
+    assert b"slope" in L.cine_last_error()
     assert L.cine_conv_stat_partials(16, 208, 16, 0) == 4 and L.cine_conv_stat_partials(32, 104, 8, 0) == 2
     assert L.cine_conv_stat_partials(16, 104, 8, 1) == 16
     assert L.cine_unet2d_ws_bytes(4, 16, 16, 2, 2, 4, 2) > 0
