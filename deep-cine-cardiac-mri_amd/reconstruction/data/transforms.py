@@ -1,11 +1,14 @@
-"""``mask_center`` and ``apply_mask`` of the reference's data/transforms.py, device-agnostic.
+"""``mask_center`` and ``apply_mask`` of the reference's data/transforms.py (:66-108), device-agnostic, plus the
+on-device forms used by the bench (``cine_hip.ops.apply_mask`` / ``mask_center``).
 
-Everything else in the reference's transforms.py (HDF5 / BART based dataset
-transforms) is outside the accelerated path and is not restated here.
+Everything else in the reference's transforms.py (``to_tensor``, ``center_crop*``, the ``*DataTransform`` classes: HDF5 /
+BART based dataset preparation) is outside the accelerated path; those names are forwarded to the reference checkout
+(``CINE_REFERENCE_ROOT``) on first use, so ``pl_modules`` and ``mri_data`` keep working against this module.
 """
 import torch
 
 from cine_hip.synth import apply_mask  # noqa: F401  (reference transforms.py:66-92)
+from .._fallthrough import load_shadowed as _load_shadowed
 
 
 def mask_center(x: torch.Tensor, mask_from: int, mask_to: int) -> torch.Tensor:
@@ -13,3 +16,12 @@ def mask_center(x: torch.Tensor, mask_from: int, mask_to: int) -> torch.Tensor:
     out = torch.zeros_like(x)
     out[:, :, mask_from:mask_to] = x[:, :, mask_from:mask_to]
     return out
+
+
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    try:
+        return getattr(_load_shadowed("reconstruction.data", "transforms"), name)
+    except AttributeError:
+        raise AttributeError(f"module {__name__!r} has no attribute {name!r}") from None

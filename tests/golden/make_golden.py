@@ -309,9 +309,44 @@ def g_rnn():
     save("rnn", **a)
 
 
+def _fingerprint(name, out, ex, **extra):
+    """Full-size model fingerprint: strided output + scalar summaries (inputs / weights regenerate from seeds)."""
+    save(name, out_strided=out[:, :, ::4, ::4].contiguous(), out_sum=out.double().sum(), out_l2=out.double().norm(),
+         out_max=out.max(), mask=ex["mask"], **extra)
+
+
+def g_xpdnet_cfg3():
+    """cfg 3: XT-XPDNet, MWCNN regulariser (script defaults), 10 cascades, n_primal 5, 15 coils x 15 frames x 200x200, R=8
+    (reference models/xpdnet.py:301-326; widths traintest_scripts/xpdnet/train_test_xpdnet.py:258-271)."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=8, seed=5)
+    net = RM.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT").eval()
+    synth.fill_parameters_(net, 6, keep=())
+    out = net(ex["masked_kspace"], ex["mask"])
+    _fingerprint("xpdnet_cfg3", out, ex, data_seed=5, weight_seed=6, accel=8)
+
+
+def g_cinenet_cfg4():
+    """cfg 4: 3D CineNet, 6 cascades, CG 6, chans 16, pools 3, analytic sens maps, R=6 (reference models/cinenet.py:61-73)."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=6, seed=4)
+    net = RM.CineNet(6, 6, 16, 3, "3D").eval()
+    synth.fill_parameters_(net, 7)
+    out = net(ex["masked_kspace"], ex["mask"], ex["sens_maps"])
+    _fingerprint("cinenet_cfg4", out, ex, data_seed=4, weight_seed=7, accel=6)
+
+
+def g_rnn_cfg5():
+    """cfg 5: CRNN-VarNet, 5 cascades, sens 8/3, chans 16, R=8 (reference models/recurrent_varnet.py:93-150)."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=8, seed=8)
+    net = RM.VarNet_RNN(5, 8, 3, 16).eval()
+    synth.fill_parameters_(net, 9)
+    out = net(ex["masked_kspace"], ex["mask"])
+    _fingerprint("rnn_cfg5", out, ex, data_seed=8, weight_seed=9, accel=8)
+
+
 GENERATORS = dict(rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
-                  varnet_cfg1=g_varnet_cfg1)
+                  varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
+                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -619,3 +619,105 @@ def test_cinenet_3d_cfg4_shape_vs_oracle(dev):
         want = ref(ex["masked_kspace"], ex["mask"], ex["sens_maps"])
     got = hip.to(dev)(ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["sens_maps"].to(dev)).cpu()
     assert rel_err(got, want) < MODEL_TOL
+
+
+# ------------------------------------------------------------------ full-size BASELINE configs 3 / 4 / 5 vs the reference's fingerprints
+def _check_full_fingerprint(out, g, ex):
+    """max|d|/peak <= 1e-4, NMSE <= 1e-8, |dSSIM| <= 1e-4 against the reference's strided output (tests/golden/make_golden.py)."""
+    from reconstruction.utils import evaluate
+    ref = torch.from_numpy(g["out_strided"])
+    got = out[:, :, ::4, ::4]
+    assert rel_err(got, ref) < MODEL_TOL
+    assert float(((got - ref).double() ** 2).sum() / (ref.double() ** 2).sum()) < 1e-8
+    assert abs(float(out.double().sum()) - float(g["out_sum"])) / float(g["out_sum"]) < 1e-5
+    assert abs(float(out.double().norm()) - float(g["out_l2"])) / float(g["out_l2"]) < 1e-5
+    tgt = ex["target"][0, :, ::4, ::4].numpy()
+    assert abs(evaluate.ssim(tgt, got[0].numpy()) - evaluate.ssim(tgt, ref[0].numpy())) < 1e-4
+
+
+def test_xpdnet_cfg3_vs_reference_golden(golden, dev):
+    """BASELINE configs[2]: XT-XPDNet with the MWCNN regulariser, 10 cascades, n_primal 5, 15 coils x 15 frames x 200x200, R=8."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    g = golden("xpdnet_cfg3")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    net = M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
+    synth.fill_parameters_(net, int(g["weight_seed"]), keep=())
+    net.to(dev).eval()
+    out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev)).cpu()
+    _check_full_fingerprint(out, g, ex)
+
+
+def test_cinenet_cfg4_vs_reference_golden(golden, dev):
+    """BASELINE configs[3]: 3D CineNet, all 6 cascades, CG 6, 15 coils x 15 frames x 200x200, R=6."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    g = golden("cinenet_cfg4")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    net = M.CineNet(6, 6, 16, 3, "3D")
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net.to(dev).eval()
+    out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["sens_maps"].to(dev)).cpu()
+    _check_full_fingerprint(out, g, ex)
+
+
+def test_rnn_cfg5_vs_reference_golden(golden, dev):
+    """BASELINE configs[4]: CRNN-VarNet, 5 cascades, 15 coils x 15 frames x 200x200, R=8."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    g = golden("rnn_cfg5")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    net = M.VarNet_RNN(5, 8, 3, 16)
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net.to(dev).eval()
+    out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev)).cpu()
+    _check_full_fingerprint(out, g, ex)
+
+
+# ------------------------------------------------------------------ hipGraph replay == eager == reference
+def test_cfg2_graph_replay_bitexact_and_vs_golden(golden, dev):
+    """Capture the cfg-2 forward in a hipGraph on a side stream (as bench.py does), replay it twice: both replays
+    equal the eager output bit for bit, and the replayed output matches the reference's cfg-2 fingerprint."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    g = golden("varnet_cfg2")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=int(g["data_seed"]))
+    net = M.VarNet(6, 8, 3, 16, 3, "XF")
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net.to(dev).eval()
+    mk, mask = ex["masked_kspace"].to(dev), ex["mask"].to(dev)
+    acs = net.sens_net.acs_window(mask)
+    eager = net(mk, mask, acs=acs).clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        net(mk, mask, acs=acs)                       # warm this stream's caches outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=st):
+        gout = net(mk, mask, acs=acs)
+    for _ in range(2):
+        gout.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gout, eager)
+    _check_full_fingerprint(gout.cpu(), g, ex)
+
+
+# ------------------------------------------------------------------ utils.math / coil_combine vs the reference's cm_* vectors
+def test_complex_math_helpers_vs_reference_golden(golden, dev):
+    import reconstruction.utils as U
+    g = golden("ops")
+    x, y = cuda(g["cm_x"], dev), cuda(g["cm_y"], dev)
+    assert rel_err(U.complex_mul(x, y).cpu(), g["cm_mul"]) < OP_TOL
+    assert torch.equal(U.complex_conj(x).cpu(), torch.from_numpy(g["cm_conj"]))
+    assert rel_err(U.complex_abs(x).cpu(), g["cm_abs"]) < OP_TOL
+    assert rel_err(U.complex_abs_sq(x).cpu(), g["cm_abs_sq"]) < OP_TOL
+    assert rel_err(U.rss(x, dim=1).cpu(), g["cm_rss"]) < OP_TOL
+    assert rel_err(U.rss_complex(x, dim=1).cpu(), g["cm_rss_complex"]) < OP_TOL
+    from cine_hip import ops
+    assert rel_err(ops.complex_abs(x).cpu(), g["cm_abs"]) < OP_TOL
+    with pytest.raises(ValueError):
+        U.complex_abs(x[..., :1])
+    with pytest.raises(ValueError):
+        U.complex_mul(x[..., :1], y)

@@ -68,3 +68,48 @@ def test_oracle_cfg2_full(golden):
         out = net(ex["masked_kspace"], ex["mask"])
     assert rel_err(out[:, :, ::4, ::4], g["out_strided"]) < 1e-4
     assert abs(float(out.double().sum()) - float(g["out_sum"])) / float(g["out_sum"]) < 1e-5
+
+
+def _check_fingerprint(out, g, tol=1e-4):
+    assert rel_err(out[:, :, ::4, ::4], g["out_strided"]) < tol
+    assert abs(float(out.double().sum()) - float(g["out_sum"])) / float(g["out_sum"]) < 1e-5
+    assert abs(float(out.double().norm()) - float(g["out_l2"])) / float(g["out_l2"]) < 1e-5
+
+
+def test_oracle_cfg3_full(golden):
+    """BASELINE configs[2]: XT-XPDNet (MWCNN, script defaults), 10 cascades, n_primal 5, 15 coils x 15 frames x 200x200, R=8."""
+    from oracle import xpdnet_ref as X
+    g = golden("xpdnet_cfg3")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    assert np.array_equal(ex["mask"].numpy(), g["mask"])
+    net = X.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT").eval()
+    synth.fill_parameters_(net, int(g["weight_seed"]), keep=())
+    with torch.no_grad():
+        out = net(ex["masked_kspace"], ex["mask"])
+    _check_fingerprint(out, g)
+
+
+def test_oracle_cfg4_full(golden):
+    """BASELINE configs[3]: 3D CineNet, 6 cascades, CG 6, 15 coils x 15 frames x 200x200, R=6."""
+    from oracle import cinenet_ref as C
+    g = golden("cinenet_cfg4")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    assert np.array_equal(ex["mask"].numpy(), g["mask"])
+    net = C.CineNet(6, 6, 16, 3, "3D").eval()
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    with torch.no_grad():
+        out = net(ex["masked_kspace"], ex["mask"], ex["sens_maps"])
+    _check_fingerprint(out, g)
+
+
+def test_oracle_cfg5_full(golden):
+    """BASELINE configs[4]: CRNN-VarNet, 5 cascades, 15 coils x 15 frames x 200x200, R=8."""
+    from oracle import recurrent_ref as R
+    g = golden("rnn_cfg5")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    assert np.array_equal(ex["mask"].numpy(), g["mask"])
+    net = R.VarNet_RNN(5, 8, 3, 16).eval()
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    with torch.no_grad():
+        out = net(ex["masked_kspace"], ex["mask"])
+    _check_fingerprint(out, g)
