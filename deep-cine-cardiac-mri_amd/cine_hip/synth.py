@@ -171,7 +171,7 @@ def _pairs(z: np.ndarray) -> torch.Tensor:
 
 
 def make_cine_slice(t: int = 15, c: int = 15, h: int = 200, w: int = 200, accel: int = 4,
-                    center_lines: int = 10, seed: int = 0, mask_type: str = "random"):
+                    center_lines: int = 10, seed: int = 0, mask_type: str = "random", noise_std: float = 0.0):
     """One synthetic cine example in the layout the models consume.
 
     Returns dict with
@@ -180,12 +180,19 @@ def make_cine_slice(t: int = 15, c: int = 15, h: int = 200, w: int = 200, accel:
       kspace (1, t, c, h, w, 2) f32 fully sampled.
     Masks come from ``np.random.seed(seed)`` + RandomMaskFunc, as a reference
     run with the same seed would draw them (mask shape / dtype per
-    transforms.py:341-343).
+    transforms.py:341-343).  ``noise_std`` > 0 adds complex white noise of that
+    standard deviation per k-space sample (RandomState(seed + 7919)), as a
+    measurement has: the noise-free phantom has image columns that are exactly
+    empty, and networks without an input normalisation (XPDNet's MWCNN) turn
+    the rounding noise of such planes into O(1) output.
     """
     img = cine_phantom(t, h, w, seed)
     sens = coil_maps(c, h, w)
     k = _fft2c_np(img[:, None] * sens[None])                      # (t, c, h, w)
     kspace = _pairs(k)
+    if noise_std > 0:
+        rs = np.random.RandomState(seed + 7919)
+        kspace = kspace + torch.from_numpy((noise_std * rs.standard_normal(tuple(kspace.shape))).astype(np.float32))
     np.random.seed(seed)
     mf = create_mask_for_mask_type(mask_type, [center_lines], [accel])
     masked, mask = apply_mask(kspace, mf, None)

@@ -80,7 +80,7 @@ def test_oracle_cfg3_full(golden):
     """BASELINE configs[2]: XT-XPDNet (MWCNN, script defaults), 10 cascades, n_primal 5, 15 coils x 15 frames x 200x200, R=8."""
     from oracle import xpdnet_ref as X
     g = golden("xpdnet_cfg3")
-    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]))
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=int(g["accel"]), seed=int(g["data_seed"]), noise_std=float(g["noise_std"]))
     assert np.array_equal(ex["mask"].numpy(), g["mask"])
     net = X.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT").eval()
     synth.fill_parameters_(net, int(g["weight_seed"]), keep=())
