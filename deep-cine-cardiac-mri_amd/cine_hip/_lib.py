@@ -33,6 +33,10 @@ _SIGS = {
     "cine_kspace_to_hybrid": (c_int, [P, P, c_long, c_int, c_int, P]),
     "cine_hybrid_reduce": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_expand_dc_hybrid": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_image_dc_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cine_image_dc": (c_int, [P, P, P, P, P, c_float, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                              P, c_size_t, P]),
+    "cine_masked_kspace_to_hybrid": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_sens_prologue": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_rss_normalise": (c_int, [P, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

@@ -108,15 +108,57 @@ def sens_expand_dc(img: torch.Tensor, sens: torch.Tensor, kref: Optional[torch.T
     return out
 
 
-def kspace_to_hybrid(k: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Centered column IFFT (first half of ifft2c): k-space -> hybrid space (image along h, k along w)."""
+def kspace_to_hybrid(k: torch.Tensor, out: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Centered column IFFT (first half of ifft2c): k-space -> hybrid space (image along h, k along w).
+    With ``mask`` ((b,t,1,h,1,1) uint8, k (b,t,c,h,w,2)): the transform of mask * k, reading only the sampled rows."""
     _pair(k)
     k = _dev(k, "k-space")
     h, w = k.shape[-3], k.shape[-2]
     if out is None:
         out = torch.empty_like(k)
+    if mask is not None:
+        mask = _dev(mask, "mask", torch.uint8)
+        b, t, c = k.shape[:3]
+        if k.dim() != 6 or mask.numel() != b * t * h:
+            raise ValueError(f"mask shape {tuple(mask.shape)}: expected (b, t, 1, h, 1, 1) for k-space {tuple(k.shape)}")
+        check(lib().cine_masked_kspace_to_hybrid(k.data_ptr(), mask.data_ptr(), out.data_ptr(), b * t, c, h, w, _stream()),
+              "cine_masked_kspace_to_hybrid")
+        return out
     check(lib().cine_kspace_to_hybrid(k.data_ptr(), out.data_ptr(), k.numel() // (h * w * 2), h, w, _stream()),
           "cine_kspace_to_hybrid")
+    return out
+
+
+def is_row_mask(mask: torch.Tensor, kspace: torch.Tensor) -> bool:
+    """True for the reference's mask layout (b, t, 1, h, 1, 1) (data/transforms.py:341-343)."""
+    b, t, _, h, _, _ = kspace.shape
+    return mask.dim() == 6 and tuple(mask.shape) == (b, t, 1, h, 1, 1)
+
+
+def image_dc(img: torch.Tensor, sens: torch.Tensor, zf: Optional[torch.Tensor], mask: torch.Tensor,
+             lambda_reg: Optional[torch.Tensor] = None, weights=(1.0, 0.0, 0.0), magnitude: bool = False,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sens_reduce(DC(sens_expand(img))) of reference varnet.py:181-194, 281-282 on the coil-combined image (row masks):
+    sum_c conj(S_c) IFFT_h[wgt * FFT_h(S_c img)] + beta * zf.  ``lambda_reg``: soft-DC weights from softplus(lambda);
+    else ``weights`` = (w_sampled, w_unsampled, beta).  img (b,t,[1,]h,w,2) -> (b,t,1,h,w,2), or (b,t,h,w) magnitude."""
+    _pair(img); _pair(sens)
+    img = _dev(img, "image"); sens = _dev(sens, "sens_maps"); mask = _dev(mask, "mask", torch.uint8)
+    b, _, c, h, w, _ = sens.shape
+    t = img.shape[1]
+    if img.numel() != b * t * h * w * 2 or mask.numel() != b * t * h:
+        raise ValueError(f"image_dc: image {tuple(img.shape)} / mask {tuple(mask.shape)} do not match sens_maps {tuple(sens.shape)}")
+    if zf is not None:
+        zf = _dev(zf, "zero-filled image")
+        if zf.numel() != img.numel():
+            raise ValueError("image_dc: zero-filled image shape mismatch")
+    lam = None if lambda_reg is None else _dev(lambda_reg.detach(), "lambda_reg")
+    if out is None:
+        out = torch.empty((b, t, h, w) if magnitude else (b, t, 1, h, w, 2), device=img.device, dtype=img.dtype)
+    w1, w0, beta = (float(v) for v in weights)
+    nbytes = lib().cine_image_dc_ws_bytes(b, t, c, h, w)
+    ws = torch.empty(nbytes, device=img.device, dtype=torch.uint8) if nbytes else None
+    check(lib().cine_image_dc(img.data_ptr(), sens.data_ptr(), _p(zf), mask.data_ptr(), _p(lam), w1, w0, beta,
+                              out.data_ptr(), b, t, c, h, w, int(magnitude), _p(ws), nbytes, _stream()), "cine_image_dc")
     return out
 
 

@@ -10,6 +10,7 @@
 //   col pass store : soft / hard DC blend   (varnet.py:281-282, cinenet.py:129)
 //   row pass store : conj(S) * x, coil sum, optional magnitude (varnet.py:187-194, 150-151)
 // N == 200 uses the 10 x 20 Cooley-Tukey engine; any other N <= 400 a direct DFT.
+#include <algorithm>
 #include "common.h"
 #include "fft_core.h"
 
@@ -72,6 +73,7 @@ struct ColArgs {
     int s_in, s_out;
     const cf* kref; const uint8_t* mask; const float* lam;
     int coils;            // images per mask row-set (mask index = img / coils)
+    const uint8_t* premask;   // optional: rows with premask == 0 enter the transform as zeros and are not read
 };
 
 template <bool F200, int DIR, int POST, int LINES>
@@ -92,7 +94,7 @@ __global__ void col_pass_kernel(ColArgs a) {
     for (int e = tid; e < H * LINES; e += nt) {
         const int g = e / LINES, l = e % LINES, col = w0 + l;
         cf v = mk(0.f, 0.f);
-        if (col < a.W) v = in[(long)g * a.W + col];
+        if (col < a.W && (!a.premask || a.premask[(img / a.coils) * H + g])) v = in[(long)g * a.W + col];
         int n = g + a.s_in; if (n >= H) n -= H;
         t0[n * LP + l] = v;
     }
@@ -263,7 +265,7 @@ __device__ __forceinline__ int rot10(int k, int g) { return 10 * k + g + (k < 10
 // INV_AFTER the inverse transform of the blended column right away (k-space -> DC -> hybrid space
 // without the k-space ever leaving the CU):
 //   global -> r10 -> LDS -> r20 [-> DC -> r20^-1 -> LDS -> r10^-1] -> global
-template <int DIR, int POST, bool INV_AFTER>
+template <int DIR, int POST, bool INV_AFTER, bool PREMASK = false>
 __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
     constexpr int LP = kLP200c;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -302,8 +304,20 @@ __global__ __launch_bounds__(kFT, 3) void col200_kernel(ColArgs a) {
         const int col = w0 + line;
         const int colc = min(col, a.W - 1);                     // clamped: lanes past the edge load a valid
         cf v[10];                                               // column and are never stored (no branches)
+        if (PREMASK) {
+            // rows the mask drops enter as zeros and are not fetched (they re-read one cached line instead: no branches)
+            const uint8_t* pm = a.premask + (img / a.coils) * 200;
+            bool keep[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) v[j] = in[rot20(j, c) * a.W + colc];   // x'[n] = x[(n - 100) mod N]
+            for (int j = 0; j < 10; ++j) keep[j] = pm[rot20(j, c)] != 0;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = in[keep[j] ? rot20(j, c) * a.W + colc : 0];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = keep[j] ? v[j] : mk(0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = in[rot20(j, c) * a.W + colc];   // x'[n] = x[(n - 100) mod N]
+        }
         Fft200::r10_regs<DIR, false, true>(v, c, TW200);
 #pragma unroll
         for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
@@ -520,6 +534,251 @@ __global__ __launch_bounds__(kFT, 3) void row200_expand_kernel(RowArgs a) {
     }
 }
 
+// ================================================================== image-space data consistency
+// The reference's cascade step  x -> sens_expand -> FFT2 -> DC -> (next cascade) IFFT2 -> sens_reduce  (varnet.py:181-194,
+// 253, 281-282) with a Cartesian ROW mask (b, t, 1, h, 1, 1) never needs the transform along w: the mask and the blend
+// weights depend on the k-space row only, so they commute with the row FFT and
+//     IFFT2( wgt(ky) * FFT2(y) ) = IFFT_h( wgt(ky) * FFT_h(y) )          (all transforms centered, ortho)
+// Hence, with y_c = S_c x,  v = softplus(lambda),  zf = sum_c conj(S_c) IFFT2(mask * k_ref)  (constant over the cascades):
+//     x_next = sum_c conj(S_c) IFFT_h[ (mask ? 1/(1+v) : 1) * FFT_h(S_c x) ]  +  v/(1+v) * zf
+// which is exactly sens_reduce(DC(sens_expand(x))) of the reference -- and one kernel that reads x, S and zf (14.4 MB at
+// cfg 2) instead of three passes over the 72 MB coil-wise k-space.  The same operator with weights (1, 0) and beta 0 is
+// CineNet's normal operator A^H M A (cinenet.py:121-133, 255-257); with (1, 0), beta -1 it is XPDNet's backward image
+// A^H M (A x - k_ref) (xpdnet.py:128-131, 161-167, 295-298).
+struct ImgDcArgs {
+    const cf* img;          // (b, t, h, w)
+    const cf* sens;         // (b, c, h, w)
+    const cf* zf;           // (b, t, h, w) or null
+    const uint8_t* mask;    // (b, t, h)
+    const float* lam;       // device scalar (soft DC weights) or null (w1 / w0 / beta below)
+    float w1, w0, beta;     // weight of sampled / unsampled rows, factor of zf
+    cf* out; float* out_abs;
+    int T, C, H, W;
+    cf* partial; long part_stride;   // H == 200 with more than one coil group: per-group partial sums (workspace)
+};
+
+__device__ __forceinline__ void imgdc_weights(const ImgDcArgs& a, float& w1, float& w0, float& beta) {
+    w1 = a.w1; w0 = a.w0; beta = a.beta;
+    if (a.lam) {                                 // varnet.py:281-282: (1 - m) K + m (K + v K_ref) / (1 + v)
+        const float v = softplus1(*a.lam);
+        w1 = 1.0f / (1.f + v); w0 = 1.f; beta = v * w1;
+    }
+}
+
+// H == 200.  Laid out for parallelism and for 64-byte global segments at the same time: one workgroup = one frame x 8
+// adjacent columns x ONE group of 4 coils (kDcL = 32 lines, 10 threads per line, one LDS tile, no coil loop); the coil
+// groups are separate workgroups (blockIdx.z) whose partial sums a small second kernel adds up in a fixed order
+// (deterministic: no atomics).  Measured alternatives: all coils in one workgroup over 2 columns (16-byte segments: every
+// segment drags a 128-byte line from L2, 102 us) and a coil loop inside the workgroup (too few workgroups, 77 us).
+//   P1  S x -> r10 -> tile                                  (two radix-10 items per thread)
+//   P2  tile -> r20 -> row weights -> r20^-1 -> tile        (one radix-20 item per thread)
+//   P3  tile -> r10^-1 -> conj(S) -> tile (in place)
+//   P4  sum over the 4 coil slots -> partial[z] (or, with a single group, + beta * zf -> out)
+#ifndef CINE_DC_MINW
+#define CINE_DC_MINW 3
+#endif
+constexpr int kDcL = 32, kDcT = 10 * kDcL, kDcCS = 4, kDcCW = kDcL / kDcCS;
+__device__ __forceinline__ void imgdc_store(const ImgDcArgs& a, long o, cf s, float beta) {
+    if (a.zf) { const cf z = a.zf[o]; s.x = fmaf(beta, z.x, s.x); s.y = fmaf(beta, z.y, s.y); }
+    if (a.out_abs) a.out_abs[o] = sqrtf(s.x * s.x + s.y * s.y);
+    else a.out[o] = s;
+}
+__global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs a) {
+    constexpr int CS = kDcCS, CW = kDcCW, LP = kDcL;
+    constexpr int NOUT = (200 * CW + kDcT - 1) / kDcT;         // outputs per thread
+    extern __shared__ __align__(16) unsigned char smem[];
+    cf* t = reinterpret_cast<cf*>(smem);
+    const int tid = threadIdx.x;
+    const int w0c = blockIdx.x * CW;
+    const int bt = blockIdx.y, b = bt / a.T;
+    const int c0 = blockIdx.z * CS;
+    const long HW = 200L * a.W;
+    float w1, w0, beta;
+    imgdc_weights(a, w1, w0, beta);
+    // P2 geometry: mask bits of the rows k = g + 10 k2 -> centered row rot10(k2, g)
+    const int line2 = tid % kDcL, g2 = tid / kDcL;
+    unsigned mbits = 0;
+    {
+        const uint8_t* mrow = a.mask + (long)bt * 200;
+#pragma unroll
+        for (int k2 = 0; k2 < 20; ++k2) mbits |= (mrow[rot10(k2, g2)] ? 1u : 0u) << k2;
+    }
+    const cf* xp = a.img + (long)bt * HW;
+    CINE_STAMP(0);
+    // ---- P1: all 40 loads of the thread's two radix-10 items go out first (one exposed memory latency, not two)
+    {
+        cf y[2][10];
+        int lineR[2], cR[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int item = tid + r * kDcT;
+            const int line = item % kDcL, c = item / kDcL;                  // c = 0..19: rows rot20(j, c)
+            const int slot = line / CW;
+            const int colc = min(w0c + line % CW, a.W - 1);                 // clamped: lanes past the edge are never stored
+            const cf* sp = a.sens + ((long)b * a.C + min(c0 + slot, a.C - 1)) * HW + colc;
+            const cf* xq = xp + colc;
+            lineR[r] = line; cR[r] = c;
+            cf sv[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) { sv[j] = sp[rot20(j, c) * a.W]; y[r][j] = xq[rot20(j, c) * a.W]; }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) y[r][j] = cmul(y[r][j], sv[j]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            Fft200::r10_regs<1, false, true>(y[r], cR[r], TW200);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) t[(20 * j + cR[r]) * LP + lineR[r]] = y[r][j];
+            CINE_STAMP(1 + r);
+        }
+    }
+    __syncthreads();
+    CINE_STAMP(3);
+    // ---- P2
+    {
+        cf v[20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) v[j] = t[(20 * g2 + j) * LP + line2];
+        dft20<1>(v);                                            // v[k2] = X'[g + 10 k2] -> centered row (k + 100) % 200
+#pragma unroll
+        for (int k2 = 0; k2 < 20; ++k2) v[k2] = cscale(v[k2], ((mbits >> k2) & 1u) ? w1 : w0);
+        dft20<-1>(v);
+#pragma unroll
+        for (int j = 0; j < 20; ++j) t[(20 * g2 + j) * LP + line2] = v[j];
+    }
+    CINE_STAMP(4);
+    __syncthreads();
+    CINE_STAMP(5);
+    // ---- P3 (sensitivities again: L1 / L2 hits, both items' loads first; nothing of P1 is kept alive across P2)
+    {
+        cf sv[2][10];
+        int lineR[2], cR[2]; bool live[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int item = tid + r * kDcT;
+            const int line = item % kDcL, c = item / kDcL;
+            const int slot = line / CW;
+            const int colc = min(w0c + line % CW, a.W - 1);
+            const cf* sp = a.sens + ((long)b * a.C + min(c0 + slot, a.C - 1)) * HW + colc;
+            lineR[r] = line; cR[r] = c; live[r] = c0 + slot < a.C;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) sv[r][j] = sp[rot20(j, c) * a.W];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            cf v[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) v[j] = t[(20 * j + cR[r]) * LP + lineR[r]];
+            Fft200::r10_regs<-1, true, false>(v, cR[r], TW200);
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const cf m = cmulc(v[j], sv[r][j]);
+                t[(20 * j + cR[r]) * LP + lineR[r]] = live[r] ? m : mk(0.f, 0.f);
+            }
+            CINE_STAMP(6 + r);
+        }
+    }
+    __syncthreads();
+    CINE_STAMP(8);
+    // ---- P4: this thread's outputs, summed over the coil slots
+    const bool single = gridDim.z == 1;
+    cf* part = a.partial + (long)blockIdx.z * a.part_stride;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) {
+        const int e = tid + k * kDcT;
+        const int row = e / CW, cl = e - row * CW, col = w0c + cl;
+        if (e >= 200 * CW || col >= a.W) continue;
+        const int pos = wrap200(row - 100);                     // row = rot20(j, c) <-> position 20 j + c
+        cf s = t[pos * LP + cl];
+#pragma unroll
+        for (int sl = 1; sl < CS; ++sl) { const cf u = t[pos * LP + sl * CW + cl]; s.x += u.x; s.y += u.y; }
+        const long o = (long)bt * HW + (long)row * a.W + col;
+        if (single) imgdc_store(a, o, s, beta);
+        else part[o] = s;
+    }
+    CINE_STAMP(9);
+}
+
+// out = sum_z partial[z] (fixed order) + beta * zf
+__global__ __launch_bounds__(256) void imgdc_sum_kernel(ImgDcArgs a, int nz, long n) {
+    float w1, w0, beta;
+    imgdc_weights(a, w1, w0, beta);
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
+        cf s = a.partial[o];
+        for (int z = 1; z < nz; ++z) { const cf u = a.partial[z * a.part_stride + o]; s.x += u.x; s.y += u.y; }
+        imgdc_store(a, o, s, beta);
+    }
+}
+
+// Any H <= kMaxGenericN: direct DFT in LDS, kLinesGen columns per workgroup, one coil at a time.
+constexpr int kDcAcc = (kMaxGenericN * kLinesGen + kThreadsGen - 1) / kThreadsGen;
+__global__ __launch_bounds__(kThreadsGen) void imgdc_generic_kernel(ImgDcArgs a) {
+    constexpr int LINES = kLinesGen, LP = LINES + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int H = a.H;
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    cf* t1 = t0 + H * LP;
+    cf* tw = t1 + H * LP;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int w0c = blockIdx.x * LINES;
+    const int bt = blockIdx.y, b = bt / a.T;
+    const long HW = (long)H * a.W;
+    float w1, w0, beta;
+    imgdc_weights(a, w1, w0, beta);
+    load_twiddles<false>(tw, H);
+    const uint8_t* mrow = a.mask + (long)bt * H;
+    const int s_in = (H + 1) / 2, s_out = H / 2;               // ifftshift before, fftshift after (fftc.py:75-81)
+    const cf* xp = a.img + (long)bt * HW;
+    cf acc[kDcAcc];
+#pragma unroll
+    for (int m = 0; m < kDcAcc; ++m) acc[m] = mk(0.f, 0.f);
+    for (int coil = 0; coil < a.C; ++coil) {
+        const cf* sp = a.sens + ((long)b * a.C + coil) * HW;
+        __syncthreads();
+        for (int e = tid; e < H * LINES; e += nt) {
+            const int g = e / LINES, l = e - g * LINES, col = w0c + l;
+            cf v = mk(0.f, 0.f);
+            if (col < a.W) v = cmul(xp[(long)g * a.W + col], sp[(long)g * a.W + col]);
+            int n = g + s_in; if (n >= H) n -= H;
+            t0[n * LP + l] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < DirectDft::items(LINES, H); i += nt) DirectDft::stage<1>(t0, t1, LP, i, LINES, H, tw);
+        __syncthreads();
+        for (int e = tid; e < H * LINES; e += nt) {
+            const int i = e / LINES, l = e - i * LINES;
+            int k = i - s_out; if (k < 0) k += H;
+            int n = i + s_in; if (n >= H) n -= H;
+            t0[n * LP + l] = cscale(t1[k * LP + l], mrow[i] ? w1 : w0);
+        }
+        __syncthreads();
+        for (int i = tid; i < DirectDft::items(LINES, H); i += nt) DirectDft::stage<-1>(t0, t1, LP, i, LINES, H, tw);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kDcAcc; ++m) {
+            const int e = tid + m * nt;
+            if (e >= H * LINES) break;
+            const int i = e / LINES, l = e - i * LINES, col = w0c + l;
+            if (col >= a.W) continue;
+            int k = i - s_out; if (k < 0) k += H;
+            const cf mm = cmulc(t1[k * LP + l], sp[(long)i * a.W + col]);
+            acc[m].x += mm.x; acc[m].y += mm.y;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kDcAcc; ++m) {
+        const int e = tid + m * nt;
+        if (e >= H * LINES) break;
+        const int i = e / LINES, l = e - i * LINES, col = w0c + l;
+        if (col >= a.W) continue;
+        const long o = (long)bt * HW + (long)i * a.W + col;
+        cf s = acc[m];
+        if (a.zf) { const cf z = a.zf[o]; s.x = fmaf(beta, z.x, s.x); s.y = fmaf(beta, z.y, s.y); }
+        if (a.out_abs) a.out_abs[o] = sqrtf(s.x * s.x + s.y * s.y);
+        else a.out[o] = s;
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static size_t lds_bytes(bool f200, int n, int lines) {
     const size_t tile = (size_t)n * (lines + 1) * sizeof(cf);
@@ -533,7 +792,7 @@ static int check_n(int n, const char* what) {
     return CINE_OK;
 }
 
-template <int POST, bool INV_AFTER = false>
+template <int POST, bool INV_AFTER = false, bool PREMASK = false>
 static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st) {
     if (nimg == 0) return CINE_OK;
     const bool f200 = a.H == 200;
@@ -543,8 +802,8 @@ static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st)
     ProfScope prof(F_FFT_COL, st);
     if (f200) {
         const size_t lds = (size_t)200 * kLP200c * sizeof(cf);
-        if (inverse) hipLaunchKernelGGL((col200_kernel<-1, POST, INV_AFTER>), grid, dim3(kFT), lds, st, a);
-        else hipLaunchKernelGGL((col200_kernel<1, POST, INV_AFTER>), grid, dim3(kFT), lds, st, a);
+        if (inverse) hipLaunchKernelGGL((col200_kernel<-1, POST, INV_AFTER, PREMASK>), grid, dim3(kFT), lds, st, a);
+        else hipLaunchKernelGGL((col200_kernel<1, POST, INV_AFTER, PREMASK>), grid, dim3(kFT), lds, st, a);
     } else {
         static_assert(!INV_AFTER || true, "");
         const size_t lds = lds_bytes(false, a.H, lines);
@@ -646,6 +905,66 @@ extern "C" int cine_kspace_to_hybrid(const float* k, float* hyb, long nimg, int 
         if (int e = launch_col<POST_NONE>(ca, ni, true, st)) return e;
     }
     return CINE_OK;
+}
+
+extern "C" int cine_masked_kspace_to_hybrid(const float* k, const uint8_t* mask, float* hyb, int bt, int c, int h, int w,
+                                            void* stream) {
+    CINE_REQUIRE(k && mask && hyb, CINE_EINVAL, "cine_masked_kspace_to_hybrid: null pointer");
+    CINE_REQUIRE(bt > 0 && c > 0 && c <= 32768 && h > 0 && w > 0, CINE_EINVAL, "cine_masked_kspace_to_hybrid: bad sizes");
+    if (int e = check_n(h, "cine_masked_kspace_to_hybrid(h)")) return e;
+    hipStream_t st = as_stream(stream);
+    const long nimg = (long)bt * c, step = 32768 / c * c;
+    for (long i0 = 0; i0 < nimg; i0 += step) {
+        const long ni = (nimg - i0) < step ? (nimg - i0) : step;
+        ColArgs ca{};
+        ca.in = reinterpret_cast<const cf*>(k) + i0 * h * w;
+        ca.out = reinterpret_cast<cf*>(hyb) + i0 * h * w;
+        ca.H = h; ca.W = w; ca.s_in = (h + 1) / 2; ca.s_out = h / 2; ca.coils = c;
+        ca.premask = mask + (i0 / c) * h;
+        if (int e = launch_col<POST_NONE, false, true>(ca, ni, true, st)) return e;
+    }
+    return CINE_OK;
+}
+
+extern "C" size_t cine_image_dc_ws_bytes(int b, int t, int c, int h, int w) {
+    if (b <= 0 || t <= 0 || c <= 0 || h != 200 || w <= 0 || c <= kDcCS) return 0;
+    return (size_t)ceil_div(c, kDcCS) * b * t * h * w * sizeof(cf);
+}
+
+extern "C" int cine_image_dc(const float* img, const float* sens, const float* zf, const uint8_t* mask,
+                             const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
+                             float* out, int b, int t, int c, int h, int w, int magnitude,
+                             void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(img && sens && mask && out, CINE_EINVAL, "cine_image_dc: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_image_dc: bad sizes");
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_image_dc: b*t > 65535");
+    CINE_REQUIRE(img != out, CINE_EINVAL, "cine_image_dc: out must not alias img (workgroups read neighbouring columns' rows)");
+    if (int e = check_n(h, "cine_image_dc(h)")) return e;
+    const size_t need = cine_image_dc_ws_bytes(b, t, c, h, w);
+    CINE_REQUIRE(need == 0 || (ws && ws_bytes >= need), CINE_EWORKSPACE, "cine_image_dc: workspace %zu < %zu", ws_bytes, need);
+    ImgDcArgs a{};
+    a.img = reinterpret_cast<const cf*>(img); a.sens = reinterpret_cast<const cf*>(sens);
+    a.zf = reinterpret_cast<const cf*>(zf); a.mask = mask; a.lam = lambda_dev;
+    a.w1 = w_sampled; a.w0 = w_unsampled; a.beta = beta;
+    a.out = magnitude ? nullptr : reinterpret_cast<cf*>(out); a.out_abs = magnitude ? out : nullptr;
+    a.T = t; a.C = c; a.H = h; a.W = w;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(F_FFT_COL, st);
+    if (h == 200) {
+        const int nz = ceil_div(c, kDcCS);
+        CINE_REQUIRE(nz <= 65535, CINE_EUNSUPPORTED, "cine_image_dc: %d coils", c);
+        a.partial = reinterpret_cast<cf*>(ws); a.part_stride = (long)b * t * h * w;
+        hipLaunchKernelGGL(imgdc200_kernel, dim3(ceil_div(w, kDcCW), b * t, nz), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
+        if (int e = check_launch("imgdc200_kernel")) return e;
+        if (nz > 1) {
+            const long n = a.part_stride;
+            hipLaunchKernelGGL(imgdc_sum_kernel, dim3((unsigned)std::min<long>(ceil_div(n, 256L), 2048)), dim3(256), 0, st, a, nz, n);
+        }
+    } else {
+        hipLaunchKernelGGL(imgdc_generic_kernel, dim3(ceil_div(w, kLinesGen), b * t), dim3(kThreadsGen),
+                           lds_bytes(false, h, kLinesGen), st, a);
+    }
+    return check_launch("imgdc_kernel");
 }
 
 extern "C" int cine_hybrid_reduce(const float* hyb, const float* sens, float* out,

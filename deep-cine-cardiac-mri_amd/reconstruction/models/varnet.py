@@ -125,11 +125,24 @@ class VarNet(nn.Module):
         read-back of the mask (needed inside hipGraph capture)."""
         if sens_maps is None:
             sens_maps = self.sens_net(masked_kspace, mask, acs)
-        # Cascade chain in hybrid space (image along h, k-space along w): the k-space between two
-        # cascades (reference varnet.py:147-148) is consumed only by the next sens_reduce, so the DC
-        # kernel hands over its column-IFFT'd tile instead of writing k-space to HBM.
+        if not ops.is_row_mask(mask, masked_kspace):
+            # not the reference's (b, t, 1, h, 1, 1) row mask: the literal k-space chain of reference varnet.py:145-151
+            kspace = masked_kspace.clone()
+            for cascade in self.cascades:
+                kspace = cascade(kspace, masked_kspace, mask, sens_maps, _destroy_current=True)
+            return ops.sens_reduce(kspace, sens_maps, magnitude=True, destroy_input=True)
+        # Cascade chain on the coil-combined image.  The k-space between two cascades (reference varnet.py:147-148) is
+        # consumed only by the next sens_reduce, and with a row mask the DC commutes with the transform along w, so
+        #   reduce(DC(expand(x))) = sum_c conj(S_c) IFFT_h[(m ? 1/(1+v) : 1) FFT_h(S_c x)] + v/(1+v) reduce(m k_ref)
+        # (cine_image_dc): per cascade the FFT+DC step reads x, S and the constant zero-filled term instead of making
+        # three passes over the 72 MB coil-wise k-space.
         hyb = ops.kspace_to_hybrid(masked_kspace)
-        for cascade in self.cascades:
-            image = ops.hybrid_reduce(hyb, sens_maps)
-            ops.expand_dc_hybrid(cascade.regularise(image), sens_maps, masked_kspace, mask, cascade.lambda_reg, out=hyb)
-        return ops.hybrid_reduce(hyb, sens_maps, magnitude=True)
+        image = ops.hybrid_reduce(hyb, sens_maps)                      # first cascade's sens_reduce(masked_kspace)
+        if len(self.cascades) == 0:
+            return ops.complex_abs(image.squeeze(2))
+        ops.kspace_to_hybrid(masked_kspace, out=hyb, mask=mask)
+        zf = ops.hybrid_reduce(hyb, sens_maps)                         # sens_reduce(mask * k_ref)
+        last = len(self.cascades) - 1
+        for i, cascade in enumerate(self.cascades):
+            image = ops.image_dc(cascade.regularise(image), sens_maps, zf, mask, cascade.lambda_reg, magnitude=(i == last))
+        return image

@@ -91,6 +91,32 @@ int cine_expand_dc_hybrid(const float* img, const float* sens, const float* kref
                           const float* lambda_dev, float* hyb, int b, int t, int c, int h, int w,
                           int hard_mask, void* stream);
 
+/* Image-space data consistency: one cascade's  sens_expand -> FFT2 -> DC -> [next cascade] IFFT2 -> sens_reduce
+ * (models/varnet.py:181-194, 253, 281-282) as ONE operator on the coil-combined image, for Cartesian ROW masks
+ * (mask (b, t, 1, h, 1, 1), the only layout the reference produces: data/transforms.py:341-343, subsample.py:146-150).
+ * Mask and blend weights depend on the k-space row only, so they commute with the transform along w and
+ *     out = sum_c conj(S_c) IFFT_h[ wgt(ky) * FFT_h(S_c img) ] + beta * zf,
+ *     wgt = mask ? w_sampled : w_unsampled          (centered ortho 1-D transforms along h)
+ * equals sens_reduce(DC(sens_expand(img))) with  zf = sens_reduce(mask * k_ref)  (constant over the cascades).
+ *   lambda_dev != NULL : soft DC, v = softplus(*lambda_dev): w_sampled = 1/(1+v), w_unsampled = 1, beta = v/(1+v)
+ *                        (the float arguments are ignored)
+ *   lambda_dev == NULL : the float arguments are used as given, e.g. (1, 0, 0) = CineNet's normal operator A^H M A
+ *                        (models/cinenet.py:121-133, 255-257), (1, 0, -1) = XPDNet's backward image A^H M (A x - k_ref)
+ *                        (models/xpdnet.py:128-131, 161-167, 295-298).
+ * img, zf (may be NULL), out: (b, t, h, w, 2); sens (b, 1, c, h, w, 2); mask uint8 (b, t, h).  magnitude != 0: out is
+ * (b, t, h, w) = |result| (varnet.py:150-151).  out must not alias img.  ws: cine_image_dc_ws_bytes() of scratch
+ * (per-coil-group partial sums of the h == 200 kernel; 0 bytes / NULL for other sizes or <= 4 coils). */
+size_t cine_image_dc_ws_bytes(int b, int t, int c, int h, int w);
+int cine_image_dc(const float* img, const float* sens, const float* zf, const uint8_t* mask,
+                  const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
+                  float* out, int b, int t, int c, int h, int w, int magnitude,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* cine_kspace_to_hybrid of (mask * k) without reading the rows the mask drops: the hybrid-space image of the
+ * measured lines only (the zero-filled term zf above: cine_hybrid_reduce of it).  k, hyb (bt, c, h, w, 2); mask (bt, h). */
+int cine_masked_kspace_to_hybrid(const float* k, const uint8_t* mask, float* hyb, int bt, int c, int h, int w,
+                                 void* stream);
+
 /* SensitivityModel prologue (varnet.py:62-74): mean over frames, keep rows [row_lo, row_hi) of
  * dim h (transforms.mask_center, data/transforms.py:95-108), ifft2c.  k (b,t,c,h,w,2) -> out (b,c,h,w,2). */
 int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,

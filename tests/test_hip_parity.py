@@ -787,3 +787,70 @@ def test_complex_math_helpers_vs_reference_golden(golden, dev):
         U.complex_abs(x[..., :1])
     with pytest.raises(ValueError):
         U.complex_mul(x[..., :1], y)
+
+
+# ------------------------------------------------------------------ image-space data consistency (cine_image_dc)
+def _row_mask(t, h, seed, keep=0.35):
+    g = torch.Generator().manual_seed(seed)
+    m = (torch.rand(1, t, 1, h, 1, 1, generator=g) < keep).byte()
+    m[:, :, :, h // 2] = 1
+    return m
+
+
+@pytest.mark.parametrize("t,c,h,w", [(5, 3, 24, 20), (2, 1, 7, 5), (3, 4, 15, 33), (1, 2, 400, 9),      # direct-DFT engine
+                                     (2, 15, 200, 200), (1, 1, 200, 37), (3, 16, 200, 8), (2, 17, 200, 203), (1, 5, 200, 1)])
+def test_image_dc_vs_oracle(dev, t, c, h, w):
+    """cine_image_dc == sens_reduce(DC(sens_expand(x))) of reference varnet.py:181-194, 281-282 for row masks: soft DC
+    for several lambdas, CineNet's normal operator (cinenet.py:121-133), XPDNet's backward image (xpdnet.py:128-167),
+    and the magnitude output; ragged widths, coil counts around the kernel's coil-slot grouping, both FFT engines."""
+    from cine_hip import ops
+    from oracle import varnet_ref as V
+    import torch.nn.functional as F
+    img, sens, kref = rnd(1, 1, t, 1, h, w, 2), rnd(2, 1, 1, c, h, w, 2), rnd(3, 1, t, c, h, w, 2)
+    mask = _row_mask(t, h, 4)
+    imgd, sensd, maskd = img.to(dev), sens.to(dev), mask.to(dev)
+    zf = V.VarNetBlock.sens_reduce(kref * mask, sens)
+    zfd = ops.sens_reduce((kref * mask).to(dev), sensd)
+    assert rel_err(zfd.cpu(), zf) < OP_TOL
+    # zero-filled term through the masked hybrid pass, on k-space that is NOT pre-masked (unsampled rows must be ignored)
+    hyb = ops.kspace_to_hybrid(kref.to(dev), mask=maskd)
+    assert rel_err(ops.hybrid_reduce(hyb, sensd).cpu(), zf) < OP_TOL
+    kth = V.VarNetBlock.sens_expand(img, sens)
+    for lam in (-1.3, 0.5413, 25.0):
+        lam_t = torch.tensor([lam])
+        v = F.softplus(lam_t)
+        ref = V.VarNetBlock.sens_reduce((1 - mask) * kth + mask * (kth + v * kref) / (1 + v), sens)
+        got = ops.image_dc(imgd, sensd, zfd, maskd, lam_t.to(dev))
+        assert got.shape == ref.shape and rel_err(got.cpu(), ref) < OP_TOL, lam
+    ref = V.VarNetBlock.sens_reduce(kth * mask + 0.0, sens)                       # A^H M A x
+    assert rel_err(ops.image_dc(imgd, sensd, None, maskd, weights=(1.0, 0.0, 0.0)).cpu(), ref) < OP_TOL
+    ref = V.VarNetBlock.sens_reduce((kth - kref) * mask + 0.0, sens)              # A^H M (A x - k_ref)
+    assert rel_err(ops.image_dc(imgd, sensd, zfd, maskd, weights=(1.0, 0.0, -1.0)).cpu(), ref) < OP_TOL
+    lam_t = torch.tensor([0.2])
+    v = F.softplus(lam_t)
+    ref = V.VarNetBlock.sens_reduce((1 - mask) * kth + mask * (kth + v * kref) / (1 + v), sens).squeeze(2).pow(2).sum(-1).sqrt()
+    got = ops.image_dc(imgd, sensd, zfd, maskd, lam_t.to(dev), magnitude=True)
+    assert got.shape == (1, t, h, w) and rel_err(got.cpu(), ref) < OP_TOL
+    assert torch.equal(imgd.cpu(), img)                                           # input untouched
+
+
+def test_image_dc_batch_and_identities(dev):
+    """b > 1 (per-sample sens maps and masks), and two size-independent properties at cfg-2 size: with every row sampled
+    and weights (1, 1, 0) the operator is sum_c |S_c|^2 x; it is linear in x."""
+    from cine_hip import ops
+    from oracle import varnet_ref as V
+    b, t, c, h, w = 2, 3, 4, 200, 24
+    img, sens = rnd(11, b, t, 1, h, w, 2), rnd(12, b, 1, c, h, w, 2)
+    mask = torch.cat([_row_mask(t, h, 5), _row_mask(t, h, 6)])
+    ref = V.VarNetBlock.sens_reduce(V.VarNetBlock.sens_expand(img, sens) * mask + 0.0, sens)
+    assert rel_err(ops.image_dc(img.to(dev), sens.to(dev), None, mask.to(dev), weights=(1.0, 0.0, 0.0)).cpu(), ref) < OP_TOL
+    t, c, h, w = 15, 15, 200, 200
+    x, y, sens = torch.randn(1, t, 1, h, w, 2, device=dev), torch.randn(1, t, 1, h, w, 2, device=dev), torch.randn(1, 1, c, h, w, 2, device=dev)
+    ones = torch.ones(1, t, 1, h, 1, 1, dtype=torch.uint8, device=dev)
+    got = ops.image_dc(x, sens, None, ones, weights=(1.0, 1.0, 0.0))
+    want = x * (sens ** 2).sum(dim=(2, 5), keepdim=True)
+    assert rel_err(got.cpu(), want.cpu()) < OP_TOL
+    mask = _row_mask(t, h, 7).to(dev)
+    lam = torch.tensor([0.3], device=dev)
+    f = lambda z: ops.image_dc(z, sens, None, mask, lam)
+    assert rel_err(f(2 * x - 3 * y).cpu(), (2 * f(x) - 3 * f(y)).cpu()) < OP_TOL
