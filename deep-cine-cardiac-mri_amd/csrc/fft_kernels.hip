@@ -555,6 +555,7 @@ struct ImgDcArgs {
     cf* out; float* out_abs;
     int T, C, H, W;
     cf* partial; long part_stride;   // H == 200 with more than one coil group: per-group partial sums (workspace)
+    int BT, ntx, nz;                 // H == 200: frames x batch, column tiles, coil groups
 };
 
 __device__ __forceinline__ void imgdc_weights(const ImgDcArgs& a, float& w1, float& w0, float& beta) {
@@ -565,19 +566,22 @@ __device__ __forceinline__ void imgdc_weights(const ImgDcArgs& a, float& w1, flo
     }
 }
 
-// H == 200.  Laid out for parallelism and for 64-byte global segments at the same time: one workgroup = one frame x 8
-// adjacent columns x ONE group of 4 coils (kDcL = 32 lines, 10 threads per line, one LDS tile, no coil loop); the coil
-// groups are separate workgroups (blockIdx.z) whose partial sums a small second kernel adds up in a fixed order
-// (deterministic: no atomics).  Measured alternatives: all coils in one workgroup over 2 columns (16-byte segments: every
-// segment drags a 128-byte line from L2, 102 us) and a coil loop inside the workgroup (too few workgroups, 77 us).
+// H == 200.  The arithmetic is small (0.6 GFLOP per launch at cfg 2); the kernel is laid out for occupancy and parallelism:
+// one workgroup = one frame x 5 adjacent columns x ONE group of 5 coils = 25 lines, 10 threads per line = 250 of 256
+// threads: four full waves (one per SIMD; the 5-wave shapes of 32 lines packed 1-2 workgroups per CU), one 40 KB LDS tile,
+// no coil loop.  Coil groups are separate workgroups (blockIdx.z) whose partial sums a small second
+// kernel adds in a fixed order (deterministic: no atomics).  Measured alternatives at cfg 2: all coils in one workgroup
+// over 2 columns (16-byte segments, every one drags a 128-byte line from L2: 102 us), a coil loop inside the workgroup
+// (375 workgroups: 77 us), 32 lines x 4 coils in 5 waves (50 us); this shape 41 us + 7 us for the partial sums.  Ablation
+// of this shape: global loads 20 us, radix-10 math 8 us, radix-20 math 3 us, the rest LDS traffic, barriers and stores.
 //   P1  S x -> r10 -> tile                                  (two radix-10 items per thread)
 //   P2  tile -> r20 -> row weights -> r20^-1 -> tile        (one radix-20 item per thread)
 //   P3  tile -> r10^-1 -> conj(S) -> tile (in place)
-//   P4  sum over the 4 coil slots -> partial[z] (or, with a single group, + beta * zf -> out)
+//   P4  sum over the coil slots -> partial[z] (or, with a single group, + beta * zf -> out)
 #ifndef CINE_DC_MINW
 #define CINE_DC_MINW 3
 #endif
-constexpr int kDcL = 32, kDcT = 10 * kDcL, kDcCS = 4, kDcCW = kDcL / kDcCS;
+constexpr int kDcCS = 5, kDcCW = 5, kDcL = kDcCS * kDcCW, kDcT = 256, kDcAct = 10 * kDcL;
 __device__ __forceinline__ void imgdc_store(const ImgDcArgs& a, long o, cf s, float beta) {
     if (a.zf) { const cf z = a.zf[o]; s.x = fmaf(beta, z.x, s.x); s.y = fmaf(beta, z.y, s.y); }
     if (a.out_abs) a.out_abs[o] = sqrtf(s.x * s.x + s.y * s.y);
@@ -589,14 +593,22 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     extern __shared__ __align__(16) unsigned char smem[];
     cf* t = reinterpret_cast<cf*>(smem);
     const int tid = threadIdx.x;
-    const int w0c = blockIdx.x * CW;
-    const int bt = blockIdx.y, b = bt / a.T;
-    const int c0 = blockIdx.z * CS;
+    const bool active = tid < kDcAct;
+    // XCD-aware decode of a 1-D grid.  Workgroup ids go round-robin over the 8 XCDs, and the sensitivities a workgroup
+    // reads depend on (column tile, coil group) but not on the frame: all frames of one (tile, group) pair are given to
+    // ONE XCD, so every XCD's L2 holds 1/8 of the maps instead of each of them streaming all 4.8 MB (twice).
+    const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
+    const int pair = (kq / a.BT) * 8 + xcd, bt = kq % a.BT;
+    if (pair >= a.ntx * a.nz) return;                           // padding of the pair count to a multiple of 8
+    const int zg = pair / a.ntx;
+    const int w0c = (pair - zg * a.ntx) * CW;
+    const int b = bt / a.T;
+    const int c0 = zg * CS;
     const long HW = 200L * a.W;
     float w1, w0, beta;
     imgdc_weights(a, w1, w0, beta);
     // P2 geometry: mask bits of the rows k = g + 10 k2 -> centered row rot10(k2, g)
-    const int line2 = tid % kDcL, g2 = tid / kDcL;
+    const int line2 = tid % kDcL, g2 = min(tid / kDcL, 9);
     unsigned mbits = 0;
     {
         const uint8_t* mrow = a.mask + (long)bt * 200;
@@ -605,37 +617,34 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     }
     const cf* xp = a.img + (long)bt * HW;
     CINE_STAMP(0);
-    // ---- P1: all 40 loads of the thread's two radix-10 items go out first (one exposed memory latency, not two)
-    {
-        cf y[2][10];
-        int lineR[2], cR[2];
+    cf svk[2][10];          // the sensitivities stay in registers for P3: 140 VGPRs, three workgroups per CU (48 vs 56 us re-reading them)
+    // ---- P1
+    if (active) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int item = tid + r * kDcT;
+            const int item = tid + r * kDcAct;
             const int line = item % kDcL, c = item / kDcL;                  // c = 0..19: rows rot20(j, c)
             const int slot = line / CW;
             const int colc = min(w0c + line % CW, a.W - 1);                 // clamped: lanes past the edge are never stored
             const cf* sp = a.sens + ((long)b * a.C + min(c0 + slot, a.C - 1)) * HW + colc;
             const cf* xq = xp + colc;
-            lineR[r] = line; cR[r] = c;
-            cf sv[10];
+            cf v[10], sv[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) { sv[j] = sp[rot20(j, c) * a.W]; y[r][j] = xq[rot20(j, c) * a.W]; }
+            for (int j = 0; j < 10; ++j) { sv[j] = sp[rot20(j, c) * a.W]; v[j] = xq[rot20(j, c) * a.W]; }
 #pragma unroll
-            for (int j = 0; j < 10; ++j) y[r][j] = cmul(y[r][j], sv[j]);
-        }
+            for (int j = 0; j < 10; ++j) v[j] = cmul(v[j], sv[j]);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            Fft200::r10_regs<1, false, true>(y[r], cR[r], TW200);
+            for (int j = 0; j < 10; ++j) svk[r][j] = sv[j];
+            Fft200::r10_regs<1, false, true>(v, c, TW200);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) t[(20 * j + cR[r]) * LP + lineR[r]] = y[r][j];
+            for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
             CINE_STAMP(1 + r);
         }
     }
     __syncthreads();
     CINE_STAMP(3);
     // ---- P2
-    {
+    if (active) {
         cf v[20];
 #pragma unroll
         for (int j = 0; j < 20; ++j) v[j] = t[(20 * g2 + j) * LP + line2];
@@ -649,31 +658,24 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     CINE_STAMP(4);
     __syncthreads();
     CINE_STAMP(5);
-    // ---- P3 (sensitivities again: L1 / L2 hits, both items' loads first; nothing of P1 is kept alive across P2)
-    {
-        cf sv[2][10];
-        int lineR[2], cR[2]; bool live[2];
+    // ---- P3
+    if (active) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const int item = tid + r * kDcT;
+            const int item = tid + r * kDcAct;
             const int line = item % kDcL, c = item / kDcL;
             const int slot = line / CW;
-            const int colc = min(w0c + line % CW, a.W - 1);
-            const cf* sp = a.sens + ((long)b * a.C + min(c0 + slot, a.C - 1)) * HW + colc;
-            lineR[r] = line; cR[r] = c; live[r] = c0 + slot < a.C;
+            const bool live = c0 + slot < a.C;
+            cf v[10], sv[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) sv[r][j] = sp[rot20(j, c) * a.W];
-        }
+            for (int j = 0; j < 10; ++j) sv[j] = svk[r][j];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            cf v[10];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = t[(20 * j + cR[r]) * LP + lineR[r]];
-            Fft200::r10_regs<-1, true, false>(v, cR[r], TW200);
+            for (int j = 0; j < 10; ++j) v[j] = t[(20 * j + c) * LP + line];
+            Fft200::r10_regs<-1, true, false>(v, c, TW200);
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                const cf m = cmulc(v[j], sv[r][j]);
-                t[(20 * j + cR[r]) * LP + lineR[r]] = live[r] ? m : mk(0.f, 0.f);
+                const cf m = cmulc(v[j], sv[j]);
+                t[(20 * j + c) * LP + line] = live ? m : mk(0.f, 0.f);
             }
             CINE_STAMP(6 + r);
         }
@@ -681,8 +683,8 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     __syncthreads();
     CINE_STAMP(8);
     // ---- P4: this thread's outputs, summed over the coil slots
-    const bool single = gridDim.z == 1;
-    cf* part = a.partial + (long)blockIdx.z * a.part_stride;
+    const bool single = a.nz == 1;
+    cf* part = a.partial + (long)zg * a.part_stride;
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
         const int e = tid + k * kDcT;
@@ -954,7 +956,10 @@ extern "C" int cine_image_dc(const float* img, const float* sens, const float* z
         const int nz = ceil_div(c, kDcCS);
         CINE_REQUIRE(nz <= 65535, CINE_EUNSUPPORTED, "cine_image_dc: %d coils", c);
         a.partial = reinterpret_cast<cf*>(ws); a.part_stride = (long)b * t * h * w;
-        hipLaunchKernelGGL(imgdc200_kernel, dim3(ceil_div(w, kDcCW), b * t, nz), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
+        a.BT = b * t; a.ntx = ceil_div(w, kDcCW); a.nz = nz;
+        const long nblk = 8L * ceil_div(a.ntx * nz, 8) * a.BT;
+        CINE_REQUIRE(nblk <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_image_dc: grid too large");
+        hipLaunchKernelGGL(imgdc200_kernel, dim3((unsigned)nblk), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
         if (int e = check_launch("imgdc200_kernel")) return e;
         if (nz > 1) {
             const long n = a.part_stride;

@@ -21,7 +21,7 @@ int main() {
     hipDeviceSynchronize();
     std::vector<unsigned long long> st(1 << 20);
     hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_cine_stamps), st.size() * 8);
-    const int nwg = 25 * 15 * 4;
+    const int nwg = 40 * 15 * 3;
     double acc[10] = {0}; std::vector<double> life;
     unsigned long long tmin = ~0ull, tmax = 0;
     for (int b = 0; b < nwg; ++b) {
