@@ -55,3 +55,36 @@ def test_single_process_assembly_is_identity():
     x = torch.rand(5, 2, 3)
     assert torch.equal(shard.assemble_volume(x, 5), x)
     assert shard.slice_indices(10, 1, 4) == [1, 5, 9] and shard.padded_count(10, 4) == 3
+
+
+def _bench(*argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                       timeout=300, cwd="/tmp")
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks_gloo_world2():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts 2 ranks itself (child processes, no exec) and the real
+    timed region -- barrier, K steps, slice-sharded volume assembly by all-gather, barrier, max over ranks -- runs on gloo
+    with a stand-in for the forward: the assembled volume holds every slice of both ranks in slice order."""
+    r, line = _bench("--gpus", "2", "--steps", "5", "--warmup", "1", "--selftest-cpu")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["volume_ok"] and line["volume_slices"] == 10
+    assert line["valid"] is False and line["value"] is None            # the self-test line can never pass for a measurement
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    r, line = _bench("--gpus", "2", "--selftest-cpu", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode != 0 and line is None and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_without_a_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        return
+    r, line = _bench("--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode != 0 and line is None and "no CPU fallback" in (r.stderr + r.stdout)
