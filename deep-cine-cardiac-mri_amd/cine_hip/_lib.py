@@ -9,7 +9,7 @@ library is missing -- there is no CPU fallback.
 import ctypes
 import os
 import re
-from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CINE_HIP_LIB") or os.path.join(_HERE, "libcine_hip.so")   # override: A/B builds of the library
@@ -37,6 +37,12 @@ _SIGS = {
     "cine_image_dc": (c_int, [P, P, P, P, P, c_float, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int,
                               P, c_size_t, P]),
     "cine_masked_kspace_to_hybrid": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "cine_apply_mask": (c_int, [P, P, P, c_long, c_int, c_int, c_int, P]),
+    "cine_scale": (c_int, [P, c_long, c_float, P]),
+    "cine_zero_filled_rss": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_image_metrics_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "cine_image_metrics": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_double,
+                                   P, P, c_size_t, P]),
     "cine_sens_prologue": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_rss_normalise": (c_int, [P, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

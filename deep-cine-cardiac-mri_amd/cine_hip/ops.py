@@ -233,6 +233,63 @@ def complex_abs(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------ the steps either side of the path
+def apply_mask(kspace: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """kspace * mask + 0.0 (reference data/transforms.py:66-92) for a row mask; kspace (..., c, h, w, 2) with the mask's
+    (..., 1, h, 1, 1) leading dims, e.g. (b, t, c, h, w, 2) & (b, t, 1, h, 1, 1) or (t, c, h, w, 2) & (t, 1, h, 1, 1)."""
+    _pair(kspace)
+    kspace = _dev(kspace, "k-space"); mask = _dev(mask, "mask", torch.uint8)
+    c, h, w = kspace.shape[-4], kspace.shape[-3], kspace.shape[-2]
+    bt = kspace.numel() // (c * h * w * 2)
+    if mask.numel() != bt * h:
+        raise ValueError(f"apply_mask: mask {tuple(mask.shape)} does not match k-space {tuple(kspace.shape)}")
+    if out is None:
+        out = torch.empty_like(kspace)
+    check(lib().cine_apply_mask(kspace.data_ptr(), mask.data_ptr(), out.data_ptr(), bt, c, h, w, _stream()), "cine_apply_mask")
+    return out
+
+
+def scale_(x: torch.Tensor, s: float) -> torch.Tensor:
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32
+    check(lib().cine_scale(x.data_ptr(), x.numel(), float(s), _stream()), "cine_scale")
+    return x
+
+
+def zero_filled_rss(kspace: torch.Tensor, destroy_input: bool = False) -> torch.Tensor:
+    """Zero-filled reconstruction of reference run_inference.py:64-67: (b,t,c,h,w,2) -> (b,t,h,w)."""
+    _pair(kspace)
+    k = _dev(kspace, "k-space")
+    b, t, c, h, w, _ = k.shape
+    tmp = k if destroy_input else torch.empty_like(k)
+    out = torch.empty((b, t, h, w), device=k.device, dtype=k.dtype)
+    check(lib().cine_zero_filled_rss(k.data_ptr(), out.data_ptr(), tmp.data_ptr(), b, t, c, h, w, _stream()), "cine_zero_filled_rss")
+    return out
+
+
+def image_metrics(gt: torch.Tensor, pred: torch.Tensor, maxval: Optional[float] = None, per_frame_range: bool = False,
+                  win_size: int = 7, k1: float = 0.01, k2: float = 0.03) -> dict:
+    """SSIM / NMSE / PSNR / MSE of pred (t, hp, wp) against gt (t, hg, wg) on the device, after the reference's
+    center_crop_to_smallest (data/transforms.py:161-183): reference utils/evaluate.py:6-50, and utils/losses.py:25-58 with
+    ``per_frame_range``.  Returns 0-d / (t,) float64 device tensors: ssim, nmse, psnr, mse, ssim_frames."""
+    gt = _dev(gt, "target"); pred = _dev(pred, "reconstruction")
+    if gt.dim() != 3:
+        raise ValueError("Unexpected number of dimensions in ground truth.")
+    if pred.dim() != 3 or pred.shape[0] != gt.shape[0]:
+        raise ValueError("Ground truth dimensions does not match pred.")
+    t, hg, wg = gt.shape
+    _, hp, wp = pred.shape
+    nbytes = lib().cine_image_metrics_ws_bytes(t, hg, wg, hp, wp, win_size)
+    if nbytes == 0:
+        raise ValueError(f"image_metrics: frames {tuple(gt.shape)} / {tuple(pred.shape)} too small for a {win_size} window")
+    ws = torch.empty(nbytes, device=gt.device, dtype=torch.uint8)
+    out = torch.empty(4 + t, device=gt.device, dtype=torch.float64)
+    mode = 1 if per_frame_range else (0 if maxval is None else 2)
+    check(lib().cine_image_metrics(gt.data_ptr(), pred.data_ptr(), t, hg, wg, hp, wp, win_size, k1, k2, mode,
+                                   0.0 if maxval is None else float(maxval), out.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+          "cine_image_metrics")
+    return {"ssim": out[0], "nmse": out[1], "psnr": out[2], "mse": out[3], "ssim_frames": out[4:]}
+
+
 # ------------------------------------------------------------------ CG vector ops (device-side scalars)
 _dot_ws = {}
 

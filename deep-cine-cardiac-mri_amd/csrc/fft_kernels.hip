@@ -27,7 +27,7 @@ constexpr int kMaxOut = 4;                          // reduce outputs per thread
 
 enum { POST_NONE = 0, POST_DC = 1, POST_HARD = 2, POST_RESID = 3 };   // RESID: mask ? k - kref : 0 (xpdnet.py:128-131,295-298)
 enum { PRE_NONE = 0, PRE_SMUL = 1 };
-enum { RPOST_NONE = 0, RPOST_REDUCE = 1, RPOST_REDUCE_ABS = 2 };
+enum { RPOST_NONE = 0, RPOST_REDUCE = 1, RPOST_REDUCE_ABS = 2, RPOST_RSS = 3 };   // RSS: sqrt(sum_c |x_c|^2) (coil_combine.py:21-34)
 
 template <bool F200> __device__ __forceinline__ void load_twiddles(cf* tw, int n) {
     if (F200) {
@@ -221,6 +221,7 @@ __global__ void row_pass_kernel(RowArgs a) {
                 cf s_acc = acc[o];
                 for (int cl = 0; cl < nc; ++cl) {
                     cf x = res[p + cl * a.rpw + r];
+                    if (POST == RPOST_RSS) { s_acc.x += x.x * x.x + x.y * x.y; continue; }
                     cf s = a.sens[((long)b * a.C + c0 + cl) * HW + (long)h * W + i];
                     cf m = cmulc(x, s);       // x * conj(s)
                     s_acc.x += m.x; s_acc.y += m.y;
@@ -240,6 +241,8 @@ __global__ void row_pass_kernel(RowArgs a) {
             if (h >= a.H) continue;
             if (POST == RPOST_REDUCE_ABS)
                 a.out_abs[(long)bt * HW + (long)h * W + i] = sqrtf(acc[o].x * acc[o].x + acc[o].y * acc[o].y);
+            else if (POST == RPOST_RSS)
+                a.out_abs[(long)bt * HW + (long)h * W + i] = sqrtf(acc[o].x);
             else
                 a.out[(long)bt * HW + (long)h * W + i] = acc[o];
         }
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(kFT, 3) void row200_reduce_kernel(RowArgs a) {
         // sensitivities of this thread's first output pixel, fetched up front (up to kSPre coils)
         constexpr int kSPre = 16;
         cf spre[kSPre];
-        {
+        if (POST != RPOST_RSS) {
             const int rr0 = tid / 200, i0 = tid - rr0 * 200;
             const cf* sb = a.sens + ((long)b * a.C + c0) * HW + (long)min(h0 + rr0, a.H - 1) * 200 + i0;
 #pragma unroll
@@ -440,6 +443,11 @@ __global__ __launch_bounds__(kFT, 3) void row200_reduce_kernel(RowArgs a) {
             const int k = wrap200(i - 100);
             const int p = Fft200::pos_of(k) * LP;
             cf s_acc = acc[o];
+            if (POST == RPOST_RSS) {
+                for (int cl = 0; cl < nc; ++cl) { const cf x = t[p + cl * a.rpw + rr]; s_acc.x += x.x * x.x + x.y * x.y; }
+                acc[o] = s_acc;
+                continue;
+            }
             const cf* sbase = a.sens + ((long)b * a.C + c0) * HW + (long)h * 200 + i;
             int cg0 = 0;
             if (o == 0) {                                   // first output: sensitivities already in registers
@@ -477,6 +485,8 @@ __global__ __launch_bounds__(kFT, 3) void row200_reduce_kernel(RowArgs a) {
         if (h >= a.H) continue;
         if (POST == RPOST_REDUCE_ABS)
             a.out_abs[(long)bt * HW + (long)h * 200 + i] = sqrtf(acc[o].x * acc[o].x + acc[o].y * acc[o].y);
+        else if (POST == RPOST_RSS)
+            a.out_abs[(long)bt * HW + (long)h * 200 + i] = sqrtf(acc[o].x);
         else
             a.out[(long)bt * HW + (long)h * 200 + i] = acc[o];
     }
@@ -988,6 +998,24 @@ extern "C" int cine_hybrid_reduce(const float* hyb, const float* sens, float* ou
     dim3 grid(ceil_div(h, r.rpw), b * t);
     return magnitude ? launch_row<PRE_NONE, RPOST_REDUCE_ABS>(r, grid, true, as_stream(stream))
                      : launch_row<PRE_NONE, RPOST_REDUCE>(r, grid, true, as_stream(stream));
+}
+
+// Zero-filled reconstruction (traintest_scripts/run_inference.py:64-67): rss_complex(ifft2c(k, norm=None) * sqrt(h w), dim=coil)
+// = root-sum-of-squares over the coils of the ORTHO inverse transform.  tmp: scratch of k's size (may alias k: destroys it).
+extern "C" int cine_zero_filled_rss(const float* k, float* out, float* tmp, int b, int t, int c, int h, int w, void* stream) {
+    CINE_REQUIRE(k && out && tmp, CINE_EINVAL, "cine_zero_filled_rss: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_zero_filled_rss: bad sizes");
+    if (int e = check_n(w, "cine_zero_filled_rss(w)")) return e;
+    if (int e = cine_kspace_to_hybrid(k, tmp, (long)b * t * c, h, w, stream)) return e;
+    RowArgs r{};
+    r.in = reinterpret_cast<const cf*>(tmp);
+    r.out = nullptr; r.out_abs = out;
+    r.W = w; r.s_in = (w + 1) / 2; r.s_out = w / 2;
+    r.sens = nullptr;
+    r.T = t; r.C = c; r.H = h;
+    coil_tiling(c, w, r.rpw, r.cc);
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_zero_filled_rss: b*t > 65535");
+    return launch_row<PRE_NONE, RPOST_RSS>(r, dim3(ceil_div(h, r.rpw), b * t), true, as_stream(stream));
 }
 
 extern "C" int cine_sens_reduce(const float* k, const float* sens, float* out, float* tmp,

@@ -7,8 +7,21 @@ BART based dataset preparation) is outside the accelerated path; those names are
 """
 import torch
 
-from cine_hip.synth import apply_mask  # noqa: F401  (reference transforms.py:66-92)
+from cine_hip import synth as _synth
 from .._fallthrough import load_shadowed as _load_shadowed
+
+
+def apply_mask(data: torch.Tensor, mask_func, seed=None):
+    """reference transforms.py:66-92: one row mask per frame from ``mask_func`` (host RNG, as in the reference), applied
+    on the device (cine_apply_mask) when ``data`` lives there."""
+    if not data.is_cuda:
+        return _synth.apply_mask(data, mask_func, seed)
+    import numpy as np
+    from cine_hip import ops
+    shape = np.array(data.shape)
+    shape[1] = 1
+    mask = mask_func(shape, seed)                                    # (t, 1, h, 1, 1) float, values 0 / 1
+    return ops.apply_mask(data, mask.to(torch.uint8).to(data.device)), mask.to(data.device)
 
 
 def mask_center(x: torch.Tensor, mask_from: int, mask_to: int) -> torch.Tensor:

@@ -1,5 +1,9 @@
 """SSIM / NMSE / PSNR as the reference's utils/evaluate.py defines them, without scikit-image.
 
+Two forms: the reference's numpy interface (``mse / nmse / psnr / ssim`` on host arrays, used by mri_module.py:201-209 and
+by the tests as the independent check) and ``metrics_device`` / ``ssim_device``: the fused HIP kernel (cine_image_metrics)
+on GPU tensors -- center crop, 7x7 window moments, SSIM map, frame means, NMSE and PSNR without leaving the device.
+
 ``structural_similarity(gt, pred, data_range=maxval)`` with skimage's defaults is a 7x7
 uniform window, sample covariance (N/(N-1)), K1 = 0.01, K2 = 0.03, mean over the window-valid
 interior; ``ssim`` averages it over frames (reference evaluate.py:25-42).  Host side (numpy).
@@ -43,6 +47,17 @@ def ssim(gt: np.ndarray, pred: np.ndarray, maxval: Optional[float] = None) -> fl
         raise ValueError("Ground truth dimensions does not match pred.")
     maxval = gt.max() if maxval is None else maxval
     return sum(_ssim2d(gt[i], pred[i], maxval) for i in range(gt.shape[0])) / gt.shape[0]
+
+
+def metrics_device(gt, pred, maxval: Optional[float] = None) -> dict:
+    """All four metrics of (t, h, w) GPU tensors in one pass; crops both to the smaller size first
+    (data/transforms.py:161-183).  Values are 0-d float64 device tensors (no host sync)."""
+    from cine_hip import ops
+    return ops.image_metrics(gt, pred, maxval=maxval)
+
+
+def ssim_device(gt, pred, maxval: Optional[float] = None):
+    return metrics_device(gt, pred, maxval)["ssim"]
 
 
 METRIC_FUNCS = dict(MSE=mse, NMSE=nmse, PSNR=psnr, SSIM=ssim)

@@ -16,29 +16,45 @@ def _check(data: torch.Tensor) -> None:
         raise ValueError("Tensor does not have separate complex dim.")
 
 
-def fft1c(data: torch.Tensor, norm: str = "ortho") -> torch.Tensor:
-    _check(data); _ortho(norm)
-    return ops.fft1c(data, inverse=False)
+def _scale(norm: Optional[str], n: int, inverse: bool) -> float:
+    """Factor on top of the ortho kernels for torch.fft's other normalisations (reference passes ``norm`` through:
+    fftc.py:23-25, 78; run_inference.py:66 uses norm=None)."""
+    if norm == "ortho":
+        return 1.0
+    if norm is None or norm == "backward":        # forward unscaled, inverse 1/n
+        return n ** -0.5 if inverse else n ** 0.5
+    if norm == "forward":                          # forward 1/n, inverse unscaled
+        return n ** 0.5 if inverse else n ** -0.5
+    raise ValueError(f"Invalid normalization mode: {norm!r}")
 
 
-def ifft1c(data: torch.Tensor, norm: str = "ortho") -> torch.Tensor:
-    _check(data); _ortho(norm)
-    return ops.fft1c(data, inverse=True)
+def _run(data: torch.Tensor, two_d: bool, inverse: bool, norm: Optional[str]) -> torch.Tensor:
+    _check(data)
+    n = data.shape[-2] * (data.shape[-3] if two_d else 1)
+    s = _scale(norm, n, inverse)
+    # the reference's callers also hand over CPU tensors (run_inference.py:66): they are staged through the GPU -- the
+    # arithmetic still runs in the HIP kernels; without a GPU ops raises (no CPU fallback)
+    x = data if data.is_cuda or not torch.cuda.is_available() else data.cuda()
+    out = ops.fft2c(x, inverse=inverse) if two_d else ops.fft1c(x, inverse=inverse)
+    if s != 1.0:
+        ops.scale_(out, s)
+    return out if out.device == data.device else out.to(data.device)
 
 
-def fft2c(data: torch.Tensor, norm: str = "ortho") -> torch.Tensor:
-    _check(data); _ortho(norm)
-    return ops.fft2c(data, inverse=False)
+def fft1c(data: torch.Tensor, norm: Optional[str] = "ortho") -> torch.Tensor:
+    return _run(data, False, False, norm)
 
 
-def ifft2c(data: torch.Tensor, norm: str = "ortho") -> torch.Tensor:
-    _check(data); _ortho(norm)
-    return ops.fft2c(data, inverse=True)
+def ifft1c(data: torch.Tensor, norm: Optional[str] = "ortho") -> torch.Tensor:
+    return _run(data, False, True, norm)
 
 
-def _ortho(norm: str) -> None:
-    if norm != "ortho":
-        raise NotImplementedError("only norm='ortho' (the mode every reference call site uses) is implemented")
+def fft2c(data: torch.Tensor, norm: Optional[str] = "ortho") -> torch.Tensor:
+    return _run(data, True, False, norm)
+
+
+def ifft2c(data: torch.Tensor, norm: Optional[str] = "ortho") -> torch.Tensor:
+    return _run(data, True, True, norm)
 
 
 def roll(x: torch.Tensor, shift: List[int], dim: List[int]) -> torch.Tensor:

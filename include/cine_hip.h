@@ -117,6 +117,33 @@ int cine_image_dc(const float* img, const float* sens, const float* zf, const ui
 int cine_masked_kspace_to_hybrid(const float* k, const uint8_t* mask, float* hyb, int bt, int c, int h, int w,
                                  void* stream);
 
+/* ---- the steps either side of the path ------------------------------------------------------------ */
+
+/* out = kspace * mask + 0.0 for a Cartesian row mask (reference data/transforms.py:66-92 `apply_mask`, :91).
+ * kspace, out (bt, c, h, w, 2) (may alias); mask uint8 (bt, h). */
+int cine_apply_mask(const float* kspace, const uint8_t* mask, float* out, long bt, int c, int h, int w, void* stream);
+
+/* x[i] *= s, in place: the "backward" / "forward" normalisations of torch.fft on top of the ortho kernels
+ * (reference utils/fftc.py:59-110 with norm=None, traintest_scripts/run_inference.py:66). */
+int cine_scale(float* x, long n, float s, void* stream);
+
+/* Zero-filled reconstruction of traintest_scripts/run_inference.py:64-67:
+ * rss_complex(ifft2c(k, norm=None) * sqrt(h w), dim=coil) (utils/coil_combine.py:21-34) -> out (b, t, h, w).
+ * k (b, t, c, h, w, 2); tmp: scratch of k's size (tmp == k destroys k). */
+int cine_zero_filled_rss(const float* k, float* out, float* tmp, int b, int t, int c, int h, int w, void* stream);
+
+/* SSIM / NMSE / PSNR / MSE of a reconstruction against its target, on the device (reference utils/evaluate.py:6-50 --
+ * skimage structural_similarity / peak_signal_noise_ratio defaults -- after data/transforms.py:161-183
+ * center_crop_to_smallest; utils/losses.py:25-58 for SSIMLoss's per-frame data range).  gt (t, hg, wg), pred (t, hp, wp)
+ * float32; both are center-cropped to (min h, min w).  SSIM: win x win uniform window (odd, <= 11; reference 7), sample
+ * covariance, K1, K2, mean over the window-valid region, then over frames; float64 arithmetic like skimage.
+ * range_mode 0: data range = max of the cropped gt volume (evaluate.py:31); 1: max of each gt frame (losses.py:34);
+ * 2: `maxval`.  out (device, 4 + t doubles) = {ssim, nmse, psnr, mse, ssim of frame 0..t-1}. */
+size_t cine_image_metrics_ws_bytes(int t, int hg, int wg, int hp, int wp, int win);
+int cine_image_metrics(const float* gt, const float* pred, int t, int hg, int wg, int hp, int wp,
+                       int win, double k1, double k2, int range_mode, double maxval,
+                       double* out, void* ws, size_t ws_bytes, void* stream);
+
 /* SensitivityModel prologue (varnet.py:62-74): mean over frames, keep rows [row_lo, row_hi) of
  * dim h (transforms.mask_center, data/transforms.py:95-108), ifft2c.  k (b,t,c,h,w,2) -> out (b,c,h,w,2). */
 int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,

@@ -360,10 +360,32 @@ def g_rnn_cfg5():
     _fingerprint("rnn_cfg5", out, ex, data_seed=8, weight_seed=9, accel=8)
 
 
+def g_metrics():
+    """SSIMLoss (reference utils/losses.py:6-58) on a (1, 1, 15, 180, 180) pair; inputs regenerate from seeds.  The
+    reference hard-wires `.to('cuda')` (:34): Tensor.to is pinned to the CPU for this call.  Also the zero-filled
+    reconstruction of traintest_scripts/run_inference.py:64-67 (ifft2c norm=None, rss_complex) on a small k-space."""
+    from reconstruction.utils.losses import SSIMLoss
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else orig_to(self, *a, **k)
+    try:
+        rs = np.random.RandomState(91)
+        tgt = torch.from_numpy(rs.uniform(0, 1.5, size=(15, 180, 180)).astype(np.float32))
+        rec = (tgt + torch.from_numpy((0.1 * rs.standard_normal((15, 180, 180))).astype(np.float32))).clamp_min(0)
+        loss = SSIMLoss()(rec[None, None], tgt[None, None], torch.tensor([1.0]))
+        frames = [float(SSIMLoss()(rec[None, None, t:t + 1], tgt[None, None, t:t + 1], torch.tensor([1.0]))) for t in range(15)]
+    finally:
+        torch.Tensor.to = orig_to
+    k = rnd(92, 1, 3, 4, 24, 20, 2)
+    scaling = torch.sqrt(torch.prod(torch.as_tensor(k.shape[-3:-1])))
+    zf = RU.rss_complex(RU.ifft2c(k, norm=None) * scaling, dim=2)
+    save("metrics", seed=91, ssim_loss=loss, ssim_loss_frames=np.array(frames), zf_k=k, zf_out=zf,
+         ifft2c_none=RU.ifft2c(k, norm=None), fft2c_none=RU.fft2c(k, norm=None))
+
+
 GENERATORS = dict(rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
-                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5)
+                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -854,3 +854,87 @@ def test_image_dc_batch_and_identities(dev):
     lam = torch.tensor([0.3], device=dev)
     f = lambda z: ops.image_dc(z, sens, None, mask, lam)
     assert rel_err(f(2 * x - 3 * y).cpu(), (2 * f(x) - 3 * f(y)).cpu()) < OP_TOL
+
+
+# ------------------------------------------------------------------ the steps either side of the path
+def _metric_pair(seed):
+    rs = np.random.RandomState(seed)
+    tgt = rs.uniform(0, 1.5, size=(15, 180, 180)).astype(np.float32)
+    rec = np.maximum(tgt + (0.1 * rs.standard_normal((15, 180, 180))).astype(np.float32), 0)
+    return tgt, rec
+
+
+def test_device_metrics_vs_reference_ssimloss_and_host(golden, dev):
+    """cine_image_metrics at (15, 180, 180): per-frame-range SSIM against the reference's SSIMLoss vector (fp32 conv2d
+    arithmetic there, hence 2e-5), and SSIM / NMSE / PSNR / MSE against the float64 numpy forms of utils/evaluate.py."""
+    from cine_hip import ops
+    from reconstruction.utils import evaluate
+    g = golden("metrics")
+    tgt, rec = _metric_pair(int(g["seed"]))
+    td, rd = cuda(tgt, dev), cuda(rec, dev)
+    m = ops.image_metrics(td, rd, per_frame_range=True)
+    assert np.abs((1.0 - m["ssim_frames"].cpu().numpy()) - g["ssim_loss_frames"]).max() < 2e-5
+    assert abs(1.0 - float(m["ssim"]) - float(g["ssim_loss"])) < 2e-5
+    m = evaluate.metrics_device(td, rd)
+    # 1e-8: the host form squares K * data_range with data_range a float32 scalar (the image's max), the kernel in float64
+    assert abs(float(m["ssim"]) - evaluate.ssim(tgt, rec)) < 1e-8
+    assert abs(float(m["nmse"]) - float(evaluate.nmse(tgt.astype(np.float64), rec.astype(np.float64)))) < 1e-12
+    assert abs(float(m["psnr"]) - float(evaluate.psnr(tgt, rec))) < 1e-8
+    assert abs(float(m["mse"]) - float(evaluate.mse(tgt.astype(np.float64), rec.astype(np.float64)))) < 1e-12
+    assert abs(float(evaluate.ssim_device(td, rd, maxval=2.0)) - evaluate.ssim(tgt, rec, maxval=2.0)) < 1e-8
+
+
+def test_device_metrics_center_crop_and_edges(dev):
+    """Reconstruction 200x200 against a 180x150 target: both are center-cropped to the smaller size first
+    (transforms.py:161-183); odd sizes, one frame, a window as large as the frame."""
+    from cine_hip import ops
+    from reconstruction.utils import evaluate
+    rs = np.random.RandomState(5)
+    pred = rs.uniform(0, 1, size=(3, 200, 200)).astype(np.float32)
+    tgt = rs.uniform(0, 1, size=(3, 180, 150)).astype(np.float32)
+    crop = pred[:, 10:190, 25:175]
+    m = ops.image_metrics(cuda(tgt, dev), cuda(pred, dev))
+    assert abs(float(m["ssim"]) - evaluate.ssim(tgt, crop)) < 1e-8
+    assert abs(float(m["nmse"]) - float(evaluate.nmse(tgt.astype(np.float64), crop.astype(np.float64)))) < 1e-12
+    a, b = rs.uniform(0, 1, size=(1, 33, 7)).astype(np.float32), rs.uniform(0, 1, size=(1, 33, 7)).astype(np.float32)
+    assert abs(float(ops.image_metrics(cuda(a, dev), cuda(b, dev))["ssim"]) - evaluate.ssim(a, b)) < 1e-8
+    with pytest.raises(ValueError):
+        ops.image_metrics(cuda(a[:, :5], dev), cuda(b[:, :5], dev))
+    with pytest.raises(ValueError):
+        ops.image_metrics(cuda(a[0], dev), cuda(b[0], dev))
+
+
+def test_apply_mask_zero_filled_and_fft_norms_vs_reference_golden(golden, dev):
+    import reconstruction.utils as U
+    from reconstruction.data import transforms as T
+    from cine_hip import ops, synth
+    g = golden("masks")
+    # apply_mask on the device with the reference's mask draw (np.random.seed(2), RandomMaskFunc([4], [4]))
+    np.random.seed(2)
+    mf = synth.create_mask_for_mask_type("random", [4], [4])
+    md, m = T.apply_mask(cuda(g["am_data"], dev), mf, None)
+    assert torch.equal(md.cpu(), torch.from_numpy(g["am_masked"])) and torch.equal(m.cpu(), torch.from_numpy(g["am_mask"]))
+    k = cuda(g["am_data"], dev)
+    out = ops.apply_mask(k, cuda(g["am_mask"], dev).to(torch.uint8), out=k)           # in place
+    assert out.data_ptr() == k.data_ptr() and torch.equal(k.cpu(), torch.from_numpy(g["am_masked"]))
+    g = golden("metrics")
+    k = cuda(g["zf_k"], dev)
+    assert rel_err(ops.zero_filled_rss(k).cpu(), g["zf_out"]) < OP_TOL
+    assert torch.equal(k.cpu(), torch.from_numpy(g["zf_k"]))
+    # the literal lines of run_inference.py:64-67 against this build's utils, GPU and CPU-resident input
+    for kk in (k, k.cpu()):
+        scaling = torch.sqrt(torch.prod(torch.as_tensor(kk.shape[-3:-1])))
+        images = U.ifft2c(kk, norm=None) * scaling.to(kk.device)
+        assert images.device == kk.device
+        assert rel_err(U.rss_complex(images, dim=2).cpu(), g["zf_out"]) < OP_TOL
+    assert rel_err(U.ifft2c(k, norm=None).cpu(), g["ifft2c_none"]) < OP_TOL
+    assert rel_err(U.fft2c(k, norm=None).cpu(), g["fft2c_none"]) < OP_TOL
+    assert rel_err(U.fft2c(k, norm="forward").cpu(), g["fft2c_none"] / (24 * 20)) < OP_TOL
+    with pytest.raises(ValueError):
+        U.fft2c(k, norm="bogus")
+    # full-size zero-filled reconstruction of the bench slice: every pixel >= the coil-combined magnitude's scale, finite
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+    zf = ops.zero_filled_rss(ex["masked_kspace"].to(dev))
+    from oracle import centered_fft as cfo, complex_ops as co
+    want = co.rss_complex(cfo.ifft2c(ex["masked_kspace"]), dim=2)
+    assert zf.shape == (1, 15, 200, 200) and rel_err(zf.cpu(), want) < OP_TOL

@@ -113,3 +113,19 @@ def test_oracle_cfg5_full(golden):
     with torch.no_grad():
         out = net(ex["masked_kspace"], ex["mask"])
     _check_fingerprint(out, g)
+
+
+def test_host_metrics_vs_reference_ssimloss(golden):
+    """The numpy SSIM (utils/evaluate.py restatement of skimage's defaults) with SSIMLoss's per-frame data range reproduces
+    the reference's SSIMLoss (utils/losses.py:25-58) on the committed vector."""
+    import importlib.util, os
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("_ev", os.path.join(PKG, "reconstruction", "utils", "evaluate.py"))
+    ev = importlib.util.module_from_spec(spec); spec.loader.exec_module(ev)
+    g = golden("metrics")
+    rs = np.random.RandomState(int(g["seed"]))
+    tgt = rs.uniform(0, 1.5, size=(15, 180, 180)).astype(np.float32)
+    rec = np.maximum(tgt + (0.1 * rs.standard_normal((15, 180, 180))).astype(np.float32), 0)
+    frames = np.array([1.0 - ev._ssim2d(tgt[i], rec[i], float(tgt[i].max())) for i in range(15)])
+    assert np.abs(frames - g["ssim_loss_frames"]).max() < 2e-5
+    assert abs(frames.mean() - float(g["ssim_loss"])) < 2e-5
