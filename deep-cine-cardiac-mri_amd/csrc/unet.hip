@@ -12,6 +12,20 @@ using namespace cine;
 
 extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 
+namespace cine {
+// unet_bottom.hip: levels P-1 and P of the U as one kernel per plane
+struct BottomArgs {
+    const float* x1; const float* px1; int np1;
+    const float* w[7][2];
+    int set_split;
+    float* skip2;
+    float* y; float* py;
+    float eps, slope;
+};
+bool unet_bottom_applies(int chans2, int h2, int w2);
+int launch_unet_bottom(const BottomArgs& a, int n, hipStream_t st);
+}  // namespace cine
+
 namespace {
 
 constexpr float kEps = 1e-5f;     // nn.InstanceNorm2d default (unet.py:161)
@@ -126,10 +140,11 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     const int split = n / nsets;
     // every step below reads only its own sample's data, so the launches are recorded and issued together: as one
     // plane-persistent kernel when the layer shapes are the ones it is built for, else layer by layer (conv_kernels.hip)
+    // (recording only for the opt-in plane-persistent kernel; otherwise every launch is issued where it stands)
     struct Guard {
         PlaneRecorder* r;
         ~Guard() { if (r) plane_record_abort(r); }
-    } guard{plane_record_begin()};
+    } guard{plane_kernel_enabled() ? plane_record_begin() : nullptr};
     int wi = 0;
     const float *w0, *w1;
     auto next = [&]() {
@@ -138,8 +153,13 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
         ++wi;
     };
     int e;
+    // levels P-1 / P (second-lowest ConvBlock, pool, bottleneck, transpose conv, first up-path ConvBlock): one fused kernel per
+    // plane when the planes are cfg 2's 52 x 4 with 64 channels (unet_bottom.hip); its output carries ONE statistics record
+    const bool fuse = pools >= 2 && !plane_kernel_enabled() && unet_bottom_applies(p.ch[pools - 1], p.hs[pools - 1], p.wsz[pools - 1]) &&
+                      p.ch[pools - 2] * 2 == p.ch[pools - 1] && p.hs[pools - 2] == 2 * p.hs[pools - 1] && p.wsz[pools - 2] == 2 * p.wsz[pools - 1];
     // ---- down path (unet.py:94-97) + bottleneck (:99)
     for (int d = 0; d <= pools; ++d) {
+        if (fuse && d >= pools - 1) { wi += 2; continue; }
         const bool last = d == pools;
         float* mid = p.mid[d]; float* pmid = p.pmid[d];
         float* out = last ? p.bott : p.skip[d];
@@ -163,6 +183,21 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     int np_cur = p.np_conv[pools];
     for (int u = 0; u < pools; ++u) {
         const int d = pools - 1 - u;
+        if (fuse && u == 0) {
+            // weights in module order: [2(P-1)], [2(P-1)+1] level P-1 block; [2P], [2P+1] bottleneck; then tconv, conv, conv
+            BottomArgs ba{};
+            ba.x1 = p.skip[d - 1]; ba.px1 = p.pskip[d - 1]; ba.np1 = p.np_conv[d - 1];
+            const int base = 2 * d;
+            for (int l = 0; l < 7; ++l) {
+                ba.w[l][0] = reinterpret_cast<const float*>(weights[base + l]);
+                ba.w[l][1] = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + base + l]) : ba.w[l][0];
+            }
+            ba.set_split = split; ba.skip2 = p.skip[d]; ba.y = p.cb[d]; ba.py = p.pcb[d]; ba.eps = kEps; ba.slope = kSlope;
+            if ((e = launch_unet_bottom(ba, n, as_stream(stream)))) return e;
+            wi = base + 7;
+            cur = p.cb[d]; pcur = p.pcb[d]; np_cur = 1;
+            continue;
+        }
         next();   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
         e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
                              p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
@@ -188,5 +223,5 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     if (e) return e;
     PlaneRecorder* rec = guard.r;
     guard.r = nullptr;
-    return plane_record_end(rec, as_stream(stream), p.prog);
+    return rec ? plane_record_end(rec, as_stream(stream), p.prog) : CINE_OK;
 }

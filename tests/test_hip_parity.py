@@ -328,6 +328,7 @@ def test_plane_persistent_unet_matches_per_layer_launches(dev, tmp_path):
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "plane_debug.py")
     env = dict(os.environ)
     env.pop("CINE_PLANE_KERNEL", None)
+    env.pop("CINE_UNET_BOTTOM", None)             # per-layer launches at every level
     env["TMPDIR"] = str(tmp_path)
     a = subprocess.run([sys.executable, script, "256", "3", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
     assert a.returncode == 0 and "saved reference" in a.stdout, a.stdout + a.stderr
@@ -938,3 +939,30 @@ def test_apply_mask_zero_filled_and_fft_norms_vs_reference_golden(golden, dev):
     from oracle import centered_fft as cfo, complex_ops as co
     want = co.rss_complex(cfo.ifft2c(ex["masked_kspace"]), dim=2)
     assert zf.shape == (1, 15, 200, 200) and rel_err(zf.cpu(), want) < OP_TOL
+
+
+# ------------------------------------------------------------------ fused bottom of the U (unet_bottom.hip)
+@pytest.mark.parametrize("n,sets", [(6, 2), (3, 1), (1, 1)])
+def test_unet_cfg2_planes_fused_bottom_vs_oracle(dev, n, sets, monkeypatch):
+    """U-Net(16 ch, 3 pools) on cfg 2's 208 x 16 planes with the opt-in fused bottom-of-U kernel (CINE_UNET_BOTTOM=1: levels
+    2 / 3 = 52 x 4 x 64 / 26 x 2 x 128 channels in one workgroup per plane) and with the default per-layer launches, one and
+    two weight sets (x-f / y-f nets in the same launches), against the CPU oracle's Unet."""
+    from cine_hip import ops, synth
+    from oracle import regularisers as R
+    from reconstruction.models.denoisers.unet import Unet
+    nets_h, nets_r = [], []
+    for k in range(sets):
+        hnet = Unet(in_chans=2, out_chans=2, chans=16, num_pool_layers=3).eval(); synth.fill_parameters_(hnet, 31 + k, keep=())
+        rnet = R.Unet(in_chans=2, out_chans=2, chans=16, num_pool_layers=3).eval(); rnet.load_state_dict(hnet.state_dict(), strict=True)
+        nets_h.append(hnet.to(dev)); nets_r.append(rnet)
+    x = rnd(77, n, 2, 208, 16)
+    with torch.no_grad():
+        per = n // sets
+        want = torch.cat([nets_r[k](x[k * per:(k + 1) * per]) for k in range(sets)])
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CINE_UNET_BOTTOM", flag)
+        outs[flag] = ops.unet2d_forward(x.to(dev), ops.UnetWeights(nets_h)).cpu()
+        assert rel_err(outs[flag], want) < BLOCK_TOL, flag
+    assert not torch.equal(outs["0"], outs["1"]) or n == 0            # two different code paths were really taken
+    assert rel_err(outs["1"], outs["0"]) < 1e-5
