@@ -307,8 +307,8 @@ def main():
     net = cfg["hip"]().eval()
     synth.fill_parameters_(net, cfg["wseed"], keep=cfg["keep"])
     net = net.to(dev)
-    has_acs = hasattr(net, "sens_net")
-    acss = [net.sens_net.acs_window(m) for m in masks] if has_acs else None     # host read-back of the 1-D mask, outside capture
+    from reconstruction.models.varnet import SensitivityModel
+    acss = [SensitivityModel.acs_window(m) for m in masks]                       # host read-back of the 1-D mask, outside capture
 
     def forward(i=0):
         if cfg["needs_sens"]:

@@ -19,6 +19,14 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _no_capture(what: str) -> None:
+    """Caches that outlive a call (packed weights, per-stream scratch) must not be filled during hipGraph capture: the
+    tensors would come from the graph's private pool yet stay referenced afterwards."""
+    if torch.cuda.is_current_stream_capturing():
+        raise CineHipError(f"{what} would be created during hipGraph capture; run one eager forward on this stream first "
+                           "(and re-capture after changing weights)")
+
+
 def _dev(x: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
@@ -304,6 +312,7 @@ def dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     key = (a.device, torch.cuda.current_stream().cuda_stream)
     ws = _dot_ws.get(key)
     if ws is None:
+        _no_capture("the dot-product workspace of this stream")
         ws = _dot_ws[key] = torch.empty(lib().cine_dot_ws_bytes(), device=a.device, dtype=torch.uint8)
     check(lib().cine_dot(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "cine_dot")
     return out
@@ -538,6 +547,8 @@ class UnetWeights:
         params = self._params()
         key = tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
         if key != self._key:
+            _no_capture("packed U-Net weights")
+            self._old = getattr(self, "_old", []) + [self._keep]     # graphs captured earlier still hold the old pointers
             keep, ptrs = [], []
             for seq in params:
                 for kind, p in seq:
@@ -599,6 +610,8 @@ class MwcnnWeights:
         params = self._params()
         key = tuple((p.data_ptr(), p._version) for _, p in params)
         if key != self._key:
+            _no_capture("packed MWCNN weights")
+            self._old = getattr(self, "_old", []) + [self._keep]     # graphs captured earlier still hold the old pointers
             keep = [(_dev(p.detach(), "mwcnn bias") if kind == "raw" else _pack(kind, p)) for kind, p in params]
             self._keep, self._key = keep, key
             self._ptrs = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])

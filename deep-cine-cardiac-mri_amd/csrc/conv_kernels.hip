@@ -878,6 +878,20 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
     }
 }
 
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: raise it once per (kernel, device), and report a failure
+template <typename K>
+static int allow_big_lds(K kern, std::once_flag (&once)[64], const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    hipError_t err = hipSuccess;
+    std::call_once(once[dev & 63], [&] {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    CINE_REQUIRE(err == hipSuccess, CINE_EHIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(err));
+    return CINE_OK;
+}
+
 // ---------------------------------------------------------------- launch recorder (plane-persistent U-Net)
 struct RecStep {
     int cfg; ConvArgs a; dim3 grid; size_t lds; int fam;
@@ -898,8 +912,8 @@ size_t plane_program_bytes() { return sizeof(PlaneProgram); }
 // (12.5 vs 13.0 ms) but loses with three in flight (102 vs 134 slices/s): two workgroups per CU cannot hide a 17-layer
 // latency chain.  It is kept as the base for a version with more parallelism per sample.
 bool plane_kernel_enabled() {
-    static const bool on = getenv("CINE_PLANE_KERNEL") != nullptr && atoi(getenv("CINE_PLANE_KERNEL")) != 0;
-    return on;
+    const char* e = getenv("CINE_PLANE_KERNEL");
+    return e != nullptr && atoi(e) != 0;
 }
 
 int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
@@ -925,10 +939,8 @@ int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
         PlaneStep& s = pp.s[pp.nsteps++];
         s.cfg = q.cfg; s.ntiles = (int)q.grid.x; s.ncoblk = (int)q.grid.y; s.a = q.a;
     }
-    static std::once_flag once;
-    std::call_once(once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(unet_plane_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
+    static std::once_flag once[64];
+    if (int e = allow_big_lds(unet_plane_kernel, once, "unet_plane_kernel")) return e;
     ProfScope prof(F_UNET_PLANE, st);
     PlaneProgram* dprog = reinterpret_cast<PlaneProgram*>(prog_dev);
     hipLaunchKernelGGL(plane_program_write_kernel, dim3(1), dim3(256), 0, st, pp, dprog);
@@ -951,13 +963,12 @@ constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel l
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
 static int launch_cfg(ConvArgs a, hipStream_t st) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
-    static std::once_flag once;
+    static std::once_flag once[64];
     auto kern = conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
-    std::call_once(once, [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
     const size_t lds = C::lds_bytes(a.s0.c + a.s1.c);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv: %d input channels need %zu bytes of LDS", a.cin, lds);
+    if (lds > 64 * 1024)
+        if (int e = allow_big_lds(kern, once, "conv_mfma_kernel")) return e;
     a.tiles_w = ceil_div(a.W, TW);
     a.tiles_hw = a.tiles_w * ceil_div(a.H, C::TH);
     a.tiles = a.tiles_hw * a.D;
@@ -1321,21 +1332,26 @@ extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x
 
 // np partial records per plane -> ONE record per plane (volumes emit one record per tile and depth slice; merging
 // them once keeps the consumers' prologue short)
-__global__ void instnorm_merge_kernel(const float* part, float* out, long planes, int np) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per plane: the records are summed lane-strided, then across the wave (same two-pass formula as merge_partials;
+// a volume has hundreds of records per plane and only n * cout planes -- one thread per plane took 115 us per call at cfg 4)
+__global__ __launch_bounds__(256) void instnorm_merge_kernel(const float* part, float* out, long planes, int np) {
+    const long i = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= planes) return;
+    const int lane = threadIdx.x & 63;
     const float* p = part + i * np * 3;
-    float cnt = 0.f, mean = 0.f;
-    for (int k = 0; k < np; ++k) { cnt += p[3 * k]; mean += p[3 * k] * p[3 * k + 1]; }
-    mean /= cnt;
+    float cnt = 0.f, wsum = 0.f;
+    for (int k = lane; k < np; k += 64) { cnt += p[3 * k]; wsum += p[3 * k] * p[3 * k + 1]; }
+    cnt = wave_sum_f(cnt); wsum = wave_sum_f(wsum);
+    const float mean = wsum / cnt;
     float m2 = 0.f;
-    for (int k = 0; k < np; ++k) { const float dlt = p[3 * k + 1] - mean; m2 += p[3 * k + 2] + p[3 * k] * dlt * dlt; }
-    out[3 * i] = cnt; out[3 * i + 1] = mean; out[3 * i + 2] = m2;
+    for (int k = lane; k < np; k += 64) { const float dlt = p[3 * k + 1] - mean; m2 += p[3 * k + 2] + p[3 * k] * dlt * dlt; }
+    m2 = wave_sum_f(m2);
+    if (lane == 0) { out[3 * i] = cnt; out[3 * i + 1] = mean; out[3 * i + 2] = m2; }
 }
 extern "C" int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream) {
     CINE_REQUIRE(part && out && planes > 0 && np > 0, CINE_EINVAL, "cine_instnorm_merge: bad arguments");
     ProfScope prof(F_STATS, as_stream(stream));
-    hipLaunchKernelGGL(instnorm_merge_kernel, dim3((unsigned)ceil_div(planes, 256L)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(instnorm_merge_kernel, dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, as_stream(stream),
                        part, out, planes, np);
     return check_launch("instnorm_merge_kernel");
 }

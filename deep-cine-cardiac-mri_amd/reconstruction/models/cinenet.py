@@ -34,14 +34,18 @@ class CineNetBlock(nn.Module):
         return ops.sens_reduce(x, sens_maps)
 
     def HOperator(self, x, mask, sens_maps, _hyb=None):
-        """A^H M A x + softplus(lambda) x  (reference cinenet.py:121-133)."""
+        """A^H M A x + softplus(lambda) x  (reference cinenet.py:121-133).  With the reference's row mask the normal
+        operator is one image-space kernel (cine_image_dc with weights (1, 0, 0)): the mask commutes with the row FFT."""
+        if ops.is_row_mask(mask, sens_maps.expand(-1, x.shape[1], -1, -1, -1, -1)):
+            return ops.axpby_dev(ops.image_dc(x, sens_maps, None, mask, weights=(1.0, 0.0, 0.0)), x, lambda_reg=self.lambda_reg)
         hyb = ops.expand_mask_hybrid(x, sens_maps, mask, out=_hyb)
         return ops.axpby_dev(ops.hybrid_reduce(hyb, sens_maps), x, lambda_reg=self.lambda_reg)
 
     def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int):
         """Hx = b with exactly CG_iters iterations (reference cinenet.py:136-171)."""
         bsz, t, _, h, w, _ = x.shape
-        hyb = torch.empty((bsz, t, sens_maps.shape[2], h, w, 2), device=x.device, dtype=x.dtype)
+        rowmask = ops.is_row_mask(mask, sens_maps.expand(-1, t, -1, -1, -1, -1))
+        hyb = None if rowmask else torch.empty((bsz, t, sens_maps.shape[2], h, w, 2), device=x.device, dtype=x.dtype)
         r = ops.axpby_dev(b, self.HOperator(x, mask, sens_maps, hyb), num=_one(x), sign=-1.0)
         p = r.clone()
         rr_old = ops.dot(r, r)

@@ -26,11 +26,18 @@ class VarNet_RNN(CRNNBody):
             raise NotImplementedError("the CRNN models assume batch 1, like the reference (recurrent_varnet.py:110-113)")
         hyb = ops.kspace_to_hybrid(ref_kspace)
         img = ops.hybrid_reduce(hyb, sens_maps)                                   # (1, t, 1, h, w, 2)
+        rowmask = ops.is_row_mask(mask, ref_kspace)
+        if rowmask:                                                               # image-space DC (see VarNet.forward)
+            ops.kspace_to_hybrid(ref_kspace, out=hyb, mask=mask)
+            zf = ops.hybrid_reduce(hyb, sens_maps)
         state = self.zero_state(t, b, h, w, img)
         for _ in range(self.num_cascades):
             planes, _ = ops.normunet_pack(img.view(t, h, w, 2), norm=False)      # (t, 2, h, w)
             out, state = self.body(planes.view(t, 1, 2, h, w), state, planes)
             new_img = ops.normunet_unpack(out, None, h, w).view(1, t, 1, h, w, 2)
-            ops.expand_dc_hybrid(new_img, sens_maps, ref_kspace, mask, self.lambda_reg, out=hyb)   # :80-90
-            img = ops.hybrid_reduce(hyb, sens_maps)
+            if rowmask:
+                img = ops.image_dc(new_img, sens_maps, zf, mask, self.lambda_reg)                  # :80-90 + next reduce
+            else:
+                ops.expand_dc_hybrid(new_img, sens_maps, ref_kspace, mask, self.lambda_reg, out=hyb)   # :80-90
+                img = ops.hybrid_reduce(hyb, sens_maps)
         return ops.complex_abs(img.squeeze(2))

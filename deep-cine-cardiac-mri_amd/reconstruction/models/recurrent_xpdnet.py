@@ -37,7 +37,10 @@ class XPDNet_RNN(CRNNBody):
             raise NotImplementedError("the CRNN models assume batch 1, like the reference")
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         image_buffer = ops.repeat_complex(ops.sens_reduce(ref_kspace, sens_maps), n)       # (1, t, 1, h, w, 2n)
-        hyb = torch.empty_like(ref_kspace)
+        rowmask = ops.is_row_mask(mask, ref_kspace) and not self.k_buffer_mode
+        hyb = None if rowmask else torch.empty_like(ref_kspace)
+        if rowmask:
+            zf = ops.hybrid_reduce(ops.kspace_to_hybrid(ref_kspace, mask=mask), sens_maps)
         state = self.zero_state(t, b, h, w, image_buffer)
         keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]                  # channels [:n] and [n+1:-1]
         nd = self.k_buffer_size
@@ -50,6 +53,8 @@ class XPDNet_RNN(CRNNBody):
                                    kbuf[..., nd:], fwd[..., 1:], ref_kspace[..., 1:]], dim=-1)
                 kbuf = self.kspace_net[i](cat_k).contiguous()
                 bwd = ops.sens_reduce(ops.extract_complex(kbuf, 0, nd) * mask + 0.0, sens_maps)
+            elif rowmask:
+                bwd = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0))      # A^H M (A x0 - k_ref) (:110-163)
             else:
                 ops.expand_resid_hybrid(x0, sens_maps, ref_kspace, mask, out=hyb)           # K step (:110-140)
                 bwd = ops.hybrid_reduce(hyb, sens_maps)                                     # masked backward op (:142-163)

@@ -142,7 +142,10 @@ class XPDNet(nn.Module):
         sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ops.sens_reduce(masked_kspace, sens_maps)                       # unmasked backward op (:303)
         image_buffer = ops.repeat_complex(image, n)                             # (:307)
-        hyb = torch.empty_like(masked_kspace)
+        rowmask = ops.is_row_mask(mask, masked_kspace) and not self.k_buffer_mode
+        hyb = None if rowmask else torch.empty_like(masked_kspace)
+        if rowmask:     # A^H M k_ref, constant over the cascades: the K + backward step becomes A^H M A x0 - zf in one kernel
+            zf = ops.hybrid_reduce(ops.kspace_to_hybrid(masked_kspace, mask=mask), sens_maps)
         nd = self.k_buffer_size
         kbuf = ops.repeat_complex(masked_kspace, nd) if self.k_buffer_mode else None          # (:306)
         for i_domain in range(1, len(self.domain_sequence), 2):                 # each 'K' then 'I' pair (:310-319)
@@ -155,6 +158,8 @@ class XPDNet(nn.Module):
                 kbuf = self.kspace_net[i_domain // 2](cat).contiguous()
                 k0 = ops.extract_complex(kbuf, 0, nd) * mask + 0.0              # masked backward op (:161-167)
                 backward_img = ops.sens_reduce(k0, sens_maps)
+            elif rowmask:
+                backward_img = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0))   # A^H M (A x0 - k_ref)
             else:
                 ops.expand_resid_hybrid(x0, sens_maps, masked_kspace, mask, out=hyb)    # K: M A x0 - k_ref
                 backward_img = ops.hybrid_reduce(hyb, sens_maps)                # I: masked backward op

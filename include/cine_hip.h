@@ -16,7 +16,9 @@
  *   - `stream` is the caller's hipStream_t passed as void* (NULL = default stream);
  *     every launch goes onto it, so the calls are hipGraph-capturable.
  *   - scratch comes from the caller: `ws`/`ws_bytes` with a matching *_ws_bytes() query.
- *   - re-entrant; no global mutable state besides the thread-local error string.
+ *   - re-entrant: per-call state only.  Process-wide state is limited to the thread-local error string, the optional launch
+ *     profiler (cine_profile_begin/end: a mutex-guarded event list, off by default), per-(kernel, device) once-flags for the
+ *     > 64 KB LDS opt-in, and two environment switches read at call time (CINE_PLANE_KERNEL, CINE_UNET_BOTTOM).
  */
 #ifndef CINE_HIP_H
 #define CINE_HIP_H

@@ -249,7 +249,10 @@ def test_conv3x3_fused_sources_vs_torch(dev):
         y, _ = ops.conv3x3_in([(up.to(dev), p_up, 1), (skip.to(dev), p_skip, 1)], ops.pack_conv3x3(wt.to(dev)), 16, h, w)
         ref = F.conv2d(torch.cat([F.pad(act(up), [0, 0, 0, h - uh]), act(skip)], 1), wt, padding=1)
         assert rel_err(y.cpu(), ref) < BLOCK_TOL
-    for (n, c, H2, W2) in ((2, 8, 26, 20), (2, 16, 104, 16), (2, 8, 27, 21), (2, 64, 8, 4)):
+    # pooled sources incl. odd widths / heights (avg_pool2d floors): 208 x 15 -> 104 x 7 is what the bare CineNet / XPDNet
+    # U-Nets see at full size (15 frames), 2h x (2w + 1) and (2h + 1) x 2w the generic odd cases
+    for (n, c, H2, W2) in ((2, 8, 26, 20), (2, 16, 104, 16), (2, 8, 27, 21), (2, 64, 8, 4), (2, 16, 208, 15), (3, 16, 26, 17),
+                           (2, 8, 27, 16), (1, 32, 104, 7)):
         big = rnd(4, n, c, H2, W2)
         p_big = ops.instnorm_partials(big.to(dev))
         wt2 = rnd(5, 16, c, 3, 3) / 8
