@@ -9,7 +9,8 @@ def fam(k):
     if "conv_mfma" in k and ", 9>" in k: return "conv3x3_mfma"
     if "conv_mfma" in k: return "tconv_conv1x1_mfma"
     if "conv1x1_stream" in k: return "conv1x1_stream"
-    if "col200" in k or "col_pass" in k: return "fft_col_pass"
+    if "col200" in k or "col_pass" in k or "imgdc" in k: return "fft_col_pass"
+    if "unet_bottom" in k: return "conv3x3_mfma"
     if "row200" in k or "row_pass" in k: return "fft_row_pass"
     if "cine::" in k: return "pack_unpack_misc"
     return "other"
@@ -31,5 +32,6 @@ for f in sorted(set(fetch) | set(write)):
               "hbm_MB_per_slice": round((rd + wr) / 1e6, 1), "hbm_MB_per_launch": round((rd + wr) / 1e6 / max(nf[f] / fw, 1e-9), 2)}
     print(f"{f:22s} {out[f]}")
 if len(sys.argv) > 4:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read side x2 (gfx950), per cfg-2 slice", "families": out},
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read side x2 (gfx950), per cfg-2 slice",
+               "commit": sys.argv[5] if len(sys.argv) > 5 else None, "families": out},
               open(sys.argv[4], "w"), indent=1)
