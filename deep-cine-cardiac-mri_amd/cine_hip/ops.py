@@ -725,6 +725,20 @@ def conv3x3_sum(srcs: Sequence, wpacked: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def crnn_step(x: torch.Tensor, w_hh: torch.Tensor, addend: torch.Tensor, out: torch.Tensor,
+              accum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = ReLU(conv3x3(x; w_hh) + addend) [and accum += out]: one step of the BCRNN time sweep
+    (reference recurrent_varnet.py:241-254); every tensor (n, c, h, w), `out` / `accum` written in place."""
+    x = _dev(x, "hidden state"); addend = _dev(addend, "input term")
+    n, c, h, w = x.shape
+    for t_, name in ((out, "out"), (accum, "accum")):
+        if t_ is not None and not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.shape == x.shape):
+            raise ValueError(f"crnn_step: {name} must be a contiguous float32 GPU tensor shaped like x")
+    check(lib().cine_crnn_step(x.data_ptr(), w_hh.data_ptr(), addend.data_ptr(), out.data_ptr(), _p(accum), n, c, h, w, _stream()),
+          "cine_crnn_step")
+    return out
+
+
 # ------------------------------------------------------------------ 3-D U-Net path (dynamic_type '3D')
 def normunet3d_pack(x: torch.Tensor, norm: bool = True):
     """(n, t, h, w, 2) -> planes (n, 2, Tp, Hp, Wp) [+ stats (n, 2, 2)]; reference norm_unet.py:149-189."""

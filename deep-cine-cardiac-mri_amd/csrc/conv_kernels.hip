@@ -81,6 +81,7 @@ struct ConvArgs {
     const float* wp0; const float* wp1; int set_split;   // samples >= set_split use wp1
     const float* bias;
     const float* addend; int relu;       // epilogue: y = [relu](conv + bias + addend), addend shaped like y
+    float* accum;                        // optional second output, shaped like y: accum += y (BCRNN: output_f + output_b, recurrent_varnet.py:254)
     float* y; float* ypart;
     int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout / 8*cout for tconv), padded to 16
     int D, tiles_hw;                     // output depth (1 in 2-D); tiles per depth slice
@@ -552,7 +553,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
             }
             continue;
         }
-        float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W;
+        const long ybase = (((long)n * a.rows + m) * a.D + z0) * a.H * a.W;
+        float* yb = a.y + ybase;
+        float* ab2 = a.accum ? a.accum + ybase : nullptr;
         const bool vec = (a.W % PPR) == 0 && ((long)a.H * a.W) % PPR == 0;   // rows stay 16-byte (8-byte) aligned
 #pragma unroll
         for (int f = 0; f < MT; ++f) {
@@ -561,14 +564,22 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                 const int gy = r0 + (wn * MT + f) * C::RPF + pr0 + hrow;
                 const int j0 = hrow * PPR;
                 if (!full && !((vmask >> (4 * f + j0)) & 1ull)) continue;
-                float* dst = yb + (long)gy * a.W + gx0;
+                const long off = (long)gy * a.W + gx0;
+                float* dst = yb + off;
                 if (vec) {
-                    if (PPR == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
-                    else *reinterpret_cast<float2*>(dst) = make_float2(acc[ct][f][j0], acc[ct][f][j0 + 1]);
+                    if (PPR == 4) {
+                        const float4 o = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+                        *reinterpret_cast<float4*>(dst) = o;
+                        if (ab2) { float4 t = *reinterpret_cast<float4*>(ab2 + off); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; *reinterpret_cast<float4*>(ab2 + off) = t; }
+                    } else {
+                        const float2 o = make_float2(acc[ct][f][j0], acc[ct][f][j0 + 1]);
+                        *reinterpret_cast<float2*>(dst) = o;
+                        if (ab2) { float2 t = *reinterpret_cast<float2*>(ab2 + off); t.x += o.x; t.y += o.y; *reinterpret_cast<float2*>(ab2 + off) = t; }
+                    }
                 } else {
 #pragma unroll
                     for (int u = 0; u < PPR; ++u)
-                        if ((vmask >> (4 * f + j0 + u)) & 1ull) dst[u] = acc[ct][f][j0 + u];
+                        if ((vmask >> (4 * f + j0 + u)) & 1ull) { dst[u] = acc[ct][f][j0 + u]; if (ab2) ab2[off + u] += acc[ct][f][j0 + u]; }
                 }
             }
         }
@@ -955,6 +966,9 @@ int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
 #ifndef CINE_WN32
 #define CINE_WN32 4
 #endif
+#ifndef CINE_SMALL_MT
+#define CINE_SMALL_MT 2
+#endif
 constexpr int kWN16 = CINE_WN16, kWN32 = CINE_WN32;   // waves (each 13 pixel fragments) per workgroup for <= 16 / <= 32 output rows
 constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
 constexpr int kCK1 = 16;    // 1x1 / tconv
@@ -1004,6 +1018,10 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
 template <int TW, int TAPS, int CK>
 static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * TW, 16) * ceil_div(a.W, TW);   // fragments per sample
+    // few samples, no statistics record (the CRNN cells' single-plane convolutions, recurrent_varnet.py:241-252): 52-fragment
+    // tiles would give 52 workgroups for a 200 x 200 plane; 16-fragment tiles give 169
+    if (a.rowsp <= 16 && !a.ypart && TAPS == 9 && !a.vol && (long)a.n * ceil_div(frags, 52L) < 200)
+        return launch_cfg<CK, 1, 1, 4, CINE_SMALL_MT, TW, TAPS>(a, st);
     if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, 13, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
     // workgroups per CU): a touch slower than one 4-wave workgroup per plane in isolation, but it packs better with the
@@ -1123,7 +1141,7 @@ static int check_slope(float slope, const char* what) {
 static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
-                        const float* addend, int relu,
+                        const float* addend, int relu, float* accum,
                         float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
@@ -1131,7 +1149,7 @@ extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int
                                const float* wpacked, const float* wpacked2, int set_split,
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, 0, wpacked, wpacked2, set_split,
-                        nullptr, nullptr, 0, y, part_y, n, cout, h, w, eps, slope, stream);
+                        nullptr, nullptr, 0, nullptr, y, part_y, n, cout, h, w, eps, slope, stream);
 }
 
 extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
@@ -1139,7 +1157,17 @@ extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int
                                const float* wpacked, const float* bias, const float* addend, int relu,
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, add_src1, wpacked, nullptr, 0,
-                        bias, addend, relu, y, part_y, n, cout, h, w, eps, slope, stream);
+                        bias, addend, relu, nullptr, y, part_y, n, cout, h, w, eps, slope, stream);
+}
+
+// one step of a convolutional-RNN time sweep (reference recurrent_varnet.py:241-254): y = ReLU(conv3x3(x; w) + addend) and,
+// when accum != NULL, accum += y in the same epilogue (the backward sweep adding onto the forward sweep's outputs)
+extern "C" int cine_crnn_step(const float* x, const float* wpacked, const float* addend, float* y, float* accum,
+                              int n, int c, int h, int w, void* stream) {
+    CINE_REQUIRE(x && wpacked && addend && y, CINE_EINVAL, "cine_crnn_step: null pointer");
+    CINE_REQUIRE(y != x && accum != x && accum != y, CINE_EINVAL, "cine_crnn_step: outputs must not alias the input or each other");
+    return conv3x3_full(x, nullptr, 0, c, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, 0, wpacked, nullptr, 0,
+                        nullptr, addend, 1, accum, y, nullptr, n, c, h, w, 1e-5f, 0.2f, stream);
 }
 
 // mode encoding of the extended entry: low 3 bits = mode (0..4), bit 3 set = source is raw and gets
@@ -1147,7 +1175,7 @@ extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int
 static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
-                        const float* addend, int relu,
+                        const float* addend, int relu, float* accum,
                         float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3x3_in: null pointer");
     if (int e = check_slope(slope, "cine_conv3x3_in")) return e;
@@ -1162,7 +1190,7 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
     a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, act0, 1};
     a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, act1, 1};
     a.add_src1 = add_src1 && c1 > 0;
-    a.bias = bias; a.addend = addend; a.relu = relu;
+    a.bias = bias; a.addend = addend; a.relu = relu; a.accum = accum;
     if (a.add_src1) CINE_REQUIRE(src_cin(a.s0) == src_cin(a.s1), CINE_EINVAL, "cine_conv3x3_in: added sources differ in channels");
     a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
     a.y = y; a.ypart = part_y; a.n = n;

@@ -62,12 +62,11 @@ class BCRNNlayer(nn.Module):
         out = torch.empty_like(p)
         hid = zero
         for i in range(t):                                                      # forward pass over time (:241-245)
-            hid = ops.conv3x3_sum([hid], w_hh, None, c, addend=p[i], relu=True)
-            out[i].copy_(hid)
+            hid = ops.crnn_step(hid, w_hh, p[i], out[i])                        # written straight into output_f[i]
         hid = zero
-        for i in range(t - 1, -1, -1):                                          # backward pass, same cell (:247-252)
-            hid = ops.conv3x3_sum([hid], w_hh, None, c, addend=p[i], relu=True)
-            ops.axpby_dev(out[i], hid, num=_one(hid), out=out[i])               # output_f + output_b (:254)
+        scratch = (torch.empty_like(zero), torch.empty_like(zero))
+        for k, i in enumerate(range(t - 1, -1, -1)):                            # backward pass, same cell (:247-252)
+            hid = ops.crnn_step(hid, w_hh, p[i], scratch[k & 1], accum=out[i])  # output_f + output_b (:254) in the epilogue
         return out
 
 

@@ -241,6 +241,13 @@ int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mo
                     const float* wpacked, const float* bias, const float* addend, int relu,
                     float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
+/* One step of a convolutional-RNN time sweep (reference models/recurrent_varnet.py:241-254, CRNNcell :172-178 with the
+ * input terms precomputed): y = ReLU(conv3x3(x; wpacked) + addend), and accum += y when accum != NULL (the backward sweep
+ * adding onto the forward sweep's outputs, :254).  x, addend, y, accum (n, c, h, w); wpacked = cine_pack_conv3x3 of the
+ * (c, c, 3, 3) hidden-to-hidden weight (its bias belongs in addend).  y / accum must not alias x or each other. */
+int cine_crnn_step(const float* x, const float* wpacked, const float* addend, float* y, float* accum,
+                   int n, int c, int h, int w, void* stream);
+
 /* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)
  * and the partial statistics of y.  x mode 0|1 as above. */
 int cine_tconv2x2_in(const float* x, const float* part_x, int np_x, int mode,

@@ -16,8 +16,9 @@ done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE \
   -d $O/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph > $O/pmc_mfma.log 2>&1
 cd $R
-python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv 5 $O/pmc_traffic.json $COMMIT > $O/pmc_traffic.txt
-python3 tools/pmc_mfma.py $O/pmc_mfma/p_counter_collection.csv 5 $O/pmc_mfma.json $COMMIT > $O/pmc_mfma.txt
+python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv 7 $O/pmc_traffic.json $COMMIT > $O/pmc_traffic.txt
+python3 tools/pmc_mfma.py $O/pmc_mfma/p_counter_collection.csv 7 $O/pmc_mfma.json $COMMIT > $O/pmc_mfma.txt
+# (the PMC runs execute 7 forwards: first call, 1 timed step, 1 step with H2D, 3 for the per-family events, 1 parity check)
 # the other BASELINE configurations: one bench line (CPU baseline bounded to 16 threads, one forward) and one trace each
 for c in 3 4 5; do
   python3 bench.py --config $c --steps 12 --warmup 3 --cpu-forwards 1 --cpu-threads 16 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err
