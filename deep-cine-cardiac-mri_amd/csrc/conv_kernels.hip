@@ -91,6 +91,7 @@ struct ConvArgs {
                                          //    instead of concatenated
     float slope, eps;
     int tiles_w, tiles, nchunks, fast;
+    int wav;                             // fast staging of a Haar DWT / IWT source (modes 3 / 4), optionally + an added plain / normalised skip
     int tvec;                            // transpose conv: paired 16-byte stores (W multiple of the lane's pixel run, aligned y)
 };
 
@@ -259,7 +260,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         }
         int cl0;
         const Src& s = chunk_src(chunk, cl0);
-        if (a.fast && s.mode != 2) {
+        if (a.fast && !a.wav && s.mode != 2) {
             const char* sb = reinterpret_cast<const char*>(s.x + ((long)n * s.c + cl0) * s.h * a.W);
             const unsigned cstride = (unsigned)(s.h * a.W) * 4u;        // bytes between channels
             const int cmax = s.c - 1 - cl0;                              // last channel of this source, chunk-relative
@@ -321,7 +322,79 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         const Src& s = chunk_src(chunk, cl0);
         if (a.fast) {
             // ---- vectorised staging: every piece = PW consecutive floats of one (channel, row)
-            if (s.mode != 2) {
+            if (a.wav) {
+                // Haar wavelets on load (mwcnn.py:216-263).  DWT: a piece of PW outputs of band b, channel c comes from the
+                // 2 x 2PW block of source channel c; IWT: from PW/2 pixels of the four source channels c + k C/4.  16 / 8-byte
+                // loads, the butterflies in registers, same operation order as fetch_scalar (bit-identical results).
+                const Src& w0 = a.s0;
+#pragma unroll 2
+                for (int i = 0; i < C::NPT; ++i) {
+                    const int p = tid + i * C::NT;
+                    if (p >= C::NPIECE) break;
+                    const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
+                    const int row = rem / C::PR, j = rem % C::PR;
+                    const int gy = r0 - HALO + row, gx = c0 + PW * j;
+                    const int ci = ci0 + ck;
+                    float o[PW];
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) o[u] = 0.f;
+                    if (ci < a.cin && gy >= 0 && gy < a.H && gx < a.W) {
+                        const bool actv = w0.act & 1;
+                        if (w0.mode == 3) {
+                            const int band = ci / w0.c, c = ci - band * w0.c;
+                            const float sc = st_lds[2 * c], sh = st_lds[2 * c + 1];
+                            const float* src = w0.x + (((long)n * w0.c + c) * w0.h + 2 * gy) * w0.w + 2 * gx;
+                            float t0[2 * PW], t1[2 * PW];
+#pragma unroll
+                            for (int u = 0; u < 2 * PW; u += 4) {
+                                *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(src + u);
+                                *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(src + w0.w + u);
+                            }
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) {
+                                float x1 = t0[2 * u], x3 = t0[2 * u + 1], x2 = t1[2 * u], x4 = t1[2 * u + 1];
+                                if (actv) { x1 = act(x1, sc, sh, a.slope); x2 = act(x2, sc, sh, a.slope); x3 = act(x3, sc, sh, a.slope); x4 = act(x4, sc, sh, a.slope); }
+                                x1 *= 0.5f; x2 *= 0.5f; x3 *= 0.5f; x4 *= 0.5f;
+                                o[u] = band == 0 ? x1 + x2 + x3 + x4 : band == 1 ? -x1 - x2 + x3 + x4 : band == 2 ? -x1 + x2 - x3 + x4 : x1 - x2 - x3 + x4;
+                            }
+                        } else {
+                            const int cq = w0.c / 4, sy = gy >> 1, sx = gx >> 1;
+                            const bool ry = gy & 1;
+                            constexpr int NS = PW / 2;
+                            float v[4][NS];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int c = ci + k * cq;
+                                const float* src = w0.x + (((long)n * w0.c + c) * w0.h + sy) * w0.w + sx;
+                                if (NS == 2) { const float2 t = *reinterpret_cast<const float2*>(src); v[k][0] = t.x; v[k][NS - 1] = t.y; }
+                                else v[k][0] = src[0];
+                                const float sc = st_lds[2 * c], sh = st_lds[2 * c + 1];
+#pragma unroll
+                                for (int e = 0; e < NS; ++e) v[k][e] = 0.5f * (actv ? act(v[k][e], sc, sh, a.slope) : v[k][e]);
+                            }
+#pragma unroll
+                            for (int e = 0; e < NS; ++e) {
+                                o[2 * e] = ry ? v[0][e] - v[1][e] + v[2][e] - v[3][e] : v[0][e] - v[1][e] - v[2][e] + v[3][e];
+                                o[2 * e + 1] = ry ? v[0][e] + v[1][e] + v[2][e] + v[3][e] : v[0][e] + v[1][e] - v[2][e] - v[3][e];
+                            }
+                        }
+                        if (a.add_src1) {                           // additive skip (mwcnn.py:164,172): same channel, same pixel
+                            const Src& w1 = a.s1;
+                            const float* q1 = w1.x + (((long)n * w1.c + ci) * w1.h + gy) * w1.w + gx;
+                            piece_t t = *reinterpret_cast<const piece_t*>(q1);
+                            const float* tv = reinterpret_cast<const float*>(&t);
+                            const float sc = st_lds[2 * (w0.c + ci)], sh = st_lds[2 * (w0.c + ci) + 1];
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) o[u] += w1.mode == 0 ? tv[u] : act(tv[u], sc, sh, a.slope);
+                        }
+                    }
+                    piece_t ov;
+                    float* ovf = reinterpret_cast<float*>(&ov);
+#pragma unroll
+                    for (int u = 0; u < PW; ++u) ovf[u] = o[u];
+                    *reinterpret_cast<piece_t*>(in_lds + ck * C::PS + row * C::COLS + PW * j) = ov;
+                }
+            } else if (s.mode != 2) {
                 const bool plain = s.mode == 0, fullchunk = ci0 + CK <= a.cin;
 #pragma unroll
                 for (int k = 0; k < KR; ++k) {
@@ -996,6 +1069,15 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     };
     a.fast = !a.vol && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
+    // Haar DWT / IWT source (+ added skip): whole-plane tiles in x (no halo columns to fetch), exact 2:1 extents, aligned rows
+    a.wav = 0;
+    if (!a.fast && !a.vol && TAPS == 9 && a.s0.mode >= 3 && a.W % PW == 0 && a.W <= TW && reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) {
+        const bool dwt_ok = a.s0.mode == 3 && a.s0.w == 2 * a.W && a.s0.h == 2 * a.H && (a.s0.w % 4) == 0;
+        const bool iwt_ok = a.s0.mode == 4 && 2 * a.s0.w == a.W && 2 * a.s0.h == a.H && a.s0.c % 4 == 0 && (PW == 2 || a.s0.w % 2 == 0);
+        const bool skip_ok = a.s1.c == 0 || (a.add_src1 && a.s1.mode <= 1 && a.s1.w == a.W && a.s1.h == a.H &&
+                                            reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
+        if ((dwt_ok || iwt_ok) && skip_ok) a.fast = a.wav = 1;
+    }
     a.tvec = a.tconv_cout > 0 && a.W % (TW >= 4 ? 4 : 2) == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
