@@ -91,6 +91,7 @@ struct ConvArgs {
                                          //    instead of concatenated
     float slope, eps;
     int tiles_w, tiles, nchunks, fast;
+    int vfast;                           // volumes (TAPS 27): row-wise 16-byte staging of plain / normalised / 2x2x2-pooled sources
     int wav;                             // fast staging of a Haar DWT / IWT source (modes 3 / 4), optionally + an added plain / normalised skip
     int tvec;                            // transpose conv: paired 16-byte stores (W multiple of the lane's pixel run, aligned y)
 };
@@ -472,6 +473,66 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     if (ci0 + ck < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
                         v = fetch_scalar(s, n, cl0 + ck, 0, gy, gx, st_lds + (first ? 0 : 2 * a.s0.c), a.slope);
                     in_lds[ck * C::PS + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
+                }
+            }
+        } else if (TAPS == 27 && a.vfast) {
+            // ---- volumes: one unit = 4 consecutive voxels of one (channel, depth slice, row) -- a 16-byte load (eight for a
+            // 2x2x2-pooled source) -- or that row's two halo columns.  Same operation order as fetch_scalar (bit-identical).
+            // (Measured and rejected: batches of four units with all loads issued first, and prefetching the pieces one chunk
+            // ahead like the 2-D path -- both spill 100-1000 registers in the 27-tap instantiations and run slower.)
+            constexpr int NU = CK * C::ZP * C::ROWS * (C::PR + 1);
+            const int c0n = src_cin(a.s0);
+            for (int un = tid; un < NU; un += C::NT) {
+                const int j = un % (C::PR + 1), r2 = un / (C::PR + 1);
+                const int ck = r2 / (C::ZP * C::ROWS), rem = r2 - ck * (C::ZP * C::ROWS);
+                const int zp = rem / C::ROWS, row = rem - zp * C::ROWS;
+                const int ci = ci0 + ck, gz = z0 + zp - 1, gy = r0 - HALO + row;
+                const bool f0 = ci < c0n;
+                const Src& v = f0 ? a.s0 : a.s1;
+                const int cl = f0 ? ci : ci - c0n;
+                const float* stp = st_lds + (f0 ? 0 : 2 * a.s0.c);
+                const bool inb = ci < a.cin && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H;
+                float* lrow = in_lds + ck * C::PS + zp * C::ZS + row * C::COLS;
+                if (j < C::PR) {
+                    const int gx = c0 + 4 * j;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (inb && gx < a.W) {
+                        const float sc = stp[2 * cl], sh = stp[2 * cl + 1];
+                        const long plane = (long)n * v.c + cl;
+                        if (v.mode == 2) {
+                            if (2 * gz + 1 < v.d && 2 * gy + 1 < v.h) {       // avg_pool3d(2, 2) floors (unet.py:88,97)
+                                float acc8[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                                for (int dz = 0; dz < 2; ++dz) {
+                                    const float* p0 = v.x + ((plane * v.d + 2 * gz + dz) * v.h + 2 * gy) * v.w + 2 * gx;
+                                    float t0[8], t1[8];
+#pragma unroll
+                                    for (int u = 0; u < 8; u += 4) {
+                                        *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(p0 + u);
+                                        *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(p0 + v.w + u);
+                                    }
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u)
+                                        acc8[u] += act(t0[2 * u], sc, sh, a.slope) + act(t0[2 * u + 1], sc, sh, a.slope) +
+                                                   act(t1[2 * u], sc, sh, a.slope) + act(t1[2 * u + 1], sc, sh, a.slope);
+                                }
+                                o = make_float4(0.125f * acc8[0], 0.125f * acc8[1], 0.125f * acc8[2], 0.125f * acc8[3]);
+                            }
+                        } else if (gz < v.d && gy < v.h) {
+                            o = *reinterpret_cast<const float4*>(v.x + ((plane * v.d + gz) * v.h + gy) * v.w + gx);
+                            if (v.mode == 1)
+                                o = make_float4(act(o.x, sc, sh, a.slope), act(o.y, sc, sh, a.slope), act(o.z, sc, sh, a.slope), act(o.w, sc, sh, a.slope));
+                        }
+                    }
+                    *reinterpret_cast<float4*>(lrow + 4 * j) = o;
+                } else if (HALO) {
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        const int gx = side ? c0 + TW : c0 - 1;
+                        float hv = 0.f;
+                        if (inb && gx >= 0 && gx < a.W) hv = fetch_scalar(v, n, cl, gz, gy, gx, stp, a.slope);
+                        lrow[side ? TW : C::COLS - 1] = hv;
+                    }
                 }
             }
         } else {
@@ -1069,6 +1130,16 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     };
     a.fast = !a.vol && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
+    // volumes: 16-byte row pieces need widths that are multiples of 4 and sources of exactly the output's (or twice its) width
+    a.vfast = 0;
+    if (a.vol && TAPS == 27 && PW == 4 && a.W % 4 == 0 && !a.add_src1) {
+        auto vol_ok = [&](const Src& v) {
+            if (v.c == 0) return true;
+            if (reinterpret_cast<uintptr_t>(v.x) % 16 != 0 || v.mode > 2) return false;
+            return v.mode == 2 ? (v.w == 2 * a.W) : (v.w == a.W);
+        };
+        a.vfast = vol_ok(a.s0) && vol_ok(a.s1);
+    }
     // Haar DWT / IWT source (+ added skip): whole-plane tiles in x (no halo columns to fetch), exact 2:1 extents, aligned rows
     a.wav = 0;
     if (!a.fast && !a.vol && TAPS == 9 && a.s0.mode >= 3 && a.W % PW == 0 && a.W <= TW && reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) {
