@@ -6,7 +6,7 @@
 One "step" = one full forward of a BASELINE.json configuration on one synthetic cine slice already resident in HBM.
 Default (and the driver's line) is configs[1]: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, R=4 (sens-map network
 + 6 x [x-f / y-f U-Nets, image-space data consistency] + magnitude), fp32 end to end through the hand-written HIP kernels.
-Slices are independent, so a GPU keeps `--inflight` (default 3) DIFFERENT slices in flight, each replaying its own hipGraph
+Slices are independent, so a GPU keeps `--inflight` (default 8) DIFFERENT slices in flight, each replaying its own hipGraph
 on its own stream: their memory-bound and MFMA-bound phases interleave.  K steps = K slices in total.
 
 N > 1: one process per GPU over RCCL (backend "nccl").  Either the caller starts the ranks (torch.distributed.run: RANK /
@@ -18,7 +18,7 @@ timed region.  Time = max over ranks, value = N*K / time.
 Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel family (3x3 conv on fp32 MFMA): `frac` from the kernels'
 ISOLATED duration (eager launches, one slice in flight, hipEvent pairs on the launch stream -- agrees with
 profiles/r02_rocprofv3_kernel_stats_isolated.csv); `in_flight` = the same FLOPs over the driver-timed wall time of the
-3-in-flight graph replay (a lower bound on the family's rate in the timed mode, see profiles/r02_..._inflight.csv).
+in-flight graph replay (a lower bound on the family's rate in the timed mode, see profiles/r02_..._inflight.csv).
 `roofline_fft_dc` = the HBM-bound FFT + data-consistency family against SURVEY 8(d)'s algorithmic bytes.  `cpu_baseline` =
 the CPU oracle on this host's cores (thread sweep, then >= 3 forwards at the best setting).
 """
@@ -35,6 +35,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "deep-cine-cardiac-mri_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+# Each slice in flight replays its graph on its own HIP stream; the runtime maps streams onto 4 hardware queues unless told
+# otherwise, and with more slices than queues the graphs serialise (measured at cfg 2: 4 queues 143-147 slices/s, 16 queues
+# 150-152).  Must be set before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -119,7 +124,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2 = the metric's config)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=8,
                     help="independent slices in flight per GPU, each on its own HIP stream (its own hipGraph)")
     ap.add_argument("--batch", type=int, default=1,
                     help="slices per step: one forward over a (batch, t, coil, h, w, 2) k-space batch, the reference's batch axis")
@@ -409,7 +414,8 @@ def main():
         "config": {"workload": cfg["name"] + f"; {B} slice(s) per step (k-space batch axis), seeded random-init weights, "
                                f"{S} different slices per rank",
                    "slices_per_step": B,
-                   "launch": ("hipGraph replay" if use_graph else "eager") + f", {S} independent steps in flight on {S} HIP streams",
+                   "launch": ("hipGraph replay" if use_graph else "eager") + f", {S} independent steps in flight on {S} HIP streams, "
+                             f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                    "parallelism": f"slice-sharded x{world}, one all-gather for volume assembly"},
         "rccl_ranks": world,
         "timed_region_s": dt,
