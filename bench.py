@@ -6,7 +6,7 @@
 One "step" = one full forward of a BASELINE.json configuration on one synthetic cine slice already resident in HBM.
 Default (and the driver's line) is configs[1]: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, R=4 (sens-map network
 + 6 x [x-f / y-f U-Nets, image-space data consistency] + magnitude), fp32 end to end through the hand-written HIP kernels.
-Slices are independent, so a GPU keeps `--inflight` (default 8) DIFFERENT slices in flight, each replaying its own hipGraph
+Slices are independent, so a GPU keeps `--inflight` (default: 6..12, a divisor of K) DIFFERENT slices in flight, each replaying its own hipGraph
 on its own stream: their memory-bound and MFMA-bound phases interleave.  K steps = K slices in total.
 
 N > 1: one process per GPU over RCCL (backend "nccl").  Either the caller starts the ranks (torch.distributed.run: RANK /
@@ -124,8 +124,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json configs[N-1] (default 2 = the metric's config)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--inflight", type=int, default=8,
-                    help="independent slices in flight per GPU, each on its own HIP stream (its own hipGraph)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="independent slices in flight per GPU, each on its own HIP stream (its own hipGraph); 0 = auto: the "
+                         "largest count in 6..12 that divides --steps (whole rounds of streams: no half-empty last round), else 8")
     ap.add_argument("--batch", type=int, default=1,
                     help="slices per step: one forward over a (batch, t, coil, h, w, 2) k-space batch, the reference's batch axis")
     ap.add_argument("--repeats", type=int, default=4, help="extra timed K-step regions after the contract one (median reported beside value)")
@@ -300,7 +301,10 @@ def main():
 
     from cine_hip import synth
     cfg = CONFIGS[args.config]()
-    S = max(1, min(args.inflight, args.steps))
+    if args.inflight > 0:
+        S = max(1, min(args.inflight, args.steps))
+    else:
+        S = next((c for c in range(12, 5, -1) if args.steps % c == 0), 8) if args.steps >= 6 else max(1, args.steps)
     B = max(1, args.batch)
     # S DIFFERENT slices per rank (x B on the batch axis): seeds rank * S * B + ...
     exs = [[synth.make_cine_slice(FRAMES, COILS, H, W, accel=cfg["accel"], seed=(rank * S + i) * B + j, noise_std=cfg["noise"])
