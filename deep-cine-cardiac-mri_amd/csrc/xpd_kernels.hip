@@ -81,21 +81,20 @@ struct XpdPlaneArgs {
     int nc, T, I, Ip, Jp, pad_i, pad_j;
     int ninner; long s_outer, s_inner, s_i;       // element strides in X (complex units of [k][t] blocks)
 };
-__global__ void xpd_plane_pack_kernel(XpdPlaneArgs a) {
-    const int nidx = blockIdx.x;
+// one workgroup = one plane sample x kXRows padded rows; a thread reads a complex value once and writes both of its planes
+constexpr int kXRows = 25;
+__global__ __launch_bounds__(256) void xpd_plane_pack_kernel(XpdPlaneArgs a) {
+    const int nidx = blockIdx.x, ip0 = blockIdx.y * kXRows;
     const cf* src = a.X + ((long)(nidx / a.ninner) * a.s_outer + (long)(nidx % a.ninner) * a.s_inner) * a.nc * a.T;
     float* dst = a.planes + (long)nidx * 2 * a.nc * a.Ip * a.Jp;
-    const int per = a.Ip * a.Jp;
-    for (int e = threadIdx.x; e < 2 * a.nc * per; e += blockDim.x) {
-        const int ch = e / per, r = e - ch * per, ip = r / a.Jp, jp = r - ip * a.Jp;
+    const int per = a.Ip * a.Jp, rows = min(kXRows, a.Ip - ip0), blk = rows * a.Jp;
+    for (int e = threadIdx.x; e < a.nc * blk; e += blockDim.x) {
+        const int k = e / blk, r = e - k * blk, ip = ip0 + r / a.Jp, jp = r % a.Jp;
         const int i = ip - a.pad_i, j = jp - a.pad_j;
-        float v = 0.f;
-        if (i >= 0 && i < a.I && j >= 0 && j < a.T) {
-            const int part = ch / a.nc, k = ch - part * a.nc;
-            const cf z = src[((long)i * a.s_i) * a.nc * a.T + (long)k * a.T + j];
-            v = part ? z.y : z.x;
-        }
-        dst[e] = v;
+        cf z = mk(0.f, 0.f);
+        if (i >= 0 && i < a.I && j >= 0 && j < a.T) z = src[((long)i * a.s_i) * a.nc * a.T + (long)k * a.T + j];
+        dst[(long)k * per + ip * a.Jp + jp] = z.x;
+        dst[(long)(a.nc + k) * per + ip * a.Jp + jp] = z.y;
     }
 }
 
@@ -233,11 +232,11 @@ extern "C" int cine_xpd_pack(const float* buf, const float* extra, float* planes
     // x-f: sample (b, h), rows = w                      (xpdnet.py:470)
     a.planes = planes_xf; a.I = w; a.Ip = wp; a.Jp = tp; a.pad_i = lw; a.pad_j = lt;
     a.ninner = h; a.s_outer = HW; a.s_inner = w; a.s_i = 1;
-    hipLaunchKernelGGL(xpd_plane_pack_kernel, dim3(b * h), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(xpd_plane_pack_kernel, dim3(b * h, ceil_div(wp, kXRows)), dim3(256), 0, st, a);
     // y-f: sample (b, w), rows = h                      (xpdnet.py:471)
     a.planes = planes_yf; a.I = h; a.Ip = hp; a.Jp = tp; a.pad_i = lh; a.pad_j = lt;
     a.ninner = w; a.s_outer = HW; a.s_inner = 1; a.s_i = w;
-    hipLaunchKernelGGL(xpd_plane_pack_kernel, dim3(b * w), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(xpd_plane_pack_kernel, dim3(b * w, ceil_div(hp, kXRows)), dim3(256), 0, st, a);
     return check_launch("xpd_plane_pack_kernel");
 }
 
