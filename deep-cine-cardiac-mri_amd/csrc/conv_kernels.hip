@@ -31,6 +31,7 @@
 namespace cine {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };      // 4 floats at 4-byte alignment (rows of widths like 50 or 25)
 
 // ---------------------------------------------------------------- statistics helpers
 // partial record = {count, mean, M2}; merged InstanceNorm stats = {mean, 1/sqrt(M2/count + eps)}
@@ -499,7 +500,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     if (inb && gx < a.W) {
                         const float sc = stp[2 * cl], sh = stp[2 * cl + 1];
                         const long plane = (long)n * v.c + cl;
-                        if (v.mode == 2) {
+                        const bool whole = v.mode == 2 ? (2 * gx + 8 <= v.w && gx + 4 <= a.W) : (gx + 4 <= a.W && gx + 4 <= v.w);
+                        if (!whole) {                               // ragged right edge (width not a multiple of 4, or a narrower
+                            float ov[4];                            // `up` source): element by element
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) ov[u] = gx + u < a.W ? fetch_scalar(v, n, cl, gz, gy, gx + u, stp, a.slope) : 0.f;
+                            o = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                        } else if (v.mode == 2) {
                             if (2 * gz + 1 < v.d && 2 * gy + 1 < v.h) {       // avg_pool3d(2, 2) floors (unet.py:88,97)
                                 float acc8[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -508,8 +515,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                                     float t0[8], t1[8];
 #pragma unroll
                                     for (int u = 0; u < 8; u += 4) {
-                                        *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(p0 + u);
-                                        *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(p0 + v.w + u);
+                                        *reinterpret_cast<f4u*>(t0 + u) = *reinterpret_cast<const f4u*>(p0 + u);
+                                        *reinterpret_cast<f4u*>(t1 + u) = *reinterpret_cast<const f4u*>(p0 + v.w + u);
                                     }
 #pragma unroll
                                     for (int u = 0; u < 4; ++u)
@@ -519,7 +526,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                                 o = make_float4(0.125f * acc8[0], 0.125f * acc8[1], 0.125f * acc8[2], 0.125f * acc8[3]);
                             }
                         } else if (gz < v.d && gy < v.h) {
-                            o = *reinterpret_cast<const float4*>(v.x + ((plane * v.d + gz) * v.h + gy) * v.w + gx);
+                            const f4u t = *reinterpret_cast<const f4u*>(v.x + ((plane * v.d + gz) * v.h + gy) * v.w + gx);
+                            o = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
                             if (v.mode == 1)
                                 o = make_float4(act(o.x, sc, sh, a.slope), act(o.y, sc, sh, a.slope), act(o.z, sc, sh, a.slope), act(o.w, sc, sh, a.slope));
                         }
@@ -1130,16 +1138,8 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     };
     a.fast = !a.vol && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
-    // volumes: 16-byte row pieces need widths that are multiples of 4 and sources of exactly the output's (or twice its) width
-    a.vfast = 0;
-    if (a.vol && TAPS == 27 && PW == 4 && a.W % 4 == 0 && !a.add_src1) {
-        auto vol_ok = [&](const Src& v) {
-            if (v.c == 0) return true;
-            if (reinterpret_cast<uintptr_t>(v.x) % 16 != 0 || v.mode > 2) return false;
-            return v.mode == 2 ? (v.w == 2 * a.W) : (v.w == a.W);
-        };
-        a.vfast = vol_ok(a.s0) && vol_ok(a.s1);
-    }
+    // volumes: 4-float row pieces (4-byte aligned loads: rows of any width), ragged right edges element by element
+    a.vfast = a.vol && TAPS == 27 && PW == 4 && !a.add_src1 && a.s0.mode <= 2 && (a.s1.c == 0 || a.s1.mode <= 2);
     // Haar DWT / IWT source (+ added skip): whole-plane tiles in x (no halo columns to fetch), exact 2:1 extents, aligned rows
     a.wav = 0;
     if (!a.fast && !a.vol && TAPS == 9 && a.s0.mode >= 3 && a.W % PW == 0 && a.W <= TW && reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) {
@@ -1168,6 +1168,22 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     return check_launch("conv_mfma_kernel");
 }
 
+// fragments per tile of the regular configurations (mirrored by tiles_for)
+static int regular_nf(int rowsp, long frags) {
+    if (rowsp <= 16) return 13 * CINE_WN16;
+    if (rowsp <= 32) return 26;
+    if (rowsp <= 64 || frags > 8) return 13;
+    return 4;
+}
+// volumes whose regular tiling gives fewer than 128 workgroups per sample (the rule depends on the layer shape only, so the
+// statistics-record count of cine_conv_stat_partials3d stays a function of the shape)
+static bool vol_small_tiles(int rowsp, int h, int w, int d) {
+    const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
+    const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
+    const int TH = regular_nf(rowsp, frags) * 16 / TW;
+    return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < 128;
+}
+
 template <int TW, int TAPS, int CK>
 static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * TW, 16) * ceil_div(a.W, TW);   // fragments per sample
@@ -1175,6 +1191,13 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     // tiles would give 52 workgroups for a 200 x 200 plane; 16-fragment tiles give 169
     if (a.rowsp <= 16 && !a.ypart && TAPS == 9 && !a.vol && (long)a.n * ceil_div(frags, 52L) < 200)
         return launch_cfg<CK, 1, 1, 4, CINE_SMALL_MT, TW, TAPS>(a, st);
+    if (TAPS == 27 && vol_small_tiles(a.rowsp, a.H, a.W, a.D)) {
+        // a volume level with only a handful of 13-fragment tiles (cfg 4: 3 x 50 x 50 -> 48 workgroups, 1 x 25 x 25 -> 8): 4-fragment tiles
+        if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, 4, 1, TW, TAPS>(a, st);
+        if (a.rowsp <= 32) return launch_cfg<CK, 1, 2, 2, 2, TW, TAPS>(a, st);
+        if (a.rowsp <= 64) return launch_cfg<CK, 1, 4, 1, 4, TW, TAPS>(a, st);
+        return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
+    }
     if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, 13, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
     // workgroups per CU): a touch slower than one 4-wave workgroup per plane in isolation, but it packs better with the
@@ -1193,14 +1216,11 @@ static int dispatch(const ConvArgs& a, hipStream_t st) {
 }
 
 // tiles per sample of the configuration dispatch() picks (must mirror dispatch_tw)
-int tiles_for(int rowsp, int h, int w, int d = 1) {
+int tiles_for(int rowsp, int h, int w, int d = 1, bool vol3 = false) {
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
-    int nf;
-    if (rowsp <= 16) nf = 13 * kWN16;
-    else if (rowsp <= 32) nf = 26;
-    else if (rowsp <= 64 || frags > 8) nf = 13;
-    else nf = 4;
+    int nf = regular_nf(rowsp, frags);
+    if (vol3 && vol_small_tiles(rowsp, h, w, d)) nf = 4;          // every small-tile volume configuration has 4 fragments
     const int TH = nf * 16 / TW;
     return ceil_div(w, TW) * ceil_div(h, TH) * d;
 }
@@ -1227,7 +1247,7 @@ extern "C" int cine_conv_stat_partials3d(int cout, int d, int h, int w, int is_t
     if (cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
     const int rows = is_tconv ? 8 * cout : cout;
     const int rowsp = ceil_div(rows, 16) * 16;
-    return tiles_for(rowsp, h, w, d) * (is_tconv ? 8 : 1);
+    return tiles_for(rowsp, h, w, d, !is_tconv) * (is_tconv ? 8 : 1);
 }
 
 static size_t packed_floats(int rows, int cin, int taps, int ck) {
