@@ -31,6 +31,12 @@
 namespace cine {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Diagnostic variant builds only (tools/build_variant.sh NAME conv_kernels.hip -DCINE_ABL=bits, run by tools/variant_run.sh):
+// leave out a phase of conv_tile to see what the rest costs -- 1 the MFMA sweep, 2 the global loads + staging.  Results are
+// wrong by design; the product build has CINE_ABL 0 and the compiler drops the tests.
+#ifndef CINE_ABL
+#define CINE_ABL 0
+#endif
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };      // 4 floats at 4-byte alignment (rows of widths like 50 or 25)
 
 // ---------------------------------------------------------------- statistics helpers
@@ -252,6 +258,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         return first ? a.s0 : a.s1;
     };
     auto issue = [&](int chunk) {
+        if (CINE_ABL & 2) return;
         const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
@@ -312,7 +319,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         if (chunk == 0) CINE_STAMP(2);
         // ---- commit: weight slab [tap][ck][COT] (packed layout [chunk][tap][ck][rowsp])
 #pragma unroll
-        for (int i = 0; i < NWT; ++i) {
+        for (int i = 0; i < ((CINE_ABL & 2) ? 0 : NWT); ++i) {
             const int e = tid + i * C::NT;
             if (e >= TAPS * CK * (C::COT / 4)) break;
             const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
@@ -322,7 +329,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         const bool first = ci0 < a.s0.c;
         int cl0;
         const Src& s = chunk_src(chunk, cl0);
-        if (a.fast) {
+        if (CINE_ABL & 2) {
+        } else if (a.fast) {
             // ---- vectorised staging: every piece = PW consecutive floats of one (channel, row)
             if (a.wav) {
                 // Haar wavelets on load (mwcnn.py:216-263).  DWT: a piece of PW outputs of band b, channel c comes from the
@@ -602,7 +610,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        sweep(std::integral_constant<int, CK / 4>{});
+        if (!(CINE_ABL & 1)) sweep(std::integral_constant<int, CK / 4>{});
         if (chunk == 0) CINE_STAMP(5);
     }
 
