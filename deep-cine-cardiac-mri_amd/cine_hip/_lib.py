@@ -99,6 +99,11 @@ _SIGS = {
     "cine_dot_ws_bytes": (c_size_t, []),
     "cine_dot": (c_int, [P, P, c_long, P, P, P]),
     "cine_axpby_dev": (c_int, [P, P, P, c_long, P, P, P, c_float, P]),
+    "cine_crop_select": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_gauss_axis": (c_int, [P, P, c_long, c_int, c_long, c_double, P]),
+    "cine_combine_target": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_espirit_lag_kernels": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
+    "cine_espirit_eig": (c_int, [P, P, P, c_int, c_long, c_int, c_float, P]),
     "cine_profile_begin": (c_int, []),
     "cine_profile_end": (c_int, [P, P, c_int]),
     "cine_profile_families": (c_int, []),

@@ -31,6 +31,15 @@ def mask_center(x: torch.Tensor, mask_from: int, mask_to: int) -> torch.Tensor:
     return out
 
 
+def filtered_crop_center_and_slices(data, shape, n_slices, filter_size):
+    """reference transforms.py:186-220.  A GPU tensor of (t, c, h, w, 2) float32 pairs is cropped and Gaussian-filtered by the
+    HIP kernels (cine_crop_select / cine_gauss_axis); numpy input goes to the reference's scipy implementation."""
+    if isinstance(data, torch.Tensor) and data.is_cuda:
+        from cine_hip import frontend
+        return frontend.filtered_crop_center_and_slices(data, shape, n_slices, filter_size)
+    return _load_shadowed("reconstruction.data", "transforms").filtered_crop_center_and_slices(data, shape, n_slices, filter_size)
+
+
 def __getattr__(name):
     if name.startswith("__"):
         raise AttributeError(name)

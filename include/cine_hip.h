@@ -365,6 +365,30 @@ int cine_axpby_dev(float* out, const float* a, const float* b, long n, const flo
                    const float* lambda_dev, float sign, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * data front-end + sensitivity calibration (the step BEFORE the path)
+ *                                              reference: reconstruction/data/mri_data.py:283-303,
+ *                                                         reconstruction/data/transforms.py:186-220, 425-432
+ * ------------------------------------------------------------------------------------------ */
+/* data[:t_out, :, y0:y0+hout, x0:x0+wout] with y0 = (hin - hout) / 2, x0 = (win - wout) / 2 (transforms.py:209-214):
+ * in (t_in, c, hin, win, 2) -> out (t_out, c, hout, wout, 2). */
+int cine_crop_select(const float* in, float* out, int t_in, int c, int hin, int win, int t_out, int hout, int wout, void* stream);
+/* One axis pass of scipy.ndimage.gaussian_filter as transforms.py:216-217 calls it (mode 'reflect', truncate 4.0, weights and
+ * accumulation in float64, float32 result) over a (outer, n, inner) array of complex pairs: the real and imaginary parts
+ * are filtered alike.  The caller runs one pass per axis with sigma > 0, in axis order (mri_data.py:279: [0.7, 0, 0.3, 0.3]). */
+int cine_gauss_axis(const float* in, float* out, long outer, int n, long inner, double sigma, void* stream);
+/* target = center_crop(|sum_c img * conj(sens)|, (ch, cw))  (mri_data.py:302-303, transforms.py:136-158):
+ * img (t, c, h, w, 2), sens (c, h, w, 2) -> out (t, ch, cw). */
+int cine_combine_target(const float* img, const float* sens, float* out, int t, int c, int h, int w, int ch, int cw, void* stream);
+/* ESPIRiT calibration in place of `bart ecalib` (mri_data.py:296 `-r 200`, transforms.py:429 `-r 15`; BART is a third-party
+ * program the reference shells out to).  proj = V V^H (kk*kk*c square, complex pairs, index (py, px, coil)) is the
+ * projector onto the row space of the calibration matrix; cine_espirit_lag_kernels writes the (2 kk - 1)^2 lag kernels of
+ * every coil pair, centered and scaled, into kpad (c*c, ny, nx, 2) so that cine_fft2c(kpad, inverse) is the c x c
+ * image-space operator M(r) of every pixel.  cine_espirit_eig: dominant eigenpair of M(r) by `iters` power iterations;
+ * maps (c, npix, 2) unit norm with coil 0 real and non-negative, zero where the eigenvalue < crop; lam (npix). */
+int cine_espirit_lag_kernels(const float* proj, float* kpad, int c, int kk, int ny, int nx, void* stream);
+int cine_espirit_eig(const float* m, float* maps, float* lam, int c, long npix, int iters, float crop, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * small element-wise helpers                   reference: reconstruction/utils/math.py
  * ------------------------------------------------------------------------------------------ */
 int cine_complex_abs(const float* x, float* y, long n, void* stream);          /* math.py:48-62 */

@@ -382,10 +382,37 @@ def g_metrics():
          ifft2c_none=RU.ifft2c(k, norm=None), fft2c_none=RU.fft2c(k, norm=None))
 
 
+def g_frontend():
+    """The reference's data front-end (data/mri_data.py:283-303) on a small seeded raw k-space (t=7, x=40, y=36, c=3):
+    the numpy lines of SliceDataset.__getitem__ with the reference's own filtered_crop_center_and_slices / center_crop
+    (data/transforms.py:186-220, 136-158; scipy.ndimage.gaussian_filter underneath).  h5py and bart.ecalib are not part of
+    the vector: the raw array is generated here and the sensitivity maps are a seeded input."""
+    rs = np.random.RandomState(77)
+    nt, nx, ny, nc = 7, 40, 36, 3
+    raw = (rs.standard_normal((nt, nx, ny, nc)) + 1j * rs.standard_normal((nt, nx, ny, nc))).astype(np.complex64) * 1e-6
+    scaling, crop_shape, crop_target, n_slices, filter_size = 1e6, (24, 20), (20, 16), 5, [0.7, 0., 0.3, 0.3]
+    kspace = np.array(raw, dtype="complex64") * scaling
+    kspace = kspace.transpose(0, 3, 1, 2)
+    scaling_factor = np.sqrt(np.prod(kspace.shape[-2:]))
+    images = np.fft.fftshift(np.fft.ifftn(np.fft.ifftshift(kspace, axes=(-2, -1)), axes=(-2, -1), norm=None), axes=(-2, -1)) * scaling_factor
+    images_cropped, images_filter = r_tf.filtered_crop_center_and_slices(images, crop_shape, n_slices, filter_size)
+    scaling_factor = np.sqrt(np.prod(images_filter.shape[-2:]))
+    k2 = np.fft.ifftshift(np.fft.fftn(np.fft.fftshift(images_filter, axes=(-2, -1)), axes=(-2, -1), norm=None), axes=(-2, -1)) / scaling_factor
+    k2 = k2.transpose(0, 2, 3, 1).astype("complex64")
+    sens = (rs.standard_normal((nc,) + crop_shape) + 1j * rs.standard_normal((nc,) + crop_shape)).astype(np.complex64)
+    target = np.abs(np.sum(images_filter * np.conjugate(np.expand_dims(sens, axis=0)), axis=1)).astype("float32")
+    target = r_tf.center_crop(target, crop_target)
+    time_avg = np.mean(k2, axis=0, keepdims=True)
+    save("frontend", raw=raw, sens=sens, crop_shape=np.array(crop_shape), crop_target=np.array(crop_target), n_slices=n_slices,
+         filter_size=np.array(filter_size), images_cropped=images_cropped.astype(np.complex64),
+         images_filter=images_filter.astype(np.complex64), kspace=k2.transpose(0, 3, 1, 2), target=target,
+         time_avg_kspace=time_avg[0].transpose(2, 0, 1).astype(np.complex64))
+
+
 GENERATORS = dict(rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
-                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics)
+                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
