@@ -37,24 +37,36 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef CINE_ABL
 #define CINE_ABL 0
 #endif
+#ifndef CINE_PRIO
+#define CINE_PRIO 2          // s_setprio level of the non-MFMA phases of conv_tile (the sweeps run at 0)
+#endif
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };      // 4 floats at 4-byte alignment (rows of widths like 50 or 25)
 
 // ---------------------------------------------------------------- statistics helpers
 // partial record = {count, mean, M2}; merged InstanceNorm stats = {mean, 1/sqrt(M2/count + eps)}
+// the usual case (a handful of records per plane) in two halves, so that a kernel can put other loads between them: one round
+// of loads into registers, then the arithmetic (same summation order as the loop below: bit-identical)
+template <int NPMAX>
+__device__ __forceinline__ void load_partials(const float* p, int np, float (&r)[3 * NPMAX]) {
+#pragma unroll
+    for (int i = 0; i < 3 * NPMAX; ++i) r[i] = p[min(i, 3 * np - 1)];
+}
+template <int NPMAX>
+__device__ __forceinline__ float2 merge_loaded(const float (&r)[3 * NPMAX], int np, float eps) {
+    float cnt = 0.f, mean = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPMAX; ++i) if (i < np) { cnt += r[3 * i]; mean += r[3 * i] * r[3 * i + 1]; }
+    mean /= cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPMAX; ++i) if (i < np) { const float d = r[3 * i + 1] - mean; m2 += r[3 * i + 2] + r[3 * i] * d * d; }
+    return make_float2(mean, 1.0f / sqrtf(m2 / cnt + eps));
+}
 __device__ __forceinline__ float2 merge_partials(const float* p, int np, float eps) {
     if (np <= 8) {
-        // the usual case (a handful of tiles per plane): one round of loads, then arithmetic in registers
         float r[24];
-#pragma unroll
-        for (int i = 0; i < 24; ++i) r[i] = p[min(i, 3 * np - 1)];
-        float cnt = 0.f, mean = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (i < np) { cnt += r[3 * i]; mean += r[3 * i] * r[3 * i + 1]; }
-        mean /= cnt;
-        float m2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (i < np) { const float d = r[3 * i + 1] - mean; m2 += r[3 * i + 2] + r[3 * i] * d * d; }
-        return make_float2(mean, 1.0f / sqrtf(m2 / cnt + eps));
+        load_partials<8>(p, np, r);
+        return merge_loaded<8>(r, np, eps);
     }
     float cnt = 0.f, mean = 0.f;
     for (int i = 0; i < np; ++i) { cnt += p[3 * i]; mean += p[3 * i] * p[3 * i + 1]; }
@@ -71,6 +83,21 @@ __device__ __forceinline__ float2 merge_partials(const float* p, int np, float e
 __device__ __forceinline__ float act(float x, float scale, float shift, float slope) {
     const float v = fmaf(x, scale, shift);
     return fmaxf(v, v * slope);
+}
+
+// act() of PW (2 or 4) consecutive values with the packed fp32 instructions (v_pk_fma_f32, v_pk_mul_f32: two lanes of IEEE
+// arithmetic per instruction, the same results as the scalar form) -- fewer vector instructions in the staging phase, which
+// shares the SIMD's issue with the other workgroups' MFMA sweeps
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int PW>
+__device__ __forceinline__ void act_piece(float* ov, float scale, float shift, float slope) {
+#pragma unroll
+    for (int u = 0; u < PW; u += 2) {
+        const f32x2 x = {ov[u], ov[u + 1]};
+        const f32x2 v = __builtin_elementwise_fma(x, (f32x2){scale, scale}, (f32x2){shift, shift});
+        const f32x2 w = v * (f32x2){slope, slope};
+        ov[u] = fmaxf(v.x, w.x); ov[u + 1] = fmaxf(v.y, w.y);
+    }
 }
 
 struct Src {
@@ -239,6 +266,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     // B operand (k x rows): lane = output row q of the 16-row tile, channel kk
     const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
 
+    __builtin_amdgcn_s_setprio(CINE_PRIO);
     CINE_STAMP_RT(9);
     CINE_STAMP(0);
     // ---- chunk pipeline.  issue(c) puts the global loads of chunk c (weight slab + raw input pieces) in
@@ -286,21 +314,54 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
             }
         }
     };
+    // ---- the statistics records of the input channels go out FIRST (loads return in order: behind the first chunk's 16-byte
+    // loads their latency would be paid twice), then the first chunk, then the merge arithmetic
+    auto src_needs_stats = [](const Src& s) { return (s.mode == 1 || s.mode == 2) || (s.mode >= 3 && (s.act & 1)); };
+    const int nch = a.s0.c + a.s1.c;
+    const int npm = max(src_needs_stats(a.s0) ? a.s0.np : 0, a.s1.c > 0 && src_needs_stats(a.s1) ? a.s1.np : 0);   // uniform
+    constexpr int NPQ = 16;                           // records per plane the early path holds in registers
+    const bool early = npm <= NPQ && nch <= C::NT;
+    float prec[3 * NPQ];
+    const bool pfirst = tid < a.s0.c;
+    const Src& psrc = pfirst ? a.s0 : a.s1;
+    const bool pneed = early && tid < nch && src_needs_stats(psrc);
+    if (pneed) {
+        const float* pp = psrc.part + ((long)n * psrc.c + (pfirst ? tid : tid - a.s0.c)) * psrc.np * 3;
+        if (npm <= 4) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) prec[i] = pp[min(i, 3 * psrc.np - 1)];
+        } else load_partials<NPQ>(pp, psrc.np, prec);
+    }
+    CINE_STAMP(11);
     issue(0);
     __builtin_amdgcn_sched_barrier(0);
+    CINE_STAMP(12);
 
     // ---- prologue: merged InstanceNorm stats of every input channel; zero the tile once
     // table layout: source 0's channels, then source 1's (for modes 0/1/2 that is the concat channel order)
-    for (int ci = tid; ci < a.s0.c + a.s1.c; ci += C::NT) {
+    if (early) {
+        if (tid < nch) {
+            float2 mr = make_float2(0.f, 1.f);
+            if (pneed && !(CINE_ABL & 16)) {
+                if (npm <= 4) { float r4[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) r4[i] = prec[i];
+                    mr = merge_loaded<4>(r4, psrc.np, a.eps);
+                } else mr = merge_loaded<NPQ>(prec, psrc.np, a.eps);
+            }
+            st_lds[2 * tid] = mr.y; st_lds[2 * tid + 1] = -mr.x * mr.y;   // {scale, shift} of act()
+        }
+    } else
+    for (int ci = tid; ci < nch; ci += C::NT) {
         const bool first = ci < a.s0.c;
         const Src& s = first ? a.s0 : a.s1;
         const int cl = first ? ci : ci - a.s0.c;
         float2 mr = make_float2(0.f, 1.f);
-        const bool need = (s.mode == 1 || s.mode == 2) || (s.mode >= 3 && (s.act & 1));
-        if (need) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+        if (src_needs_stats(s)) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
         st_lds[2 * ci] = mr.y; st_lds[2 * ci + 1] = -mr.x * mr.y;      // {scale, shift} of act()
     }
-    if (HALO) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
+    CINE_STAMP(13);
+    if (HALO && !(CINE_ABL & 16)) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
         for (int e = tid; e < CK * C::ZP * C::ROWS * 2; e += C::NT) {
             const int ck = e / (C::ZP * C::ROWS * 2), rem = e % (C::ZP * C::ROWS * 2);
             in_lds[ck * C::PS + (rem >> 1) * C::COLS + ((rem & 1) ? C::COLS - 1 : TW)] = 0.f;
@@ -423,8 +484,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                                 if (!plain) {
                                     const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
                                     float* ov = reinterpret_cast<float*>(&o);
-#pragma unroll
-                                    for (int u = 0; u < PW; ++u) ov[u] = act(ov[u], ss.x, ss.y, a.slope);
+                                    act_piece<PW>(ov, ss.x, ss.y, a.slope);
                                 }
                                 *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
                             }
@@ -610,7 +670,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+        // The fp32 MFMA shares the SIMD's vector issue with ordinary vector instructions, and at equal priority a wave in a
+        // vector-instruction phase (prologue, staging, epilogue) gets one instruction in per 32-cycle MFMA of a sweeping wave
+        // on the same SIMD.  Sweeps run at the lowest priority, everything else above it: the short phases finish at their own
+        // pace and the workgroup is back in a sweep sooner (the sweeping wave loses 4 cycles per such instruction either way).
+        __builtin_amdgcn_s_setprio(0);
         if (!(CINE_ABL & 1)) sweep(std::integral_constant<int, CK / 4>{});
+        __builtin_amdgcn_s_setprio(CINE_PRIO);
         if (chunk == 0) CINE_STAMP(5);
     }
 
@@ -735,7 +801,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         }
     }
     CINE_STAMP(7);
-    if (a.ypart) {
+    if (a.ypart && !(CINE_ABL & 8)) {
         // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass
         // per WAVE in registers (sum -> wave mean -> squared deviations), the WN wave records are merged
         // with Chan's formula by one thread per row.
@@ -932,6 +998,7 @@ __global__ __launch_bounds__(256, 2) void unet_plane_kernel(const PlaneProgram* 
         for (int cb = 0; cb < ncb; ++cb)
             for (int t = 0; t < nt; ++t) {
                 switch (cfg) {
+#ifndef CINE_FAST_BUILD
                     case 0: conv_tile_call<8, 1, 1, 4, 13, 16, 9>(a, t, cb, n, smem_f); break;
                     case 1: conv_tile_call<8, 1, 2, 2, 13, 8, 9>(a, t, cb, n, smem_f); break;
                     case 2: conv_tile_call<8, 1, 4, 1, 13, 4, 9>(a, t, cb, n, smem_f); break;
@@ -939,6 +1006,9 @@ __global__ __launch_bounds__(256, 2) void unet_plane_kernel(const PlaneProgram* 
                     case 4: conv_tile_call<16, 2, 4, 1, 4, 2, 1>(a, t, cb, n, smem_f); break;
                     case 5: conv_tile_call<16, 1, 4, 1, 13, 4, 1>(a, t, cb, n, smem_f); break;
                     default: conv_tile_call<16, 1, 4, 1, 13, 8, 1>(a, t, cb, n, smem_f); break;
+#else
+                    default: break;
+#endif
                 }
                 __syncthreads();      // the tile's stores and statistics are ordered before whatever reads them next; LDS is free again
             }
@@ -1217,6 +1287,10 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
 
 template <int TAPS, int CK>
 static int dispatch(const ConvArgs& a, hipStream_t st) {
+#ifdef CINE_FAST_BUILD      // diagnostic builds (tools/conv_stamps.hip): only the 16-wide 3x3 / transpose-conv instantiations
+    if constexpr (TAPS == 27) return CINE_EUNSUPPORTED;
+    else return dispatch_tw<16, TAPS, CK>(a, st);
+#endif
     if (a.W > 8) return dispatch_tw<16, TAPS, CK>(a, st);
     if (a.W > 4) return dispatch_tw<8, TAPS, CK>(a, st);
     if (a.W > 2) return dispatch_tw<4, TAPS, CK>(a, st);

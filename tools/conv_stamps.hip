@@ -1,5 +1,6 @@
 // Diagnostic: phase shares of one conv3x3 workgroup (layer 16->16 on 400 planes of 208x16, cfg-2 level 0).
 #define CINE_STAMPS 1
+#define CINE_FAST_BUILD 1
 #include "conv_kernels.hip"
 #include <vector>
 #include <algorithm>
@@ -53,6 +54,16 @@ int main(int argc, char** argv) {
     double tot = 0; for (int i = 1; i <= 8; ++i) tot += acc[i];
     for (int i = 1; i <= 8; ++i) printf("%-36s %9.0f cycles  %5.1f %%\n", nm[i], acc[i] / cnt, 100 * acc[i] / tot);
     printf("workgroup lifetime %.0f cycles over %d sampled workgroups\n", tot / cnt, cnt);
+    {   // inside the prologue: 0 -> 11 (thread / tile decode, statistics loads issued), 11 -> 12 (first chunk's loads issued),
+        // 12 -> 13 (statistics merged, table written), 13 -> 1 (halo columns zeroed)
+        double sub[4] = {0, 0, 0, 0}; int c2 = 0;
+        for (int b = 0; b < 65536; ++b) {
+            const unsigned long long* s = &st[b * 16];
+            if (!s[0] || !s[1] || !s[11] || !s[12] || !s[13] || s[1] < s[0] || s[1] - s[0] > 10000000ull) continue;
+            sub[0] += (double)(s[11] - s[0]); sub[1] += (double)(s[12] - s[11]); sub[2] += (double)(s[13] - s[12]); sub[3] += (double)(s[1] - s[13]); ++c2;
+        }
+        if (c2) printf("prologue split: decode+stat loads %.0f | issue(0) %.0f | merge+table %.0f | halo zero %.0f cycles\n", sub[0] / c2, sub[1] / c2, sub[2] / c2, sub[3] / c2);
+    }
     {   // wall-clock residency: per (xcc, se, cu) count how many workgroups overlap on average
         struct Iv { unsigned long long a, b; unsigned long long id; };
         std::vector<Iv> iv;
