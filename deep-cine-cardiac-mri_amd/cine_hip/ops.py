@@ -739,6 +739,29 @@ def crnn_step(x: torch.Tensor, w_hh: torch.Tensor, addend: torch.Tensor, out: to
     return out
 
 
+def crnn_step2(w_hh: torch.Tensor, fwd, bwd=None) -> None:
+    """One step of BOTH directions of the BCRNN time sweep in one launch (reference recurrent_varnet.py:241-254: the forward
+    and the backward pass over time are independent chains).  fwd / bwd = (x, addend, y, accum, store): y = ReLU(conv3x3(x;
+    w_hh) + addend); accum = y when `store` (the first direction to reach that frame) else accum += y.  bwd None: fwd alone."""
+    def prep(s):
+        x, addend, y, accum, store = s
+        x = _dev(x, "hidden state"); addend = _dev(addend, "input term")
+        for t_, name in ((y, "y"), (accum, "accum")):
+            if t_ is not None and not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.shape == x.shape):
+                raise ValueError(f"crnn_step2: {name} must be a contiguous float32 GPU tensor shaped like x")
+        return x, addend, y, accum, int(bool(store))
+    xf, af, yf, cf, sf = prep(fwd)
+    n, c, h, w = xf.shape
+    if bwd is None:
+        xb = ab = yb = cb = None; sb = 0
+    else:
+        xb, ab, yb, cb, sb = prep(bwd)
+        if xb.shape != xf.shape:
+            raise ValueError("crnn_step2: the two directions differ in shape")
+    check(lib().cine_crnn_step2(xf.data_ptr(), af.data_ptr(), yf.data_ptr(), _p(cf), sf, _p(xb), _p(ab), _p(yb), _p(cb), sb,
+                                w_hh.data_ptr(), n, c, h, w, _stream()), "cine_crnn_step2")
+
+
 # ------------------------------------------------------------------ 3-D U-Net path (dynamic_type '3D')
 def normunet3d_pack(x: torch.Tensor, norm: bool = True):
     """(n, t, h, w, 2) -> planes (n, 2, Tp, Hp, Wp) [+ stats (n, 2, 2)]; reference norm_unet.py:149-189."""

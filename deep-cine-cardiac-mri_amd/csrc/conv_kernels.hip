@@ -128,6 +128,11 @@ struct ConvArgs {
     int vfast;                           // volumes (TAPS 27): row-wise 16-byte staging of plain / normalised / 2x2x2-pooled sources
     int wav;                             // fast staging of a Haar DWT / IWT source (modes 3 / 4), optionally + an added plain / normalised skip
     int tvec;                            // transpose conv: paired 16-byte stores (W multiple of the lane's pixel run, aligned y)
+    int accum_store;                     // 1: the second output is written (accum = y), not added to
+    // pair launches (conv_mfma_pair_kernel, the two directions of a BCRNN time sweep in one grid): samples >= pair_n take
+    // these pointers instead (and count from 0 again)
+    int pair_n, accum_store_b;
+    const float* x_b; const float* addend_b; float* y_b; float* accum_b;
 };
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
@@ -786,16 +791,24 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     if (PPR == 4) {
                         const float4 o = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
                         *reinterpret_cast<float4*>(dst) = o;
-                        if (ab2) { float4 t = *reinterpret_cast<float4*>(ab2 + off); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; *reinterpret_cast<float4*>(ab2 + off) = t; }
+                        if (ab2) {
+                            float4 t = o;
+                            if (!a.accum_store) { t = *reinterpret_cast<float4*>(ab2 + off); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+                            *reinterpret_cast<float4*>(ab2 + off) = t;
+                        }
                     } else {
                         const float2 o = make_float2(acc[ct][f][j0], acc[ct][f][j0 + 1]);
                         *reinterpret_cast<float2*>(dst) = o;
-                        if (ab2) { float2 t = *reinterpret_cast<float2*>(ab2 + off); t.x += o.x; t.y += o.y; *reinterpret_cast<float2*>(ab2 + off) = t; }
+                        if (ab2) {
+                            float2 t = o;
+                            if (!a.accum_store) { t = *reinterpret_cast<float2*>(ab2 + off); t.x += o.x; t.y += o.y; }
+                            *reinterpret_cast<float2*>(ab2 + off) = t;
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < PPR; ++u)
-                        if ((vmask >> (4 * f + j0 + u)) & 1ull) { dst[u] = acc[ct][f][j0 + u]; if (ab2) ab2[off + u] += acc[ct][f][j0 + u]; }
+                        if ((vmask >> (4 * f + j0 + u)) & 1ull) { dst[u] = acc[ct][f][j0 + u]; if (ab2) ab2[off + u] = a.accum_store ? acc[ct][f][j0 + u] : ab2[off + u] + acc[ct][f][j0 + u]; }
                 }
             }
         }
@@ -877,6 +890,18 @@ template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
 __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __align__(16) float smem_f[];
     conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
+}
+
+// Two independent sample sets in one grid: samples [0, pair_n) use the ordinary pointers, samples [pair_n, n) the *_b set.
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_pair_kernel(ConvArgs a) {
+    extern __shared__ __align__(16) float smem_f[];
+    int n = blockIdx.z;
+    if (n >= a.pair_n) {
+        n -= a.pair_n;
+        a.s0.x = a.x_b; a.addend = a.addend_b; a.y = a.y_b; a.accum = a.accum_b; a.accum_store = a.accum_store_b;
+    }
+    conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(a, blockIdx.x, blockIdx.y, n, smem_f);
 }
 
 // ---------------------------------------------------------------- final 1x1 conv, few output channels
@@ -1187,18 +1212,20 @@ int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
 #define CINE_WN32 4
 #endif
 #ifndef CINE_SMALL_MT
-#define CINE_SMALL_MT 2
+#define CINE_SMALL_MT 4      // 16-fragment tiles: 2 is ~5 % faster with ONE slice in flight, 4 is ~8 % faster with 12 (cfg 5: 286 -> 309 slices/s)
 #endif
 constexpr int kWN16 = CINE_WN16, kWN32 = CINE_WN32;   // waves (each 13 pixel fragments) per workgroup for <= 16 / <= 32 output rows
 constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
 constexpr int kCK1 = 16;    // 1x1 / tconv
 constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel live in LDS
 
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, bool PAIR = false>
 static int launch_cfg(ConvArgs a, hipStream_t st) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     static std::once_flag once[64];
-    auto kern = conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
+    void (*kern)(ConvArgs);
+    if constexpr (PAIR) kern = conv_mfma_pair_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
+    else kern = conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
     const size_t lds = C::lds_bytes(a.s0.c + a.s1.c);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv: %d input channels need %zu bytes of LDS", a.cin, lds);
     if (lds > 64 * 1024)
@@ -1230,7 +1257,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     a.tvec = a.tconv_cout > 0 && a.W % (TW >= 4 ? 4 : 2) == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
-    if (g_rec) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
+    if (g_rec && !PAIR) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
         RecStep r{};
         r.cfg = plane_cfg_id<CK, CT, WM, WN, MT, TW, TAPS>(); r.a = a; r.grid = grid; r.lds = lds; r.fam = fam;
         r.launch = [](const RecStep& q, hipStream_t s2) {
@@ -1267,8 +1294,11 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * TW, 16) * ceil_div(a.W, TW);   // fragments per sample
     // few samples, no statistics record (the CRNN cells' single-plane convolutions, recurrent_varnet.py:241-252): 52-fragment
     // tiles would give 52 workgroups for a 200 x 200 plane; 16-fragment tiles give 169
-    if (a.rowsp <= 16 && !a.ypart && TAPS == 9 && !a.vol && (long)a.n * ceil_div(frags, 52L) < 200)
+    if (a.rowsp <= 16 && !a.ypart && TAPS == 9 && !a.vol && (long)a.n * ceil_div(frags, 52L) < 200) {
+        if (a.pair_n > 0) return launch_cfg<CK, 1, 1, 4, CINE_SMALL_MT, TW, 9, true>(a, st);
         return launch_cfg<CK, 1, 1, 4, CINE_SMALL_MT, TW, TAPS>(a, st);
+    }
+    CINE_REQUIRE(a.pair_n == 0, CINE_EUNSUPPORTED, "conv: pair launches exist for the single-plane CRNN configuration only");
     if (TAPS == 27 && vol_small_tiles(a.rowsp, a.H, a.W, a.D)) {
         // a volume level with only a handful of 13-fragment tiles (cfg 4: 3 x 50 x 50 -> 48 workgroups, 1 x 25 x 25 -> 8): 4-fragment tiles
         if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, 4, 1, TW, TAPS>(a, st);
@@ -1423,6 +1453,38 @@ extern "C" int cine_crnn_step(const float* x, const float* wpacked, const float*
     CINE_REQUIRE(y != x && accum != x && accum != y, CINE_EINVAL, "cine_crnn_step: outputs must not alias the input or each other");
     return conv3x3_full(x, nullptr, 0, c, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, 0, wpacked, nullptr, 0,
                         nullptr, addend, 1, accum, y, nullptr, n, c, h, w, 1e-5f, 0.2f, stream);
+}
+
+// both directions of a BCRNN time sweep (recurrent_varnet.py:241-252: the forward and the backward pass over time are independent
+// chains; only their sum couples them, :254) in ONE launch: set f and set b are two cine_crnn_step calls on different tensors.
+extern "C" int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f,
+                               const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b,
+                               const float* wpacked, int n, int c, int h, int w, void* stream) {
+    CINE_REQUIRE(x_f && addend_f && y_f && wpacked, CINE_EINVAL, "cine_crnn_step2: null pointer");
+    CINE_REQUIRE(n > 0 && 2 * n <= 65535 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_crnn_step2: bad sizes");
+    CINE_REQUIRE(y_f != x_f && accum_f != x_f && accum_f != y_f, CINE_EINVAL, "cine_crnn_step2: outputs must not alias the input or each other");
+    ConvArgs a{};
+    a.s0 = Src{x_f, nullptr, c, 0, h, w, 0, 0, 1};
+    a.s1 = Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    a.addend = addend_f; a.relu = 1; a.accum = accum_f; a.accum_store = store_f && accum_f;
+    a.wp0 = a.wp1 = wpacked; a.set_split = 2 * n;
+    a.y = y_f; a.ypart = nullptr; a.n = n; a.cin = c; a.rows = c; a.rowsp = ceil_div(c, 16) * 16;
+    a.H = h; a.W = w; a.D = 1; a.slope = 0.2f; a.eps = 1e-5f; a.nchunks = ceil_div(c, kCK3);
+    if (!x_b) return dispatch<9, kCK3>(a, as_stream(stream));
+    CINE_REQUIRE(addend_b && y_b, CINE_EINVAL, "cine_crnn_step2: null pointer in set b");
+    CINE_REQUIRE(y_b != x_b && accum_b != x_b && accum_b != y_b && y_b != y_f && y_b != x_f && y_f != x_b, CINE_EINVAL,
+                 "cine_crnn_step2: the two sets must not write what the other reads");
+    CINE_REQUIRE(!accum_f || accum_f != accum_b, CINE_EINVAL, "cine_crnn_step2: both sets accumulate into the same tensor (run them one after the other)");
+    const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
+    const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
+    if (a.rowsp <= 16 && 2L * n * ceil_div(frags, 52L) < 200) {
+        a.n = 2 * n; a.pair_n = n;
+        a.x_b = x_b; a.addend_b = addend_b; a.y_b = y_b; a.accum_b = accum_b; a.accum_store_b = store_b && accum_b;
+        return dispatch<9, kCK3>(a, as_stream(stream));
+    }
+    if (int e = dispatch<9, kCK3>(a, as_stream(stream))) return e;      // shapes outside the pair configuration: two launches
+    a.s0.x = x_b; a.addend = addend_b; a.y = y_b; a.accum = accum_b; a.accum_store = store_b && accum_b;
+    return dispatch<9, kCK3>(a, as_stream(stream));
 }
 
 // mode encoding of the extended entry: low 3 bits = mode (0..4), bit 3 set = source is raw and gets

@@ -60,13 +60,22 @@ class BCRNNlayer(nn.Module):
         p = p.view(t, b, c, h, w)
         zero = torch.zeros((b, c, h, w), device=p.device, dtype=p.dtype)       # hid_init (:236)
         out = torch.empty_like(p)
-        hid = zero
-        for i in range(t):                                                      # forward pass over time (:241-245)
-            hid = ops.crnn_step(hid, w_hh, p[i], out[i])                        # written straight into output_f[i]
-        hid = zero
-        scratch = (torch.empty_like(zero), torch.empty_like(zero))
-        for k, i in enumerate(range(t - 1, -1, -1)):                            # backward pass, same cell (:247-252)
-            hid = ops.crnn_step(hid, w_hh, p[i], scratch[k & 1], accum=out[i])  # output_f + output_b (:254) in the epilogue
+        # The forward pass over time (:241-245) and the backward pass (:247-252, same cell) are independent chains; only their
+        # sum couples them (:254).  Step s advances both in ONE launch: frame s of the forward chain, frame t-1-s of the
+        # backward chain.  The first direction to reach a frame stores its hidden state into `out`, the second adds to it.
+        hf, hb = (torch.empty_like(zero), torch.empty_like(zero)), (torch.empty_like(zero), torch.empty_like(zero))
+        hid_f = hid_b = zero
+        for s in range(t):
+            i_f, i_b = s, t - 1 - s
+            first = i_f < i_b                # before the chains cross, each of them is the first to reach its frame
+            fwd = (hid_f, p[i_f], hf[s & 1], out[i_f], first)
+            bwd = (hid_b, p[i_b], hb[s & 1], out[i_b], first)
+            if i_f == i_b:                                                      # the middle frame of an odd t: one after the other
+                ops.crnn_step2(w_hh, (hid_f, p[i_f], hf[s & 1], out[i_f], True))
+                ops.crnn_step2(w_hh, (hid_b, p[i_b], hb[s & 1], out[i_b], False))
+            else:
+                ops.crnn_step2(w_hh, fwd, bwd)
+            hid_f, hid_b = hf[s & 1], hb[s & 1]
         return out
 
 

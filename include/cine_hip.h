@@ -247,6 +247,13 @@ int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mo
  * (c, c, 3, 3) hidden-to-hidden weight (its bias belongs in addend).  y / accum must not alias x or each other. */
 int cine_crnn_step(const float* x, const float* wpacked, const float* addend, float* y, float* accum,
                    int n, int c, int h, int w, void* stream);
+/* Both directions of the BCRNN time sweep in one launch (recurrent_varnet.py:241-252: two independent chains, summed at :254):
+ * set f and set b are each a cine_crnn_step on their own tensors; store_* != 0 writes accum_* = y_* instead of adding (the
+ * first direction to reach a frame).  x_b == NULL runs set f alone.  The sets must not write what the other reads, and must
+ * not accumulate into the same tensor. */
+int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f,
+                    const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b,
+                    const float* wpacked, int n, int c, int h, int w, void* stream);
 
 /* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)
  * and the partial statistics of y.  x mode 0|1 as above. */
