@@ -1216,7 +1216,10 @@ int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
 #endif
 constexpr int kWN16 = CINE_WN16, kWN32 = CINE_WN32;   // waves (each 13 pixel fragments) per workgroup for <= 16 / <= 32 output rows
 constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
-constexpr int kCK1 = 16;    // 1x1 / tconv
+#ifndef CINE_CK1
+#define CINE_CK1 16
+#endif
+constexpr int kCK1 = CINE_CK1;    // 1x1 / tconv: input channels per chunk
 constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel live in LDS
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, bool PAIR = false>

@@ -138,3 +138,28 @@ def test_espirit_full_size_recovers_analytic_maps(dev):
     calib = FE.ecalib(kavg.transpose(1, 2, 0)[None], r=24)
     assert isinstance(calib, np.ndarray) and calib.shape == (200, 200, 15)
     assert np.abs(calib.transpose(2, 0, 1) - maps).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_cinenet_on_espirit_maps(dev):
+    """The reference's CineNet input preparation (data/transforms.py:395-440: time-averaged masked k-space -> ecalib -r 15 ->
+    coils_maps) with the device calibration, then one CineNet forward on those maps: finite, and close to the forward on the
+    analytic maps where both sets of maps exist."""
+    import reconstruction.models as M
+    from cine_hip import frontend as FE, synth
+    ex = synth.make_cine_slice(5, 6, 64, 64, accel=4, center_lines=12, seed=4)
+    mk = ex["masked_kspace"].to(dev)
+    kavg = mk[0].mean(0)                                                     # (c, h, w, 2)
+    maps, lam = FE.espirit_maps(kavg, r=12)
+    net = M.CineNet(2, 3, 4, 2, "XF").eval(); synth.fill_parameters_(net, 5)
+    net = net.to(dev)
+    out_e = net(mk, ex["mask"].to(dev), maps[None, None])
+    assert torch.isfinite(out_e).all() and float(out_e.abs().max()) > 0
+    # ESPIRiT's gauge is unit norm with coil 0 real; the magnitude output does not depend on that per-pixel phase
+    s = torch.view_as_complex(ex["sens_maps"][0, 0].contiguous())
+    sn = s / s.abs().pow(2).sum(0, keepdim=True).sqrt()
+    sn = sn * torch.exp(-1j * torch.angle(sn[:1]))
+    out_a = net(mk, ex["mask"].to(dev), torch.view_as_real(sn)[None, None].contiguous().to(dev))
+    keep = (lam >= 0.8).cpu() & (ex["target"][0].mean(0) > 0.1 * ex["target"].max())
+    d = (out_e - out_a).abs().cpu()[0][:, keep]
+    assert keep.sum() > 500 and float(d.mean()) < 0.05 * float(out_a.abs().max())

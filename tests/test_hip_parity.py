@@ -569,6 +569,32 @@ def test_conv3x3_sum_epilogue_vs_torch(dev):
     assert rel_err(y.cpu(), ref) < OP_TOL
 
 
+@pytest.mark.parametrize("c,h,w,n", [(6, 24, 20, 1), (16, 200, 200, 1), (16, 52, 16, 2), (16, 208, 208, 15)])
+def test_crnn_step2_vs_torch(dev, c, h, w, n):
+    """Both directions of the BCRNN time sweep in one launch: y = ReLU(conv(x) + addend) per direction, second output stored by
+    the first direction to reach a frame and added to by the second; the single-direction form; the pair launch is
+    bit-identical to two separate launches (shapes inside and outside the pair configuration)."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    wt = (rnd(1, c, c, 3, 3) / (3.0 * c ** 0.5)).to(dev)
+    wp = ops.pack_conv3x3(wt)
+    xf, xb, af, ab = (rnd(s, n, c, h, w).to(dev) for s in (2, 3, 4, 5))
+    ref_f = F.relu(F.conv2d(xf, wt, padding=1) + af)
+    ref_b = F.relu(F.conv2d(xb, wt, padding=1) + ab)
+    yf, yb = torch.empty_like(xf), torch.empty_like(xb)
+    of, ob = torch.full_like(xf, 7.0), torch.full_like(xb, 3.0)
+    ops.crnn_step2(wp, (xf, af, yf, of, True), (xb, ab, yb, ob, False))
+    assert rel_err(yf.cpu(), ref_f.cpu()) < OP_TOL and rel_err(yb.cpu(), ref_b.cpu()) < OP_TOL
+    assert torch.equal(of, yf) and rel_err((ob - 3.0).cpu(), ref_b.cpu()) < OP_TOL
+    y1, o1 = torch.empty_like(xf), torch.full_like(xf, 7.0)
+    ops.crnn_step2(wp, (xf, af, y1, o1, True))
+    y2, o2 = torch.empty_like(xb), torch.full_like(xb, 3.0)
+    ops.crnn_step2(wp, (xb, ab, y2, o2, False))
+    assert torch.equal(y1, yf) and torch.equal(o1, of) and torch.equal(y2, yb) and torch.equal(o2, ob)
+    with pytest.raises(Exception, match="same tensor"):
+        ops.crnn_step2(wp, (xf, af, yf, of, True), (xb, ab, yb, of, False))
+
+
 def test_rnn_models_vs_reference_golden(golden, dev):
     import reconstruction.models as M
     g = golden("rnn")
