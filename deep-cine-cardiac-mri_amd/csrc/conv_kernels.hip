@@ -1277,7 +1277,11 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
 }
 
 // fragments per tile of the regular configurations (mirrored by tiles_for)
-static int regular_nf(int rowsp, long frags) {
+// plane3x3: a 2-D 3x3 convolution, whose small planes get tiles that fit them (MWCNN's coarse scales: a 50 x 4 plane is 13
+// fragments, a 25 x 2 plane 4 -- in the 26- and 13-fragment tiles most MFMAs worked on padding)
+static int regular_nf(int rowsp, long frags, bool plane3x3 = false) {
+    if (plane3x3 && rowsp > 16 && rowsp <= 32 && frags <= 14) return 14;
+    if (plane3x3 && rowsp > 32 && rowsp <= 64 && frags <= 4) return 4;
     if (rowsp <= 16) return 13 * CINE_WN16;
     if (rowsp <= 32) return 26;
     if (rowsp <= 64 || frags > 8) return 13;
@@ -1309,6 +1313,10 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
         if (a.rowsp <= 64) return launch_cfg<CK, 1, 4, 1, 4, TW, TAPS>(a, st);
         return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
     }
+    if constexpr (TAPS == 9) {
+        if (!a.vol && regular_nf(a.rowsp, frags, true) == 14) return launch_cfg<CK, 1, 2, 2, 7, TW, 9>(a, st);
+        if (!a.vol && regular_nf(a.rowsp, frags, true) == 4 && a.rowsp <= 64) return launch_cfg<CK, 1, 4, 1, 4, TW, 9>(a, st);
+    }
     if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, 13, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
     // workgroups per CU): a touch slower than one 4-wave workgroup per plane in isolation, but it packs better with the
@@ -1331,10 +1339,10 @@ static int dispatch(const ConvArgs& a, hipStream_t st) {
 }
 
 // tiles per sample of the configuration dispatch() picks (must mirror dispatch_tw)
-int tiles_for(int rowsp, int h, int w, int d = 1, bool vol3 = false) {
+int tiles_for(int rowsp, int h, int w, int d = 1, bool vol3 = false, bool plane3x3 = false) {
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
-    int nf = regular_nf(rowsp, frags);
+    int nf = regular_nf(rowsp, frags, plane3x3);
     if (vol3 && vol_small_tiles(rowsp, h, w, d)) nf = 4;          // every small-tile volume configuration has 4 fragments
     const int TH = nf * 16 / TW;
     return ceil_div(w, TW) * ceil_div(h, TH) * d;
@@ -1355,7 +1363,7 @@ extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv) {
     if (cout <= 0 || h <= 0 || w <= 0) return 0;
     const int rows = is_tconv ? 4 * cout : cout;
     const int rowsp = ceil_div(rows, 16) * 16;
-    return tiles_for(rowsp, h, w) * (is_tconv ? 4 : 1);
+    return tiles_for(rowsp, h, w, 1, false, !is_tconv) * (is_tconv ? 4 : 1);
 }
 
 extern "C" int cine_conv_stat_partials3d(int cout, int d, int h, int w, int is_tconv) {
