@@ -1310,8 +1310,10 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
         // a volume level with only a handful of 13-fragment tiles (cfg 4: 3 x 50 x 50 -> 48 workgroups, 1 x 25 x 25 -> 8): 4-fragment tiles
         if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, 4, 1, TW, TAPS>(a, st);
         if (a.rowsp <= 32) return launch_cfg<CK, 1, 2, 2, 2, TW, TAPS>(a, st);
-        if (a.rowsp <= 64) return launch_cfg<CK, 1, 4, 1, 4, TW, TAPS>(a, st);
-        return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
+        // > 64 rows: two workgroups of 64 rows per tile (cfg 4's 1 x 25 x 25 level has 14 tiles; finer row splits are faster
+        // still with one slice in flight -- 41.2 / 44.0 / 44.8 / 45.4 slices/s for 128 / 64 / 32 / 16 rows per workgroup -- but
+        // not with twelve: 88.0 / 89.3 / 87.9 / 87.3)
+        return launch_cfg<CK, 1, 4, 1, 4, TW, TAPS>(a, st);
     }
     if constexpr (TAPS == 9) {
         if (!a.vol && regular_nf(a.rowsp, frags, true) == 14) return launch_cfg<CK, 1, 2, 2, 7, TW, 9>(a, st);

@@ -5,6 +5,8 @@ set -u
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 COMMIT=${1:-unknown}
+PART=${2:-all}          # "main" = the cfg-2 evidence, "others" = cfg 3/4/5, "all" = both (two gpurun calls fit the 20-minute limit)
+if [ "$PART" != others ]; then
 python3 bench.py --steps 30 --warmup 3 > $O/bench.json 2> $O/bench.err
 cd /tmp
 # kernel traces of the default command in BOTH modes: the timed one (3 graphs in flight) and one slice in flight
@@ -19,6 +21,8 @@ cd $R
 python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv 7 $O/pmc_traffic.json $COMMIT > $O/pmc_traffic.txt
 python3 tools/pmc_mfma.py $O/pmc_mfma/p_counter_collection.csv 7 $O/pmc_mfma.json $COMMIT > $O/pmc_mfma.txt
 # (the PMC runs execute 7 forwards: first call, 1 timed step, 1 step with H2D, 3 for the per-family events, 1 parity check)
+fi
+if [ "$PART" != main ]; then
 # the other BASELINE configurations: one bench line (CPU baseline bounded to 16 threads, one forward) and one trace each
 for c in 3 4 5; do
   python3 bench.py --config $c --steps 12 --warmup 3 --cpu-forwards 1 --cpu-threads 16 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err
@@ -26,5 +30,6 @@ for c in 3 4 5; do
   rocprofv3 --kernel-trace --stats -d $O/trace_cfg$c -o t --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --repeats 0 --inflight 1 > $O/trace_cfg$c.log 2>&1
   cd $R
 done
+fi
 find $O -name "*_counter_collection.csv" -delete; find $O -name "*_kernel_trace.csv" -delete
 ls -la $O $O/trace_inflight
