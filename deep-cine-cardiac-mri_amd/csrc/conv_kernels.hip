@@ -128,6 +128,7 @@ struct ConvArgs {
     int vfast;                           // volumes (TAPS 27): row-wise 16-byte staging of plain / normalised / 2x2x2-pooled sources
     int wav;                             // fast staging of a Haar DWT / IWT source (modes 3 / 4), optionally + an added plain / normalised skip
     int tvec;                            // transpose conv: paired 16-byte stores (W multiple of the lane's pixel run, aligned y)
+    int ncc;                             // V3 kernels: channel chunks per depth offset (nchunks = 3 * ncc, chunk = (dz + 1) * ncc + cc)
     int accum_store;                     // 1: the second output is written (accum = y), not added to
     // pair launches (conv_mfma_pair_kernel, the two directions of a BCRNN time sweep in one grid): samples >= pair_n take
     // these pointers instead (and count from 0 again)
@@ -245,8 +246,12 @@ template <> struct Piece<2> { typedef float2 T; };
 
 // One workgroup's share of one layer: tile `tile` (depth slice, tile row, tile column) of sample n, output-row block
 // `coblk`.  Called once per workgroup by conv_mfma_kernel and once per (layer, tile) by the plane-persistent U-Net kernel.
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+// V3 = 1 (with TAPS = 9): a 3x3x3 convolution over (depth, h, w) volumes as three 3x3 passes -- chunk = (depth offset dz, 8 input
+// channels), staged from slice z + dz exactly like a 2-D plane (same LDS footprint, prefetch and vectorised transforms as the 2-D
+// kernel), accumulated into the same MFMA accumulators; chunks whose slice lies outside the volume are skipped.
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3 = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, const int coblk, const int n, float* smem_f) {
+    static_assert(!V3 || TAPS == 9, "V3 rides on the 3x3 kernel");
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     constexpr int HALO = C::HALO, PW = C::PW;
     typedef typename Piece<PW>::T piece_t;
@@ -284,27 +289,39 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     const int sg = KR == 1 ? tid / C::RP : 0;         // my channel group of the staging map (a slot if < G)
     const int srp = KR == 1 ? tid - sg * C::RP : tid; // my (row, piece) slot
     const int sgc = G == 1 ? 0 : min(sg, G - 1);
+    auto chunk_cc = [&](int chunk) { return V3 ? chunk % a.ncc : chunk; };          // channel chunk of a pipeline chunk
+    auto chunk_zs = [&](int chunk) { return V3 ? z0 + chunk / a.ncc - 1 : 0; };     // V3: the input slice it stages
+    auto chunk_live = [&](int chunk) { return !V3 || (chunk_zs(chunk) >= 0 && chunk_zs(chunk) < a.D); };
     auto chunk_src = [&](int chunk, int& cl0) -> const Src& {
-        const int ci0 = chunk * CK;
+        const int ci0 = chunk_cc(chunk) * CK;
         const bool first = ci0 < a.s0.c;
         cl0 = first ? ci0 : ci0 - a.s0.c;
         return first ? a.s0 : a.s1;
     };
     auto issue = [&](int chunk) {
         if (CINE_ABL & 2) return;
+        if (V3 && !chunk_live(chunk)) return;
         const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int e = tid + i * C::NT;
-            const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
+            int row = e / (C::COT / 4);
+            const int c4 = (e % (C::COT / 4)) * 4;
             const bool v = e < TAPS * CK * (C::COT / 4) && co0 + c4 < a.rowsp;
-            wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wsrc);
+            if (TAPS == 27) {
+                // 3-D weights are packed once, in the V3 order [dz][8-channel chunk][3x3 tap][8 channels][rows]: this kernel's
+                // chunk of CK = 4 channels is half of an 8-channel chunk
+                const int tap = row / CK, ck = row % CK, c = chunk * CK + ck;
+                row = (((tap / 9) * a.ncc + c / 8) * 9 + tap % 9) * 8 + c % 8;
+            }
+            wraw[i] = *reinterpret_cast<const float4*>(v ? (TAPS == 27 ? wp : wsrc) + (long)row * a.rowsp + co0 + c4 : wp);
         }
         int cl0;
         const Src& s = chunk_src(chunk, cl0);
         if (a.fast && !a.wav && s.mode != 2) {
-            const char* sb = reinterpret_cast<const char*>(s.x + ((long)n * s.c + cl0) * s.h * a.W);
-            const unsigned cstride = (unsigned)(s.h * a.W) * 4u;        // bytes between channels
+            const int zsc = V3 ? min(chunk_zs(chunk), s.d - 1) : 0;     // V3: a plain / normalised source slice of a volume
+            const char* sb = reinterpret_cast<const char*>(s.x + (((long)n * s.c + cl0) * (V3 ? s.d : 1) + zsc) * s.h * a.W);
+            const unsigned cstride = (unsigned)((V3 ? s.d : 1) * s.h * a.W) * 4u;        // bytes between channels
             const int cmax = s.c - 1 - cl0;                              // last channel of this source, chunk-relative
 #pragma unroll
             for (int k = 0; k < KR; ++k) {
@@ -381,6 +398,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
 
     CINE_STAMP(1);
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        if (V3 && !chunk_live(chunk)) {               // slice outside the volume: nothing to add; keep the load pipeline going
+            if (chunk + 1 < a.nchunks) issue(chunk + 1);
+            continue;
+        }
         __syncthreads();                              // stats table ready / previous sweep done with LDS
         if (chunk == 0) CINE_STAMP(2);
         // ---- commit: weight slab [tap][ck][COT] (packed layout [chunk][tap][ck][rowsp])
@@ -391,8 +412,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
             const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
             *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = co0 + c4 < a.rowsp ? wraw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const int ci0 = chunk * CK;
+        const int ci0 = chunk_cc(chunk) * CK;
         const bool first = ci0 < a.s0.c;
+        const int zs = chunk_zs(chunk);                 // V3: the volume slice this chunk stages (0 otherwise)
         int cl0;
         const Src& s = chunk_src(chunk, cl0);
         if (CINE_ABL & 2) {
@@ -477,7 +499,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     const int rp = srp + k * C::NT, row = rp / C::PR, j = rp % C::PR;
                     const int gy = r0 - HALO + row, gx = c0 + PW * j;
                     const bool slot = rp < C::RP && sg < G;
-                    const bool rowok = gy >= 0 && gy < s.h && gx < a.W;
+                    const bool rowok = gy >= 0 && gy < s.h && gx < a.W && (!V3 || zs < s.d);
                     float* lrow = in_lds + sgc * C::PS + row * C::COLS + PW * j;
                     const float* stp = st_lds + 2 * (ci0 + sgc);
                     // wave-uniform: every slot of this wave is inside the image and the chunk has all CK channels
@@ -516,10 +538,31 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     const int ck = p / (C::ROWS * C::PR), rem = p % (C::ROWS * C::PR);
                     const int row = rem / C::PR, j = rem % C::PR;
                     const int gy = r0 - HALO + row, gx = c0 + PW * j;
-                    const bool ok = ci0 + ck < a.cin && gy >= 0 && 2 * gy + 1 < s.h && gx < a.W;
+                    const bool ok = ci0 + ck < a.cin && gy >= 0 && 2 * gy + 1 < s.h && gx < a.W && (!V3 || 2 * zs + 1 < s.d);
                     float* dst = in_lds + ck * C::PS + row * C::COLS + PW * j;
                     if (ok) {
                         const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
+                        if (V3) {       // avg_pool3d 2x2x2 (unet.py:88,97): two source slices, same summation order as fetch_scalar
+                            float acc8[PW];
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) acc8[u] = 0.f;
+#pragma unroll
+                            for (int dzz = 0; dzz < 2; ++dzz) {
+                                const float* src = s.x + ((((long)n * s.c + cl0 + ck) * s.d + 2 * zs + dzz) * s.h + 2 * gy) * s.w + 2 * gx;
+                                float t0[2 * PW], t1[2 * PW];
+#pragma unroll
+                                for (int u = 0; u < 2 * PW; u += 4) {
+                                    *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(src + u);
+                                    *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(src + s.w + u);
+                                }
+#pragma unroll
+                                for (int u = 0; u < PW; ++u)
+                                    acc8[u] += act(t0[2 * u], mean, rstd, a.slope) + act(t0[2 * u + 1], mean, rstd, a.slope) +
+                                               act(t1[2 * u], mean, rstd, a.slope) + act(t1[2 * u + 1], mean, rstd, a.slope);
+                            }
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) dst[u] = 0.125f * acc8[u];
+                        } else {
                         const float* src = s.x + (((long)n * s.c + cl0 + ck) * s.h + 2 * gy) * s.w + 2 * gx;
                         float t0[2 * PW], t1[2 * PW];
 #pragma unroll
@@ -531,6 +574,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                         for (int u = 0; u < PW; ++u)
                             dst[u] = 0.25f * (act(t0[2 * u], mean, rstd, a.slope) + act(t0[2 * u + 1], mean, rstd, a.slope) +
                                               act(t1[2 * u], mean, rstd, a.slope) + act(t1[2 * u + 1], mean, rstd, a.slope));
+                        }
                     } else {
 #pragma unroll
                         for (int u = 0; u < PW; ++u) dst[u] = 0.f;
@@ -545,7 +589,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     const int gy = r0 - 1 + row, gx = side ? c0 + TW : c0 - 1;
                     float v = 0.f;
                     if (ci0 + ck < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                        v = fetch_scalar(s, n, cl0 + ck, 0, gy, gx, st_lds + (first ? 0 : 2 * a.s0.c), a.slope);
+                        v = fetch_scalar(s, n, cl0 + ck, V3 ? zs : 0, gy, gx, st_lds + (first ? 0 : 2 * a.s0.c), a.slope);
                     in_lds[ck * C::PS + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
                 }
             }
@@ -626,7 +670,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                 const int row = rem2 / XC, xcol = rem2 - row * XC;
                 const int col = (xcol - HALO + C::COLS) % C::COLS;
                 const int ci = ci0 + ck;
-                const int gz = z0 + zp - (C::ZP == 3 ? 1 : 0), gy = r0 - HALO + row, gx = c0 - HALO + xcol;
+                const int gz = V3 ? zs : z0 + zp - (C::ZP == 3 ? 1 : 0), gy = r0 - HALO + row, gx = c0 - HALO + xcol;
                 float v = 0.f;
                 if (ci < a.cin && gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                     const int c0n = src_cin(a.s0);
@@ -886,10 +930,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     CINE_STAMP_RT(10);
 }
 
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3 = 0>
 __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __align__(16) float smem_f[];
-    conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
+    conv_tile<CK, CT, WM, WN, MT, TW, TAPS, V3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
 }
 
 // Two independent sample sets in one grid: samples [0, pair_n) use the ordinary pointers, samples [pair_n, n) the *_b set.
@@ -1060,11 +1104,26 @@ __global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout
         if (m < rows && ci < cin) {
             if (kind == 0) v = w[((long)m * cin + ci) * 9 + tap];
             else if (kind == 1) { const int b = m & 1, co = (m >> 1) % cout, a_ = (m >> 1) / cout; v = w[((long)ci * cout + co) * 4 + 2 * a_ + b]; }
-            else if (kind == 3) v = w[((long)m * cin + ci) * 27 + tap];                                   // conv3d
+            else if (kind == 3) v = w[((long)m * cin + ci) * 27 + tap];                                   // (conv3d: pack_conv3d_kernel)
             else if (kind == 4) { const int c_ = m & 1, co = (m >> 1) % cout, ab = (m >> 1) / cout; v = w[((long)ci * cout + co) * 8 + 2 * ab + c_]; }   // tconv3d
             else v = w[(long)m * cin + ci];
         }
         p[e] = v;
+    }
+}
+
+// conv3d (cout, cin, 3, 3, 3) -> [dz][8-channel chunk][3x3 tap][8 channels][rowsp]: the chunk order of the V3 kernels (the
+// 27-tap kernel reads the same buffer through an index map)
+__global__ void pack_conv3d_kernel(const float* w, float* p, int cout, int cin, int rowsp, int ncc) {
+    const long total = 3L * ncc * 9 * 8 * rowsp;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(e % rowsp);
+        long r = e / rowsp;
+        const int ck = (int)(r % 8); r /= 8;
+        const int t9 = (int)(r % 9); r /= 9;
+        const int cc = (int)(r % ncc), dz = (int)(r / ncc);
+        const int ci = cc * 8 + ck;
+        p[e] = (m < cout && ci < cin) ? w[((long)m * cin + ci) * 27 + dz * 9 + t9] : 0.f;
     }
 }
 
@@ -1222,13 +1281,13 @@ constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
 constexpr int kCK1 = CINE_CK1;    // 1x1 / tconv: input channels per chunk
 constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel live in LDS
 
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, bool PAIR = false>
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, bool PAIR = false, int V3 = 0>
 static int launch_cfg(ConvArgs a, hipStream_t st) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     static std::once_flag once[64];
     void (*kern)(ConvArgs);
     if constexpr (PAIR) kern = conv_mfma_pair_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
-    else kern = conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>;
+    else kern = conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS, V3>;
     const size_t lds = C::lds_bytes(a.s0.c + a.s1.c);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv: %d input channels need %zu bytes of LDS", a.cin, lds);
     if (lds > 64 * 1024)
@@ -1244,7 +1303,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
         if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0;
         return s.w == a.W && s.h <= a.H;
     };
-    a.fast = !a.vol && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
+    a.fast = (!a.vol || V3) && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
              (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
     // volumes: 4-float row pieces (4-byte aligned loads: rows of any width), ragged right edges element by element
     a.vfast = a.vol && TAPS == 27 && PW == 4 && !a.add_src1 && a.s0.mode <= 2 && (a.s1.c == 0 || a.s1.mode <= 2);
@@ -1260,7 +1319,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     a.tvec = a.tconv_cout > 0 && a.W % (TW >= 4 ? 4 : 2) == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
-    if (g_rec && !PAIR) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
+    if (g_rec && !PAIR && !V3) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
         RecStep r{};
         r.cfg = plane_cfg_id<CK, CT, WM, WN, MT, TW, TAPS>(); r.a = a; r.grid = grid; r.lds = lds; r.fam = fam;
         r.launch = [](const RecStep& q, hipStream_t s2) {
@@ -1326,6 +1385,26 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     if (a.rowsp <= 32) return launch_cfg<CK, 1, 2, 2, 13, TW, TAPS>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<CK, 1, 4, 1, 13, TW, TAPS>(a, st);
     return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
+}
+
+// 3x3x3 convolutions of volumes wider than 8 voxels with 16-byte rows: the regular 16-wide configurations of the 3x3 kernel in V3
+// form (the tile geometry -- and with it the statistics-record count -- is that of the 27-tap configurations it replaces)
+static bool conv3d_v3_ok(const ConvArgs& a) {
+    auto src_ok = [&](const Src& s) {
+        if (s.c == 0) return true;
+        if (reinterpret_cast<uintptr_t>(s.x) % 16 != 0) return false;
+        if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0 && (((long)s.h * s.w) % 4) == 0;
+        return s.w == a.W && s.h <= a.H && (((long)s.h * s.w) % 4) == 0;
+    };
+    return a.vol && a.W > 8 && a.W % 4 == 0 && !a.add_src1 && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % kCK3 == 0) &&
+           !vol_small_tiles(a.rowsp, a.H, a.W, a.D);
+}
+static int dispatch_v3(const ConvArgs& a, hipStream_t st) {
+    const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
+    if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, 13, 16, 9, false, 1>(a, st);
+    if (a.rowsp <= 32) return launch_cfg<kCK3, 1, 2, 2, 13, 16, 9, false, 1>(a, st);
+    if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK3, 1, 4, 1, 13, 16, 9, false, 1>(a, st);
+    return launch_cfg<kCK3, 2, 4, 1, 4, 16, 9, false, 1>(a, st);
 }
 
 template <int TAPS, int CK>
@@ -1409,13 +1488,17 @@ extern "C" int cine_pack_conv1x1(const float* w, float* packed, int cout, int ci
     return pack(w, packed, 2, cout, cin, stream, "cine_pack_conv1x1");
 }
 extern "C" size_t cine_conv3d_packed_floats(int cout, int cin) {
-    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(cout, cin, 27, kCK27);
+    return (cout <= 0 || cin <= 0) ? 0 : packed_floats(cout, cin, 27, kCK3);
 }
 extern "C" size_t cine_tconv3d_packed_floats(int cin, int cout) {
     return (cout <= 0 || cin <= 0) ? 0 : packed_floats(8 * cout, cin, 1, kCK1);
 }
 extern "C" int cine_pack_conv3d(const float* w, float* packed, int cout, int cin, void* stream) {
-    return pack(w, packed, 3, cout, cin, stream, "cine_pack_conv3d");
+    CINE_REQUIRE(w && packed && cout > 0 && cin > 0, CINE_EINVAL, "cine_pack_conv3d: bad arguments");
+    const int rowsp = ceil_div(cout, 16) * 16, ncc = ceil_div(cin, kCK3);
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(pack_conv3d_kernel, dim3(grid1d(27L * ncc * 8 * rowsp, 256)), dim3(256), 0, as_stream(stream), w, packed, cout, cin, rowsp, ncc);
+    return check_launch("pack_conv3d_kernel");
 }
 extern "C" int cine_pack_tconv3d(const float* w, float* packed, int cin, int cout, void* stream) {
     return pack(w, packed, 4, cout, cin, stream, "cine_pack_tconv3d");
@@ -1650,7 +1733,9 @@ extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int 
     a.vol = 1;
     a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = bias; a.addend = addend; a.relu = relu;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
-    a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK27);
+    a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.ncc = ceil_div(a.cin, kCK3);
+    if (conv3d_v3_ok(a)) { a.nchunks = 3 * a.ncc; return dispatch_v3(a, as_stream(stream)); }
+    a.nchunks = ceil_div(a.cin, kCK27);
     return dispatch<27, kCK27>(a, as_stream(stream));
 }
 
