@@ -331,6 +331,10 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
 #pragma unroll
                 for (int i = 0; i < NCI; ++i) {
                     const int ck = min(sgc + i * G, cmax);              // uniform when G == 1
+                    if constexpr (V3 && PW == 4) {      // volume rows of any width (50, 25): 4-byte aligned 16-byte loads
+                        const f4u t = *reinterpret_cast<const f4u*>(sb + (size_t)((unsigned)ck * cstride) + voff);
+                        xraw[k * NCI + i] = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
+                    } else
                     xraw[k * NCI + i] = *reinterpret_cast<const piece_t*>(sb + (size_t)((unsigned)ck * cstride) + voff);
                 }
             }
@@ -500,10 +504,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     const int gy = r0 - HALO + row, gx = c0 + PW * j;
                     const bool slot = rp < C::RP && sg < G;
                     const bool rowok = gy >= 0 && gy < s.h && gx < a.W && (!V3 || zs < s.d);
+                    // V3, width not a multiple of the piece: the last piece of a row was loaded from W - PW (issue() clamps the
+                    // start), i.e. shifted by rsh elements; its tail beyond the row is zero
+                    const int rsh = V3 ? max(gx + PW - a.W, 0) : 0;
                     float* lrow = in_lds + sgc * C::PS + row * C::COLS + PW * j;
                     const float* stp = st_lds + 2 * (ci0 + sgc);
                     // wave-uniform: every slot of this wave is inside the image and the chunk has all CK channels
-                    if (fullchunk && __builtin_amdgcn_ballot_w64(slot && !rowok) == 0) {
+                    if (fullchunk && __builtin_amdgcn_ballot_w64(slot && (!rowok || rsh > 0)) == 0) {
                         if (slot) {
 #pragma unroll
                             for (int i = 0; i < NCI; ++i) {
@@ -523,8 +530,20 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                             piece_t o = xraw[k * NCI + i];
                             float* ov = reinterpret_cast<float*>(&o);
                             const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                            if (V3 && rsh > 0) {            // element u of the piece sits at position u + rsh of the loaded one
+                                float t[PW];
 #pragma unroll
-                            for (int u = 0; u < PW; ++u) ov[u] = ok ? (plain ? ov[u] : act(ov[u], ss.x, ss.y, a.slope)) : 0.f;
+                                for (int u = 0; u < PW; ++u) t[u] = ov[u];
+#pragma unroll
+                                for (int u = 0; u < PW; ++u) {
+                                    float v = 0.f;
+#pragma unroll
+                                    for (int q2 = u; q2 < PW; ++q2) v = (q2 == u + rsh) ? t[q2] : v;
+                                    ov[u] = v;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) ov[u] = ok && (!V3 || gx + u < a.W) ? (plain ? ov[u] : act(ov[u], ss.x, ss.y, a.slope)) : 0.f;
                             *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
                         }
                     }
@@ -540,7 +559,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     const int gy = r0 - HALO + row, gx = c0 + PW * j;
                     const bool ok = ci0 + ck < a.cin && gy >= 0 && 2 * gy + 1 < s.h && gx < a.W && (!V3 || 2 * zs + 1 < s.d);
                     float* dst = in_lds + ck * C::PS + row * C::COLS + PW * j;
-                    if (ok) {
+                    if (V3 && ok && gx + PW > a.W) {        // ragged last piece of a row: element by element
+#pragma unroll
+                        for (int u = 0; u < PW; ++u)
+                            dst[u] = gx + u < a.W ? fetch_scalar(s, n, cl0 + ck, zs, gy, gx + u, st_lds + (first ? 0 : 2 * a.s0.c), a.slope) : 0.f;
+                    } else if (ok) {
                         const float mean = st_lds[2 * (ci0 + ck)], rstd = st_lds[2 * (ci0 + ck) + 1];
                         if (V3) {       // avg_pool3d 2x2x2 (unet.py:88,97): two source slices, same summation order as fetch_scalar
                             float acc8[PW];
@@ -552,8 +575,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                                 float t0[2 * PW], t1[2 * PW];
 #pragma unroll
                                 for (int u = 0; u < 2 * PW; u += 4) {
-                                    *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(src + u);
-                                    *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(src + s.w + u);
+                                    *reinterpret_cast<f4u*>(t0 + u) = *reinterpret_cast<const f4u*>(src + u);
+                                    *reinterpret_cast<f4u*>(t1 + u) = *reinterpret_cast<const f4u*>(src + s.w + u);
                                 }
 #pragma unroll
                                 for (int u = 0; u < PW; ++u)
@@ -1300,11 +1323,12 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     auto src_ok = [&](const Src& s) {
         if (s.c == 0) return true;
         if (s.mode >= 3) return false;
-        if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0;
+        if (s.mode == 2) return (s.w == 2 * a.W || (V3 && s.w == 2 * a.W + 1)) && s.h >= 2 * a.H && (V3 || (s.w % 4) == 0);
         return s.w == a.W && s.h <= a.H;
     };
-    a.fast = (!a.vol || V3) && !a.add_src1 && (a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
-             (reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
+    // (V3: rows of any width >= one piece -- 4-byte aligned 16-byte loads, ragged last pieces element-wise)
+    a.fast = (!a.vol || V3) && !a.add_src1 && (V3 ? a.W >= PW : a.W % PW == 0) && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % CK == 0) &&
+             (V3 || ((reinterpret_cast<uintptr_t>(a.s0.x) % 16 == 0) && (a.s1.c == 0 || reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0)));
     // volumes: 4-float row pieces (4-byte aligned loads: rows of any width), ragged right edges element by element
     a.vfast = a.vol && TAPS == 27 && PW == 4 && !a.add_src1 && a.s0.mode <= 2 && (a.s1.c == 0 || a.s1.mode <= 2);
     // Haar DWT / IWT source (+ added skip): whole-plane tiles in x (no halo columns to fetch), exact 2:1 extents, aligned rows
@@ -1392,14 +1416,15 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
 static bool conv3d_v3_ok(const ConvArgs& a) {
     auto src_ok = [&](const Src& s) {
         if (s.c == 0) return true;
-        if (reinterpret_cast<uintptr_t>(s.x) % 16 != 0) return false;
-        if (s.mode == 2) return s.w == 2 * a.W && s.h >= 2 * a.H && (s.w % 4) == 0 && (((long)s.h * s.w) % 4) == 0;
-        return s.w == a.W && s.h <= a.H && (((long)s.h * s.w) % 4) == 0;
+        if (s.mode == 2) return (s.w == 2 * a.W || s.w == 2 * a.W + 1) && s.h >= 2 * a.H;
+        return s.w == a.W && s.h <= a.H;
     };
-    return a.vol && a.W > 8 && a.W % 4 == 0 && !a.add_src1 && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % kCK3 == 0) &&
-           !vol_small_tiles(a.rowsp, a.H, a.W, a.D);
+    if (!(a.vol && a.W > 8 && !a.add_src1 && src_ok(a.s0) && src_ok(a.s1) && (a.s1.c == 0 || a.s0.c % kCK3 == 0))) return false;
+    // levels with a handful of tiles keep the 4-fragment tile geometry: V3 has it for > 32 rows
+    return !vol_small_tiles(a.rowsp, a.H, a.W, a.D) || a.rowsp > 32;
 }
 static int dispatch_v3(const ConvArgs& a, hipStream_t st) {
+    if (vol_small_tiles(a.rowsp, a.H, a.W, a.D)) return launch_cfg<kCK3, 1, 4, 1, 4, 16, 9, false, 1>(a, st);    // 64 rows per workgroup
     const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
     if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, 13, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 32) return launch_cfg<kCK3, 1, 2, 2, 13, 16, 9, false, 1>(a, st);
