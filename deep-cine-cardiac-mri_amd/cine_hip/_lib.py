@@ -34,6 +34,7 @@ _SIGS = {
     "cine_hybrid_reduce": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_expand_dc_hybrid": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_image_dc_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "cine_normal_op": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_image_dc": (c_int, [P, P, P, P, P, c_float, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int,
                               P, c_size_t, P]),
     "cine_masked_kspace_to_hybrid": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -98,6 +99,8 @@ _SIGS = {
     "cine_extract_complex": (c_int, [P, P, c_long, c_int, c_int, c_int, P]),
     "cine_repeat_complex": (c_int, [P, P, c_long, c_int, P]),
     "cine_dot_ws_bytes": (c_size_t, []),
+    "cine_cg_ws_bytes": (c_size_t, []),
+    "cine_cg_step": (c_int, [P, P, P, P, c_long, P, P, P, P]),
     "cine_dot": (c_int, [P, P, c_long, P, P, P]),
     "cine_axpby_dev": (c_int, [P, P, P, c_long, P, P, P, c_float, P]),
     "cine_crop_select": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

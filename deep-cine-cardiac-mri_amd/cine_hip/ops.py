@@ -170,6 +170,23 @@ def image_dc(img: torch.Tensor, sens: torch.Tensor, zf: Optional[torch.Tensor], 
     return out
 
 
+def normal_op(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor) -> torch.Tensor:
+    """A^H M A img + softplus(lambda) img for a row mask (CineNet's H operator, reference cinenet.py:121-133) -> (b,t,1,h,w,2)."""
+    _pair(img); _pair(sens)
+    img = _dev(img, "image"); sens = _dev(sens, "sens_maps"); mask = _dev(mask, "mask", torch.uint8)
+    lam = _dev(lambda_reg.detach(), "lambda_reg")
+    b, _, c, h, w, _ = sens.shape
+    t = img.shape[1]
+    if img.numel() != b * t * h * w * 2 or mask.numel() != b * t * h:
+        raise ValueError(f"normal_op: image {tuple(img.shape)} / mask {tuple(mask.shape)} do not match sens_maps {tuple(sens.shape)}")
+    out = torch.empty((b, t, 1, h, w, 2), device=img.device, dtype=img.dtype)
+    nbytes = lib().cine_image_dc_ws_bytes(b, t, c, h, w)
+    ws = torch.empty(nbytes, device=img.device, dtype=torch.uint8) if nbytes else None
+    check(lib().cine_normal_op(img.data_ptr(), sens.data_ptr(), mask.data_ptr(), lam.data_ptr(), out.data_ptr(), b, t, c, h, w,
+                               _p(ws), nbytes, _stream()), "cine_normal_op")
+    return out
+
+
 def hybrid_reduce(hyb: torch.Tensor, sens: torch.Tensor, magnitude: bool = False) -> torch.Tensor:
     """Second half of sens_reduce (reference varnet.py:187-194) on hybrid-space data."""
     hyb = _dev(hyb, "hybrid k-space"); sens = _dev(sens, "sens_maps")
@@ -316,6 +333,25 @@ def dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
         ws = _dot_ws[key] = torch.empty(lib().cine_dot_ws_bytes(), device=a.device, dtype=torch.uint8)
     check(lib().cine_dot(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), ws.data_ptr(), _stream()), "cine_dot")
     return out
+
+
+_cg_ws = {}
+
+
+def cg_step(x: torch.Tensor, r: torch.Tensor, p: torch.Tensor, d: torch.Tensor, rr_old: torch.Tensor, rr_new: torch.Tensor) -> torch.Tensor:
+    """One conjugate-gradient iteration after d = H p (reference cinenet.py:155-169), x / r / p updated in place, rr_new written
+    (a different 1-element tensor than rr_old): three launches, bit-identical to dot + axpby_dev."""
+    for t_, name in ((x, "x"), (r, "r"), (p, "p"), (d, "d")):
+        if not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.numel() == x.numel()):
+            raise ValueError(f"cg_step: {name} must be a contiguous float32 GPU tensor of x's size")
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _cg_ws.get(key)
+    if ws is None:
+        _no_capture("the conjugate-gradient workspace of this stream")
+        ws = _cg_ws[key] = torch.empty(lib().cine_cg_ws_bytes(), device=x.device, dtype=torch.uint8)
+    check(lib().cine_cg_step(x.data_ptr(), r.data_ptr(), p.data_ptr(), d.data_ptr(), x.numel(), rr_old.data_ptr(), rr_new.data_ptr(),
+                             ws.data_ptr(), _stream()), "cine_cg_step")
+    return rr_new
 
 
 def axpby_dev(a: torch.Tensor, b: torch.Tensor, num: Optional[torch.Tensor] = None, den: Optional[torch.Tensor] = None,

@@ -561,6 +561,7 @@ struct ImgDcArgs {
     const cf* zf;           // (b, t, h, w) or null
     const uint8_t* mask;    // (b, t, h)
     const float* lam;       // device scalar (soft DC weights) or null (w1 / w0 / beta below)
+    int lam_beta;           // lam != null: 0 = soft DC weights from softplus(*lam); 1 = w1 / w0 as given, beta = softplus(*lam)
     float w1, w0, beta;     // weight of sampled / unsampled rows, factor of zf
     cf* out; float* out_abs;
     int T, C, H, W;
@@ -572,7 +573,8 @@ __device__ __forceinline__ void imgdc_weights(const ImgDcArgs& a, float& w1, flo
     w1 = a.w1; w0 = a.w0; beta = a.beta;
     if (a.lam) {                                 // varnet.py:281-282: (1 - m) K + m (K + v K_ref) / (1 + v)
         const float v = softplus1(*a.lam);
-        w1 = 1.0f / (1.f + v); w0 = 1.f; beta = v * w1;
+        if (a.lam_beta) beta = v;                // cinenet.py:133: A^H M A x + v x (zf = x)
+        else { w1 = 1.0f / (1.f + v); w0 = 1.f; beta = v * w1; }
     }
 }
 
@@ -943,10 +945,29 @@ extern "C" size_t cine_image_dc_ws_bytes(int b, int t, int c, int h, int w) {
     return (size_t)ceil_div(c, kDcCS) * b * t * h * w * sizeof(cf);
 }
 
+static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
+                         const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
+                         float* out, int b, int t, int c, int h, int w, int magnitude,
+                         void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int cine_image_dc(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                              const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
                              float* out, int b, int t, int c, int h, int w, int magnitude,
                              void* ws, size_t ws_bytes, void* stream) {
+    return image_dc_impl(img, sens, zf, mask, lambda_dev, 0, w_sampled, w_unsampled, beta, out, b, t, c, h, w, magnitude, ws, ws_bytes, stream);
+}
+
+// CineNet's H operator (models/cinenet.py:121-133) for a row mask: A^H M A img + softplus(*lambda_dev) img, one kernel chain
+extern "C" int cine_normal_op(const float* img, const float* sens, const uint8_t* mask, const float* lambda_dev,
+                              float* out, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(lambda_dev, CINE_EINVAL, "cine_normal_op: null lambda");
+    return image_dc_impl(img, sens, img, mask, lambda_dev, 1, 1.f, 0.f, 0.f, out, b, t, c, h, w, 0, ws, ws_bytes, stream);
+}
+
+static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
+                         const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
+                         float* out, int b, int t, int c, int h, int w, int magnitude,
+                         void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(img && sens && mask && out, CINE_EINVAL, "cine_image_dc: null pointer");
     CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_image_dc: bad sizes");
     CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_image_dc: b*t > 65535");
@@ -956,7 +977,7 @@ extern "C" int cine_image_dc(const float* img, const float* sens, const float* z
     CINE_REQUIRE(need == 0 || (ws && ws_bytes >= need), CINE_EWORKSPACE, "cine_image_dc: workspace %zu < %zu", ws_bytes, need);
     ImgDcArgs a{};
     a.img = reinterpret_cast<const cf*>(img); a.sens = reinterpret_cast<const cf*>(sens);
-    a.zf = reinterpret_cast<const cf*>(zf); a.mask = mask; a.lam = lambda_dev;
+    a.zf = reinterpret_cast<const cf*>(zf); a.mask = mask; a.lam = lambda_dev; a.lam_beta = lam_beta;
     a.w1 = w_sampled; a.w0 = w_unsampled; a.beta = beta;
     a.out = magnitude ? nullptr : reinterpret_cast<cf*>(out); a.out_abs = magnitude ? out : nullptr;
     a.T = t; a.C = c; a.H = h; a.W = w;

@@ -483,9 +483,53 @@ __global__ void axpby_dev_kernel(float* out, const float* a, const float* b, lon
     s *= sign;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + s * b[i];
 }
+// One conjugate-gradient iteration after d = H p (reference cinenet.py:155-169) in three launches instead of eight: the p.d partial
+// sums (dot_partial_kernel), then cg_update_kernel -- every workgroup adds the 256 partials itself (same order as dot_final_kernel),
+// alpha = rr_old / (p.d), x += alpha p, r -= alpha d, partial sums of r.r -- then cg_direction_kernel: rr_new from the partials,
+// beta = rr_new / rr_old, p = r + beta p.  Same arithmetic and summation orders as cine_dot / cine_axpby_dev: bit-identical.
+__global__ __launch_bounds__(256) void cg_update_kernel(float* x, float* r, const float* p, const float* d, long n,
+                                                        const float* pd_part, const float* rr_old, float* rr_part) {
+    __shared__ float red[16];
+    const float pd = block_sum(pd_part[threadIdx.x], red);
+    const float alpha = *rr_old / pd;
+    const float nalpha = alpha * -1.0f;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        x[i] = x[i] + alpha * p[i];
+        const float rn = r[i] + nalpha * d[i];
+        r[i] = rn;
+        s += rn * rn;
+    }
+    __syncthreads();
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) rr_part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void cg_direction_kernel(float* p, const float* r, long n, const float* rr_part, const float* rr_old,
+                                                           float* rr_new) {
+    __shared__ float red[16];
+    const float rn = block_sum(rr_part[threadIdx.x], red);
+    const float beta = rn / *rr_old;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = r[i] + beta * p[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *rr_new = rn;
+}
 }  // namespace cine
 
 extern "C" size_t cine_dot_ws_bytes(void) { return kDotBlocks * sizeof(float); }
+extern "C" size_t cine_cg_ws_bytes(void) { return 2 * kDotBlocks * sizeof(float); }
+
+extern "C" int cine_cg_step(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
+                            void* ws, void* stream) {
+    CINE_REQUIRE(x && r && p && d && rr_old_dev && rr_new_dev && ws && n > 0, CINE_EINVAL, "cine_cg_step: bad arguments");
+    CINE_REQUIRE(rr_old_dev != rr_new_dev, CINE_EINVAL, "cine_cg_step: rr_old and rr_new must be different scalars");
+    static_assert(kDotBlocks == 256, "the fused kernels add one partial per thread");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, d, n, part);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks);
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, r, n, part + kDotBlocks, rr_old_dev, rr_new_dev);
+    return check_launch("cine_cg_step");
+}
 
 extern "C" int cine_dot(const float* a, const float* b, long n, float* out_dev, void* ws, void* stream) {
     CINE_REQUIRE(a && b && out_dev && ws && n > 0, CINE_EINVAL, "cine_dot: bad arguments");

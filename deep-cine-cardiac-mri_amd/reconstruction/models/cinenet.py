@@ -37,7 +37,7 @@ class CineNetBlock(nn.Module):
         """A^H M A x + softplus(lambda) x  (reference cinenet.py:121-133).  With the reference's row mask the normal
         operator is one image-space kernel (cine_image_dc with weights (1, 0, 0)): the mask commutes with the row FFT."""
         if ops.is_row_mask(mask, sens_maps.expand(-1, x.shape[1], -1, -1, -1, -1)):
-            return ops.axpby_dev(ops.image_dc(x, sens_maps, None, mask, weights=(1.0, 0.0, 0.0)), x, lambda_reg=self.lambda_reg)
+            return ops.normal_op(x, sens_maps, mask, self.lambda_reg)
         hyb = ops.expand_mask_hybrid(x, sens_maps, mask, out=_hyb)
         return ops.axpby_dev(ops.hybrid_reduce(hyb, sens_maps), x, lambda_reg=self.lambda_reg)
 
@@ -50,14 +50,12 @@ class CineNetBlock(nn.Module):
         p = r.clone()
         rr_old = ops.dot(r, r)
         x = x.clone()
+        rr_new = torch.empty_like(rr_old)
         for _ in range(CG_iters):
             d = self.HOperator(p, mask, sens_maps, hyb)
-            pd = ops.dot(p, d)
-            ops.axpby_dev(x, p, num=rr_old, den=pd, out=x)                  # x += alpha p
-            ops.axpby_dev(r, d, num=rr_old, den=pd, sign=-1.0, out=r)       # r -= alpha d
-            rr_new = ops.dot(r, r)
-            ops.axpby_dev(r, p, num=rr_new, den=rr_old, out=p)              # p = r + beta p
-            rr_old = rr_new
+            # alpha = rr / p.d; x += alpha p; r -= alpha d; rr' = r.r; p = r + (rr' / rr) p   (:155-169), scalars on the device
+            ops.cg_step(x, r, p, d, rr_old, rr_new)
+            rr_old, rr_new = rr_new, rr_old
         return x
 
     def _xfyf_weights(self):

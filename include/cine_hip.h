@@ -113,6 +113,11 @@ int cine_image_dc(const float* img, const float* sens, const float* zf, const ui
                   const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
                   float* out, int b, int t, int c, int h, int w, int magnitude,
                   void* ws, size_t ws_bytes, void* stream);
+/* CineNet's normal operator with its regulariser weight (models/cinenet.py:121-133): out = A^H M A img + softplus(*lambda_dev) img
+ * for a row mask -- cine_image_dc with weights (1, 0), zf = img and beta = softplus(lambda) read on the device.  Same
+ * shapes / workspace as cine_image_dc. */
+int cine_normal_op(const float* img, const float* sens, const uint8_t* mask, const float* lambda_dev,
+                   float* out, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
 
 /* cine_kspace_to_hybrid of (mask * k) without reading the rows the mask drops: the hybrid-space image of the
  * measured lines only (the zero-filled term zf above: cine_hybrid_reduce of it).  k, hyb (bt, c, h, w, 2); mask (bt, h). */
@@ -370,6 +375,12 @@ int cine_dot(const float* a, const float* b, long n, float* out_dev, void* ws, v
  * the rhs x_ref + v x_reg (:255-257) and H's "+ v x" (:133) without the reference's .item() host syncs. */
 int cine_axpby_dev(float* out, const float* a, const float* b, long n, const float* num_dev, const float* den_dev,
                    const float* lambda_dev, float sign, void* stream);
+/* One conjugate-gradient iteration after d = H p (:155-169): alpha = rr_old / (p.d); x += alpha p; r -= alpha d; rr_new = r.r;
+ * p = r + (rr_new / rr_old) p -- three launches, scalars in device memory, bit-identical to the cine_dot / cine_axpby_dev
+ * sequence.  x, r, p updated in place; rr_old_dev != rr_new_dev; ws holds cine_cg_ws_bytes(). */
+size_t cine_cg_ws_bytes(void);
+int cine_cg_step(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
+                 void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * data front-end + sensitivity calibration (the step BEFORE the path)
