@@ -251,7 +251,7 @@ template <> struct Piece<2> { typedef float2 T; };
 // kernel), accumulated into the same MFMA accumulators; chunks whose slice lies outside the volume are skipped.
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3 = 0>
 __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, const int coblk, const int n, float* smem_f) {
-    static_assert(!V3 || TAPS == 9, "V3 rides on the 3x3 kernel");
+    static_assert(V3 != 1 || TAPS == 9, "V3 = 1 rides on the 3x3 kernel");      // V3 = 2: volume addressing only (1x1x1 kinds)
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>;
     constexpr int HALO = C::HALO, PW = C::PW;
     typedef typename Piece<PW>::T piece_t;
@@ -289,9 +289,9 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     const int sg = KR == 1 ? tid / C::RP : 0;         // my channel group of the staging map (a slot if < G)
     const int srp = KR == 1 ? tid - sg * C::RP : tid; // my (row, piece) slot
     const int sgc = G == 1 ? 0 : min(sg, G - 1);
-    auto chunk_cc = [&](int chunk) { return V3 ? chunk % a.ncc : chunk; };          // channel chunk of a pipeline chunk
-    auto chunk_zs = [&](int chunk) { return V3 ? z0 + chunk / a.ncc - 1 : 0; };     // V3: the input slice it stages
-    auto chunk_live = [&](int chunk) { return !V3 || (chunk_zs(chunk) >= 0 && chunk_zs(chunk) < a.D); };
+    auto chunk_cc = [&](int chunk) { return V3 == 1 ? chunk % a.ncc : chunk; };     // channel chunk of a pipeline chunk
+    auto chunk_zs = [&](int chunk) { return V3 == 1 ? z0 + chunk / a.ncc - 1 : (V3 == 2 ? z0 : 0); };     // the input slice it stages
+    auto chunk_live = [&](int chunk) { return V3 != 1 || (chunk_zs(chunk) >= 0 && chunk_zs(chunk) < a.D); };
     auto chunk_src = [&](int chunk, int& cl0) -> const Src& {
         const int ci0 = chunk_cc(chunk) * CK;
         const bool first = ci0 < a.s0.c;
@@ -300,7 +300,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     };
     auto issue = [&](int chunk) {
         if (CINE_ABL & 2) return;
-        if (V3 && !chunk_live(chunk)) return;
+        if (V3 == 1 && !chunk_live(chunk)) return;
         const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
@@ -402,7 +402,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
 
     CINE_STAMP(1);
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        if (V3 && !chunk_live(chunk)) {               // slice outside the volume: nothing to add; keep the load pipeline going
+        if (V3 == 1 && !chunk_live(chunk)) {               // slice outside the volume: nothing to add; keep the load pipeline going
             if (chunk + 1 < a.nchunks) issue(chunk + 1);
             continue;
         }
@@ -1340,7 +1340,8 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
                                             reinterpret_cast<uintptr_t>(a.s1.x) % 16 == 0);
         if ((dwt_ok || iwt_ok) && skip_ok) a.fast = a.wav = 1;
     }
-    a.tvec = a.tconv_cout > 0 && a.W % (TW >= 4 ? 4 : 2) == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
+    // (each lane stores the 4 output floats of 2 adjacent input pixels: an even width keeps the pairs whole and the rows 16-byte aligned)
+    a.tvec = a.tconv_cout > 0 && a.W % 2 == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
     if (g_rec && !PAIR && !V3) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
@@ -1430,6 +1431,19 @@ static int dispatch_v3(const ConvArgs& a, hipStream_t st) {
     if (a.rowsp <= 32) return launch_cfg<kCK3, 1, 2, 2, 13, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK3, 1, 4, 1, 13, 16, 9, false, 1>(a, st);
     return launch_cfg<kCK3, 2, 4, 1, 4, 16, 9, false, 1>(a, st);
+}
+
+// transpose conv k2 s2 / 1x1x1 conv of volumes wider than 8 voxels: the 16-wide 1x1 configurations with volume addressing (V3 = 2)
+// and the vectorised staging (the generic path stages volumes element by element)
+static bool vol1x1_fast_ok(const ConvArgs& a) {
+    return a.vol && a.W > 8 && a.s1.c == 0 && a.s0.mode <= 1 && a.s0.w == a.W && a.s0.h <= a.H && a.s0.d == a.D;
+}
+static int dispatch_vol1x1(const ConvArgs& a, hipStream_t st) {
+    const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
+    if (a.rowsp <= 16) return launch_cfg<kCK1, 1, 1, kWN16, 13, 16, 1, false, 2>(a, st);
+    if (a.rowsp <= 32) return launch_cfg<kCK1, 1, 2, 2, 13, 16, 1, false, 2>(a, st);
+    if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK1, 1, 4, 1, 13, 16, 1, false, 2>(a, st);
+    return launch_cfg<kCK1, 2, 4, 1, 4, 16, 1, false, 2>(a, st);
 }
 
 template <int TAPS, int CK>
@@ -1778,6 +1792,7 @@ extern "C" int cine_tconv3d_in(const float* x, const float* part_x, int np_x, in
     a.wp0 = a.wp1 = wpacked; a.set_split = n;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = cin; a.rows = 8 * cout; a.rowsp = ceil_div(8 * cout, 16) * 16;
     a.tconv_cout = cout; a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+    if (vol1x1_fast_ok(a)) return dispatch_vol1x1(a, as_stream(stream));
     return dispatch<1, kCK1>(a, as_stream(stream));
 }
 
@@ -1795,6 +1810,7 @@ extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x
     a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = bias;
     a.y = y; a.n = n; a.cin = cin; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
+    if (vol1x1_fast_ok(a)) return dispatch_vol1x1(a, as_stream(stream));
     return dispatch<1, kCK1>(a, as_stream(stream));
 }
 
