@@ -5,7 +5,7 @@
 #include <vector>
 #include <algorithm>
 int main(int argc, char** argv) {
-    const int n = 400, cin = argc > 1 ? atoi(argv[1]) : 16, cout = argc > 2 ? atoi(argv[2]) : 16;
+    const int n = argc > 6 ? atoi(argv[6]) : 400, cin = argc > 1 ? atoi(argv[1]) : 16, cout = argc > 2 ? atoi(argv[2]) : 16;
     const int h = argc > 3 ? atoi(argv[3]) : 208, w = argc > 4 ? atoi(argv[4]) : 16;
     const bool tconv = argc > 5 && atoi(argv[5]) == 2;     // 5th argument 2: transpose conv k2 s2 instead of conv3x3
     const size_t xe = (size_t)n * cin * h * w, ye = (size_t)n * cout * h * w * (tconv ? 4 : 1);
