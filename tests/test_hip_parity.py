@@ -862,6 +862,36 @@ def test_image_dc_vs_oracle(dev, t, c, h, w):
     got = ops.image_dc(imgd, sensd, zfd, maskd, lam_t.to(dev), magnitude=True)
     assert got.shape == (1, t, h, w) and rel_err(got.cpu(), ref) < OP_TOL
     assert torch.equal(imgd.cpu(), img)                                           # input untouched
+    # CineNet's H operator with its regulariser weight in the same chain (cinenet.py:121-133): A^H M A x + softplus(lambda) x
+    for lam in (-1.3, 0.5413):
+        lam_t = torch.tensor([lam])
+        ref = V.VarNetBlock.sens_reduce(kth * mask + 0.0, sens) + F.softplus(lam_t) * img
+        got = ops.normal_op(imgd, sensd, maskd, lam_t.to(dev))
+        assert got.shape == ref.shape and rel_err(got.cpu(), ref) < OP_TOL, lam
+        two = ops.axpby_dev(ops.image_dc(imgd, sensd, None, maskd, weights=(1.0, 0.0, 0.0)), imgd.view_as(got), lambda_reg=lam_t.to(dev))
+        assert torch.equal(got, two)                                              # bit-identical to the two-kernel form
+
+
+def test_cg_step_vs_separate_kernels(dev):
+    """cine_cg_step (three launches) == dot + axpby_dev sequence of reference cinenet.py:155-169, bit for bit, at cfg-4 size."""
+    from cine_hip import ops
+    n = 15 * 200 * 200 * 2
+    x, r, p, d = (rnd(s_, n).to(dev) for s_ in (1, 2, 3, 4))
+    d = d + 3.0 * p                                                               # keep p.d away from zero
+    rr_old = ops.dot(r, r)
+    x2, r2, p2 = x.clone(), r.clone(), p.clone()
+    pd = ops.dot(p2, d)
+    ops.axpby_dev(x2, p2, num=rr_old, den=pd, out=x2)
+    ops.axpby_dev(r2, d, num=rr_old, den=pd, sign=-1.0, out=r2)
+    rr_new2 = ops.dot(r2, r2)
+    ops.axpby_dev(r2, p2, num=rr_new2, den=rr_old, out=p2)
+    rr_new = torch.empty_like(rr_old)
+    ops.cg_step(x, r, p, d, rr_old, rr_new)
+    assert torch.equal(x, x2) and torch.equal(r, r2) and torch.equal(p, p2) and torch.equal(rr_new, rr_new2)
+    ref = (r2.double() ** 2).sum()
+    assert abs(float(rr_new) - float(ref)) / float(ref) < 1e-5
+    with pytest.raises(Exception, match="different scalars"):
+        ops.cg_step(x, r, p, d, rr_old, rr_old)
 
 
 def test_image_dc_batch_and_identities(dev):
