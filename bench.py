@@ -79,7 +79,7 @@ def _cfg2():
                      "Cartesian mask, sens net 8ch/3 pools, U-Net 16ch/3 pools",
                 metric="cine slices/sec, XF-VarNet R=4 15-coil 200x200x15t", accel=4, noise=0.0, wseed=1, keep=("lambda",),
                 hip=lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), ref=lambda: V.VarNet(6, 8, 3, 16, 3, "XF"), needs_sens=False,
-                conv_flop=flop, conv_kernel="cine::conv_mfma_kernel<8, CT, WM, WN, MT, TW, 9> (the 3x3 instantiations)",
+                conv_flop=flop, conv_kernel="cine::conv_mfma_kernel<8, CT, WM, WN, MT, TW, 9, 0> (the 3x3 instantiations)",
                 fft_bytes=fft_bytes)
 
 
@@ -100,7 +100,7 @@ def _cfg4():
     return dict(name="BASELINE.json configs[3]: 3D CineNet, 6 cascades, CG 6, U-Net3D 16ch/3 pools, 15 coils x 15 frames x 200x200, R=6",
                 metric="cine slices/sec, 3D CineNet R=6 15-coil 200x200x15t", accel=6, noise=0.0, wseed=7, keep=("lambda",),
                 hip=lambda: M.CineNet(6, 6, 16, 3, "3D"), ref=lambda: C.CineNet(6, 6, 16, 3, "3D"), needs_sens=True,
-                conv_flop=365.2e9, conv_kernel="cine::conv_mfma_kernel<4, ..., 27> (3x3x3 convs)", fft_bytes=None)
+                conv_flop=365.2e9, conv_kernel="cine::conv_mfma_kernel<8, ..., 9, 1> (3x3x3 convs as three 3x3 passes) + <4, ..., 27, 0> (small / narrow levels)", fft_bytes=None)
 
 
 def _cfg5():

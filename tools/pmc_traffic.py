@@ -3,10 +3,10 @@
 gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B requests of wide (16 B/lane) streaming reads at 64 B,
 so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Calibrated here on conv1x1_stream_kernel, whose
 algorithmic bytes are known (85.2 MB read, 10.6 MB written per launch at cfg 2)."""
-import csv, collections, json, sys
+import csv, re, collections, json, sys
 
 def fam(k):
-    if "conv_mfma" in k and ", 9>" in k: return "conv3x3_mfma"
+    if "conv_mfma" in k and re.search(r", 9(, \d)?>", k): return "conv3x3_mfma"
     if "conv_mfma" in k: return "tconv_conv1x1_mfma"
     if "conv1x1_stream" in k: return "conv1x1_stream"
     if "col200" in k or "col_pass" in k or "imgdc" in k: return "fft_col_pass"
