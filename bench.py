@@ -408,7 +408,7 @@ def main():
                 tj = json.load(f)
             tr, tr_src = tj["families"], f"profiles/{name}" + (f" @ {tj['commit']}" if "commit" in tj else "")
             break
-    if tr:
+    if tr and "conv3x3_mfma" in tr:
         roofline["traffic"] = tr["conv3x3_mfma"]["hbm_MB_per_launch"] * 1e6
         roofline["traffic_unit"] = f"HBM bytes per launch (mean over the launches of a slice), PMC FETCH_SIZE x2 + WRITE_SIZE, {tr_src}"
     line = {
@@ -439,7 +439,7 @@ def main():
                             "moves far fewer bytes than that (traffic), so this is the step's speed in the survey's units, not a bandwidth"}
         roof_fft["frac"] = roof_fft["achieved"] / roof_fft["peak"]
         if tr and "fft_col_pass" in tr:
-            roof_fft["traffic"] = (tr["fft_col_pass"]["hbm_MB_per_slice"] + tr["fft_row_pass"]["hbm_MB_per_slice"]) * 1e6
+            roof_fft["traffic"] = (tr.get("fft_col_pass", {}).get("hbm_MB_per_slice", 0.0) + tr.get("fft_row_pass", {}).get("hbm_MB_per_slice", 0.0)) * 1e6 or None
             roof_fft["traffic_unit"] = f"HBM bytes per slice over all FFT / DC passes, PMC, {tr_src}"
         line["roofline_fft_dc"] = roof_fft
     # ---- parity of a GRAPH-REPLAYED output (stream 0's slice) and the CPU baseline
