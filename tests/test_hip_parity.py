@@ -630,6 +630,55 @@ def test_conv3d_vs_torch(dev, cin, cout, d, h, w):
     assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3, 4), unbiased=False) + 1e-5)) < 1e-4
 
 
+@pytest.mark.parametrize("case", ["plain16", "ragged50", "partial_chunk", "norm_concat", "pooled", "pooled_odd", "concat_unaligned", "bias_relu"])
+def test_conv3d_v3_paths_vs_torch(dev, case):
+    """The V3 form of the 3x3x3 convolution (three 3x3 passes on the 2-D kernel) at volumes large enough for its regular tiles:
+    vectorised staging of plain / normalised / 2x2x2-pooled sources, ragged row widths (4-byte aligned loads, shifted last
+    piece), a channel chunk that is only partly filled, concatenation, the element-wise fallback inside the V3 kernel
+    (first source not a multiple of 8 channels), bias + ReLU epilogue, depth-boundary slices skipped."""
+    from cine_hip import ops, _lib
+    import torch.nn.functional as F
+    L = _lib.lib()
+    n = 1
+    cfgs = {  # c0, mode0, c1, mode1, cout, d, h, w
+        "plain16": (16, 0, 0, 0, 16, 16, 104, 64), "ragged50": (8, 1, 0, 0, 32, 16, 104, 50), "partial_chunk": (12, 1, 0, 0, 16, 16, 104, 64),
+        "norm_concat": (16, 1, 16, 1, 16, 16, 104, 64), "pooled": (16, 2, 0, 0, 32, 16, 104, 52), "pooled_odd": (8, 2, 0, 0, 32, 16, 104, 25),
+        "concat_unaligned": (12, 1, 4, 0, 16, 16, 104, 64), "bias_relu": (16, 0, 0, 0, 16, 16, 104, 64)}
+    c0, m0, c1, m1, cout, d, h, w = cfgs[case]
+    def source(seed, c, mode):
+        if c == 0:
+            return None, None, 0, (0, 0, 0), None
+        dd, hh, ww = (2 * d, 2 * h, 2 * w + (1 if case == "pooled_odd" else 0)) if mode == 2 else (d, h, w)
+        x = rnd(seed, n, c, dd, hh, ww) * 1.5 + 0.3
+        part = ops.instnorm_partials(x.to(dev)) if mode else None
+        xr = x
+        if mode:
+            xr = F.leaky_relu(F.instance_norm(x), 0.2)
+            if mode == 2:
+                xr = F.avg_pool3d(xr, 2, 2)
+        return x.to(dev), part, 1 if mode else 0, (dd, hh, ww), xr
+    x0, p0, np0, e0, r0 = source(11, c0, m0)
+    x1, p1, np1, e1, r1 = source(12, c1, m1)
+    cin = c0 + c1
+    wt = rnd(13, cout, cin, 3, 3, 3) / (5 * cin ** 0.5)
+    bias = rnd(14, cout) if case == "bias_relu" else None
+    wp = ops._pack("c27", wt.to(dev))
+    y = torch.empty((n, cout, d, h, w), device=dev)
+    part = torch.empty((n, cout, L.cine_conv_stat_partials3d(cout, d, h, w, 0), 3), device=dev)
+    bd = None if bias is None else bias.to(dev)
+    P = lambda t_: None if t_ is None else t_.data_ptr()
+    _lib.check(L.cine_conv3d_in(P(x0), P(p0), np0, c0, m0, e0[0], e0[1], e0[2], P(x1), P(p1), np1, c1, m1, e1[0], e1[1], e1[2],
+                                wp.data_ptr(), P(bd), None, 1 if bias is not None else 0,
+                                y.data_ptr(), part.data_ptr(), n, cout, d, h, w, 1e-5, 0.2, torch.cuda.current_stream().cuda_stream))
+    xin = r0 if r1 is None else torch.cat([r0, r1], 1)
+    ref = F.conv3d(xin, wt, bias, padding=1)
+    if bias is not None:
+        ref = F.relu(ref)
+    assert rel_err(y.cpu(), ref) < 2 * OP_TOL
+    st = ops.instnorm_finalize(part)
+    assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3, 4))) < 1e-4
+
+
 def test_unet3d_and_normunet3d_vs_reference_golden(golden, dev):
     from reconstruction.models.denoisers import NormUnet3D
     g = golden("unet")
