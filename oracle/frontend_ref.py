@@ -51,9 +51,8 @@ def gaussian_filter_axis(x: np.ndarray, sigma: float, axis: int) -> np.ndarray:
 
 def filtered_crop_center_and_slices(data: np.ndarray, shape, n_slices: int, filter_size):
     """reference data/transforms.py:186-220: data (t, c, x, y) complex -> (crop, Gaussian-filtered crop)."""
-    w_from = (data.shape[-2] - shape[0]) // 2
-    h_from = (data.shape[-1] - shape[1]) // 2
-    crop = data[:n_slices, :, w_from:w_from + shape[0], h_from:h_from + shape[1]]
+    y0, x0 = (data.shape[-2] - shape[0]) // 2, (data.shape[-1] - shape[1]) // 2
+    crop = data[:n_slices, :, y0:y0 + shape[0], x0:x0 + shape[1]]
     re, im = np.ascontiguousarray(crop.real), np.ascontiguousarray(crop.imag)
     for ax, s in enumerate(filter_size):
         re, im = gaussian_filter_axis(re, s, ax), gaussian_filter_axis(im, s, ax)

@@ -391,17 +391,19 @@ def g_frontend():
     nt, nx, ny, nc = 7, 40, 36, 3
     raw = (rs.standard_normal((nt, nx, ny, nc)) + 1j * rs.standard_normal((nt, nx, ny, nc))).astype(np.complex64) * 1e-6
     scaling, crop_shape, crop_target, n_slices, filter_size = 1e6, (24, 20), (20, 16), 5, [0.7, 0., 0.3, 0.3]
-    kspace = np.array(raw, dtype="complex64") * scaling
-    kspace = kspace.transpose(0, 3, 1, 2)
-    scaling_factor = np.sqrt(np.prod(kspace.shape[-2:]))
-    images = np.fft.fftshift(np.fft.ifftn(np.fft.ifftshift(kspace, axes=(-2, -1)), axes=(-2, -1), norm=None), axes=(-2, -1)) * scaling_factor
-    images_cropped, images_filter = r_tf.filtered_crop_center_and_slices(images, crop_shape, n_slices, filter_size)
-    scaling_factor = np.sqrt(np.prod(images_filter.shape[-2:]))
-    k2 = np.fft.ifftshift(np.fft.fftn(np.fft.fftshift(images_filter, axes=(-2, -1)), axes=(-2, -1), norm=None), axes=(-2, -1)) / scaling_factor
-    k2 = k2.transpose(0, 2, 3, 1).astype("complex64")
+    ax = (-2, -1)
+
+    def unnormalised(fn, a):                              # the reference's shift / transform / shift order around numpy's norm=None transforms
+        return np.fft.fftshift(fn(np.fft.ifftshift(a, axes=ax), axes=ax, norm=None), axes=ax) if fn is np.fft.ifftn else \
+            np.fft.ifftshift(fn(np.fft.fftshift(a, axes=ax), axes=ax, norm=None), axes=ax)
+
+    coilfirst = (np.array(raw, dtype="complex64") * scaling).transpose(0, 3, 1, 2)            # (t, c, x, y)
+    images = unnormalised(np.fft.ifftn, coilfirst) * np.sqrt(np.prod(coilfirst.shape[-2:]))  # mri_data.py:288-289
+    images_cropped, images_filter = r_tf.filtered_crop_center_and_slices(images, crop_shape, n_slices, filter_size)   # :290
+    k2 = unnormalised(np.fft.fftn, images_filter) / np.sqrt(np.prod(images_filter.shape[-2:]))                     # :291-292
+    k2 = k2.transpose(0, 2, 3, 1).astype("complex64")                                                              # :293
     sens = (rs.standard_normal((nc,) + crop_shape) + 1j * rs.standard_normal((nc,) + crop_shape)).astype(np.complex64)
-    target = np.abs(np.sum(images_filter * np.conjugate(np.expand_dims(sens, axis=0)), axis=1)).astype("float32")
-    target = r_tf.center_crop(target, crop_target)
+    target = r_tf.center_crop(np.abs(np.sum(images_filter * np.conjugate(sens[None]), axis=1)).astype("float32"), crop_target)   # :302-303
     time_avg = np.mean(k2, axis=0, keepdims=True)
     save("frontend", raw=raw, sens=sens, crop_shape=np.array(crop_shape), crop_target=np.array(crop_target), n_slices=n_slices,
          filter_size=np.array(filter_size), images_cropped=images_cropped.astype(np.complex64),
