@@ -468,6 +468,10 @@ def main():
         tgt = ex0["target"][0].numpy()
         line["parity_d_ssim_vs_cpu_oracle"] = abs(float(evaluate.ssim(tgt, got[0].numpy())) - float(evaluate.ssim(tgt, ref_out[0].numpy())))
         line["parity_nmse_vs_cpu_oracle"] = float(evaluate.nmse(ref_out[0].numpy(), got[0].numpy()))
+        if args.config == 3:
+            line["parity_note"] = ("a 10-cascade XPDNet with random weights amplifies rounding: the reference's own fp32 output is 7.0e-4 of the "
+                                   "peak (NMSE 2.9e-7) from its fp64 evaluation (tests/golden/xpdnet_cfg3.npz); every cascade alone agrees with "
+                                   "the oracle to 1.6e-6 (tests/test_hip_parity.py::test_xpdnet_cfg3_every_cascade_vs_oracle)")
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
