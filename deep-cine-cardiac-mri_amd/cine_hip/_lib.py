@@ -65,6 +65,9 @@ _SIGS = {
     "cine_crnn_step": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_crnn_step2": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "cine_mwcnn_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
+    "cine_mwcnn_forward2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_conv3x3_ex2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 P, P, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "cine_mwcnn_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_tconv2x2_in": (c_int, [P, P, c_int, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_float, P]),

@@ -654,8 +654,9 @@ class MwcnnWeights:
         return self._ptrs
 
 
-def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights) -> torch.Tensor:
-    """reference denoisers/mwcnn.py:135-179 on (n, in_ch, h, w), h and w multiples of 2^n_scales."""
+def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights, w2: Optional[MwcnnWeights] = None, split: int = 0) -> torch.Tensor:
+    """reference denoisers/mwcnn.py:135-179 on (n, in_ch, h, w), h and w multiples of 2^n_scales.  ``w2`` / ``split``: samples
+    [split, n) go through a second network of the same topology in the same launches (XPDNet's x-t / y-t networks)."""
     x = _dev(x, "mwcnn input")
     net = w.net
     n, cin, h, wd = x.shape
@@ -664,6 +665,15 @@ def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights) -> torch.Tensor:
     need = lib().cine_mwcnn_ws_bytes(n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters)
     ws = torch.empty(max(need, 1), device=x.device, dtype=torch.uint8)
     y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
+    if w2 is not None and w2 is not w:
+        n2 = w2.net
+        if (n2.in_chans, n2.out_chans, n2.n_scales, list(n2.n_filters_per_scale), list(n2.n_convs_per_scale), n2.first_conv_n_filters) != \
+                (net.in_chans, net.out_chans, net.n_scales, list(net.n_filters_per_scale), list(net.n_convs_per_scale), net.first_conv_n_filters):
+            raise ValueError("mwcnn_forward: the two networks differ in topology")
+        check(lib().cine_mwcnn_forward2(x.data_ptr(), y.data_ptr(), w.pointers(), w2.pointers(), int(split), n, h, wd, cin, net.out_chans,
+                                        net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res),
+                                        ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward2")
+        return y
     check(lib().cine_mwcnn_forward(x.data_ptr(), y.data_ptr(), w.pointers(), n, h, wd, cin, net.out_chans, net.n_scales,
                                    w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res),
                                    ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward")
@@ -678,8 +688,12 @@ def xpd_pack(buf: torch.Tensor, extra: torch.Tensor, n_primal: int, n_scales: in
         raise ValueError("image buffer channel count")
     nc = n_primal + 1
     tp, wp, hp = mwcnn_pad(t, n_scales)[0], mwcnn_pad(w, n_scales)[0], mwcnn_pad(h, n_scales)[0]
-    pxf = torch.empty((b * h, 2 * nc, wp, tp), device=buf.device, dtype=buf.dtype)
-    pyf = torch.empty((b * w, 2 * nc, hp, tp), device=buf.device, dtype=buf.dtype)
+    if wp == hp:        # both plane sets have one shape: one buffer, so that the two networks can run in the same launches
+        joint = torch.empty((b * h + b * w, 2 * nc, wp, tp), device=buf.device, dtype=buf.dtype)
+        pxf, pyf = joint[:b * h], joint[b * h:]
+    else:
+        pxf = torch.empty((b * h, 2 * nc, wp, tp), device=buf.device, dtype=buf.dtype)
+        pyf = torch.empty((b * w, 2 * nc, hp, tp), device=buf.device, dtype=buf.dtype)
     mean = torch.empty((b, h, w, nc, 2), device=buf.device, dtype=buf.dtype)
     nbytes = lib().cine_xpd_ws_bytes(b, t, h, w, n_primal)
     ws = torch.empty(nbytes, device=buf.device, dtype=torch.uint8)

@@ -113,7 +113,7 @@ __host__ __device__ inline int src_cin(const Src& s) { return s.mode == 3 ? 4 * 
 struct ConvArgs {
     Src s0, s1;
     const float* wp0; const float* wp1; int set_split;   // samples >= set_split use wp1
-    const float* bias;
+    const float* bias; const float* bias1;   // bias1: samples >= set_split (two weight sets in one launch)
     const float* addend; int relu;       // epilogue: y = [relu](conv + bias + addend), addend shaped like y
     float* accum;                        // optional second output, shaped like y: accum += y (BCRNN: output_f + output_b, recurrent_varnet.py:254)
     float* y; float* ypart;
@@ -759,10 +759,11 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     const int pr0 = (4 * kk) / TW, pc0 = (4 * kk) % TW;
     const int gx0 = c0 + pc0;
     if (a.bias) {
+        const float* bsel = n >= a.set_split ? a.bias1 : a.bias;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int m = co0 + 16 * (wm * CT + ct) + q;
-            const float bv = m < a.rows ? a.bias[m] : 0.f;
+            const float bv = m < a.rows ? bsel[m] : 0.f;
 #pragma unroll
             for (int f = 0; f < MT; ++f)
 #pragma unroll
@@ -1562,7 +1563,8 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
                         const float* addend, int relu, float* accum,
-                        float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+                        float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream,
+                        const float* bias2 = nullptr);
 
 extern "C" int cine_conv3x3_in(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
                                const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1,
@@ -1578,6 +1580,18 @@ extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int
                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
     return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, add_src1, wpacked, nullptr, 0,
                         bias, addend, relu, nullptr, y, part_y, n, cout, h, w, eps, slope, stream);
+}
+
+// cine_conv3x3_ex with two weight / bias sets: samples [0, set_split) use (wpacked, bias), the rest (wpacked2, bias2)
+extern "C" int cine_conv3x3_ex2(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                                const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                                const float* wpacked, const float* bias, const float* wpacked2, const float* bias2, int set_split,
+                                const float* addend, int relu,
+                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
+    CINE_REQUIRE(!wpacked2 || (set_split >= 0 && set_split <= n), CINE_EINVAL, "cine_conv3x3_ex2: set_split outside [0, n]");
+    CINE_REQUIRE(!bias == !bias2 || !wpacked2, CINE_EINVAL, "cine_conv3x3_ex2: both sets need a bias, or neither");
+    return conv3x3_full(x0, part0, np0, c0, mode0, h0, w0, x1, part1, np1, c1, mode1, h1, w1, add_src1, wpacked, wpacked2, set_split,
+                        bias, addend, relu, nullptr, y, part_y, n, cout, h, w, eps, slope, stream, wpacked2 ? bias2 : nullptr);
 }
 
 // one step of a convolutional-RNN time sweep (reference recurrent_varnet.py:241-254): y = ReLU(conv3x3(x; w) + addend) and,
@@ -1628,7 +1642,8 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
                         const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                         const float* wpacked, const float* wpacked2, int set_split, const float* bias,
                         const float* addend, int relu, float* accum,
-                        float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream) {
+                        float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream,
+                        const float* bias2) {
     CINE_REQUIRE(wpacked && y, CINE_EINVAL, "cine_conv3x3_in: null pointer");
     if (int e = check_slope(slope, "cine_conv3x3_in")) return e;
     CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && h > 0 && w > 0 && c0 > 0, CINE_EINVAL, "cine_conv3x3_in: bad sizes");
@@ -1642,7 +1657,7 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
     a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, act0, 1};
     a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, act1, 1};
     a.add_src1 = add_src1 && c1 > 0;
-    a.bias = bias; a.addend = addend; a.relu = relu; a.accum = accum;
+    a.bias = bias; a.bias1 = bias2 ? bias2 : bias; a.addend = addend; a.relu = relu; a.accum = accum;
     if (a.add_src1) CINE_REQUIRE(src_cin(a.s0) == src_cin(a.s1), CINE_EINVAL, "cine_conv3x3_in: added sources differ in channels");
     a.wp0 = wpacked; a.wp1 = wpacked2 ? wpacked2 : wpacked; a.set_split = wpacked2 ? set_split : n;
     a.y = y; a.ypart = part_y; a.n = n;
@@ -1717,7 +1732,7 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
         if (n1 <= n0) continue;
         ConvArgs a{};
         a.s0 = Src{x + (size_t)n0 * cin * h * w, part_x ? part_x + (size_t)n0 * cin * np_x * 3 : nullptr, cin, mode, h, w, np_x, 0, 1};
-        a.wp0 = a.wp1 = s ? wpacked2 : wpacked; a.set_split = n1 - n0; a.bias = s ? bias2 : bias;
+        a.wp0 = a.wp1 = s ? wpacked2 : wpacked; a.set_split = n1 - n0; a.bias = a.bias1 = s ? bias2 : bias;
         a.y = y + (size_t)n0 * cout * h * w; a.ypart = nullptr; a.n = n1 - n0; a.cin = cin; a.rows = cout;
         a.rowsp = ceil_div(cout, 16) * 16; a.H = h; a.W = w; a.D = 1; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
         if (int e = dispatch<1, kCK1>(a, as_stream(stream))) return e;
@@ -1770,7 +1785,7 @@ extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int 
     a.s0 = Src{x0, part0, c0, mode0, h0, w0, np0, 2, d0};          // act bit 1 marks a volume source
     a.s1 = Src{x1, part1, c1, c1 > 0 ? mode1 : 0, h1, w1, np1, 2, d1 > 0 ? d1 : 1};
     a.vol = 1;
-    a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = bias; a.addend = addend; a.relu = relu;
+    a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = a.bias1 = bias; a.addend = addend; a.relu = relu;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.ncc = ceil_div(a.cin, kCK3);
     if (conv3d_v3_ok(a)) { a.nchunks = 3 * a.ncc; return dispatch_v3(a, as_stream(stream)); }
@@ -1807,7 +1822,7 @@ extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x
     ConvArgs a{};
     a.s0 = Src{x, part_x, cin, mode, h, w, np_x, 2, d};
     a.vol = 1;
-    a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = bias;
+    a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = a.bias1 = bias;
     a.y = y; a.n = n; a.cin = cin; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(cin, kCK1);
     if (vol1x1_fast_ok(a)) return dispatch_vol1x1(a, as_stream(stream));

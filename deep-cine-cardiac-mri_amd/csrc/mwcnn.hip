@@ -10,10 +10,11 @@
 using namespace cine;
 
 extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
-extern "C" int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
-                               const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
-                               const float* wpacked, const float* bias, const float* addend, int relu,
-                               float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+extern "C" int cine_conv3x3_ex2(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                                const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                                const float* wpacked, const float* bias, const float* wpacked2, const float* bias2, int set_split,
+                                const float* addend, int relu,
+                                float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 namespace {
 constexpr float kEps = 1e-5f, kSlope = 0.2f;
@@ -94,9 +95,30 @@ extern "C" size_t cine_mwcnn_ws_bytes(int n, int h, int w, int in_ch, int out_ch
 
 // weights (host array of device pointers): first_convs[0] (packed 3x3), then for every scale s and conv i
 // conv_blocks_per_scale[s][i] (packed 3x3), then first_convs[1] weight (packed 3x3) and its bias.
+static int mwcnn_impl(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split, int n, int h, int w,
+                      int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                      int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int cine_mwcnn_forward(const float* x, float* y, const void* const* weights, int n, int h, int w,
                                   int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
                                   int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+    return mwcnn_impl(x, y, weights, nullptr, n, n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, n_first_convs, first_filters, res,
+                      ws, ws_bytes, stream);
+}
+
+// two MWCNNs of the same topology in one launch sequence: samples [0, set_split) go through `weights`, the rest through `weights2`
+// (XPDNet's x-t and y-t networks, xpdnet.py:424-446, on planes of equal shape)
+extern "C" int cine_mwcnn_forward2(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
+                                   int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                                   int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(weights2 && set_split > 0 && set_split < n, CINE_EINVAL, "cine_mwcnn_forward2: needs a second weight set and 0 < set_split < n");
+    return mwcnn_impl(x, y, weights, weights2, set_split, n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, n_first_convs, first_filters, res,
+                      ws, ws_bytes, stream);
+}
+
+static int mwcnn_impl(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split, int n, int h, int w,
+                      int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                      int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(x && y && weights && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_forward: null pointer");
     CINE_REQUIRE(n > 0 && h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && first_filters > 0, CINE_EINVAL, "cine_mwcnn_forward: bad sizes");
     if (int e = check_topology(n_scales, n_filters, n_convs, n_first_convs, res)) return e;
@@ -112,12 +134,19 @@ extern "C" int cine_mwcnn_forward(const float* x, float* y, const void* const* w
     int woff[kMaxScales + 1]; woff[0] = 1;
     for (int s = 0; s < p.S; ++s) woff[s + 1] = woff[s] + 2 * p.nc[s];
     auto WB = [&](int s, int i) { return reinterpret_cast<const float*>(weights[woff[s] + i]); };
-    for (int i = 0; i < woff[p.S] + 2; ++i) CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_mwcnn_forward: weights[%d] is null", i);
+    for (int i = 0; i < woff[p.S] + 2; ++i) CINE_REQUIRE(weights[i] && (!weights2 || weights2[i]), CINE_EINVAL, "cine_mwcnn_forward: weights[%d] is null", i);
+    // the second set's pointer for the same slot (weights and weights2 are parallel arrays)
+    auto second = [&](const float* first) -> const float* {
+        if (!weights2 || !first) return nullptr;
+        for (int i = 0; i < woff[p.S] + 2; ++i) if (weights[i] == first) return reinterpret_cast<const float*>(weights2[i]);
+        return nullptr;
+    };
     auto conv = [&](const Feat& s0, int mode0, const Feat* s1, int mode1, int add, const float* wp, const float* bias,
                     float* yo, float* po, int cout, int ho, int wo) {
-        return cine_conv3x3_ex(s0.x, s0.part, s0.np, s0.c, mode0, s0.h, s0.w,
-                               s1 ? s1->x : nullptr, s1 ? s1->part : nullptr, s1 ? s1->np : 0, s1 ? s1->c : 0, mode1,
-                               s1 ? s1->h : 0, s1 ? s1->w : 0, add, wp, bias, nullptr, 0, yo, po, n, cout, ho, wo, kEps, kSlope, stream);
+        return cine_conv3x3_ex2(s0.x, s0.part, s0.np, s0.c, mode0, s0.h, s0.w,
+                                s1 ? s1->x : nullptr, s1 ? s1->part : nullptr, s1 ? s1->np : 0, s1 ? s1->c : 0, mode1,
+                                s1 ? s1->h : 0, s1 ? s1->w : 0, add, wp, bias, second(wp), second(bias), set_split,
+                                nullptr, 0, yo, po, n, cout, ho, wo, kEps, kSlope, stream);
     };
     int e;
     // first conv block (mwcnn.py:143-146): in_ch -> first filters at full resolution

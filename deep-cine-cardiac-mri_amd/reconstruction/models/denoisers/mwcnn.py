@@ -86,9 +86,12 @@ class MWCNN(nn.Module):
                 else 4 * self.n_filters_per_scale[i_scale - 1]
         return in_chans, n_filters
 
+    def hip_weights(self):
+        if self._hip is None:
+            self._hip = ops.MwcnnWeights(self)
+        return self._hip
+
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         if self.dims != 2:
             raise NotImplementedError("3-D MWCNN is not on the HIP path")
-        if self._hip is None:
-            self._hip = ops.MwcnnWeights(self)
-        return ops.mwcnn_forward(inputs, self._hip)
+        return ops.mwcnn_forward(inputs, self.hip_weights())

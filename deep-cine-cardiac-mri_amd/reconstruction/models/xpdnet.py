@@ -82,6 +82,11 @@ class XPDNetBlock(nn.Module):
             xf = self.dynamic_type == 'XF'
             pxf, pyf, mean = ops.xpd_pack(image_buffer, backward_img, n, self.n_scales, xf)
             net_x, net_y = (nets, nets) if self.weight_sharing else (nets[0], nets[1])
+            if pxf.shape[1:] == pyf.shape[1:] and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr() and getattr(net_x, "dims", 2) == 2:
+                # x-t and y-t planes of one shape, adjacent in memory: both networks in the same launches (two weight sets)
+                joint = torch.as_strided(pxf, (pxf.shape[0] + pyf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+                out = ops.mwcnn_forward(joint, net_x.hip_weights(), net_y.hip_weights(), pxf.shape[0])
+                return ops.xpd_unpack(out[:pxf.shape[0]], out[pxf.shape[0]:], mean, b, t, h, w, n, self.n_scales, xf)
             return ops.xpd_unpack(net_x(pxf), net_y(pyf), mean, b, t, h, w, n, self.n_scales, xf)
         if self.dynamic_type == '2D':
             # (b, t, 1, h, w, 2(n+1)) channel-last -> (b*t, 2(n+1), h, w); no padding in 2-D mode (:442-444)

@@ -245,6 +245,13 @@ int cine_conv3x3_ex(const float* x0, const float* part0, int np0, int c0, int mo
                     const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
                     const float* wpacked, const float* bias, const float* addend, int relu,
                     float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
+/* cine_conv3x3_ex with two weight / bias sets in one launch: samples [0, set_split) use (wpacked, bias), the rest (wpacked2, bias2)
+ * (two networks of one topology on planes of equal shape: XPDNet's x-t / y-t MWCNNs, xpdnet.py:424-446). */
+int cine_conv3x3_ex2(const float* x0, const float* part0, int np0, int c0, int mode0, int h0, int w0,
+                     const float* x1, const float* part1, int np1, int c1, int mode1, int h1, int w1, int add_src1,
+                     const float* wpacked, const float* bias, const float* wpacked2, const float* bias2, int set_split,
+                     const float* addend, int relu,
+                     float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 /* One step of a convolutional-RNN time sweep (reference models/recurrent_varnet.py:241-254, CRNNcell :172-178 with the
  * input terms precomputed): y = ReLU(conv3x3(x; wpacked) + addend), and accum += y when accum != NULL (the backward sweep
@@ -338,6 +345,12 @@ size_t cine_mwcnn_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_sca
 int cine_mwcnn_forward(const float* x, float* y, const void* const* weights, int n, int h, int w,
                        int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
                        int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+/* Two MWCNNs of one topology in ONE launch sequence: samples [0, set_split) through `weights`, the rest through `weights2`
+ * (same pointer-array order).  XPDNet's image networks for the x-t and the y-t planes (xpdnet.py:424-446) when both plane sets
+ * have the same shape. */
+int cine_mwcnn_forward2(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
+                        int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                        int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * XPDNet primal-buffer plumbing                reference: models/xpdnet.py:301-326, 406-509
