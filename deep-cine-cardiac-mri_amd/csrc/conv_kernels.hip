@@ -1374,11 +1374,14 @@ static int regular_nf(int rowsp, long frags, bool plane3x3 = false) {
 }
 // volumes whose regular tiling gives fewer than 128 workgroups per sample (the rule depends on the layer shape only, so the
 // statistics-record count of cine_conv_stat_partials3d stays a function of the shape)
+#ifndef CINE_VOL_SMALL
+#define CINE_VOL_SMALL 128      // regular tiling with fewer workgroups than this -> 4-fragment tiles
+#endif
 static bool vol_small_tiles(int rowsp, int h, int w, int d) {
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
     const int TH = regular_nf(rowsp, frags) * 16 / TW;
-    return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < 128;
+    return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < CINE_VOL_SMALL;
 }
 
 template <int TW, int TAPS, int CK>
