@@ -314,6 +314,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                 const int tap = row / CK, ck = row % CK, c = chunk * CK + ck;
                 row = (((tap / 9) * a.ncc + c / 8) * 9 + tap % 9) * 8 + c % 8;
             }
+            if (TAPS == 9 && CK == 4) row = (row / CK) * 8 + row % CK;      // 4-channel chunks (layers with <= 4 input channels) over the 8-channel packing
             wraw[i] = *reinterpret_cast<const float4*>(v ? (TAPS == 27 ? wp : wsrc) + (long)row * a.rowsp + co0 + c4 : wp);
         }
         int cl0;
@@ -1406,6 +1407,11 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     if constexpr (TAPS == 9) {
         if (!a.vol && regular_nf(a.rowsp, frags, true) == 14) return launch_cfg<CK, 1, 2, 2, 7, TW, 9>(a, st);
         if (!a.vol && regular_nf(a.rowsp, frags, true) == 4 && a.rowsp <= 64) return launch_cfg<CK, 1, 4, 1, 4, TW, 9>(a, st);
+    }
+    if constexpr (TAPS == 9 && CK == 8) {
+        // the first layer of every U-Net (2 -> chans, unet.py:51): a 4-channel chunk and one k-step per tap instead of an 8-channel
+        // chunk that is three quarters zeros (half the MFMAs and half the staging of that layer)
+        if (a.rowsp <= 16 && !a.vol && a.cin <= 4 && a.s1.c == 0 && a.nchunks == 1) return launch_cfg<4, 1, 1, kWN16, 13, TW, 9>(a, st);
     }
     if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, 13, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
