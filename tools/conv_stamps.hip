@@ -1,6 +1,6 @@
 // Diagnostic: phase shares of one conv3x3 workgroup (layer 16->16 on 400 planes of 208x16, cfg-2 level 0).
 #define CINE_STAMPS 1
-#define CINE_FAST_BUILD 1
+// #define CINE_FAST_BUILD 1   (16-wide instantiations only: quicker to build)
 #include "conv_kernels.hip"
 #include <vector>
 #include <algorithm>
