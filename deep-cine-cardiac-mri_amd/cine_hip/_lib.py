@@ -111,6 +111,29 @@ _SIGS = {
     "cine_combine_target": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_espirit_lag_kernels": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "cine_espirit_eig": (c_int, [P, P, P, c_int, c_long, c_int, c_float, P]),
+    "cine_conv3x3_dgrad_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_tconv2x2_dgrad_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_conv1x1_dgrad_packed_floats": (c_size_t, [c_int, c_int]),
+    "cine_pack_conv3x3_dgrad": (c_int, [P, P, c_int, c_int, P]),
+    "cine_pack_tconv2x2_dgrad": (c_int, [P, P, c_int, c_int, P]),
+    "cine_pack_conv1x1_dgrad": (c_int, [P, P, c_int, c_int, P]),
+    "cine_conv3x3_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_tconv2x2_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_conv1x1_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_unet2d_train_ws_bytes": (c_size_t, [c_int] * 7),
+    "cine_unet2d_forward_train": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_unet2d_backward_ws_bytes": (c_size_t, [c_int] * 7),
+    "cine_unet2d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_size_t, P, P]),
+    "cine_normunet_unpack_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "cine_normunet_pack_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),
+    "cine_xfyf_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cine_xfyf_unpack_bwd": (c_int, [P] * 10 + [c_int] * 5 + [P, c_size_t, P]),
+    "cine_xfyf_pack_bwd": (c_int, [P] * 10 + [c_int] * 5 + [P, c_size_t, P]),
+    "cine_image_dc_sens_grad": (c_int, [P, P, P, P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_coil_accum": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_rss_normalise_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
+    "cine_complex_abs_bwd": (c_int, [P, P, P, c_long, P]),
+    "cine_axpby_lam": (c_int, [P, P, P, c_long, P, c_int, c_float, P]),
     "cine_profile_begin": (c_int, []),
     "cine_profile_end": (c_int, [P, P, c_int]),
     "cine_profile_families": (c_int, []),

@@ -1,0 +1,325 @@
+"""Training through the HIP path: ``torch.autograd.Function`` wrappers whose backward passes run hand-written kernels.
+
+What the reference differentiates with ATen autograd in ``pl_modules/varnet_module.py:97-113`` (``training_step``:
+forward + ``SSIMLoss``) is differentiated here by the gradient entry points of ``include/cine_hip.h`` ("Training"):
+
+  UnetFn       : denoisers/unet.py:73-125 -- conv3x3 / transpose-conv / 1x1 input gradients (the forward MFMA kernel on
+                 re-packed weights), weight gradients (MFMA GEMM over pixels x samples), InstanceNorm + LeakyReLU backward
+  NormUnetFn   : denoisers/norm_unet.py:98-114 around it (group norm with unbiased std, pad, un-norm)
+  XfyfFn       : models/varnet.py:196-241 (temporal mean, centered temporal DFT, x-f / y-f rotations, both NormUnets)
+  ImageDcFn    : models/varnet.py:181-194, 281-282 on the coil-combined image (self-adjoint in the image; gradients for the
+                 sensitivity maps, the zero-filled term and lambda_reg)
+  CoilReduceFn : models/varnet.py:187-194 with respect to the maps
+  RssNormFn    : models/varnet.py:58-59;  AbsFn: utils/math.py:48-62
+
+Gradient convention for complex tensors: the trailing (re, im) pair carries (dL/dre, dL/dim), as torch does for real
+views.  Every reduction in the kernels runs in a fixed order: repeated backward passes are bit-identical.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import CineHipError, check, lib
+
+_p = ops._p
+_stream = ops._stream
+
+
+def _c(x: torch.Tensor) -> torch.Tensor:
+    return x if x.is_contiguous() else x.contiguous()
+
+
+# ------------------------------------------------------------------ U-Net
+def _unet_call_shapes(x: torch.Tensor, weights: "ops.UnetWeights"):
+    n, cin, h, w = x.shape
+    if cin != weights.in_ch:
+        raise ValueError(f"unet input has {cin} channels, expected {weights.in_ch}")
+    return n, cin, h, w
+
+
+def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
+    """cine_unet2d_forward_train: returns (y, workspace with every raw layer output)."""
+    x = ops._dev(x, "unet input")
+    n, cin, h, w = _unet_call_shapes(x, weights)
+    need = lib().cine_unet2d_train_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)
+    if need == 0:
+        raise CineHipError("cine_unet2d_train_ws_bytes rejected the shape")
+    ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+    y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
+    check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(), len(weights.unets), n, h, w, cin,
+                                          weights.out_ch, weights.chans, weights.pools, ws.data_ptr(), ws.numel(), _stream()),
+          "cine_unet2d_forward_train")
+    return y, ws
+
+
+def unet2d_backward(x: torch.Tensor, gy: torch.Tensor, weights: "ops.UnetWeights", fwd_ws: torch.Tensor, need_gx: bool):
+    """cine_unet2d_backward: returns (gx | None, [per-set list of parameter gradients in ``weights.param_list()`` order])."""
+    x = ops._dev(x, "unet input"); gy = ops._dev(gy, "unet output gradient")
+    n, cin, h, w = _unet_call_shapes(x, weights)
+    nsets = len(weights.unets)
+    need = lib().cine_unet2d_backward_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)
+    ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+    plists = weights.param_lists()
+    grads = [[torch.zeros_like(p, memory_format=torch.contiguous_format) for p in pl] for pl in plists]
+    gptr = (ctypes.c_void_p * (nsets * len(plists[0])))(*[g.data_ptr() for gl in grads for g in gl])
+    gx = torch.empty_like(x) if need_gx else None
+    check(lib().cine_unet2d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, nsets, n, h, w, cin,
+                                     weights.out_ch, weights.chans, weights.pools, fwd_ws.data_ptr(), fwd_ws.numel(),
+                                     ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_unet2d_backward")
+    return gx, grads
+
+
+def _param_grads(weights: "ops.UnetWeights", grads, params: Sequence[torch.Tensor]):
+    """Map the per-set gradient lists onto the flat ``params`` tuple a Function received (one entry per DISTINCT parameter:
+    with weight sharing both sets of a launch belong to the same tensors and are summed)."""
+    out = {}
+    for pl, gl in zip(weights.param_lists(), grads):
+        for p, g in zip(pl, gl):
+            out[id(p)] = g if id(p) not in out else out[id(p)] + g
+    return tuple(out.get(id(p)) for p in params)
+
+
+class UnetFn(Function):
+    """y = Unet(x) on (n, in_ch, h, w) planes; ``params`` = the distinct parameters of ``weights`` (for autograd's bookkeeping)."""
+
+    @staticmethod
+    def forward(ctx, x, weights, *params):
+        y, ws = unet2d_forward_train(x, weights)
+        ctx.weights, ctx.ws, ctx.params = weights, ws, params
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gx, grads = unet2d_backward(x, _c(gy), ctx.weights, ctx.ws, ctx.needs_input_grad[0])
+        return (gx, None) + _param_grads(ctx.weights, grads, ctx.params)
+
+
+def unet2d(x: torch.Tensor, weights: "ops.UnetWeights") -> torch.Tensor:
+    return UnetFn.apply(x, weights, *weights.distinct_params())
+
+
+# ------------------------------------------------------------------ NormUnet (2-D)
+class NormUnetFn(Function):
+    """NormUnet.forward (norm_unet.py:98-114) on x (n, h, w, 2)."""
+
+    @staticmethod
+    def forward(ctx, x, weights, *params):
+        x = ops._dev(x, "normunet input")
+        n, h, w, _ = x.shape
+        planes, stats = ops.normunet_pack(x)
+        q, ws = unet2d_forward_train(planes, weights)
+        y = ops.normunet_unpack(q, stats, h, w)
+        ctx.weights, ctx.ws, ctx.params, ctx.hw = weights, ws, params, (h, w)
+        ctx.save_for_backward(planes, q, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        planes, q, stats = ctx.saved_tensors
+        h, w = ctx.hw
+        n = planes.shape[0]
+        gy = ops._dev(_c(gy), "normunet output gradient")
+        gq = torch.empty_like(q)
+        dstats = torch.empty_like(stats)
+        check(lib().cine_normunet_unpack_bwd(gy.data_ptr(), q.data_ptr(), stats.data_ptr(), gq.data_ptr(), dstats.data_ptr(),
+                                             n, h, w, _stream()), "cine_normunet_unpack_bwd")
+        need_gx = ctx.needs_input_grad[0]
+        gp, grads = unet2d_backward(planes, gq, ctx.weights, ctx.ws, need_gx)
+        gx = None
+        if need_gx:
+            gx = torch.empty((n, h, w, 2), device=gy.device, dtype=gy.dtype)
+            check(lib().cine_normunet_pack_bwd(gp.data_ptr(), planes.data_ptr(), stats.data_ptr(), dstats.data_ptr(), gx.data_ptr(),
+                                               n, h, w, _stream()), "cine_normunet_pack_bwd")
+        return (gx, None) + _param_grads(ctx.weights, grads, ctx.params)
+
+
+def norm_unet(x: torch.Tensor, weights: "ops.UnetWeights") -> torch.Tensor:
+    return NormUnetFn.apply(x, weights, *weights.distinct_params())
+
+
+# ------------------------------------------------------------------ x-f / y-f regulariser (both NormUnets)
+class XfyfFn(Function):
+    """VarNetBlock.xfyf_transform (varnet.py:196-241) on image (b, t, h, w, 2) -> (b, t, 1, h, w, 2).
+    ``wboth`` holds both U-Nets (x-f first); ``wx`` / ``wy`` the single ones for plane sets of different shapes."""
+
+    @staticmethod
+    def forward(ctx, image, xf, wboth, wx, wy, *params):
+        image = ops._dev(image, "image")
+        b, t, h, w, _ = image.shape
+        pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image, xf)
+        joint = pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr()
+        if joint:
+            planes = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+            q, ws = unet2d_forward_train(planes, wboth)
+            oxf, oyf = q[:pxf.shape[0]], q[pxf.shape[0]:]
+            ctx.ws = (ws,)
+        else:
+            oxf, ws0 = unet2d_forward_train(pxf, wx)
+            oyf, ws1 = unet2d_forward_train(pyf, wy)
+            ctx.ws = (ws0, ws1)
+        out = ops.xfyf_unpack(oxf, oyf, sxf, syf, mean, b, t, h, w, xf)
+        ctx.cfg = (b, t, h, w, bool(xf), joint)
+        ctx.weights, ctx.params = (wboth, wx, wy), params
+        ctx.save_for_backward(pxf, pyf, oxf, oyf, sxf, syf)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pxf, pyf, oxf, oyf, sxf, syf = ctx.saved_tensors
+        b, t, h, w, xf, joint = ctx.cfg
+        wboth, wx, wy = ctx.weights
+        gout = ops._dev(_c(gout), "xfyf output gradient")
+        dev, dt = gout.device, gout.dtype
+        nbytes = lib().cine_xfyf_bwd_ws_bytes(b, t, h, w)
+        wsb = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        if joint:
+            gq = torch.empty((pxf.shape[0] + pyf.shape[0],) + tuple(pxf.shape[1:]), device=dev, dtype=dt)
+            gqx, gqy = gq[:pxf.shape[0]], gq[pxf.shape[0]:]
+        else:
+            gqx, gqy = torch.empty_like(oxf), torch.empty_like(oyf)
+        dsx, dsy = torch.empty_like(sxf), torch.empty_like(syf)
+        gmean = torch.empty((b, h, w, 2), device=dev, dtype=dt)
+        check(lib().cine_xfyf_unpack_bwd(gout.data_ptr(), oxf.data_ptr(), oyf.data_ptr(), sxf.data_ptr(), syf.data_ptr(),
+                                         gqx.data_ptr(), gqy.data_ptr(), dsx.data_ptr(), dsy.data_ptr(), gmean.data_ptr(),
+                                         b, t, h, w, int(xf), wsb.data_ptr(), nbytes, _stream()), "cine_xfyf_unpack_bwd")
+        if joint:
+            planes = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+            gp, grads = unet2d_backward(planes, gq, wboth, ctx.ws[0], True)
+            gpx, gpy = gp[:pxf.shape[0]], gp[pxf.shape[0]:]
+            pg = _param_grads(wboth, grads, ctx.params)
+        else:
+            gpx, g0 = unet2d_backward(pxf, gqx, wx, ctx.ws[0], True)
+            gpy, g1 = unet2d_backward(pyf, gqy, wy, ctx.ws[1], True)
+            a, c = _param_grads(wx, g0, ctx.params), _param_grads(wy, g1, ctx.params)
+            pg = tuple(u if v is None else (v if u is None else u + v) for u, v in zip(a, c))
+        gimg = None
+        if ctx.needs_input_grad[0]:
+            gimg = torch.empty((b, t, h, w, 2), device=dev, dtype=dt)
+            check(lib().cine_xfyf_pack_bwd(gpx.data_ptr(), gpy.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), sxf.data_ptr(), syf.data_ptr(),
+                                           dsx.data_ptr(), dsy.data_ptr(), gmean.data_ptr(), gimg.data_ptr(), b, t, h, w, int(xf),
+                                           wsb.data_ptr(), nbytes, _stream()), "cine_xfyf_pack_bwd")
+        return (gimg, None, None, None, None) + pg
+
+
+def xfyf(image: torch.Tensor, xf: bool, wboth, wx, wy) -> torch.Tensor:
+    return XfyfFn.apply(image, xf, wboth, wx, wy, *wboth.distinct_params())
+
+
+# ------------------------------------------------------------------ coil operators
+class ImageDcFn(Function):
+    """cine_image_dc with the soft-DC weights of softplus(lambda) (varnet.py:181-194, 281-282):
+    out = sum_c conj(S_c) T(S_c m) + v / (1 + v) zf,  T = IFFT_h [mask ? 1 / (1 + v) : 1] FFT_h."""
+
+    @staticmethod
+    def forward(ctx, m, sens, zf, mask, lam):
+        out = ops.image_dc(m, sens, zf, mask, lam)
+        ctx.save_for_backward(m, sens, zf, mask, lam)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        m, sens, zf, mask, lam = ctx.saved_tensors
+        gout = ops._dev(_c(gout), "image_dc output gradient")
+        m = ops._dev(m, "image")
+        b, _, c, h, w, _ = sens.shape
+        t = m.shape[1]
+        need = ctx.needs_input_grad
+        gm = ops.image_dc(gout, sens, None, mask, lam).view(m.shape) if need[0] else None      # T is Hermitian
+        gs = None
+        if need[1]:
+            part = torch.empty((b, t, c, h, w, 2), device=m.device, dtype=m.dtype)
+            check(lib().cine_image_dc_sens_grad(m.data_ptr(), gout.data_ptr(), ops._dev(sens, "sens_maps").data_ptr(), mask.data_ptr(),
+                                                lam.detach().data_ptr(), 0.0, 0.0, part.data_ptr(), b, t, c, h, w, _stream()),
+                  "cine_image_dc_sens_grad")
+            gs = coil_accum(None, part)
+        gzf = None
+        if need[2]:
+            gzf = torch.empty_like(zf)
+            check(lib().cine_axpby_lam(gzf.data_ptr(), None, gout.data_ptr(), gout.numel(), lam.detach().data_ptr(), 1, 1.0, _stream()),
+                  "cine_axpby_lam")
+        glam = None
+        if need[4]:
+            # d out / d v = (zf - A^H M A m) / (1 + v)^2;  v = softplus(lambda), dv / dlambda = sigmoid(lambda)
+            d = ops.image_dc(m, sens, zf, mask, None, weights=(-1.0, 0.0, 1.0))
+            dot = ops.dot(gout, d)
+            lv = lam.detach()
+            v = torch.nn.functional.softplus(lv)
+            glam = (dot * torch.sigmoid(lv) / ((1 + v) * (1 + v))).view(lam.shape)
+        return gm, gs, gzf, None, glam
+
+
+def coil_accum(g: Optional[torch.Tensor], z: torch.Tensor) -> torch.Tensor:
+    """sum_t conj(g[b, t]) z[b, t, c] -> (b, 1, c, h, w, 2) (g None: sum_t z)."""
+    b, t, c, h, w, _ = z.shape
+    gs = torch.empty((b, 1, c, h, w, 2), device=z.device, dtype=z.dtype)
+    check(lib().cine_coil_accum(_p(g), z.data_ptr(), gs.data_ptr(), b, t, c, h, w, 0, _stream()), "cine_coil_accum")
+    return gs
+
+
+class CoilReduceFn(Function):
+    """sens_reduce(mask * k) (varnet.py:187-194) as a function of the maps; k-space is data (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, kspace, sens, mask):
+        hyb = ops.kspace_to_hybrid(kspace, mask=mask)
+        out = ops.hybrid_reduce(hyb, sens)
+        ctx.save_for_backward(kspace, mask if mask is not None else torch.empty(0))
+        ctx.has_mask = mask is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        kspace, mask = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        gout = ops._dev(_c(gout), "sens_reduce output gradient")
+        k = ops.apply_mask(kspace, mask) if ctx.has_mask else kspace
+        z = ops.fft2c(k, inverse=True)                        # coil images
+        return None, coil_accum(gout, z), None
+
+
+class RssNormFn(Function):
+    """x / rss_complex(x, coil) (varnet.py:58-59) on (b, c, h, w, 2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = ops._dev(x, "sens-net output")
+        ctx.save_for_backward(x)
+        return ops.rss_normalise_(x.clone())
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = ops._dev(_c(gy), "rss_normalise output gradient")
+        b, c, h, w, _ = x.shape
+        gx = torch.empty_like(x)
+        check(lib().cine_rss_normalise_bwd(gy.data_ptr(), x.data_ptr(), gx.data_ptr(), b, c, h, w, _stream()), "cine_rss_normalise_bwd")
+        return gx
+
+
+class AbsFn(Function):
+    """complex_abs (utils/math.py:48-62)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = ops._dev(x, "complex_abs input")
+        ctx.save_for_backward(x)
+        return ops.complex_abs(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = ops._dev(_c(gy), "complex_abs output gradient")
+        gx = torch.empty_like(x)
+        check(lib().cine_complex_abs_bwd(gy.data_ptr(), x.data_ptr(), gx.data_ptr(), gy.numel(), _stream()), "cine_complex_abs_bwd")
+        return gx
+
+
+def grad_mode(module: torch.nn.Module) -> bool:
+    """True when the call should build an autograd graph (what ``loss.backward()`` in a training_step needs)."""
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())

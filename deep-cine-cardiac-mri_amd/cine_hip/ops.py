@@ -137,6 +137,15 @@ def kspace_to_hybrid(k: torch.Tensor, out: Optional[torch.Tensor] = None, mask: 
     return out
 
 
+def as_mask_u8(mask: torch.Tensor) -> torch.Tensor:
+    """The kernels read uint8 masks; the reference's models accept any numeric 0 / 1 mask (``apply_mask`` returns a float
+    one, data/transforms.py:66-92).  Converted once, outside any kernel (not during hipGraph capture)."""
+    if mask.dtype == torch.uint8:
+        return mask
+    _no_capture("a uint8 copy of the sampling mask")
+    return (mask != 0).to(torch.uint8)
+
+
 def is_row_mask(mask: torch.Tensor, kspace: torch.Tensor) -> bool:
     """True for the reference's mask layout (b, t, 1, h, 1, 1) (data/transforms.py:341-343)."""
     b, t, _, h, _, _ = kspace.shape
@@ -461,6 +470,18 @@ def _pack(kind: str, w: torch.Tensor) -> torch.Tensor:
         cout, cin = w.shape[0], w.shape[1]
         out = torch.empty(L.cine_conv1x1_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
         check(L.cine_pack_conv1x1(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv1x1")
+    elif kind == "c3d":      # input-gradient packings (training): include/cine_hip.h "Training"
+        cout, cin = w.shape[:2]
+        out = torch.empty(L.cine_conv3x3_dgrad_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_conv3x3_dgrad(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv3x3_dgrad")
+    elif kind == "tcd":
+        cin, cout = w.shape[:2]
+        out = torch.empty(L.cine_tconv2x2_dgrad_packed_floats(cin, cout), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_tconv2x2_dgrad(w.data_ptr(), out.data_ptr(), cin, cout, _stream()), "cine_pack_tconv2x2_dgrad")
+    elif kind == "c1d":
+        cout, cin = w.shape[:2]
+        out = torch.empty(L.cine_conv1x1_dgrad_packed_floats(cout, cin), device=w.device, dtype=w.dtype)
+        check(L.cine_pack_conv1x1_dgrad(w.data_ptr(), out.data_ptr(), cout, cin, _stream()), "cine_pack_conv1x1_dgrad")
     else:
         raise ValueError(kind)
     return out
@@ -562,6 +583,10 @@ class UnetWeights:
         self._key = None
         self._keep = []
         self._ptrs = None
+        self._captured = False
+        self._dkey = None
+        self._dkeep = []
+        self._dptrs = None
 
     def _params(self):
         out = []
@@ -584,7 +609,11 @@ class UnetWeights:
         key = tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
         if key != self._key:
             _no_capture("packed U-Net weights")
-            self._old = getattr(self, "_old", []) + [self._keep]     # graphs captured earlier still hold the old pointers
+            # graphs captured earlier still hold the old pointers: keep the superseded packs alive only when a capture has
+            # taken place since they were made (a training loop re-packs every step and must not pile them up)
+            if self._captured:
+                self._old = getattr(self, "_old", []) + [self._keep]
+            self._captured = False
             keep, ptrs = [], []
             for seq in params:
                 for kind, p in seq:
@@ -592,7 +621,45 @@ class UnetWeights:
                     keep.append(t); ptrs.append(t.data_ptr())
             self._keep, self._key = keep, key
             self._ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
         return self._ptrs
+
+    def release_old(self) -> None:
+        """Drop packed weight sets that only earlier-captured graphs may reference (call after destroying those graphs)."""
+        self._old = []
+
+    # ---- training (cine_unet2d_backward)
+    def param_lists(self):
+        """Per weight set, the parameters in the order of the pointer lists (bias last)."""
+        return [[p for _, p in seq] for seq in self._params()]
+
+    def distinct_params(self):
+        seen, out = set(), []
+        for seq in self._params():
+            for _, p in seq:
+                if id(p) not in seen:
+                    seen.add(id(p)); out.append(p)
+        return out
+
+    def dgrad_pointers(self):
+        """Input-gradient packings in the order of ``pointers()`` (NULL in the bias slot); re-packed when a parameter changes."""
+        params = self._params()
+        key = tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
+        if key != self._dkey:
+            _no_capture("packed U-Net gradient weights")
+            keep, ptrs = [], []
+            for seq in params:
+                for kind, p in seq:
+                    if kind == "raw":
+                        ptrs.append(None); continue
+                    if kind not in ("c3", "tc", "c1"):
+                        raise CineHipError("training through the 3-D U-Net is not on the HIP path")
+                    t = _pack(kind + "d", p)
+                    keep.append(t); ptrs.append(t.data_ptr())
+            self._dkeep, self._dkey = keep, key
+            self._dptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        return self._dptrs
 
 
 def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -647,11 +714,18 @@ class MwcnnWeights:
         key = tuple((p.data_ptr(), p._version) for _, p in params)
         if key != self._key:
             _no_capture("packed MWCNN weights")
-            self._old = getattr(self, "_old", []) + [self._keep]     # graphs captured earlier still hold the old pointers
+            if getattr(self, "_captured", False):                    # graphs captured earlier still hold the old pointers
+                self._old = getattr(self, "_old", []) + [self._keep]
+            self._captured = False
             keep = [(_dev(p.detach(), "mwcnn bias") if kind == "raw" else _pack(kind, p)) for kind, p in params]
             self._keep, self._key = keep, key
             self._ptrs = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
         return self._ptrs
+
+    def release_old(self) -> None:
+        self._old = []
 
 
 def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights, w2: Optional[MwcnnWeights] = None, split: int = 0) -> torch.Tensor:

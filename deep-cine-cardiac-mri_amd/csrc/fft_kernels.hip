@@ -793,6 +793,80 @@ __global__ __launch_bounds__(kThreadsGen) void imgdc_generic_kernel(ImgDcArgs a)
     }
 }
 
+// ------------------------------------------------------------------ image-space DC, gradient with respect to the maps
+// out = sum_c conj(S_c) T(S_c m) with T = IFFT_h W FFT_h (Hermitian).  For the output gradient g (real-pair convention,
+// d loss = Re(conj(g) d out)) the maps receive, per frame,
+//     gS_c = conj(g) T(S_c m)  +  T(S_c g) conj(m)
+// (first term: the conj(S_c) factor; second: the S_c factor inside T).  One workgroup = one (frame, coil) x kLinesGen columns:
+// two transform chains through LDS, result written per frame into `part` (b, t, c, h, w); cine_coil_accum adds the frames.
+struct DcGradArgs {
+    const cf* m; const cf* g; const cf* sens; const uint8_t* mask; const float* lam; float w1, w0;
+    cf* part; int T, C, H, W;
+};
+template <bool F200>
+__global__ __launch_bounds__(kThreadsGen) void imgdc_sgrad_kernel(DcGradArgs a) {
+    constexpr int LINES = kLinesGen, LP = LINES + 1;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int H = F200 ? 200 : a.H;
+    cf* t0 = reinterpret_cast<cf*>(smem);
+    cf* t1 = t0 + H * LP;
+    cf* tw = t1 + H * LP;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int w0c = blockIdx.x * LINES, coil = blockIdx.y;
+    const int bt = blockIdx.z, b = bt / a.T;
+    const long HW = (long)H * a.W;
+    float w1 = a.w1, w0 = a.w0;
+    if (a.lam) { const float v = softplus1(*a.lam); w1 = 1.0f / (1.f + v); w0 = 1.f; }
+    load_twiddles<F200>(tw, H);
+    const uint8_t* mrow = a.mask + (long)bt * H;
+    const int s_in = (H + 1) / 2, s_out = H / 2;
+    const cf* sp = a.sens + ((long)b * a.C + coil) * HW;
+    cf acc[kDcAcc];
+#pragma unroll
+    for (int q = 0; q < kDcAcc; ++q) acc[q] = mk(0.f, 0.f);
+    for (int pass = 0; pass < 2; ++pass) {
+        const cf* src = (pass ? a.g : a.m) + (long)bt * HW;
+        const cf* oth = (pass ? a.m : a.g) + (long)bt * HW;
+        __syncthreads();
+        for (int e = tid; e < H * LINES; e += nt) {
+            const int gg = e / LINES, l = e - gg * LINES, col = w0c + l;
+            cf v = mk(0.f, 0.f);
+            if (col < a.W) v = cmul(src[(long)gg * a.W + col], sp[(long)gg * a.W + col]);
+            int n = gg + s_in; if (n >= H) n -= H;
+            t0[n * LP + l] = v;
+        }
+        __syncthreads();
+        cf* res = run_lines<F200, 1, LINES>(t0, t1, H, tw);
+        cf* other = res == t0 ? t1 : t0;
+        for (int e = tid; e < H * LINES; e += nt) {
+            const int i = e / LINES, l = e - i * LINES;
+            int k = i - s_out; if (k < 0) k += H;
+            int n = i + s_in; if (n >= H) n -= H;
+            other[n * LP + l] = cscale(res[res_pos<F200>(k) * LP + l], mrow[i] ? w1 : w0);
+        }
+        __syncthreads();
+        cf* res2 = run_lines<F200, -1, LINES>(other, res, H, tw);
+#pragma unroll
+        for (int q = 0; q < kDcAcc; ++q) {
+            const int e = tid + q * nt;
+            if (e >= H * LINES) break;
+            const int i = e / LINES, l = e - i * LINES, col = w0c + l;
+            if (col >= a.W) continue;
+            int k = i - s_out; if (k < 0) k += H;
+            const cf u = cmulc(res2[res_pos<F200>(k) * LP + l], oth[(long)i * a.W + col]);    // pass 0: T(S m) conj(g); pass 1: T(S g) conj(m)
+            acc[q].x += u.x; acc[q].y += u.y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kDcAcc; ++q) {
+        const int e = tid + q * nt;
+        if (e >= H * LINES) break;
+        const int i = e / LINES, l = e - i * LINES, col = w0c + l;
+        if (col >= a.W) continue;
+        a.part[((long)bt * a.C + coil) * HW + (long)i * a.W + col] = acc[q];
+    }
+}
+
 // ------------------------------------------------------------------ host side
 static size_t lds_bytes(bool f200, int n, int lines) {
     const size_t tile = (size_t)n * (lines + 1) * sizeof(cf);
@@ -1112,4 +1186,25 @@ extern "C" int cine_expand_dc_hybrid(const float* img, const float* sens, const 
                                      const float* lambda_dev, float* hyb, int b, int t, int c, int h, int w,
                                      int hard_mask, void* stream) {
     return expand_dc(img, sens, kref, mask, lambda_dev, hyb, b, t, c, h, w, hard_mask, true, stream, "cine_expand_dc_hybrid");
+}
+
+// Gradient of cine_image_dc's output with respect to the sensitivity maps, per frame: part (b, t, c, h, w) (see imgdc_sgrad_kernel).
+// Weights as cine_image_dc (lambda_dev != NULL: soft DC).  Sum over the frames with cine_coil_accum(NULL, part, ...).
+extern "C" int cine_image_dc_sens_grad(const float* img, const float* gout, const float* sens, const uint8_t* mask,
+                                       const float* lambda_dev, float w_sampled, float w_unsampled,
+                                       float* part, int b, int t, int c, int h, int w, void* stream) {
+    CINE_REQUIRE(img && gout && sens && mask && part, CINE_EINVAL, "cine_image_dc_sens_grad: null pointer");
+    CINE_REQUIRE(b > 0 && t > 0 && c > 0 && c <= 65535 && h > 0 && w > 0 && (long)b * t <= 65535, CINE_EINVAL, "cine_image_dc_sens_grad: bad sizes");
+    if (int e = check_n(h, "cine_image_dc_sens_grad(h)")) return e;
+    DcGradArgs a{};
+    a.m = reinterpret_cast<const cf*>(img); a.g = reinterpret_cast<const cf*>(gout); a.sens = reinterpret_cast<const cf*>(sens);
+    a.mask = mask; a.lam = lambda_dev; a.w1 = w_sampled; a.w0 = w_unsampled; a.part = reinterpret_cast<cf*>(part);
+    a.T = t; a.C = c; a.H = h; a.W = w;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(F_FFT_COL, st);
+    const dim3 grid(ceil_div(w, kLinesGen), c, b * t);
+    const size_t lds = (size_t)(2 * h * (kLinesGen + 1) + h) * sizeof(cf);
+    if (h == 200) hipLaunchKernelGGL(imgdc_sgrad_kernel<true>, grid, dim3(kThreadsGen), lds, st, a);
+    else hipLaunchKernelGGL(imgdc_sgrad_kernel<false>, grid, dim3(kThreadsGen), lds, st, a);
+    return check_launch("imgdc_sgrad_kernel");
 }

@@ -1,0 +1,371 @@
+// grad_kernels.hip -- gradients of the U-Net building blocks (training through the HIP path).
+//
+// The forward pass keeps every layer's RAW output with its InstanceNorm statistics records; normalised / activated /
+// pooled / concatenated tensors never exist in HBM (conv_kernels.hip).  The backward pass mirrors that:
+//   in_lrelu_bwd_kernel : d/d(raw) from d/d(activated) for one (sample, channel) plane -- LeakyReLU mask, the two
+//                         InstanceNorm reductions (sum g, sum g xhat) and the result in one kernel; the pieces of the
+//                         incoming gradient (concat half, zero-pad crop, 2x2 average-pool gradient) are gathered on load
+//   wgrad_mfma_kernel   : weight gradient as a GEMM on v_mfma_f32_16x16x4_f32 with K = pixels x samples:
+//                         D[ci][co] (per tap) += X[ci][p + tap] * G[co][p]; the input operand is re-activated on load
+//                         exactly like the forward's staging (modes 0 / 1 / 2, concat), partial sums per sample chunk,
+//                         added in a fixed order by wgrad_reduce_kernel (deterministic, no atomics)
+//   the input gradients (dgrad) are forward convolutions with re-packed weights (conv_kernels.hip: cine_*_dgrad).
+// Reference: reconstruction/models/denoisers/unet.py:73-125 (what autograd differentiates there).
+#include <algorithm>
+#include "grad.h"
+
+namespace cine {
+
+__device__ __forceinline__ float wave_sum_g(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- InstanceNorm + LeakyReLU backward
+// g(y, x) of the plane: concat / crop piece + pooled piece
+__device__ __forceinline__ float in_bwd_g(const InBwdArgs& a, const float* ga, const float* gb, int y, int x) {
+    float g = 0.f;
+    if (ga) g = ga[(long)y * a.wa + x];
+    if (gb) { const int py = y >> 1, px = x >> 1; if (py < a.hb && px < a.wb) g = fmaf(0.25f, gb[(long)py * a.wb + px], g); }
+    return g;
+}
+
+// WAVE = true: one wave per plane (small planes), else one workgroup per plane
+template <bool WAVE>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long plane = WAVE ? (long)blockIdx.x * 4 + wave : blockIdx.x;
+    const long planes = (long)a.n * a.c;
+    const bool live = plane < planes;
+    const long pl = live ? plane : planes - 1;
+    const int n = (int)(pl / a.c), c = (int)(pl - (long)n * a.c);
+    const int pe = a.h * a.w;
+    const float2 mr = merge_partials(a.part + pl * a.np * 3, a.np, a.eps);
+    const float scale = mr.y, shift = -mr.x * mr.y;
+    const float* r = a.r + pl * pe;
+    const float* ga = a.ga ? a.ga + ((long)n * a.ca_total + a.ca_off + c) * a.ha * a.wa : nullptr;
+    const float* gb = a.gb ? a.gb + pl * a.hb * a.wb : nullptr;
+    float* gr = a.gr + pl * pe;
+    const int t0 = WAVE ? lane : threadIdx.x, ts = WAVE ? 64 : 256;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = t0; e < pe; e += ts) {
+        const int y = e / a.w, x = e - y * a.w;
+        const float xh = fmaf(r[e], scale, shift);
+        float g = in_bwd_g(a, ga, gb, y, x);
+        g = xh > 0.f ? g : g * a.slope;
+        s1 += g; s2 = fmaf(g, xh, s2);
+    }
+    s1 = wave_sum_g(s1); s2 = wave_sum_g(s2);
+    if (!WAVE) {
+        if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+        __syncthreads();
+        s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+    if (!live) return;
+    const float m1 = s1 / pe, m2 = s2 / pe;
+    for (int e = t0; e < pe; e += ts) {
+        const int y = e / a.w, x = e - y * a.w;
+        const float xh = fmaf(r[e], scale, shift);
+        float g = in_bwd_g(a, ga, gb, y, x);
+        g = xh > 0.f ? g : g * a.slope;
+        gr[e] = scale * (g - m1 - xh * m2);
+    }
+}
+
+int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st) {
+    CINE_REQUIRE(a.r && a.part && a.gr && (a.ga || a.gb) && a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.np > 0, CINE_EINVAL,
+                 "in_lrelu_bwd: bad arguments");
+    CINE_REQUIRE(!a.ga || (a.ha >= a.h && a.wa >= a.w && a.ca_off >= 0 && a.ca_off + a.c <= a.ca_total), CINE_EINVAL,
+                 "in_lrelu_bwd: gradient window (%d, %d) smaller than the tensor (%d, %d)", a.ha, a.wa, a.h, a.w);
+    const long planes = (long)a.n * a.c;
+    ProfScope prof(F_STATS, st);
+    if ((long)a.h * a.w <= 1024) {
+        CINE_REQUIRE(ceil_div(planes, 4L) <= 0x7fffffffL, CINE_EUNSUPPORTED, "in_lrelu_bwd: too many planes");
+        hipLaunchKernelGGL(in_lrelu_bwd_kernel<true>, dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, st, a);
+    } else {
+        CINE_REQUIRE(planes <= 0x7fffffffL, CINE_EUNSUPPORTED, "in_lrelu_bwd: too many planes");
+        hipLaunchKernelGGL(in_lrelu_bwd_kernel<false>, dim3((unsigned)planes), dim3(256), 0, st, a);
+    }
+    return check_launch("in_lrelu_bwd_kernel");
+}
+
+// ---------------------------------------------------------------- weight gradient (MFMA)
+// One workgroup = 4 waves = one 16-channel chunk of the conv input x one block of 16*CT*WM output rows x one chunk of
+// samples.  Per tile of NPIX = TH x TW pixels it stages the (re-activated) input tile with its halo and the output-gradient
+// tile in LDS, channel-major with a channel stride == 2 (mod 32) floats: the MFMA operands are read with ds_read_b32 by
+// lanes (channel q, pixel kk) -> bank 2 q + kk, conflict-free.  WM waves split the row tiles, 4 / WM waves split the pixel
+// groups (K); the K-split accumulators are added through LDS in a fixed order at the end.
+struct WgLaunch {
+    WgArgs a;
+    int chunk, nchunks;        // samples per chunk, chunks per weight set
+    int rowsp, cinp;           // padded to 16
+    float* part;               // [2][nchunks][rowsp][cinp][TAPS]
+};
+
+template <int TAPS, int TW, int CT, int WM, int NPIX>
+struct WgCfg {
+    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int TH = NPIX / TW;
+    static constexpr int ROWS = TH + 2 * HALO, COLS = TW + 2 * HALO;
+    static constexpr int pad2(int v) { return ((v + 29) / 32) * 32 + 2; }       // smallest >= v with == 2 (mod 32)
+    static constexpr int PSI = pad2(ROWS * COLS), PSG = pad2(NPIX);
+    static constexpr int COB = 16 * CT * WM, WK = 4 / WM;
+    static constexpr int IN_FLOATS = 16 * PSI, G_FLOATS = COB * PSG;
+    static constexpr int RED_FLOATS = WK > 1 ? TAPS * CT * WM * 256 : 0;       // the accumulators of one K-split slice
+    static constexpr int LDS_FLOATS = (IN_FLOATS + G_FLOATS > RED_FLOATS ? IN_FLOATS + G_FLOATS : RED_FLOATS) + 32;
+    static_assert(NPIX % TW == 0 && NPIX % 4 == 0, "tile shape");
+};
+
+template <int TAPS, int TW, int CT, int WM, int NPIX>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
+    using C = WgCfg<TAPS, TW, CT, WM, NPIX>;
+    constexpr int HALO = C::HALO;
+    extern __shared__ __align__(16) float smem_g[];
+    float* in_lds = smem_g;
+    float* g_lds = smem_g + C::IN_FLOATS;
+    float* st_lds = smem_g + C::LDS_FLOATS - 32;      // {scale, shift} of the chunk's 16 input channels
+    const WgArgs& a = L.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 15, kk = lane >> 4;
+    const int wm = wave % WM, wk = wave / WM;
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * C::COB;
+    const int set = blockIdx.z / L.nchunks, ch = blockIdx.z - set * L.nchunks;
+    const int sbeg = (set ? a.set_split : 0) + ch * L.chunk;
+    const int send = min(sbeg + L.chunk, set ? a.n : a.set_split);
+    const int c0n = src_cin(a.s0);
+
+    f32x4 acc[TAPS][CT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_w = (a.W + TW - 1) / TW, tiles_h = (a.H + C::TH - 1) / C::TH;
+    // my chunk-channel's source (threads 0..15 own the statistics table; everyone needs the source of the channels it stages)
+    const Src gs{a.g, nullptr, a.g_c, a.g_mode, a.g_h, a.g_w, 0, 0, 1};
+
+    for (int n = sbeg; n < send; ++n) {
+        __syncthreads();                                        // previous sample's sweeps are done with st_lds
+        if (tid < 16) {
+            const int cg = ci0 + tid;
+            float2 mr = make_float2(0.f, 1.f);
+            if (cg < a.cin) {
+                const bool f0 = cg < c0n;
+                const Src& s = f0 ? a.s0 : a.s1;
+                const int cl = f0 ? cg : cg - c0n;
+                if (s.mode == 1 || s.mode == 2) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+            }
+            st_lds[2 * tid] = mr.y; st_lds[2 * tid + 1] = -mr.x * mr.y;
+        }
+        for (int tile = 0; tile < tiles_w * tiles_h; ++tile) {
+            const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+            const int r0 = ty * C::TH, c0 = tx * TW;
+            __syncthreads();                                    // table ready / previous tile's sweeps done
+            // ---- stage the input tile (+ halo), re-activated like the forward's operand staging
+            for (int e = tid; e < 16 * C::ROWS * C::COLS; e += 256) {
+                const int k = e / (C::ROWS * C::COLS), rem = e - k * (C::ROWS * C::COLS);
+                const int row = rem / C::COLS, col = rem - row * C::COLS;
+                const int gy = r0 - HALO + row, gx = c0 - HALO + col, cg = ci0 + k;
+                float v = 0.f;
+                if (cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                    const bool f0 = cg < c0n;
+                    const int cl = f0 ? cg : cg - c0n;
+                    v = fetch_scalar(f0 ? a.s0 : a.s1, n, cl, 0, gy, gx, st_lds + 2 * k - 2 * cl, a.slope);
+                }
+                in_lds[k * C::PSI + rem] = v;
+            }
+            // ---- stage the output-gradient tile
+            for (int e = tid; e < C::COB * NPIX; e += 256) {
+                const int co = e / NPIX, p = e - co * NPIX;
+                const int gy = r0 + p / TW, gx = c0 + p % TW;
+                float v = 0.f;
+                if (co0 + co < a.rows && gy < a.H && gx < a.W)
+                    v = a.g_mode == 5 ? fetch_scalar(gs, n, co0 + co, 0, gy, gx, st_lds, a.slope)
+                                      : a.g[(((long)n * a.rows + co0 + co) * a.H + gy) * a.W + gx];
+                g_lds[co * C::PSG + p] = v;
+            }
+            __syncthreads();
+            // ---- sweep: K = pixel groups of 4
+            for (int g = wk; g < NPIX / 4; g += C::WK) {
+                const int p = 4 * g + kk;
+                const int prow = p / TW, pcol = p % TW;
+                float gv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) gv[ct] = g_lds[(16 * (wm * CT + ct) + q) * C::PSG + p];
+                const float* ib = in_lds + q * C::PSI + prow * C::COLS + pcol;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const float xv = ib[(TAPS == 9 ? (t / 3) * C::COLS + (t % 3) : 0)];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, gv[ct], acc[t][ct], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- the partial goes out.  lane (q, kk), register j of acc[t][ct]: D[ci = 4 kk + j][co = 16 (wm CT + ct) + q]
+    float* part = L.part + (((long)blockIdx.z * L.rowsp + co0) * L.cinp + ci0) * TAPS;
+    if (C::WK == 1) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    part[((long)(16 * (wm * CT + ct) + q) * L.cinp + 4 * kk + j) * TAPS + t] = acc[t][ct][j];
+        return;
+    }
+    // K-split waves add their accumulators through LDS in a fixed order first
+    __syncthreads();
+    float* red = smem_g;                                          // [TAPS][CT * WM][16 ci][16 co]
+    for (int turn = 0; turn < C::WK; ++turn) {
+        if (wk == turn) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* o = red + ((t * (CT * WM) + wm * CT + ct) * 16 + 4 * kk + j) * 16 + q;
+                        *o = turn == 0 ? acc[t][ct][j] : *o + acc[t][ct][j];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < TAPS * C::COB * 16; e += 256) {
+        const int t = e % TAPS, r2 = e / TAPS;
+        const int ci = r2 % 16, co = r2 / 16;
+        part[((long)co * L.cinp + ci) * TAPS + t] = red[((t * (CT * WM) + co / 16) * 16 + ci) * 16 + (co % 16)];
+    }
+}
+
+// grad (+)= sum over the sample chunks of one weight set, in chunk order
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nchunks, int rows, int cin, int rowsp, int cinp,
+                                                           int taps, int kind, float* grad0, float* grad1) {
+    const int set = blockIdx.y;
+    float* grad = set ? grad1 : grad0;
+    if (!grad) return;
+    const long total = (long)rows * cin * taps;
+    const long pstride = (long)rowsp * cinp * taps;
+    const float* p0 = part + (long)set * nchunks * pstride;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(e % taps);
+        const long r2 = e / taps;
+        const int ci = (int)(r2 % cin), row = (int)(r2 / cin);
+        const float* p = p0 + ((long)row * cinp + ci) * taps + t;
+        float s = 0.f;
+        for (int c = 0; c < nchunks; ++c) s += p[c * pstride];
+        long o;
+        if (kind == 1) o = (long)ci * rows + row;                // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
+        else o = e;                                               // (rows, cin, taps)
+        grad[o] += s;
+    }
+}
+
+static int wgrad_chunks(int rows, int cin, int n_set) {
+    // enough workgroups to fill the chip a few times over, at least a handful of samples' worth of work each
+    const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
+    const long wgs = (long)ceil_div(cin, 16) * ceil_div(rows, cob);
+    long nch = ceil_div(1024L, wgs);
+    if (nch > n_set) nch = n_set;
+    if (nch < 1) nch = 1;
+    return (int)nch;
+}
+
+size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
+    const int rowsp = ceil_div(rows, 16) * 16, cinp = ceil_div(cin, 16) * 16;
+    const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
+    const int rowsb = ceil_div(rowsp, cob) * cob;
+    return (size_t)2 * wgrad_chunks(rows, cin, n) * rowsb * cinp * taps;
+}
+
+template <int TAPS, int TW, int CT, int WM, int NPIX>
+static int launch_wg_cfg(const WgLaunch& L, dim3 grid, hipStream_t st) {
+    using C = WgCfg<TAPS, TW, CT, WM, NPIX>;
+    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
+    static_assert(C::LDS_FLOATS * sizeof(float) <= 64 * 1024, "wgrad tile exceeds the default LDS limit");
+    hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX>), grid, dim3(256), lds, st, L);
+    return check_launch("wgrad_mfma_kernel");
+}
+
+template <int TAPS, int TW>
+static int launch_wg_tw(const WgLaunch& L, int cob, dim3 grid, hipStream_t st) {
+    // pixels per tile: as many as LDS allows for the row block (the fewer rows, the more pixels amortise the staging)
+    if (cob == 16) return launch_wg_cfg<TAPS, TW, 1, 1, 256>(L, grid, st);
+    if (cob == 32) return launch_wg_cfg<TAPS, TW, 1, 2, 128>(L, grid, st);
+    if (cob == 64) return launch_wg_cfg<TAPS, TW, 1, 4, 128>(L, grid, st);
+    return launch_wg_cfg<TAPS, TW, 2, 4, 64>(L, grid, st);
+}
+
+int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1, float* ws, size_t ws_floats, hipStream_t st) {
+    CINE_REQUIRE(a.g && a.s0.x && ws && grad0 && a.n > 0 && a.rows > 0 && a.cin > 0 && a.H > 0 && a.W > 0, CINE_EINVAL, "wgrad: bad arguments");
+    CINE_REQUIRE(taps == 9 || taps == 1, CINE_EINVAL, "wgrad: taps %d", taps);
+    CINE_REQUIRE(a.s0.mode <= 2 && (a.s1.c == 0 || a.s1.mode <= 2), CINE_EUNSUPPORTED, "wgrad: source modes 0..2 only");
+    CINE_REQUIRE(src_cin(a.s0) + src_cin(a.s1) == a.cin, CINE_EINVAL, "wgrad: channel counts");
+    CINE_REQUIRE(a.set_split >= 0 && a.set_split <= a.n && (a.set_split == a.n || grad1), CINE_EINVAL, "wgrad: second weight set without a gradient");
+    WgLaunch L{};
+    L.a = a;
+    L.rowsp = ceil_div(a.rows, 16) * 16; L.cinp = ceil_div(a.cin, 16) * 16;
+    const int cob = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : a.rows <= 64 ? 64 : 128;
+    const int rowsb = ceil_div(L.rowsp, cob) * cob;
+    L.rowsp = rowsb;                                      // partial rows padded to whole row blocks
+    const int n0 = a.set_split, n1 = a.n - a.set_split;
+    L.nchunks = wgrad_chunks(a.rows, a.cin, std::max(n0, n1));
+    L.chunk = ceil_div(std::max(n0, n1), L.nchunks);
+    L.part = ws;
+    const int nsets = n1 > 0 ? 2 : 1;
+    CINE_REQUIRE(ws_floats >= (size_t)nsets * L.nchunks * L.rowsp * L.cinp * taps, CINE_EWORKSPACE, "wgrad: workspace too small");
+    const dim3 grid(L.cinp / 16, rowsb / cob, nsets * L.nchunks);
+    ProfScope prof(taps == 9 ? F_CONV3 : (kind == 1 ? F_TCONV : F_CONV1), st);
+    int e;
+    const int TW = a.W > 8 ? 16 : a.W > 4 ? 8 : a.W > 2 ? 4 : 2;
+    if (taps == 9) {
+        if (TW == 16) e = launch_wg_tw<9, 16>(L, cob, grid, st);
+        else if (TW == 8) e = launch_wg_tw<9, 8>(L, cob, grid, st);
+        else if (TW == 4) e = launch_wg_tw<9, 4>(L, cob, grid, st);
+        else e = launch_wg_tw<9, 2>(L, cob, grid, st);
+    } else {
+        if (TW == 16) e = launch_wg_tw<1, 16>(L, cob, grid, st);
+        else if (TW == 8) e = launch_wg_tw<1, 8>(L, cob, grid, st);
+        else if (TW == 4) e = launch_wg_tw<1, 4>(L, cob, grid, st);
+        else e = launch_wg_tw<1, 2>(L, cob, grid, st);
+    }
+    if (e) return e;
+    const long total = (long)a.rows * a.cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256L), 1024), nsets), dim3(256), 0, st,
+                       ws, L.nchunks, a.rows, a.cin, L.rowsp, L.cinp, taps, kind, grad0, grad1);
+    return check_launch("wgrad_reduce_kernel");
+}
+
+// ---------------------------------------------------------------- bias gradient
+// one workgroup per (set, channel): fixed-order sum over the set's samples and pixels
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1) {
+    __shared__ float red[4];
+    const int co = blockIdx.x, set = blockIdx.y;
+    float* gb = set ? gb1 : gb0;
+    const int nb = set ? set_split : 0, ne = set ? n : set_split;
+    if (!gb || ne <= nb) return;
+    float s = 0.f;
+    for (int i = nb; i < ne; ++i) {
+        const float* p = g + ((long)i * cout + co) * hw;
+        float t = 0.f;
+        for (long e = threadIdx.x; e < hw; e += 256) t += p[e];
+        s += t;
+    }
+    s = wave_sum_g(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) gb[co] += red[0] + red[1] + red[2] + red[3];
+}
+
+int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, hipStream_t st) {
+    CINE_REQUIRE(g && gb0 && n > 0 && cout > 0 && hw > 0, CINE_EINVAL, "bias_grad: bad arguments");
+    ProfScope prof(F_STATS, st);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(cout, set_split < n ? 2 : 1), dim3(256), 0, st, g, n, cout, hw, set_split, gb0, gb1);
+    return check_launch("bias_grad_kernel");
+}
+
+}  // namespace cine

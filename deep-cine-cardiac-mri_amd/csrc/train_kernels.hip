@@ -1,0 +1,413 @@
+// train_kernels.hip -- adjoints of the byte-moving steps around the regulariser (training through the HIP path):
+// NormUnet group norm / pad / un-norm (denoisers/norm_unet.py:59-96), the XT / XF rotations with the temporal mean and
+// centered DFT (models/varnet.py:196-241), the sensitivity normalisation (varnet.py:58-59), complex_abs (utils/math.py:48-62)
+// and the coil-sum of sens_reduce with respect to the maps (varnet.py:187-194).  Small HBM-bound kernels; every reduction
+// is done in a fixed order (no atomics).
+#include <algorithm>
+#include "common.h"
+#include "fft_core.h"
+
+namespace cine {
+
+__device__ __forceinline__ float wave_sum_t(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float block_sum_t(float v, float* red) {
+    v = wave_sum_t(v);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+// strided view of sample n, element (i, j) of a complex tensor (see normunet_pack_kernel in pack_kernels.hip)
+struct View {
+    float* x; int ninner; long s_outer, s_inner, si, sj;
+    __device__ __forceinline__ float2* at(int n, int i, int j) const {
+        return reinterpret_cast<float2*>(x + (long)(n / ninner) * s_outer + (long)(n % ninner) * s_inner + i * si + j * sj);
+    }
+};
+
+// ---------------------------------------------------------------- NormUnet back half, adjoint
+// forward (norm_unet.py:88-96, 71-74): out[n](i, j) = q[n][ch][i + pad_i][j + pad_j] * std_ch + mean_ch
+// given gout: gq = gout * std inside the window, 0 on the pad frame;  dstats[n] = {sum gout_re, sum gout_re q_re, sum gout_im,
+// sum gout_im q_im} (the direct gradients of mean and std).  gscale multiplies gout on load (the 0.5 of varnet.py:232).
+struct UnpackBwdArgs {
+    View gout; const float* q; const float* stats; float* gq; float* dstats;
+    int n, I, J, Ip, Jp, pad_i, pad_j; float gscale;
+};
+struct UnpackBwdArgs2 { UnpackBwdArgs s[2]; };
+
+__global__ __launch_bounds__(256) void normunet_unpack_bwd_kernel(UnpackBwdArgs2 two) {
+    __shared__ float red[16];
+    const UnpackBwdArgs& a = two.s[blockIdx.y];
+    const int n = blockIdx.x;
+    if (n >= a.n) return;
+    const long pp = (long)a.Ip * a.Jp;
+    const float* qr = a.q + (long)n * 2 * pp;
+    const float* qi = qr + pp;
+    float* gr = a.gq + (long)n * 2 * pp;
+    float* gi = gr + pp;
+    float sdr = 1.f, sdi = 1.f;
+    if (a.stats) { sdr = a.stats[(long)n * 4 + 1]; sdi = a.stats[(long)n * 4 + 3]; }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int e = threadIdx.x; e < a.Ip * a.Jp; e += blockDim.x) {
+        const int ip = e / a.Jp, jp = e - ip * a.Jp;
+        const int i = ip - a.pad_i, j = jp - a.pad_j;
+        float vr = 0.f, vi = 0.f;
+        if (i >= 0 && i < a.I && j >= 0 && j < a.J) {
+            const float2 g = *a.gout.at(n, i, j);
+            const float gre = g.x * a.gscale, gim = g.y * a.gscale;
+            s0 += gre; s1 = fmaf(gre, qr[e], s1); s2 += gim; s3 = fmaf(gim, qi[e], s3);
+            vr = gre * sdr; vi = gim * sdi;
+        }
+        gr[e] = vr; gi[e] = vi;
+    }
+    if (a.dstats) {
+        s0 = block_sum_t(s0, red); s1 = block_sum_t(s1, red); s2 = block_sum_t(s2, red); s3 = block_sum_t(s3, red);
+        if (threadIdx.x == 0) { float* d = a.dstats + (long)n * 4; d[0] = s0; d[1] = s1; d[2] = s2; d[3] = s3; }
+    }
+}
+
+// ---------------------------------------------------------------- NormUnet front half, adjoint
+// forward (norm_unet.py:59-69, 76-86): p = (z - mean) / std over the window, std unbiased over the N = I J window values.
+//   gz = gp / std + (dmean - sum(gp) / std) / N + phat (dstd - sum(gp phat) / std) / (N - 1)
+// accumulate != 0 adds into gz (the y-f planes onto the x-f planes' result).
+struct PackBwdArgs {
+    const float* gp; const float* p; const float* stats; const float* dstats; View gz;
+    int n, I, J, Ip, Jp, pad_i, pad_j, accumulate;
+};
+struct PackBwdArgs2 { PackBwdArgs s[2]; };
+
+__global__ __launch_bounds__(256) void normunet_pack_bwd_kernel(PackBwdArgs a) {
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    const long pp = (long)a.Ip * a.Jp;
+    const float* gr = a.gp + (long)n * 2 * pp;
+    const float* gi = gr + pp;
+    const int cnt = a.I * a.J;
+    if (!a.stats) {       // plain repack (cinenet.py:242): the adjoint is the inverse repack
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+            const int i = e / a.J, j = e - i * a.J;
+            const long qd = (long)(i + a.pad_i) * a.Jp + j + a.pad_j;
+            float2* o = a.gz.at(n, i, j);
+            float2 v = make_float2(gr[qd], gi[qd]);
+            if (a.accumulate) { const float2 t = *o; v.x += t.x; v.y += t.y; }
+            *o = v;
+        }
+        return;
+    }
+    const float* pr = a.p + (long)n * 2 * pp;
+    const float* pi = pr + pp;
+    const float sdr = a.stats[(long)n * 4 + 1], sdi = a.stats[(long)n * 4 + 3];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const int i = e / a.J, j = e - i * a.J;
+        const long qd = (long)(i + a.pad_i) * a.Jp + j + a.pad_j;
+        s0 += gr[qd]; s1 = fmaf(gr[qd], pr[qd], s1); s2 += gi[qd]; s3 = fmaf(gi[qd], pi[qd], s3);
+    }
+    s0 = block_sum_t(s0, red); s1 = block_sum_t(s1, red); s2 = block_sum_t(s2, red); s3 = block_sum_t(s3, red);
+    const float* d = a.dstats + (long)n * 4;
+    const float cmr = (d[0] - s0 / sdr) / cnt, csr = (d[1] - s1 / sdr) / (cnt - 1);
+    const float cmi = (d[2] - s2 / sdi) / cnt, csi = (d[3] - s3 / sdi) / (cnt - 1);
+    for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+        const int i = e / a.J, j = e - i * a.J;
+        const long qd = (long)(i + a.pad_i) * a.Jp + j + a.pad_j;
+        float2 v = make_float2(gr[qd] / sdr + cmr + pr[qd] * csr, gi[qd] / sdi + cmi + pi[qd] * csi);
+        float2* o = a.gz.at(n, i, j);
+        if (a.accumulate) { const float2 t = *o; v.x += t.x; v.y += t.y; }
+        *o = v;
+    }
+}
+
+// ---------------------------------------------------------------- temporal halves, adjoint
+constexpr int kPixT = 64;
+__device__ __forceinline__ void temporal_table_t(cf* tw, int T) {
+    const double s = 1.0 / sqrt((double)T);
+    for (int j = threadIdx.x; j < T; j += blockDim.x) {
+        double sn, cs;
+        sincospi(2.0 * (double)j / (double)T, &sn, &cs);
+        tw[j] = mk((float)(cs * s), (float)(-sn * s));
+    }
+}
+// centered ortho DFT of the T values buf[g * kPixT + p], output index i (DIR +1 forward, -1 inverse): fftc.py:5-56
+template <int DIR>
+__device__ __forceinline__ cf centered_dft(const cf* buf, const cf* tw, int T, int p, int i) {
+    const int s_in = (T + 1) / 2, s_out = T / 2;
+    int k = i - s_out; if (k < 0) k += T;
+    float ax = 0.f, ay = 0.f;
+    int idx = (s_in * k) % T;
+    for (int g = 0; g < T; ++g) {
+        const cf w = tw[idx];
+        const cf x = buf[g * kPixT + p];
+        if (DIR > 0) { ax += x.x * w.x - x.y * w.y; ay += x.x * w.y + x.y * w.x; }
+        else { ax += x.x * w.x + x.y * w.y; ay += x.y * w.x - x.x * w.y; }
+        idx += k; if (idx >= T) idx -= T;
+    }
+    return mk(ax, ay);
+}
+
+// adjoint of xfyf_unpack's tail (varnet.py:232-241): gout (b, t, h, w) -> GA[b][h][w][t] = fft1c_t(gout) (XF) or gout (XT);
+// gmean[b][h][w] = sum_t gout (the temporal mean is added to every frame)
+__global__ __launch_bounds__(256) void temporal_out_bwd_kernel(const cf* gout, cf* GA, cf* gmean, int T, long HW, int xf) {
+    extern __shared__ __align__(16) unsigned char smem_t[];
+    cf* buf = reinterpret_cast<cf*>(smem_t);       // [T][kPixT]
+    cf* tw = buf + T * kPixT;
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * kPixT;
+    const int np = (int)min((long)kPixT, HW - p0);
+    if (xf) temporal_table_t(tw, T);
+    for (int e = threadIdx.x; e < T * kPixT; e += blockDim.x) {
+        const int t = e / kPixT, p = e - t * kPixT;
+        buf[e] = p < np ? gout[((long)b * T + t) * HW + p0 + p] : mk(0.f, 0.f);
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+        const int p = threadIdx.x;
+        float sx = 0.f, sy = 0.f;
+        for (int t = 0; t < T; ++t) { sx += buf[t * kPixT + p].x; sy += buf[t * kPixT + p].y; }
+        gmean[(long)b * HW + p0 + p] = mk(sx, sy);
+    }
+    for (int e = threadIdx.x; e < np * T; e += blockDim.x) {
+        const int p = e / T, i = e - p * T;
+        GA[((long)b * HW + p0 + p) * T + i] = xf ? centered_dft<1>(buf, tw, T, p, i) : buf[i * kPixT + p];
+    }
+}
+
+// adjoint of xfyf_pack's head (varnet.py:202-213): GX[b][h][w][t] -> gxc = ifft1c_t(GX) (XF) or GX (XT);
+// gimg[b][t] = gxc - mean_t(gxc) + gmean / T
+__global__ __launch_bounds__(256) void temporal_in_bwd_kernel(const cf* GX, const cf* gmean, cf* gimg, int T, long HW, int xf) {
+    extern __shared__ __align__(16) unsigned char smem_t[];
+    cf* buf = reinterpret_cast<cf*>(smem_t);       // [T][kPixT]
+    cf* out = buf + T * kPixT;                      // [T][kPixT]
+    cf* tw = out + T * kPixT;
+    const int b = blockIdx.y;
+    const long p0 = (long)blockIdx.x * kPixT;
+    const int np = (int)min((long)kPixT, HW - p0);
+    if (xf) temporal_table_t(tw, T);
+    for (int e = threadIdx.x; e < np * T; e += blockDim.x) {       // lanes over t: contiguous reads
+        const int p = e / T, t = e - p * T;
+        buf[t * kPixT + p] = GX[((long)b * HW + p0 + p) * T + t];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * np; e += blockDim.x) {
+        const int i = e / np, p = e - i * np;
+        out[i * kPixT + p] = xf ? centered_dft<-1>(buf, tw, T, p, i) : buf[i * kPixT + p];
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+        const int p = threadIdx.x;
+        float sx = 0.f, sy = 0.f;
+        for (int t = 0; t < T; ++t) { sx += out[t * kPixT + p].x; sy += out[t * kPixT + p].y; }
+        const cf gm = gmean[(long)b * HW + p0 + p];
+        buf[p] = mk((gm.x - sx) / T, (gm.y - sy) / T);            // buf row 0 is free again: per-pixel correction
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * np; e += blockDim.x) {
+        const int i = e / np, p = e - i * np;                     // lanes over pixels: coalesced stores
+        gimg[((long)b * T + i) * HW + p0 + p] = cadd(out[i * kPixT + p], buf[p]);
+    }
+}
+
+// ---------------------------------------------------------------- element-wise adjoints
+// y = x / rss(x) over the coil axis (varnet.py:58-59): gx = gy / r - x (sum_c <gy_c, x_c>) / r^3, r = sqrt(sum_c |x_c|^2)
+__global__ __launch_bounds__(256) void rss_normalise_bwd_kernel(const cf* gy, const cf* x, cf* gx, int C, long HW) {
+    const int b = blockIdx.y;
+    for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+        float s = 0.f, d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const cf v = x[((long)b * C + c) * HW + p], g = gy[((long)b * C + c) * HW + p];
+            s += v.x * v.x + v.y * v.y;
+            d += g.x * v.x + g.y * v.y;
+        }
+        const float r = sqrtf(s), ir = 1.f / r, k = d / (s * r);
+        for (int c = 0; c < C; ++c) {
+            const cf v = x[((long)b * C + c) * HW + p], g = gy[((long)b * C + c) * HW + p];
+            gx[((long)b * C + c) * HW + p] = mk(g.x * ir - v.x * k, g.y * ir - v.y * k);
+        }
+    }
+}
+
+// y = |x| (math.py:48-62): gx = gy x / |x|
+__global__ __launch_bounds__(256) void complex_abs_bwd_kernel(const float* gy, const cf* x, cf* gx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const cf v = x[i];
+        const float s = gy[i] / sqrtf(v.x * v.x + v.y * v.y);
+        gx[i] = mk(v.x * s, v.y * s);
+    }
+}
+
+// gs[b][c][p] (+)= sum_t conj(g[b][t][p]) z[b][t][c][p]: the gradient of sum_c conj(S_c) z_c with respect to S
+// (real-pair convention: d loss = Re(conj(gs) dS)); with z == NULL the summand is part[b][t][c][p] itself
+__global__ __launch_bounds__(256) void coil_accum_kernel(const cf* g, const cf* z, cf* gs, int T, int C, long HW, int accumulate) {
+    const int b = blockIdx.y;
+    const long total = (long)C * HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e / HW);
+        const long p = e - (long)c * HW;
+        float sx = 0.f, sy = 0.f;
+        for (int t = 0; t < T; ++t) {
+            cf v = z[(((long)b * T + t) * C + c) * HW + p];
+            if (g) { const cf gg = g[((long)b * T + t) * HW + p]; v = cmulc(v, gg); }   // z * conj(g) = conj(g) z
+            sx += v.x; sy += v.y;
+        }
+        cf* o = gs + (long)b * total + e;
+        if (accumulate) { sx += o->x; sy += o->y; }
+        *o = mk(sx, sy);
+    }
+}
+
+// out = a + sign * f(softplus(*lam)) * b; a may be NULL.  kind 0: f = v; 1: v / (1 + v); 2: 1 / (1 + v)^2; 3: 1 / (1 + v)
+__global__ __launch_bounds__(256) void axpby_lam_kernel(float* out, const float* a, const float* b, long n, const float* lam, int kind, float sign) {
+    const float l = *lam;
+    const float v = l > 20.f ? l : log1pf(expf(l));
+    float s = kind == 0 ? v : kind == 1 ? v / (1.f + v) : kind == 2 ? 1.f / ((1.f + v) * (1.f + v)) : 1.f / (1.f + v);
+    s *= sign;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = a ? fmaf(s, b[i], a[i]) : s * b[i];
+}
+
+static unsigned grid_t(long n, int threads, long cap = 4096) {
+    long g = ceil_div(n, (long)threads);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace cine
+
+using namespace cine;
+
+static void pad_split_t(int n, int& np, int& lo, bool norm) {
+    np = norm ? cine_pad16(n) : n;
+    lo = (np - n) / 2;
+}
+
+extern "C" int cine_normunet_unpack_bwd(const float* gout, const float* planes_q, const float* stats, float* gq, float* dstats,
+                                        int n, int h, int w, void* stream) {
+    CINE_REQUIRE(gout && planes_q && gq && (!stats == !dstats), CINE_EINVAL, "cine_normunet_unpack_bwd: null pointer");
+    CINE_REQUIRE(n > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_normunet_unpack_bwd: bad sizes");
+    UnpackBwdArgs a{};
+    a.gout = View{const_cast<float*>(gout), 1, (long)h * w * 2, 0, (long)w * 2, 2};
+    a.q = planes_q; a.stats = stats; a.gq = gq; a.dstats = dstats; a.n = n; a.I = h; a.J = w; a.gscale = 1.f;
+    pad_split_t(h, a.Ip, a.pad_i, stats != nullptr); pad_split_t(w, a.Jp, a.pad_j, stats != nullptr);
+    UnpackBwdArgs2 two{}; two.s[0] = a; two.s[1] = a;
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(normunet_unpack_bwd_kernel, dim3(n, 1), dim3(256), 0, as_stream(stream), two);
+    return check_launch("normunet_unpack_bwd_kernel");
+}
+
+extern "C" int cine_normunet_pack_bwd(const float* gp, const float* planes_p, const float* stats, const float* dstats, float* gz,
+                                      int n, int h, int w, void* stream) {
+    CINE_REQUIRE(gp && gz && (!stats || (planes_p && dstats)), CINE_EINVAL, "cine_normunet_pack_bwd: null pointer");
+    CINE_REQUIRE(n > 0 && h > 0 && w > 0 && (long)h * w > 1, CINE_EINVAL, "cine_normunet_pack_bwd: bad sizes");
+    PackBwdArgs a{};
+    a.gp = gp; a.p = planes_p; a.stats = stats; a.dstats = dstats;
+    a.gz = View{gz, 1, (long)h * w * 2, 0, (long)w * 2, 2};
+    a.n = n; a.I = h; a.J = w; a.accumulate = 0;
+    pad_split_t(h, a.Ip, a.pad_i, stats != nullptr); pad_split_t(w, a.Jp, a.pad_j, stats != nullptr);
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(normunet_pack_bwd_kernel, dim3(n), dim3(256), 0, as_stream(stream), a);
+    return check_launch("normunet_pack_bwd_kernel");
+}
+
+extern "C" size_t cine_xfyf_bwd_ws_bytes(int b, int t, int h, int w) { return (size_t)b * t * h * w * 2 * sizeof(float); }
+
+extern "C" int cine_xfyf_unpack_bwd(const float* gout, const float* q_xf, const float* q_yf, const float* stats_xf, const float* stats_yf,
+                                    float* gq_xf, float* gq_yf, float* dstats_xf, float* dstats_yf, float* gmean,
+                                    int b, int t, int h, int w, int xf, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(gout && q_xf && q_yf && gq_xf && gq_yf && gmean && ws, CINE_EINVAL, "cine_xfyf_unpack_bwd: null pointer");
+    CINE_REQUIRE((!stats_xf == !stats_yf) && (!stats_xf == !dstats_xf) && (!stats_yf == !dstats_yf), CINE_EINVAL,
+                 "cine_xfyf_unpack_bwd: statistics pointers must be all set or all null");
+    CINE_REQUIRE(b > 0 && b <= 65535 && t > 1 && t <= 64 && h > 0 && w > 0, CINE_EINVAL, "cine_xfyf_unpack_bwd: bad sizes");
+    CINE_REQUIRE(ws_bytes >= cine_xfyf_bwd_ws_bytes(b, t, h, w), CINE_EWORKSPACE, "cine_xfyf_unpack_bwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const long HW = (long)h * w;
+    cf* GA = reinterpret_cast<cf*>(ws);
+    ProfScope prof(F_PACK, st);
+    hipLaunchKernelGGL(temporal_out_bwd_kernel, dim3((unsigned)ceil_div(HW, (long)kPixT), b), dim3(256), ((size_t)t * kPixT + t) * sizeof(cf), st,
+                       reinterpret_cast<const cf*>(gout), GA, reinterpret_cast<cf*>(gmean), t, HW, xf);
+    if (int e = check_launch("temporal_out_bwd_kernel")) return e;
+    const bool nrm = stats_xf != nullptr;
+    UnpackBwdArgs2 two{};
+    UnpackBwdArgs& ax = two.s[0];
+    ax.gout = View{reinterpret_cast<float*>(GA), h, HW * t * 2, (long)w * t * 2, (long)t * 2, 2};
+    ax.q = q_xf; ax.stats = stats_xf; ax.gq = gq_xf; ax.dstats = dstats_xf; ax.n = b * h; ax.I = w; ax.J = t; ax.gscale = 0.5f;
+    pad_split_t(w, ax.Ip, ax.pad_i, nrm); pad_split_t(t, ax.Jp, ax.pad_j, nrm);
+    UnpackBwdArgs& ay = two.s[1];
+    ay.gout = View{reinterpret_cast<float*>(GA), w, HW * t * 2, (long)t * 2, (long)w * t * 2, 2};
+    ay.q = q_yf; ay.stats = stats_yf; ay.gq = gq_yf; ay.dstats = dstats_yf; ay.n = b * w; ay.I = h; ay.J = t; ay.gscale = 0.5f;
+    pad_split_t(h, ay.Ip, ay.pad_i, nrm); pad_split_t(t, ay.Jp, ay.pad_j, nrm);
+    hipLaunchKernelGGL(normunet_unpack_bwd_kernel, dim3(std::max(ax.n, ay.n), 2), dim3(256), 0, st, two);
+    return check_launch("normunet_unpack_bwd_kernel");
+}
+
+extern "C" int cine_xfyf_pack_bwd(const float* gp_xf, const float* gp_yf, const float* p_xf, const float* p_yf,
+                                  const float* stats_xf, const float* stats_yf, const float* dstats_xf, const float* dstats_yf,
+                                  const float* gmean, float* gimg, int b, int t, int h, int w, int xf,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(gp_xf && gp_yf && gmean && gimg && ws, CINE_EINVAL, "cine_xfyf_pack_bwd: null pointer");
+    CINE_REQUIRE((!stats_xf == !stats_yf) && (!stats_xf || (p_xf && p_yf && dstats_xf && dstats_yf)), CINE_EINVAL,
+                 "cine_xfyf_pack_bwd: statistics pointers must be all set or all null");
+    CINE_REQUIRE(b > 0 && b <= 65535 && t > 1 && t <= 64 && h > 0 && w > 0, CINE_EINVAL, "cine_xfyf_pack_bwd: bad sizes");
+    CINE_REQUIRE(ws_bytes >= cine_xfyf_bwd_ws_bytes(b, t, h, w), CINE_EWORKSPACE, "cine_xfyf_pack_bwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    const long HW = (long)h * w;
+    float* GX = reinterpret_cast<float*>(ws);
+    const bool nrm = stats_xf != nullptr;
+    ProfScope prof(F_PACK, st);
+    PackBwdArgs a{};
+    a.gp = gp_xf; a.p = p_xf; a.stats = stats_xf; a.dstats = dstats_xf;
+    a.gz = View{GX, h, HW * t * 2, (long)w * t * 2, (long)t * 2, 2};
+    a.n = b * h; a.I = w; a.J = t; a.accumulate = 0;
+    pad_split_t(w, a.Ip, a.pad_i, nrm); pad_split_t(t, a.Jp, a.pad_j, nrm);
+    hipLaunchKernelGGL(normunet_pack_bwd_kernel, dim3(a.n), dim3(256), 0, st, a);
+    a.gp = gp_yf; a.p = p_yf; a.stats = stats_yf; a.dstats = dstats_yf;
+    a.gz = View{GX, w, HW * t * 2, (long)t * 2, (long)w * t * 2, 2};
+    a.n = b * w; a.I = h; a.J = t; a.accumulate = 1;
+    pad_split_t(h, a.Ip, a.pad_i, nrm); pad_split_t(t, a.Jp, a.pad_j, nrm);
+    hipLaunchKernelGGL(normunet_pack_bwd_kernel, dim3(a.n), dim3(256), 0, st, a);
+    if (int e = check_launch("normunet_pack_bwd_kernel")) return e;
+    hipLaunchKernelGGL(temporal_in_bwd_kernel, dim3((unsigned)ceil_div(HW, (long)kPixT), b), dim3(256), ((size_t)2 * t * kPixT + t) * sizeof(cf), st,
+                       reinterpret_cast<const cf*>(GX), reinterpret_cast<const cf*>(gmean), reinterpret_cast<cf*>(gimg), t, HW, xf);
+    return check_launch("temporal_in_bwd_kernel");
+}
+
+extern "C" int cine_rss_normalise_bwd(const float* gy, const float* x, float* gx, int b, int c, int h, int w, void* stream) {
+    CINE_REQUIRE(gy && x && gx, CINE_EINVAL, "cine_rss_normalise_bwd: null pointer");
+    CINE_REQUIRE(b > 0 && b <= 65535 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_rss_normalise_bwd: bad sizes");
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(rss_normalise_bwd_kernel, dim3(grid_t((long)h * w, 256), b), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const cf*>(gy), reinterpret_cast<const cf*>(x), reinterpret_cast<cf*>(gx), c, (long)h * w);
+    return check_launch("rss_normalise_bwd_kernel");
+}
+
+extern "C" int cine_complex_abs_bwd(const float* gy, const float* x, float* gx, long n, void* stream) {
+    CINE_REQUIRE(gy && x && gx && n >= 0, CINE_EINVAL, "cine_complex_abs_bwd: bad arguments");
+    if (n == 0) return CINE_OK;
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(complex_abs_bwd_kernel, dim3(grid_t(n, 256)), dim3(256), 0, as_stream(stream), gy,
+                       reinterpret_cast<const cf*>(x), reinterpret_cast<cf*>(gx), n);
+    return check_launch("complex_abs_bwd_kernel");
+}
+
+extern "C" int cine_coil_accum(const float* g, const float* z, float* gs, int b, int t, int c, int h, int w, int accumulate, void* stream) {
+    CINE_REQUIRE(z && gs, CINE_EINVAL, "cine_coil_accum: null pointer");
+    CINE_REQUIRE(b > 0 && b <= 65535 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_coil_accum: bad sizes");
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(coil_accum_kernel, dim3(grid_t((long)c * h * w, 256), b), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const cf*>(g), reinterpret_cast<const cf*>(z), reinterpret_cast<cf*>(gs), t, c, (long)h * w, accumulate);
+    return check_launch("coil_accum_kernel");
+}
+
+extern "C" int cine_axpby_lam(float* out, const float* a, const float* b, long n, const float* lambda_dev, int kind, float sign, void* stream) {
+    CINE_REQUIRE(out && b && lambda_dev && n > 0 && kind >= 0 && kind <= 3, CINE_EINVAL, "cine_axpby_lam: bad arguments");
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(axpby_lam_kernel, dim3(grid_t(n, 256, 2048)), dim3(256), 0, as_stream(stream), out, a, b, n, lambda_dev, kind, sign);
+    return check_launch("axpby_lam_kernel");
+}

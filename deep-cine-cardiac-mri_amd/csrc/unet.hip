@@ -7,6 +7,7 @@
 // Workspace: one raw buffer per skip level plus three rotating scratch buffers.
 #include <algorithm>
 #include "common.h"
+#include "grad.h"
 
 using namespace cine;
 
@@ -119,9 +120,33 @@ extern "C" size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_c
     return b.off;
 }
 
+// training: every layer output keeps its own memory (the backward pass reads all of them)
+extern "C" size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools) {
+    if (n <= 0 || h <= 0 || w <= 0 || chans <= 0 || pools <= 0 || pools > 6) return 0;
+    (void)in_ch; (void)out_ch;
+    Plan p; Bump b{nullptr, 0};
+    build(p, b, n, h, w, chans, pools, true);
+    return b.off;
+}
+
+static int unet2d_forward_impl(const float* x, float* y, const void* const* weights, int nsets,
+                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                               void* ws, size_t ws_bytes, void* stream, bool train);
+
 extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
                                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                                    void* ws, size_t ws_bytes, void* stream) {
+    return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, ws, ws_bytes, stream, false);
+}
+extern "C" int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
+                                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                                         void* ws, size_t ws_bytes, void* stream) {
+    return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, ws, ws_bytes, stream, true);
+}
+
+static int unet2d_forward_impl(const float* x, float* y, const void* const* weights, int nsets,
+                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                               void* ws, size_t ws_bytes, void* stream, bool train) {
     CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet2d_forward: null pointer");
     CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_forward: nsets must be 1 or 2");
     CINE_REQUIRE(n > 0 && n % nsets == 0, CINE_EINVAL, "cine_unet2d_forward: n=%d not divisible by nsets=%d", n, nsets);
@@ -129,14 +154,15 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
                  "cine_unet2d_forward: bad sizes");
     CINE_REQUIRE((h >> pools) >= 1 && (w >> pools) >= 1, CINE_EUNSUPPORTED,
                  "cine_unet2d_forward: %dx%d too small for %d pools", h, w, pools);
-    const size_t need = cine_unet2d_ws_bytes(n, h, w, in_ch, out_ch, chans, pools);
+    const size_t need = train ? cine_unet2d_train_ws_bytes(n, h, w, in_ch, out_ch, chans, pools)
+                              : cine_unet2d_ws_bytes(n, h, w, in_ch, out_ch, chans, pools);
     CINE_REQUIRE(ws_bytes >= need, CINE_EWORKSPACE, "cine_unet2d_forward: workspace %zu < %zu", ws_bytes, need);
     const int nptr = 5 * pools + 4;
     for (int i = 0; i < nsets * nptr; ++i)
         CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", i);
 
     Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
-    build(p, b, n, h, w, chans, pools, plane_kernel_enabled() && n >= kPlaneMinSamples);
+    build(p, b, n, h, w, chans, pools, train || (plane_kernel_enabled() && n >= kPlaneMinSamples));
     const int split = n / nsets;
     // every step below reads only its own sample's data, so the launches are recorded and issued together: as one
     // plane-persistent kernel when the layer shapes are the ones it is built for, else layer by layer (conv_kernels.hip)
@@ -144,7 +170,7 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     struct Guard {
         PlaneRecorder* r;
         ~Guard() { if (r) plane_record_abort(r); }
-    } guard{plane_kernel_enabled() ? plane_record_begin() : nullptr};
+    } guard{plane_kernel_enabled() && !train ? plane_record_begin() : nullptr};
     int wi = 0;
     const float *w0, *w1;
     auto next = [&]() {
@@ -155,7 +181,7 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     int e;
     // levels P-1 / P (second-lowest ConvBlock, pool, bottleneck, transpose conv, first up-path ConvBlock): one fused kernel per
     // plane when the planes are cfg 2's 52 x 4 with 64 channels (unet_bottom.hip); its output carries ONE statistics record
-    const bool fuse = pools >= 2 && !plane_kernel_enabled() && unet_bottom_applies(p.ch[pools - 1], p.hs[pools - 1], p.wsz[pools - 1]) &&
+    const bool fuse = pools >= 2 && !train && !plane_kernel_enabled() && unet_bottom_applies(p.ch[pools - 1], p.hs[pools - 1], p.wsz[pools - 1]) &&
                       p.ch[pools - 2] * 2 == p.ch[pools - 1] && p.hs[pools - 2] == 2 * p.hs[pools - 1] && p.wsz[pools - 2] == 2 * p.wsz[pools - 1];
     // ---- down path (unet.py:94-97) + bottleneck (:99)
     for (int d = 0; d <= pools; ++d) {
@@ -224,4 +250,158 @@ extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* 
     PlaneRecorder* rec = guard.r;
     guard.r = nullptr;
     return rec ? plane_record_end(rec, as_stream(stream), p.prog) : CINE_OK;
+}
+
+// ---------------------------------------------------------------- backward pass (training)
+// Scratch of the backward pass: two rotating gradient buffers (the largest is the input gradient of a level-0 conv over
+// the 2 x chans concat), the concat gradients of every level (their skip halves are consumed on the way down), the pooled
+// gradient, and the partial sums of the weight-gradient kernel.
+namespace {
+struct BwdPlan {
+    float *A, *B, *cat[8], *pool, *wg;
+    size_t wg_floats;
+};
+void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch) {
+    const int P = p.P;
+    auto elems = [&](int d) { return (size_t)n * p.ch[d] * p.hs[d] * p.wsz[d]; };
+    size_t big = 0;
+    for (int d = 0; d <= P; ++d) big = std::max(big, elems(d));
+    big = std::max(big, (size_t)n * std::max(in_ch, 16) * p.hs[0] * p.wsz[0]);
+    q.A = b.take(big); q.B = b.take(big);
+    for (int d = 0; d < P; ++d) q.cat[d] = b.take(2 * elems(d));
+    q.pool = b.take(P > 0 ? elems(1) / 2 + 16 : 16);          // (n, ch[d], hs[d+1], wsz[d+1]) <= elems(d) / 4
+    for (int d = 0; d < P; ++d) (void)0;
+    size_t wg = 0;
+    for (int d = 0; d <= P; ++d) {
+        const int cin1 = d ? p.ch[d - 1] : in_ch;
+        wg = std::max(wg, wgrad_ws_floats(p.ch[d], cin1, 9, n));
+        wg = std::max(wg, wgrad_ws_floats(p.ch[d], p.ch[d], 9, n));
+        if (d < P) {
+            wg = std::max(wg, wgrad_ws_floats(p.ch[d], 2 * p.ch[d], 9, n));
+            wg = std::max(wg, wgrad_ws_floats(4 * p.ch[d], p.ch[d + 1], 1, n));
+        }
+    }
+    wg = std::max(wg, wgrad_ws_floats(out_ch, p.ch[0], 1, n));
+    q.wg_floats = wg;
+    q.wg = b.take(wg);
+}
+}  // namespace
+
+extern "C" size_t cine_unet2d_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools) {
+    if (n <= 0 || h <= 0 || w <= 0 || chans <= 0 || pools <= 0 || pools > 6 || in_ch <= 0 || out_ch <= 0) return 0;
+    Plan p; Bump b0{nullptr, 0};
+    build(p, b0, n, h, w, chans, pools, true);
+    BwdPlan q; Bump b{nullptr, 0};
+    build_bwd(q, p, b, n, in_ch, out_ch);
+    return b.off;
+}
+
+// Gradients of cine_unet2d_forward_train.  `fwd_ws` is the workspace that call filled (all raw layer outputs + statistics);
+// x its input, gy = d loss / d y.  `wdgrad`: host array of device pointers ordered like `weights` of the forward, holding the
+// INPUT-GRADIENT packings (cine_pack_conv3x3_dgrad / _tconv2x2_dgrad / _conv1x1_dgrad; the bias slot is unused).  `grads`:
+// host array in the same order of device pointers to the weight gradients in the parameters' own layouts ((cout, cin, 3, 3),
+// (cin, cout, 2, 2), (cout, cin), (cout)); they are ACCUMULATED into (+=).  gx (n, in_ch, h, w) may be NULL.
+extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
+                                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                                    const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream) {
+    CINE_REQUIRE(x && gy && wdgrad && grads && fwd_ws && ws, CINE_EINVAL, "cine_unet2d_backward: null pointer");
+    CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_backward: nsets must be 1 or 2");
+    CINE_REQUIRE(n > 0 && n % nsets == 0 && n <= 65535, CINE_EINVAL, "cine_unet2d_backward: n=%d", n);
+    CINE_REQUIRE(h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL, "cine_unet2d_backward: bad sizes");
+    CINE_REQUIRE(fwd_ws_bytes >= cine_unet2d_train_ws_bytes(n, h, w, in_ch, out_ch, chans, pools), CINE_EWORKSPACE,
+                 "cine_unet2d_backward: forward workspace too small");
+    CINE_REQUIRE(ws_bytes >= cine_unet2d_backward_ws_bytes(n, h, w, in_ch, out_ch, chans, pools), CINE_EWORKSPACE,
+                 "cine_unet2d_backward: workspace too small");
+    const int nptr = 5 * pools + 4;
+    for (int i = 0; i < nsets * nptr; ++i) {
+        CINE_REQUIRE(grads[i], CINE_EINVAL, "cine_unet2d_backward: grads[%d] is null", i);
+        CINE_REQUIRE(wdgrad[i] || (i % nptr) == nptr - 1, CINE_EINVAL, "cine_unet2d_backward: wdgrad[%d] is null", i);
+    }
+    Plan p; Bump bf{const_cast<char*>(reinterpret_cast<const char*>(fwd_ws)), 0};
+    build(p, bf, n, h, w, chans, pools, true);
+    BwdPlan q; Bump bb{reinterpret_cast<char*>(ws), 0};
+    build_bwd(q, p, bb, n, in_ch, out_ch);
+    hipStream_t st = as_stream(stream);
+    const int P = pools, split = n / nsets;
+    auto wd = [&](int i, int set) { return reinterpret_cast<const float*>(wdgrad[(set && nsets == 2 ? nptr : 0) + i]); };
+    auto gr = [&](int i, int set) { return nsets == 2 || set == 0 ? reinterpret_cast<float*>(grads[(set ? nptr : 0) + i]) : nullptr; };
+    auto wd2 = [&](int i) { return nsets == 2 ? wd(i, 1) : nullptr; };
+    const int sp = nsets == 2 ? split : n;
+    int e;
+    // weight-list indices (module order, as in the forward)
+    auto i_down = [&](int d, int k) { return 2 * d + k; };                  // d = 0..P (P = bottleneck), k = 0 | 1
+    auto i_up = [&](int d, int k) { return 2 * P + 2 + 3 * (P - 1 - d) + k; };   // k = 0 tconv, 1 conv1, 2 conv2
+    const int i_fin = 5 * P + 2, i_bias = 5 * P + 3;
+    auto src = [&](const float* t, const float* part, int c, int mode, int hh, int ww, int np) { return Src{t, part, c, mode, hh, ww, np, 0, 1}; };
+    const Src none{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    auto wgrad3 = [&](const Src& s0, const Src& s1, const float* g, int rows, int hh, int ww, int wi) {
+        WgArgs a{}; a.s0 = s0; a.s1 = s1; a.cin = src_cin(s0) + src_cin(s1); a.g = g; a.g_mode = 0; a.rows = rows;
+        a.n = n; a.H = hh; a.W = ww; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
+        return launch_wgrad(a, 9, 0, gr(wi, 0), gr(wi, 1), q.wg, q.wg_floats, st);
+    };
+    auto inbwd = [&](const float* r, const float* part, int np, int c, int hh, int ww, const float* ga, int ca_total, int ca_off,
+                     int ha, int wa, const float* gb, int hb, int wb, float* out) {
+        InBwdArgs a{r, part, np, ga, ca_total, ca_off, ha, wa, gb, hb, wb, out, n, c, hh, ww, kEps, kSlope};
+        return launch_in_lrelu_bwd(a, st);
+    };
+
+    // ---- final 1x1 conv + bias (unet.py:69): y = W act(cb_0) + b
+    const long hw0 = (long)h * w;
+    if ((e = launch_bias_grad(gy, n, out_ch, hw0, sp, gr(i_bias, 0), gr(i_bias, 1), st))) return e;
+    {
+        WgArgs a{}; a.s0 = src(p.cb[0], p.pcb[0], chans, 1, h, w, p.np_conv[0]); a.s1 = none; a.cin = chans;
+        a.g = gy; a.g_mode = 0; a.rows = out_ch; a.n = n; a.H = h; a.W = w; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
+        if ((e = launch_wgrad(a, 1, 2, gr(i_fin, 0), gr(i_fin, 1), q.wg, q.wg_floats, st))) return e;
+    }
+    if ((e = cine_conv1x1_dgrad(gy, wd(i_fin, 0), wd2(i_fin), sp, q.A, n, out_ch, chans, h, w, stream))) return e;   // A = d/d act(cb_0)
+
+    // ---- up path, level 0 first (reverse of unet.py:102-123)
+    for (int d = 0; d < P; ++d) {
+        const int c = p.ch[d], hh = p.hs[d], ww = p.wsz[d], npc = p.np_conv[d];
+        const int hu = 2 * p.hs[d + 1], wu = 2 * p.wsz[d + 1];           // extent of the transpose-conv output
+        // second conv of the block: cb = conv(act(ca))
+        if ((e = inbwd(p.cb[d], p.pcb[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        if ((e = wgrad3(src(p.ca[d], p.pca[d], c, 1, hh, ww, npc), none, q.B, c, hh, ww, i_up(d, 2)))) return e;
+        if ((e = cine_conv3x3_dgrad(q.B, wd(i_up(d, 2), 0), wd2(i_up(d, 2)), sp, q.A, n, c, c, hh, ww, stream))) return e;
+        // first conv: ca = conv(cat(act(up) zero-padded, act(skip)))
+        if ((e = inbwd(p.ca[d], p.pca[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        if ((e = wgrad3(src(p.up[d], p.pup[d], c, 1, hu, wu, p.np_tconv[d]), src(p.skip[d], p.pskip[d], c, 1, hh, ww, npc), q.B, c, hh, ww, i_up(d, 1)))) return e;
+        if ((e = cine_conv3x3_dgrad(q.B, wd(i_up(d, 1), 0), wd2(i_up(d, 1)), sp, q.cat[d], n, c, 2 * c, hh, ww, stream))) return e;
+        // transpose conv: up = tconv(act(cur)), cur = cb[d+1] or the bottleneck output
+        if ((e = inbwd(p.up[d], p.pup[d], p.np_tconv[d], c, hu, wu, q.cat[d], 2 * c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        const bool bott = d + 1 == P;
+        const float* cur = bott ? p.bott : p.cb[d + 1];
+        const float* pcur = bott ? p.pbott : p.pcb[d + 1];
+        const int c1 = p.ch[d + 1], h1 = p.hs[d + 1], w1 = p.wsz[d + 1];
+        {
+            WgArgs a{}; a.s0 = src(cur, pcur, c1, 1, h1, w1, p.np_conv[d + 1]); a.s1 = none; a.cin = c1;
+            a.g = q.B; a.g_mode = 5; a.g_c = c; a.g_h = hu; a.g_w = wu; a.rows = 4 * c;
+            a.n = n; a.H = h1; a.W = w1; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
+            if ((e = launch_wgrad(a, 1, 1, gr(i_up(d, 0), 0), gr(i_up(d, 0), 1), q.wg, q.wg_floats, st))) return e;
+        }
+        if ((e = cine_tconv2x2_dgrad(q.B, wd(i_up(d, 0), 0), wd2(i_up(d, 0)), sp, q.A, n, c1, c, h1, w1, stream))) return e;   // A = d/d act(cur)
+    }
+    // ---- bottleneck and down path (reverse of unet.py:94-99)
+    for (int d = P; d >= 0; --d) {
+        const int c = p.ch[d], hh = p.hs[d], ww = p.wsz[d], npc = p.np_conv[d];
+        const float* out = d == P ? p.bott : p.skip[d];
+        const float* pout = d == P ? p.pbott : p.pskip[d];
+        if (d == P) {
+            if ((e = inbwd(out, pout, npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        } else {    // the skip tensor feeds the concat (second half of cat[d]) and the 2x2 average pool
+            if ((e = inbwd(out, pout, npc, c, hh, ww, q.cat[d], 2 * c, c, hh, ww, q.pool, p.hs[d + 1], p.wsz[d + 1], q.B))) return e;
+        }
+        if ((e = wgrad3(src(p.mid[d], p.pmid[d], c, 1, hh, ww, npc), none, q.B, c, hh, ww, i_down(d, 1)))) return e;
+        if ((e = cine_conv3x3_dgrad(q.B, wd(i_down(d, 1), 0), wd2(i_down(d, 1)), sp, q.A, n, c, c, hh, ww, stream))) return e;
+        if ((e = inbwd(p.mid[d], p.pmid[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        if (d > 0) {
+            const int cp = p.ch[d - 1];
+            if ((e = wgrad3(src(p.skip[d - 1], p.pskip[d - 1], cp, 2, p.hs[d - 1], p.wsz[d - 1], p.np_conv[d - 1]), none, q.B, c, hh, ww, i_down(d, 0)))) return e;
+            if ((e = cine_conv3x3_dgrad(q.B, wd(i_down(d, 0), 0), wd2(i_down(d, 0)), sp, q.pool, n, c, cp, hh, ww, stream))) return e;
+        } else {
+            if ((e = wgrad3(src(x, nullptr, in_ch, 0, h, w, 0), none, q.B, c, hh, ww, i_down(0, 0)))) return e;
+            if (gx && (e = cine_conv3x3_dgrad(q.B, wd(i_down(0, 0), 0), wd2(i_down(0, 0)), sp, gx, n, c, in_ch, hh, ww, stream))) return e;
+        }
+    }
+    return CINE_OK;
 }

@@ -6,6 +6,7 @@ Mirrors the reference's denoisers/norm_unet.py (NormUnet :12-114, NormUnet3D
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 from .unet import Unet
 
@@ -22,6 +23,8 @@ class NormUnet(nn.Module):
         b, c, h, w, _ = x.shape
         if c != 1:
             raise NotImplementedError("HIP NormUnet handles one complex channel per sample (all reference call sites)")
+        if ag.grad_mode(self):       # training: pack -> U-Net -> unpack as one autograd node with a HIP backward
+            return ag.norm_unet(x.reshape(b, h, w, 2), self.unet.hip_weights()).view(b, 1, h, w, 2)
         planes, stats = ops.normunet_pack(x.reshape(b, h, w, 2))
         planes = self.unet(planes)
         return ops.normunet_unpack(planes, stats, h, w).view(b, 1, h, w, 2)
@@ -39,6 +42,8 @@ class NormUnet3D(nn.Module):
         if not x.shape[-1] == 2:
             raise ValueError("Last dimension must be 2 for complex.")
         b, c, t, h, w, _ = x.shape
+        if ag.grad_mode(self):
+            raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet")
         if c != 1:
             raise NotImplementedError("HIP NormUnet3D handles one complex channel per sample (all reference call sites)")
         planes, stats = ops.normunet3d_pack(x.reshape(b, t, h, w, 2))

@@ -5,11 +5,13 @@ denoisers/unet.py (Unet :6, ConvBlock :128, TransposeConvBlock :185); the
 ``torch.nn`` layers inside the blocks only HOLD the parameters.  ``forward``
 hands the raw weight pointers to ``cine_unet2d_forward`` (MFMA implicit-GEMM
 3x3 convs with InstanceNorm/LeakyReLU/pool/concat fused into the operand
-staging).  Inference only: no autograd through the HIP path.
+staging).  With gradients enabled the 2-D U-Net runs as ``cine_hip.autograd.UnetFn``
+(forward keeps the raw layer outputs, backward = cine_unet2d_backward).
 """
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 
 
@@ -92,5 +94,9 @@ class Unet(nn.Module):
         if self.training and self.drop_prob > 0:
             raise NotImplementedError("dropout > 0 in training mode is not supported by the HIP path")
         if self.dims == 3:
+            if ag.grad_mode(self):
+                raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet")
             return ops.unet3d_forward(image, self.hip_weights())
+        if ag.grad_mode(self) or (torch.is_grad_enabled() and image.requires_grad):
+            return ag.unet2d(image, self.hip_weights())
         return ops.unet2d_forward(image, self.hip_weights())

@@ -11,7 +11,15 @@ What differs is where the arithmetic runs.  Per cascade the HIP path issues
                   both U-Nets in one launch sequence, inverse (unpack)
   sens_expand+DC: row FFT pass fused with S x, column FFT pass fused with the soft DC
 and never materialises shifted copies, stacked complex temporaries or normalised
-activations.  Inference only (no autograd); GPU tensors only.
+activations.  GPU tensors only.
+
+Training: when gradients are enabled and a parameter requires them, ``forward``
+builds an autograd graph out of ``cine_hip.autograd`` Functions whose backward
+passes are hand-written HIP kernels (input / weight gradients on the MFMA conv
+kernels, InstanceNorm + LeakyReLU backward, the adjoint rotations and DFTs, the
+self-adjoint image-space DC) -- what ``pl_modules/varnet_module.py:97-113``
+(``training_step``: forward + SSIMLoss, then ``loss.backward()``) needs.  With
+gradients disabled the inference path below runs unchanged.
 """
 import math
 from typing import Optional
@@ -19,6 +27,7 @@ from typing import Optional
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 from .denoisers.norm_unet import NormUnet, NormUnet3D
 
@@ -44,6 +53,8 @@ class SensitivityModel(nn.Module):
         x = ops.sens_prologue(masked_kspace, pad, pad + n_low)            # (b, c, h, w, 2)
         b, c, h, w, _ = x.shape
         x = self.norm_unet(x.view(b * c, 1, h, w, 2)).view(b, c, h, w, 2)
+        if x.requires_grad:
+            return ag.RssNormFn.apply(x).unsqueeze(1)
         return ops.rss_normalise_(x).unsqueeze(1)
 
 
@@ -75,8 +86,10 @@ class VarNetBlock(nn.Module):
         """(b, t, h, w, 2) -> (b, t, 1, h, w, 2)."""
         b, t, h, w, _ = image_combined.shape
         xf = self.dynamic_type == 'XF'
-        pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image_combined, xf)
         both, wx, wy = self._xfyf_weights()
+        if ag.grad_mode(self):
+            return ag.xfyf(image_combined, xf, both, wx, wy)
+        pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image_combined, xf)
         if pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr():
             joint = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
             out = ops.unet2d_forward(joint, both)
@@ -117,12 +130,35 @@ class VarNet(nn.Module):
         self.cascades = nn.ModuleList(
             [VarNetBlock(self.model, dynamic_type, weight_sharing) for _ in range(num_cascades)])
 
-    @torch.no_grad()
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor,
                 sens_maps: Optional[torch.Tensor] = None, acs=None) -> torch.Tensor:
         """(b,t,c,h,w,2), (b,t,1,h,1,1) uint8 -> (b,t,h,w) magnitude.  ``sens_maps`` (optional,
         (b,1,c,h,w,2)) bypasses the sens-map network; ``acs`` = (pad, n_low) skips the host
-        read-back of the mask (needed inside hipGraph capture)."""
+        read-back of the mask (needed inside hipGraph capture).  Masks of another dtype (the reference's
+        apply_mask returns a float mask) are converted once."""
+        mask = ops.as_mask_u8(mask)
+        if ag.grad_mode(self):
+            return self._forward_train(masked_kspace, mask, sens_maps, acs)
+        with torch.no_grad():
+            return self._forward_infer(masked_kspace, mask, sens_maps, acs)
+
+    def _forward_train(self, masked_kspace, mask, sens_maps, acs):
+        """The image-space cascade chain of ``_forward_infer`` as an autograd graph (reference varnet.py:143-151)."""
+        if not ops.is_row_mask(mask, masked_kspace):
+            raise NotImplementedError("training through the HIP path needs the reference's (b, t, 1, h, 1, 1) row mask")
+        if self.cascades and self.cascades[0].dynamic_type == '3D':
+            raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet (XF / XT / 2D are)")
+        if sens_maps is None:
+            sens_maps = self.sens_net(masked_kspace, mask, acs)
+        image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)          # first cascade's sens_reduce(masked_kspace)
+        if len(self.cascades) == 0:
+            return ag.AbsFn.apply(image.squeeze(2))
+        zf = ag.CoilReduceFn.apply(masked_kspace, sens_maps, mask)             # sens_reduce(mask * k_ref)
+        for cascade in self.cascades:
+            image = ag.ImageDcFn.apply(cascade.regularise(image), sens_maps, zf, mask, cascade.lambda_reg)
+        return ag.AbsFn.apply(image.squeeze(2))
+
+    def _forward_infer(self, masked_kspace, mask, sens_maps, acs):
         if sens_maps is None:
             sens_maps = self.sens_net(masked_kspace, mask, acs)
         if not ops.is_row_mask(mask, masked_kspace):

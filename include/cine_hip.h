@@ -425,6 +425,91 @@ int cine_espirit_eig(const float* m, float* maps, float* lam, int c, long npix, 
 int cine_complex_abs(const float* x, float* y, long n, void* stream);          /* math.py:48-62 */
 
 /* ------------------------------------------------------------------------------------------
+ * Training: gradients through the path
+ *   reference: what torch.autograd differentiates in reconstruction/pl_modules/varnet_module.py:97-113 (training_step:
+ *   forward + SSIMLoss) -- models/varnet.py:143-151, 181-282; denoisers/norm_unet.py:59-114; denoisers/unet.py:73-125, 159-218
+ * Conventions: the gradient of a complex tensor is the pair (d loss / d re, d loss / d im), i.e. d loss = Re(conj(g) dx);
+ * weight gradients are ACCUMULATED (+=) into caller-zeroed tensors in the parameters' own layouts; every reduction runs in a
+ * fixed order (no atomics): two backward passes over the same data give bit-identical gradients.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Input-gradient packings of the U-Net weights: the gradient of a convolution with respect to its input is a convolution of the
+ * output gradient -- conv3x3 with (cout, cin) swapped and the taps flipped (unet.py:160,164); the k2 s2 transpose conv with its
+ * (cin, 4 cout) weight matrix over the space-to-depth view of the output gradient (unet.py:213-215); the 1x1 conv with the
+ * transposed matrix (unet.py:69).  `w` are the parameters in their own layouts. */
+size_t cine_conv3x3_dgrad_packed_floats(int cout, int cin);
+size_t cine_tconv2x2_dgrad_packed_floats(int cin, int cout);
+size_t cine_conv1x1_dgrad_packed_floats(int cout, int cin);
+int cine_pack_conv3x3_dgrad(const float* w, float* packed, int cout, int cin, void* stream);
+int cine_pack_tconv2x2_dgrad(const float* w, float* packed, int cin, int cout, void* stream);
+int cine_pack_conv1x1_dgrad(const float* w, float* packed, int cout, int cin, void* stream);
+/* gx = d loss / d (conv input) from gy = d loss / d (raw conv output); wpacked* from the packings above (two sets: samples
+ * >= set_split use wpacked2, NULL = one set).  conv3x3: gy (n, cout, h, w) -> gx (n, cin, h, w); tconv: gy (n, cout, 2h, 2w) ->
+ * gx (n, cin, h, w); conv1x1: gy (n, cout, h, w) -> gx (n, cin, h, w). */
+int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
+                       float* gx, int n, int cout, int cin, int h, int w, void* stream);
+int cine_tconv2x2_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
+                        float* gx, int n, int cin, int cout, int h, int w, void* stream);
+int cine_conv1x1_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
+                       float* gx, int n, int cout, int cin, int h, int w, void* stream);
+
+/* cine_unet2d_forward that KEEPS every layer's raw output and statistics in `ws` (cine_unet2d_train_ws_bytes) for the backward
+ * pass; same arguments and results as cine_unet2d_forward. */
+size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
+int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
+                              int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                              void* ws, size_t ws_bytes, void* stream);
+/* Backward pass of the U-Net (the autograd graph of unet.py:73-125): from gy = d loss / d y, the forward's input x and its
+ * filled workspace `fwd_ws`.  `wdgrad`: HOST array of device pointers ordered like `weights` of the forward, holding the
+ * input-gradient packings (the bias slot is ignored).  `grads`: HOST array in the same order of device pointers to the weight
+ * gradients ((cout, cin, 3, 3) / (cin, cout, 2, 2) / (out_ch, chans) / (out_ch)), accumulated into.  nsets == 2: both arrays
+ * hold two such lists back to back.  gx (n, in_ch, h, w) may be NULL (the sensitivity network's input needs no gradient).
+ * ws: cine_unet2d_backward_ws_bytes() of scratch. */
+size_t cine_unet2d_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
+int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
+                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                         const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream);
+
+/* Adjoints of cine_normunet_unpack / cine_normunet_pack (norm_unet.py:59-96).
+ *   unpack_bwd: gout (n, h, w, 2), the U-Net output planes_q -> gq (planes, zero on the pad frame) and dstats (n, 2, 2) =
+ *               {d/d mean, d/d std} per (sample, re|im) from the un-normalisation x * std + mean.
+ *   pack_bwd  : gp (gradient of the U-Net input planes), the planes themselves, stats, dstats -> gz (n, h, w, 2), through
+ *               (x - mean) / std with the unbiased std.  stats == NULL: the plain repack (cinenet.py:242-244). */
+int cine_normunet_unpack_bwd(const float* gout, const float* planes_q, const float* stats, float* gq, float* dstats,
+                             int n, int h, int w, void* stream);
+int cine_normunet_pack_bwd(const float* gp, const float* planes_p, const float* stats, const float* dstats, float* gz,
+                           int n, int h, int w, void* stream);
+/* Adjoints of cine_xfyf_unpack / cine_xfyf_pack (varnet.py:196-241): gout (b, t, 1, h, w, 2) -> gradients of the two U-Nets'
+ * output planes (+ dstats, and gmean (b, h, w, 2) = the gradient of the temporal mean image); then from the gradients of the
+ * U-Nets' input planes -> gimg (b, t, h, w, 2).  The temporal DFT is unitary: its adjoint is the inverse transform.
+ * ws: cine_xfyf_bwd_ws_bytes(). */
+size_t cine_xfyf_bwd_ws_bytes(int b, int t, int h, int w);
+int cine_xfyf_unpack_bwd(const float* gout, const float* q_xf, const float* q_yf, const float* stats_xf, const float* stats_yf,
+                         float* gq_xf, float* gq_yf, float* dstats_xf, float* dstats_yf, float* gmean,
+                         int b, int t, int h, int w, int xf, void* ws, size_t ws_bytes, void* stream);
+int cine_xfyf_pack_bwd(const float* gp_xf, const float* gp_yf, const float* p_xf, const float* p_yf,
+                       const float* stats_xf, const float* stats_yf, const float* dstats_xf, const float* dstats_yf,
+                       const float* gmean, float* gimg, int b, int t, int h, int w, int xf,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* cine_image_dc is self-adjoint in the image (T = IFFT_h W FFT_h is Hermitian): its image gradient is cine_image_dc of the output
+ * gradient (zf = NULL).  With respect to the maps it gives, per frame, part (b, t, c, h, w) = conj(g) T(S_c img) + T(S_c g) conj(img)
+ * (varnet.py:181-194, 281-282); add the frames with cine_coil_accum(NULL, part, ...).  Weights as cine_image_dc. */
+int cine_image_dc_sens_grad(const float* img, const float* gout, const float* sens, const uint8_t* mask,
+                            const float* lambda_dev, float w_sampled, float w_unsampled,
+                            float* part, int b, int t, int c, int h, int w, void* stream);
+/* gs (b, c, h, w, 2) (+)= sum_t conj(g[b, t]) z[b, t, c]: gradient of sens_reduce's coil sum sum_c conj(S_c) z_c (varnet.py:187-194)
+ * with respect to S; z (b, t, c, h, w, 2) are the coil images.  g == NULL: gs (+)= sum_t z.  accumulate == 0 overwrites gs. */
+int cine_coil_accum(const float* g, const float* z, float* gs, int b, int t, int c, int h, int w, int accumulate, void* stream);
+/* gx of y = x / rss(x, coil) (varnet.py:58-59) from gy and the UN-normalised x (b, c, h, w, 2). */
+int cine_rss_normalise_bwd(const float* gy, const float* x, float* gx, int b, int c, int h, int w, void* stream);
+/* gx (n, 2) of y = |x| (math.py:48-62). */
+int cine_complex_abs_bwd(const float* gy, const float* x, float* gx, long n, void* stream);
+/* out = a + sign * f(v) * b with v = softplus(*lambda_dev) (varnet.py:281-282): kind 0 f = v; 1 f = v / (1 + v); 2 f = 1 / (1 + v)^2;
+ * 3 f = 1 / (1 + v).  a == NULL: out = sign * f(v) * b. */
+int cine_axpby_lam(float* out, const float* a, const float* b, long n, const float* lambda_dev, int kind, float sign, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * measurement aid (no reference counterpart; the reference only wraps time.time() around the
  * model call, traintest_scripts/run_inference.py:53-61)
  * ------------------------------------------------------------------------------------------ */
