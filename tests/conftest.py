@@ -54,3 +54,12 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+@pytest.fixture(autouse=True)
+def _inference_by_default():
+    """Tests run with autograd off (the inference path); the training tests switch it on with ``torch.enable_grad()``."""
+    prev = torch.is_grad_enabled()
+    torch.set_grad_enabled(False)
+    yield
+    torch.set_grad_enabled(prev)

@@ -411,7 +411,141 @@ def g_frontend():
          time_avg_kspace=time_avg[0].transpose(2, 0, 1).astype(np.complex64))
 
 
-GENERATORS = dict(rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def _training_step(net, mk, mask, target, lr=0.0003, dtype=None):
+    """The body of reference pl_modules/varnet_module.py:97-113 (forward, center_crop_to_smallest, SSIMLoss) followed by
+    loss.backward() and one step of the optimiser of :151-154 (Adam, lr 0.0003, weight_decay 0).  Returns (loss, {name: grad},
+    {name: updated weight}, output).  dtype float64 re-runs the same reference code in double precision (the reproducibility
+    floor of any float32 implementation)."""
+    from reconstruction.utils.losses import SSIMLoss
+    orig_to = torch.Tensor.to
+    torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else orig_to(self, *a, **k)     # losses.py:34 hard-wires 'cuda'
+    try:
+        with torch.enable_grad():
+            if dtype is not None:
+                net = net.to(dtype); mk = mk.to(dtype); target = target.to(dtype)
+            lossf = SSIMLoss()
+            if dtype is not None:
+                lossf = lossf.to(dtype)
+            opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=0.0)
+            opt.zero_grad()
+            output = net(mk, mask)
+            tgt, out = r_tf.center_crop_to_smallest(target, output)
+            if dtype is not None:       # losses.py:34 builds the data range with torch.Tensor(...) (float32): keep the module's dtype
+                loss = _ssim_loss_any_dtype(lossf, out.unsqueeze(1), tgt.unsqueeze(1))
+            else:
+                loss = lossf(out.unsqueeze(1), tgt.unsqueeze(1), data_range=tgt.max())
+            loss.backward()
+            grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+            opt.step()
+            new = {k: p.detach().clone() for k, p in net.named_parameters()}
+    finally:
+        torch.Tensor.to = orig_to
+    return loss.detach(), grads, new, output.detach()
+
+
+def _ssim_loss_any_dtype(lossf, Xt, Yt):
+    """reference utils/losses.py:25-58 line for line, with the frame's data range kept in the inputs' dtype (float64 runs)."""
+    import torch.nn.functional as F
+    ssims = 0.
+    Nt = Xt.shape[2]
+    for t in range(Nt):
+        X = Xt[:, :, t, :]; Y = Yt[:, :, t, :]
+        data_range = Y.max().reshape(1)[:, None, None, None]
+        C1 = (lossf.k1 * data_range) ** 2; C2 = (lossf.k2 * data_range) ** 2
+        ux = F.conv2d(X, lossf.w); uy = F.conv2d(Y, lossf.w)
+        uxx = F.conv2d(X * X, lossf.w); uyy = F.conv2d(Y * Y, lossf.w); uxy = F.conv2d(X * Y, lossf.w)
+        vx = lossf.cov_norm * (uxx - ux * ux); vy = lossf.cov_norm * (uyy - uy * uy); vxy = lossf.cov_norm * (uxy - ux * uy)
+        A1, A2, B1, B2 = (2 * ux * uy + C1, 2 * vxy + C2, ux ** 2 + uy ** 2 + C1, vx + vy + C2)
+        S = (A1 * A2) / (B1 * B2)
+        ssims += 1 - S.mean()
+    return ssims / Nt
+
+
+def _kink_stability(net, mk, mask, target, trials=6):
+    """LeakyReLU has a kink at 0 and InstanceNorm planes whose mean is zero up to rounding (the first conv of every NormUnet on a
+    zero-padded, mean-normalised plane) put whole groups of activations within rounding of it: the reference's OWN float32
+    gradient then jumps by ~1e-3 when the input changes by 1e-6.  A fixture can pin an implementation only where that does not
+    happen: largest relative change of any parameter gradient of the reference's training step under `trials` random relative
+    input perturbations of 1e-6."""
+    import copy
+    base = _training_step(copy.deepcopy(net), mk, mask, target)[1]
+    worst = 0.0
+    for i in range(trials):
+        pert = mk * (1 + 1e-6 * rnd(900 + i, *mk.shape))
+        gi = _training_step(copy.deepcopy(net), pert, mask, target)[1]
+        worst = max(worst, max(float((gi[k] - base[k]).abs().max() / base[k].abs().max().clamp_min(1e-30)) for k in base))
+    return worst
+
+
+def g_varnet_grad():
+    """Gradients of the reference's training step (pl_modules/varnet_module.py:97-113 + loss.backward() + one Adam step,
+    :151-154) for the tiny VarNets: XF, XT, 2D, XF with weight sharing.  Stored per variant: state dict, loss, every
+    parameter's gradient, the weights after the step, and -- from the same reference code run in float64 -- the gradients'
+    float32 reproducibility floor (max |g32 - g64| / max |g64| per parameter)."""
+    import copy
+    t, c, h, w = 5, 3, 24, 20
+    mask = tiny_mask(t, h)
+    mk = rnd(44, 1, t, c, h, w, 2) * mask          # white k-space: every x-f / y-f plane carries signal (well-conditioned InstanceNorms)
+    target = rnd(45, 1, t, 20, 18).abs() + 0.1     # (1, t, 20, 18): exercises the center crop
+    a = dict(masked_kspace=mk, mask=mask, target=target)
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)):
+        # the weight seed is the first whose reference gradients are stable under 1e-6 input perturbations (see _kink_stability):
+        # about one fixture in three sits on a LeakyReLU kink and cannot pin any float32 implementation, the reference included
+        for seed in range(43, 143):
+            net = RM.VarNet(2, 4, 2, 4, 2, dyn, ws)
+            synth.fill_parameters_(net, seed)
+            with torch.no_grad():
+                for i, cas in enumerate(net.cascades):
+                    cas.lambda_reg.fill_(0.2 + 0.5 * i)
+            stab = _kink_stability(net, mk, mask, target)
+            print(f"    {tag}: weight seed {seed}: gradient change under 1e-6 input perturbations {stab:.2e}")
+            if stab <= 2e-5:
+                break
+        else:
+            raise RuntimeError("no kink-stable seed")
+        a[f"{tag}_seed"] = seed; a[f"{tag}_stability"] = stab
+        a.update(sd_np(copy.deepcopy(net), f"{tag}::sd::"))      # a copy: the optimiser step below updates the parameters in place
+        net64 = copy.deepcopy(net)
+        loss, grads, new, out = _training_step(net, mk, mask, target)
+        loss64, grads64, _, _ = _training_step(net64, mk, mask, target, dtype=torch.float64)
+        a[f"{tag}_loss"] = loss; a[f"{tag}_out"] = out; a[f"{tag}_loss64"] = loss64
+        for k, g in grads.items():
+            a[f"{tag}::grad::{k}"] = g
+            a[f"{tag}::new::{k}"] = new[k]
+            g64 = grads64[k]
+            a[f"{tag}::floor::{k}"] = float((g.double() - g64).abs().max() / g64.abs().max().clamp_min(1e-300))
+    save("varnet_grad", **a)
+
+
+def g_varnet_grad_cfg2():
+    """cfg 2 (XF-VarNet, 6 cascades, 15 coils x 15 frames x 200 x 200): strided fingerprints of the reference's parameter
+    gradients of the training step (inputs / weights regenerate from seeds 0 / 1; target = the synthetic phantom's target)."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+    net = RM.VarNet(6, 8, 3, 16, 3, "XF")
+    synth.fill_parameters_(net, 1)
+    target = ex["target"].contiguous()
+    import copy
+    net0 = copy.deepcopy(net)
+    loss, grads, new, out = _training_step(net, ex["masked_kspace"], ex["mask"], target)
+    a = dict(loss=loss, data_seed=0, weight_seed=1, out_strided=out[:, :, ::4, ::4].contiguous())
+    # the reference's own float32 gradients move when the input changes by 1e-6 (LeakyReLU kinks, see _kink_stability): that
+    # movement, per parameter, is the resolution at which ANY float32 implementation can be compared with this fixture
+    self_max, self_norm = {k: 0.0 for k in grads}, {k: 0.0 for k in grads}
+    for i in range(2):
+        gi = _training_step(copy.deepcopy(net0), ex["masked_kspace"] * (1 + 1e-6 * rnd(950 + i, *ex["masked_kspace"].shape)), ex["mask"], target)[1]
+        for k, g in grads.items():
+            self_max[k] = max(self_max[k], float((gi[k] - g).abs().max() / g.abs().max()))
+            self_norm[k] = max(self_norm[k], float((gi[k] - g).double().norm() / g.double().norm()))
+    for k, g in grads.items():
+        flat = g.reshape(-1)
+        a[f"grad::{k}"] = flat[::max(1, flat.numel() // 512)].contiguous()
+        a[f"gnorm::{k}"] = g.double().norm()
+        a[f"gmax::{k}"] = g.abs().max()
+        a[f"selfmax::{k}"] = self_max[k]; a[f"selfnorm::{k}"] = self_norm[k]
+    save("varnet_grad_cfg2", **a)
+
+
+GENERATORS = dict(varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)

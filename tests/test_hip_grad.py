@@ -1,0 +1,273 @@
+"""Training through the HIP path (second half): gradients of the drop-in models against
+
+  * the REFERENCE's own gradients of its training step (tests/golden/varnet_grad*.npz, written by make_golden.py from
+    pl_modules/varnet_module.py:97-113 + loss.backward() + one Adam step of :151-154), and
+  * the CPU oracle's autograd on seeded inputs, piece by piece (U-Net, NormUnet, x-f / y-f regulariser, image-space DC,
+    coil reduce, rss normalisation, complex_abs).
+
+Tolerance: 1e-4 of each gradient tensor's largest magnitude (float32 arithmetic on both sides; the fixtures store how far
+the reference's float32 gradients are from its own float64 run -- 2e-6 .. 8e-6 -- and the bar is max(1e-4, 20x that floor)).
+The tiny fixtures are chosen kink-stable (make_golden.py:_kink_stability): most weight seeds put a whole InstanceNorm plane
+within rounding of LeakyReLU's kink, where the reference's own float32 gradient jumps by 1e-3 under a 1e-6 input change and
+no implementation can be pinned.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, rnd, state_dict_from
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _grads(module, loss):
+    module.zero_grad(set_to_none=True)
+    loss.backward()
+    return {k: p.grad.detach().clone() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def _cmp(got, want, what, tol=TOL):
+    bad = {}
+    for k, w in want.items():
+        assert k in got and got[k] is not None, f"{what}: no gradient for {k}"
+        e = rel_err(got[k].cpu(), w)
+        if e > tol:
+            bad[k] = e
+    assert not bad, f"{what}: {bad}"
+
+
+# ------------------------------------------------------------------ U-Net / NormUnet against the oracle's autograd
+@pytest.mark.parametrize("n,chans,pools,h,w", [(6, 4, 2, 32, 16), (4, 8, 3, 48, 16), (3, 4, 2, 26, 22), (2, 18, 4, 32, 32), (5, 4, 1, 10, 6)])
+def test_unet_backward_vs_oracle(dev, n, chans, pools, h, w):
+    """cine_unet2d_backward (reference denoisers/unet.py:73-125 under autograd): every weight gradient and the input
+    gradient; odd sizes after pooling exercise the zero-pad crop of :106-120, chans 18 the ragged 16-channel chunks."""
+    from reconstruction.models.denoisers.unet import Unet
+    from oracle import regularisers as R
+    from cine_hip import synth
+    hip = Unet(chans, pools, 2, 2).to(dev)
+    synth.fill_parameters_(hip, 11)
+    ref = R.Unet(chans, pools, 2, 2)
+    ref.load_state_dict(hip.state_dict())
+    x, gy = rnd(1, n, 2, h, w), rnd(2, n, 2, h, w)
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        want = _grads(ref, (ref(xr) * gy).sum())
+        xh = x.to(dev).requires_grad_(True)
+        yh = hip(xh)
+        got = _grads(hip, (yh * gy.to(dev)).sum())
+    _cmp(got, want, "unet weight gradients")
+    assert rel_err(xh.grad.cpu(), xr.grad) < TOL
+
+
+def test_unet_two_sets_and_determinism(dev):
+    """Two weight sets in one launch sequence (the x-f / y-f U-Nets, varnet.py:224-226) == two single launches; a repeated
+    backward pass is bit-identical (fixed-order reductions)."""
+    from reconstruction.models.denoisers.unet import Unet
+    from cine_hip import ops, synth, autograd as ag
+    a, b = Unet(4, 2, 2, 2).to(dev), Unet(4, 2, 2, 2).to(dev)
+    synth.fill_parameters_(a, 21); synth.fill_parameters_(b, 22)
+    x, gy = rnd(3, 8, 2, 32, 16).to(dev), rnd(4, 8, 2, 32, 16).to(dev)
+    both = ops.UnetWeights([a, b])
+    with torch.enable_grad():
+        y = ag.unet2d(x.clone().requires_grad_(True), both)
+        g2 = _grads(torch.nn.ModuleList([a, b]), (y * gy).sum())
+        y_again = ag.unet2d(x.clone().requires_grad_(True), both)
+        g2b = _grads(torch.nn.ModuleList([a, b]), (y_again * gy).sum())
+        ya = a(x[:4].clone().requires_grad_(True)); ga = _grads(a, (ya * gy[:4]).sum())
+        yb = b(x[4:].clone().requires_grad_(True)); gb = _grads(b, (yb * gy[4:]).sum())
+    for k in g2:
+        assert torch.equal(g2[k], g2b[k]), k
+    for k, v in ga.items():
+        assert rel_err(g2["0." + k].cpu(), v.cpu()) < 1e-5, k
+    for k, v in gb.items():
+        assert rel_err(g2["1." + k].cpu(), v.cpu()) < 1e-5, k
+
+
+@pytest.mark.parametrize("h,w", [(24, 20), (33, 17)])
+def test_normunet_backward_vs_oracle(dev, h, w):
+    """NormUnet.forward under autograd (norm_unet.py:98-114): group norm with the unbiased std, pad, U-Net, unpad, un-norm."""
+    from reconstruction.models.denoisers.norm_unet import NormUnet
+    from oracle import regularisers as R
+    from cine_hip import synth
+    hip = NormUnet(4, 2).to(dev)
+    synth.fill_parameters_(hip, 31)
+    ref = R.NormUnet(4, 2)
+    ref.load_state_dict(hip.state_dict())
+    x, gy = rnd(5, 5, 1, h, w, 2) * 3 + 0.5, rnd(6, 5, 1, h, w, 2)
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        want = _grads(ref, (ref(xr) * gy).sum())
+        xh = x.to(dev).requires_grad_(True)
+        got = _grads(hip, (hip(xh) * gy.to(dev)).sum())
+    _cmp(got, want, "normunet weight gradients")
+    assert rel_err(xh.grad.cpu(), xr.grad) < TOL
+
+
+# ------------------------------------------------------------------ the pieces around the regulariser
+@pytest.mark.parametrize("dyn,share", [("XF", False), ("XT", False), ("XF", True)])
+def test_xfyf_backward_vs_oracle(dev, dyn, share):
+    """VarNetBlock.xfyf_transform under autograd (varnet.py:196-241), h != w so the two plane sets differ in shape for the
+    unshared case too."""
+    import reconstruction.models as M
+    from oracle import varnet_ref as V
+    from cine_hip import synth
+    hip = M.VarNet(1, 4, 2, 4, 2, dyn, share).to(dev)
+    synth.fill_parameters_(hip, 41)
+    ref = V.VarNet(1, 4, 2, 4, 2, dyn, share)
+    ref.load_state_dict(hip.state_dict())
+    for hh, ww in ((24, 20), (16, 16)):
+        img, g = rnd(7, 1, 5, hh, ww, 2), rnd(8, 1, 5, 1, hh, ww, 2)
+        with torch.enable_grad():
+            ir = img.clone().requires_grad_(True)
+            want = _grads(ref, (ref.cascades[0].xfyf_transform(ir) * g).sum())
+            ih = img.to(dev).requires_grad_(True)
+            got = _grads(hip, (hip.cascades[0].xfyf_transform(ih) * g.to(dev)).sum())
+        _cmp(got, want, f"xfyf {dyn} {hh}x{ww}")
+        assert rel_err(ih.grad.cpu(), ir.grad) < TOL
+
+
+@pytest.mark.parametrize("t,c,h,w", [(3, 4, 24, 20), (2, 3, 200, 12), (4, 7, 17, 9)])
+def test_image_dc_backward_vs_oracle(dev, t, c, h, w):
+    """cine_image_dc under autograd against the literal k-space formula of varnet.py:181-194, 281-282 differentiated by torch:
+    gradients for the image, the maps, the zero-filled term and lambda_reg (h = 200 takes the 10 x 20 FFT engine)."""
+    from cine_hip import autograd as ag
+    from oracle import centered_fft as cf, complex_ops as co
+    m, sens, kref = rnd(9, 1, t, 1, h, w, 2), rnd(10, 1, 1, c, h, w, 2), rnd(11, 1, t, c, h, w, 2)
+    mask = (torch.from_numpy(np.random.RandomState(12).rand(1, t, 1, h, 1, 1)) < 0.4).to(torch.uint8)
+    g = rnd(13, 1, t, 1, h, w, 2)
+    lam = torch.tensor([0.37])
+    with torch.enable_grad():
+        mr, sr, lr = m.clone().requires_grad_(True), sens.clone().requires_grad_(True), lam.clone().requires_grad_(True)
+        v = torch.nn.functional.softplus(lr)
+        kth = cf.fft2c(co.complex_mul(mr, sr))
+        mk = mask.to(kth.dtype)
+        k = (1 - mk) * kth + mk * (kth + v * (kref * mk)) / (1 + v)
+        out_r = co.complex_mul(cf.ifft2c(k), co.complex_conj(sr)).sum(dim=2, keepdim=True)
+        (out_r * g).sum().backward()
+        md, sd, ld = m.to(dev).requires_grad_(True), sens.to(dev).requires_grad_(True), lam.to(dev).requires_grad_(True)
+        zf = ag.CoilReduceFn.apply(kref.to(dev), sd, mask.to(dev))
+        out = ag.ImageDcFn.apply(md, sd, zf, mask.to(dev), ld)
+        (out * g.to(dev)).sum().backward()
+    assert rel_err(out.detach().cpu(), out_r.detach()) < 1e-5
+    assert rel_err(md.grad.cpu(), mr.grad) < TOL
+    assert rel_err(sd.grad.cpu(), sr.grad) < TOL
+    assert rel_err(ld.grad.cpu(), lr.grad) < TOL
+
+
+def test_rss_abs_backward_vs_torch(dev):
+    """divide_root_sum_of_squares (varnet.py:58-59) and complex_abs (math.py:48-62) under autograd."""
+    from cine_hip import autograd as ag
+    from oracle import complex_ops as co
+    x, g = rnd(14, 2, 5, 12, 10, 2), rnd(15, 2, 5, 12, 10, 2)
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        ((xr / co.rss_complex(xr, dim=1).unsqueeze(-1).unsqueeze(1)) * g).sum().backward()
+        xd = x.to(dev).requires_grad_(True)
+        (ag.RssNormFn.apply(xd) * g.to(dev)).sum().backward()
+        ar = x.clone().requires_grad_(True)
+        (co.complex_abs(ar) * g[..., 0]).sum().backward()
+        ad = x.to(dev).requires_grad_(True)
+        (ag.AbsFn.apply(ad) * g[..., 0].to(dev)).sum().backward()
+    assert rel_err(xd.grad.cpu(), xr.grad) < 1e-5
+    assert rel_err(ad.grad.cpu(), ar.grad) < 1e-5
+
+
+# ------------------------------------------------------------------ whole model against the reference's gradients
+def _training_step(model, mk, mask, target, lr=0.0003):
+    """Body of reference pl_modules/varnet_module.py:97-113 on the drop-in modules, loss.backward(), one Adam step (:151-154)."""
+    from reconstruction.data import transforms
+    from reconstruction.utils import SSIMLoss
+    lossf = SSIMLoss().to(mk.device)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.0)
+    opt.zero_grad()
+    output = model(mk, mask)
+    tgt, out = transforms.center_crop_to_smallest(target, output)
+    loss = lossf(out.unsqueeze(1), tgt.unsqueeze(1), data_range=tgt.max())
+    loss.backward()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    return loss.detach(), grads, output.detach()
+
+
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+def test_varnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
+    """The reference's training step on the drop-in VarNet: loss, every parameter gradient and the weights after one Adam
+    step against the reference's own (varnet_grad.npz)."""
+    import reconstruction.models as M
+    g = golden("varnet_grad")
+    net = M.VarNet(2, 4, 2, 4, 2, dyn, share)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net = net.to(dev).train()
+    mk, mask, target = (torch.from_numpy(g[k]).to(dev) for k in ("masked_kspace", "mask", "target"))
+    with torch.enable_grad():
+        loss, grads, out = _training_step(net, mk, mask, target)
+    assert rel_err(out.cpu(), g[f"{tag}_out"]) < TOL
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5
+    new = dict(net.named_parameters())
+    bad = {}
+    for k in (k[len(tag) + 8:] for k in g if k.startswith(f"{tag}::grad::")):
+        floor = float(g[f"{tag}::floor::{k}"])
+        tol = TOL if floor < 5e-6 else max(TOL, 20 * floor)
+        e = rel_err(grads[k].cpu(), g[f"{tag}::grad::{k}"])
+        if e > tol:
+            bad[k] = (e, floor)
+        # Adam's first step moves every weight by lr * g / (|g| + eps): compare where the gradient is well above eps
+        want_new, gref = torch.from_numpy(g[f"{tag}::new::{k}"]), torch.from_numpy(g[f"{tag}::grad::{k}"])
+        sel = gref.abs() > 1e-5
+        assert (new[k].detach().cpu() - want_new)[sel].abs().max() <= 0.02 * 0.0003, k
+    assert not bad, bad
+
+
+def test_varnet_cfg2_training_step_vs_reference_fingerprint(dev, golden):
+    """cfg 2 at full size (XF-VarNet, 6 cascades, 15 coils x 15 frames x 200 x 200): strided fingerprints of the reference's
+    parameter gradients (varnet_grad_cfg2.npz).  At this size the reference's own float32 gradients move by 1e-3 (median over
+    the parameters; up to 9e-3) when the k-space changes by 1e-6 -- tens of thousands of InstanceNorm planes sit on LeakyReLU's
+    kink (make_golden.py:_kink_stability) -- and the fixture stores that movement per parameter (selfmax / selfnorm).  Bar: the
+    larger of 1e-3 and 3x the reference's own movement, on the largest entry and on the L2 norm of every gradient tensor."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    g = golden("varnet_grad_cfg2")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=int(g["data_seed"]))
+    net = M.VarNet(6, 8, 3, 16, 3, "XF")
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net = net.to(dev).train()
+    with torch.enable_grad():
+        loss, grads, out = _training_step(net, ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev))
+    assert rel_err(out[:, :, ::4, ::4].cpu(), g["out_strided"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    bad = {}
+    for k in (k[6:] for k in g if k.startswith("grad::")):
+        flat = grads[k].reshape(-1)
+        got = flat[::max(1, flat.numel() // 512)].cpu()
+        e = float((got.double() - torch.from_numpy(g[f"grad::{k}"]).double()).abs().max() / float(g[f"gmax::{k}"]))
+        en = abs(float(grads[k].double().norm()) - float(g[f"gnorm::{k}"])) / float(g[f"gnorm::{k}"])
+        if e > max(1e-3, 3 * float(g[f"selfmax::{k}"])) or en > max(1e-3, 3 * float(g[f"selfnorm::{k}"])):
+            bad[k] = (e, en)
+    assert not bad, bad
+
+
+def test_inference_path_untouched_by_grad_mode(dev, golden):
+    """With autograd off the drop-in model takes the inference path (bit-identical to a no_grad call), and a grad-mode forward
+    returns the same values to rounding."""
+    import reconstruction.models as M
+    g = golden("varnet_grad")
+    net = M.VarNet(2, 4, 2, 4, 2, "XF")
+    net.load_state_dict(state_dict_from(g, "XF::sd::"), strict=True)
+    net = net.to(dev)
+    mk, mask = torch.from_numpy(g["masked_kspace"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    a = net(mk, mask)
+    with torch.no_grad():
+        b = net(mk, mask)
+    with torch.enable_grad():
+        c = net(mk, mask)
+    assert torch.equal(a, b) and not a.requires_grad and c.requires_grad
+    assert rel_err(c.detach().cpu(), a.cpu()) < 1e-5
+    assert rel_err(net(mk, mask.float()).cpu(), a.cpu()) == 0.0           # a float 0/1 mask (apply_mask's return) is accepted

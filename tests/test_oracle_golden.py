@@ -207,3 +207,24 @@ def test_rnn_models(golden):
         assert rel_err(net(mk, mask, sens), g["cinenet_rnn_out"]) < 1e-4
         net = R.XPDNet_RNN(3, 4, 2, 6, True, 2, 1).eval(); net.load_state_dict(state_dict_from(g, "xpdnet_rnn::sd::"), strict=True)
         assert rel_err(net(mk, mask), g["xpdnet_rnn_out"]) < 1e-4
+
+
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+def test_oracle_training_step_gradients_vs_reference_golden(golden, tag, dyn, share):
+    """The oracle under autograd reproduces the reference's training-step gradients (pl_modules/varnet_module.py:97-113 +
+    loss.backward(); varnet_grad.npz) -- it is the checker of the HIP backward kernels (tests/test_hip_grad.py)."""
+    from reconstruction.utils.losses import SSIMLoss        # the build's device-agnostic SSIMLoss (pinned to the reference's by metrics.npz)
+    g = golden("varnet_grad")
+    net = V.VarNet(2, 4, 2, 4, 2, dyn, share)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    mk, mask, target = (torch.from_numpy(g[k]) for k in ("masked_kspace", "mask", "target"))
+    with torch.enable_grad():
+        out = net(mk, mask)
+        h0, w0 = (out.shape[-2] - target.shape[-2]) // 2, (out.shape[-1] - target.shape[-1]) // 2
+        crop = out[..., h0:h0 + target.shape[-2], w0:w0 + target.shape[-1]]
+        loss = SSIMLoss()(crop.unsqueeze(1), target.unsqueeze(1), data_range=target.max())
+        loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-6
+    for k, p in net.named_parameters():
+        floor = float(g[f"{tag}::floor::{k}"])
+        assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k

@@ -125,3 +125,28 @@ if __name__ == "__main__":
         check_varnet("XF")
         check_varnet("XT", share=True)
         check_varnet("2D")
+
+
+def check_golden(tag="XT", dyn="XT", share=False):
+    """the varnet_grad.npz case: HIP vs the stored reference gradients, per parameter"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden, state_dict_from
+    from reconstruction.data import transforms
+    from reconstruction.utils import SSIMLoss
+    g = load_golden("varnet_grad")
+    net = M.VarNet(2, 4, 2, 4, 2, dyn, share)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net = net.to(dev)
+    mk, mask, target = (torch.from_numpy(g[k]).to(dev) for k in ("masked_kspace", "mask", "target"))
+    with torch.enable_grad():
+        out = net(mk, mask)
+        tgt, o = transforms.center_crop_to_smallest(target, out)
+        loss = SSIMLoss().to(dev)(o.unsqueeze(1), tgt.unsqueeze(1), data_range=tgt.max())
+        gh = grads_of(net, loss)
+    print("loss", float(loss), float(g[f"{tag}_loss"]), "out err", rel(out.detach(), torch.from_numpy(g[f"{tag}_out"])))
+    for k, v in gh.items():
+        print(f"  {k:60s} {rel(v, torch.from_numpy(g[f'{tag}::grad::{k}'])):.2e}  floor {float(g[f'{tag}::floor::{k}']):.1e}  gmax {float(v.abs().max()):.2e}")
+
+
+if "golden" in sys.argv[1:]:
+    check_golden()
