@@ -133,6 +133,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=3)
     ap.add_argument("--cpu-threads", type=str, default="sweep", help="'sweep' (8,16,32,64,physical) or a number")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL (backend nccl), the device barrier and the all-gather of the volume assembly even at --gpus 1 "
+                         "(start under `python -m torch.distributed.run --nproc-per-node=1`, or alone: rank 0 of a world of 1)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the other_configs / train_step extras of the default 1-GPU line")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the launcher, sharding, timed region and all-gather on "
                          "gloo/CPU with a stand-in for the forward; the line is marked invalid and measures nothing")
@@ -230,8 +234,9 @@ def cpu_baseline(cfg, ex, forwards, threads_arg):
 def timed_steps(run, nsteps, batch, outs, world, sync, barrier, device):
     """The timed region of the contract: barrier + sync, `nsteps` steps, volume assembly, sync + barrier; max over ranks."""
     from cine_hip import shard
+    coll = world > 1 or (shard.FORCE_COLLECTIVE and dist.is_initialized())
     sync()
-    if world > 1:
+    if coll:
         barrier()
     sync()
     t0 = time.perf_counter()
@@ -239,11 +244,11 @@ def timed_steps(run, nsteps, batch, outs, world, sync, barrier, device):
     volume = shard.assemble_volume(outs, world * nsteps * batch)      # one all-gather (RCCL over xGMI; no-op at N=1)
     assert volume.shape[0] == world * nsteps * batch
     sync()
-    if world > 1:
+    if coll:
         barrier()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
@@ -279,6 +284,229 @@ def selftest_cpu(args, world, rank):
         raise SystemExit(3)
 
 
+class Workload:
+    """One BASELINE configuration set up on this rank's GPU: S different slices resident in HBM, the drop-in model, one hipGraph
+    per slice (its own stream), and the timed region of the contract over them."""
+
+    def __init__(self, cfg_id, args, world, rank, local, dev, steps, inflight=0):
+        from concurrent.futures import ThreadPoolExecutor
+        from cine_hip import synth
+        self.cfg = cfg = CONFIGS[cfg_id]()
+        self.args, self.world, self.rank, self.local, self.dev, self.steps = args, world, rank, local, dev, steps
+        if inflight > 0:
+            S = max(1, min(inflight, steps))
+        else:
+            S = next((c for c in range(12, 5, -1) if steps % c == 0), 8) if steps >= 6 else max(1, steps)
+        self.S, self.B = S, max(1, args.batch)
+        B = self.B
+        # S DIFFERENT slices per rank (x B on the batch axis): seeds rank * S * B + ...; the phantoms are host work (0.8 s each):
+        # a small thread pool per rank, with the intra-op threads divided among the ranks of the node
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(max(1, nthr // max(world, 1) // 4))
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            flat = list(pool.map(lambda sd: synth.make_cine_slice(FRAMES, COILS, H, W, accel=cfg["accel"], seed=sd, noise_std=cfg["noise"]),
+                                 [(rank * S + i) * B + j for i in range(S) for j in range(B)]))
+        torch.set_num_threads(nthr)
+        self.exs = exs = [flat[i * B:(i + 1) * B] for i in range(S)]
+        self.host_mk = [torch.cat([e["masked_kspace"] for e in row]).pin_memory() for row in exs]
+        self.mks = [h.to(dev, non_blocking=True) for h in self.host_mk]
+        self.masks = [torch.cat([e["mask"] for e in row]).to(dev) for row in exs]
+        self.senss = [torch.cat([e["sens_maps"] for e in row]).to(dev) for row in exs] if cfg["needs_sens"] else None
+        net = cfg["hip"]().eval()
+        synth.fill_parameters_(net, cfg["wseed"], keep=cfg["keep"])
+        self.net = net.to(dev)
+        from reconstruction.models.varnet import SensitivityModel
+        self.acss = [SensitivityModel.acs_window(m) for m in self.masks]             # host read-back of the 1-D mask, outside capture
+        out = self.forward()                               # also packs the weights
+        torch.cuda.synchronize()
+        self.streams = [torch.cuda.Stream() for _ in range(S)]
+        self.graphs, self.gouts = [], []
+        self.use_graph = not args.no_graph
+        if self.use_graph:
+            try:
+                for i in range(S):
+                    with torch.cuda.stream(self.streams[i]):
+                        self.forward(i)                     # warm this stream's caches outside capture
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.streams[i]):
+                        o = self.forward(i)
+                    self.graphs.append(g); self.gouts.append(o)
+            except Exception as e:                                        # pragma: no cover
+                if rank == 0:
+                    print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                self.use_graph = False
+                self.graphs, self.gouts = [], []
+        torch.cuda.synchronize()
+        self.outs = torch.empty((steps * B,) + tuple(out.shape[1:]), device=dev)   # this rank's slices
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream())
+
+    def forward(self, i=0):
+        if self.cfg["needs_sens"]:
+            return self.net(self.mks[i], self.masks[i], self.senss[i])
+        return self.net(self.mks[i], self.masks[i], acs=self.acss[i])
+
+    def run(self, nsteps, keep, h2d=False):
+        """nsteps slices, round-robin over the S streams; each stream is an in-order queue."""
+        S, B = self.S, self.B
+        for k in range(nsteps):
+            i = k % S
+            with torch.cuda.stream(self.streams[i]):
+                if h2d:
+                    self.mks[i].copy_(self.host_mk[i], non_blocking=True)      # pinned host buffer -> HBM, ahead of this slice's replay
+                if self.use_graph:
+                    self.graphs[i].replay()
+                    o = self.gouts[i]
+                else:
+                    o = self.forward(i)
+                if keep:
+                    self.outs[k * B:(k + 1) * B].copy_(o)
+        for st in self.streams:
+            torch.cuda.current_stream().wait_stream(st)
+
+    def timed(self, nsteps, h2d=False):
+        return timed_steps(lambda n: self.run(n, True, h2d), nsteps, self.B, self.outs, self.world, torch.cuda.synchronize,
+                           lambda: dist.barrier(device_ids=[self.local]), self.dev)[0]
+
+    def replayed_output(self):
+        """Output of stream 0's slice through the timed mode (a graph replay when graphs are in use)."""
+        if self.use_graph:
+            self.graphs[0].replay()
+            torch.cuda.synchronize()
+            return self.gouts[0][:1].clone()
+        return self.forward(0)[:1].clone()
+
+    def release(self):
+        self.graphs, self.gouts = [], []
+        for name in ("mks", "masks", "senss", "outs", "net", "host_mk", "exs"):
+            setattr(self, name, None)
+        torch.cuda.empty_cache()
+
+
+def pmc_families(cfg_id):
+    """HBM-side bytes / MFMA busy fractions per kernel family from the committed rocprofv3 --pmc passes of this same command
+    (tools/collect_profiles.sh -> tools/pmc_traffic.py / pmc_mfma.py; PMC collection cannot run inside the bench itself)."""
+    sfx = "" if cfg_id == 2 else f"_cfg{cfg_id}"
+    for rnd_ in ("r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", f"{rnd_}_pmc_traffic{sfx}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            return tj["families"], f"profiles/{os.path.basename(tpath)}" + (f" @ {tj['commit']}" if "commit" in tj else "")
+    return None, None
+
+
+def conv_roofline(wl, fam, dt, slices):
+    cfg = wl.cfg
+    conv_ms, conv_n = fam["conv3x3_mfma"]
+    roofline = {"bound": "mfma", "kernel": cfg["conv_kernel"], "mode": "isolated: eager launches, one slice in flight, hipEvent pairs per launch",
+                "achieved": cfg["conv_flop"] / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "traffic": None, "launches_per_slice": conv_n, "ms_per_slice": conv_ms, "avg_launch_us": conv_ms * 1e3 / max(conv_n, 1),
+                "flop_per_slice": cfg["conv_flop"]}
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    # the same FLOPs over the driver-timed wall time of the in-flight graph replay: whole-chip fp32-MFMA utilisation of the
+    # timed mode, a lower bound on the conv family's own rate there (its kernels overlap other families' on other streams)
+    roofline["in_flight"] = {"tflops_lower_bound": cfg["conv_flop"] * slices / wl.world / dt / 1e12,
+                             "frac_lower_bound": cfg["conv_flop"] * slices / wl.world / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                             "mode": ("hipGraph replay" if wl.use_graph else "eager") + f", {wl.S} slices in flight (the timed region)"}
+    return roofline
+
+
+def measure_other_config(cfg_id, args, dev, threads):
+    """A shorter run of another BASELINE configuration for the default line's `other_configs`: 12 steps of the same timed region,
+    the conv family's isolated and in-flight MFMA fractions, and the parity of a replayed output against ONE CPU-oracle forward."""
+    from cine_hip import synth
+    steps = 12
+    wl = Workload(cfg_id, args, 1, 0, 0, dev, steps)
+    wl.run(2, False)
+    dt = min(wl.timed(steps) for _ in range(2))
+    fam = profile_families(wl.forward, iters=2)
+    roof = conv_roofline(wl, fam, dt, steps * wl.B)
+    tr, tr_src = pmc_families(cfg_id)
+    if tr and "conv3x3_mfma" in tr:
+        roof["traffic"] = tr["conv3x3_mfma"]["hbm_MB_per_launch"] * 1e6
+        roof["traffic_unit"] = f"HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE, {tr_src}"
+    res = {"workload": wl.cfg["name"], "metric": wl.cfg["metric"], "value": steps * wl.B / dt, "unit": "cine slices/sec", "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "slices_in_flight": wl.S, "launch": "hipGraph replay" if wl.use_graph else "eager",
+           "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_slice", "launches_per_slice")},
+           "mfma_frac_in_flight_lower_bound": roof["in_flight"]["frac_lower_bound"],
+           "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items() if v[1]}}
+    chk = wl.replayed_output().cpu()
+    ex0 = wl.exs[0][0]
+    if not args.no_cpu_baseline:
+        net = wl.cfg["ref"]().eval()
+        synth.fill_parameters_(net, wl.cfg["wseed"], keep=wl.cfg["keep"])
+        cargs = (ex0["masked_kspace"], ex0["mask"]) + ((ex0["sens_maps"],) if wl.cfg["needs_sens"] else ())
+        torch.set_num_threads(threads)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            ref_out = net(*cargs)
+            cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "cine slices/sec", "cores": threads, "kind": "port",
+                               "sample": f"ONE forward of the CPU oracle at {threads} threads, no warm-up: {cdt:.1f} s"}
+        res["parity_max_rel_err_vs_cpu_oracle"] = float((chk - ref_out).abs().max() / ref_out.abs().max())
+        if cfg_id == 3:
+            res["parity_note"] = ("10-cascade XPDNet with random weights: the reference's own fp32 output is 7.0e-4 of the peak from its fp64 "
+                                  "evaluation (tests/golden/xpdnet_cfg3.npz); every cascade alone agrees with the oracle to 1.6e-6")
+    wl.release()
+    return res
+
+
+def measure_training_step(args, dev, threads):
+    """One training step of BASELINE configs[1] through the HIP backward kernels: the body of reference
+    pl_modules/varnet_module.py:97-113 (forward + SSIMLoss), loss.backward() and one Adam step (:151-154), k-space resident in HBM;
+    and the same step of the CPU oracle on the host cores (ONE step: it takes tens of seconds)."""
+    import reconstruction.models as M
+    from reconstruction.utils import SSIMLoss
+    from cine_hip import synth
+    cfg = CONFIGS[2]()
+    ex = synth.make_cine_slice(FRAMES, COILS, H, W, accel=cfg["accel"], seed=0)
+
+    def make(model, device):
+        synth.fill_parameters_(model, cfg["wseed"], keep=cfg["keep"])
+        model = model.to(device).train()
+        lossf = SSIMLoss().to(device)
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+        mk, mask, target = ex["masked_kspace"].to(device), ex["mask"].to(device), ex["target"].to(device)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            out = model(mk, mask)
+            loss = lossf(out.unsqueeze(1), target.unsqueeze(1), target.max())
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+
+    with torch.enable_grad():
+        step = make(cfg["hip"](), dev)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        n = 5
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        fam = profile_families(step, iters=1)
+        res = {"what": "forward + SSIMLoss + backward (hand-written HIP gradient kernels) + Adam, one cfg-2 slice per step, eager launches",
+               "ms_per_step": ms, "steps_per_sec": 1e3 / ms, "loss_after_7_steps": float(loss),
+               "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+               "kernel_ms_per_step": {k: round(v[0], 3) for k, v in fam.items() if v[1]}}
+        if not args.no_cpu_baseline:
+            torch.set_num_threads(threads)
+            cstep = make(cfg["ref"](), torch.device("cpu"))
+            t0 = time.perf_counter()
+            closs = cstep()
+            cdt = time.perf_counter() - t0
+            res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "training steps/sec", "cores": threads, "kind": "port",
+                                   "sample": f"ONE training step of the CPU oracle (torch autograd, fp32) at {threads} threads: {cdt:.1f} s",
+                                   "loss_after_1_step": float(closs)}
+    return res
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -290,124 +518,43 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
     if args.selftest_cpu:
         return selftest_cpu(args, world, rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        # RCCL ("nccl" on ROCm).  --force-dist initialises it at world 1 as well, so that the process group, the device barrier
+        # and the all-gather of the volume assembly run on hardware even where only one GPU is visible.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.set_grad_enabled(False)                 # inference: the drop-in models build an autograd graph when gradients are enabled
 
-    from cine_hip import synth
-    cfg = CONFIGS[args.config]()
-    if args.inflight > 0:
-        S = max(1, min(args.inflight, args.steps))
-    else:
-        S = next((c for c in range(12, 5, -1) if args.steps % c == 0), 8) if args.steps >= 6 else max(1, args.steps)
-    B = max(1, args.batch)
-    # S DIFFERENT slices per rank (x B on the batch axis): seeds rank * S * B + ...
-    exs = [[synth.make_cine_slice(FRAMES, COILS, H, W, accel=cfg["accel"], seed=(rank * S + i) * B + j, noise_std=cfg["noise"])
-            for j in range(B)] for i in range(S)]
-    host_mk = [torch.cat([e["masked_kspace"] for e in row]).pin_memory() for row in exs]
-    mks = [h.to(dev, non_blocking=True) for h in host_mk]
-    masks = [torch.cat([e["mask"] for e in row]).to(dev) for row in exs]
-    senss = [torch.cat([e["sens_maps"] for e in row]).to(dev) for row in exs] if cfg["needs_sens"] else None
-    net = cfg["hip"]().eval()
-    synth.fill_parameters_(net, cfg["wseed"], keep=cfg["keep"])
-    net = net.to(dev)
-    from reconstruction.models.varnet import SensitivityModel
-    acss = [SensitivityModel.acs_window(m) for m in masks]                       # host read-back of the 1-D mask, outside capture
-
-    def forward(i=0):
-        if cfg["needs_sens"]:
-            return net(mks[i], masks[i], senss[i])
-        return net(mks[i], masks[i], acs=acss[i])
-
-    out = forward()                               # also packs the weights
-    torch.cuda.synchronize()
-
-    streams = [torch.cuda.Stream() for _ in range(S)]
-    graphs, gouts = [], []
-    use_graph = not args.no_graph
-    if use_graph:
-        try:
-            for i in range(S):
-                with torch.cuda.stream(streams[i]):
-                    forward(i)                     # warm this stream's caches outside capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=streams[i]):
-                    o = forward(i)
-                graphs.append(g); gouts.append(o)
-        except Exception as e:                                        # pragma: no cover
-            if rank == 0:
-                print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            use_graph = False
-            graphs, gouts = [], []
-    torch.cuda.synchronize()
-
-    outs = torch.empty((args.steps * B,) + tuple(out.shape[1:]), device=dev)   # this rank's slices
-
-    def run(nsteps, keep, h2d=False):
-        """nsteps slices, round-robin over the S streams; each stream is an in-order queue."""
-        for k in range(nsteps):
-            i = k % S
-            with torch.cuda.stream(streams[i]):
-                if h2d:
-                    mks[i].copy_(host_mk[i], non_blocking=True)      # pinned host buffer -> HBM, ahead of this slice's replay
-                if use_graph:
-                    graphs[i].replay()
-                    o = gouts[i]
-                else:
-                    o = forward(i)
-                if keep:
-                    outs[k * B:(k + 1) * B].copy_(o)
-        for st in streams:
-            torch.cuda.current_stream().wait_stream(st)
-
-    def timed(nsteps, h2d=False):
-        return timed_steps(lambda n: run(n, True, h2d), nsteps, B, outs, world, torch.cuda.synchronize,
-                           lambda: dist.barrier(device_ids=[local]), dev)[0]
-
-    for st in streams:
-        st.wait_stream(torch.cuda.current_stream())
-    run(args.warmup, False)
-    dt = timed(args.steps)                                            # THE timed region: exactly K steps
-    extra = sorted(timed(args.steps) for _ in range(max(0, args.repeats)))
-    dt_h2d = timed(args.steps, h2d=True)
+    from cine_hip import shard
+    shard.FORCE_COLLECTIVE = bool(args.force_dist)
+    wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
+    cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
+    wl.run(args.warmup, False)
+    dt = wl.timed(args.steps)                                         # THE timed region: exactly K steps
+    extra = sorted(wl.timed(args.steps) for _ in range(max(0, args.repeats)))
+    dt_h2d = wl.timed(args.steps, h2d=True)
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
     # ---- rank 0: per-family device time, ISOLATED (eager launches, one slice in flight, hipEvents on the launch stream)
-    fam = profile_families(forward)
+    fam = profile_families(wl.forward)
     fam = {k: (v[0] / B, v[1]) for k, v in fam.items()}            # per slice
-    conv_ms, conv_n = fam["conv3x3_mfma"]
     fft_ms = fam["fft_col_pass"][0] + fam["fft_row_pass"][0]
     slices = world * args.steps * B
-    roofline = {"bound": "mfma", "kernel": cfg["conv_kernel"], "mode": "isolated: eager launches, one slice in flight, hipEvent pairs per launch",
-                "achieved": cfg["conv_flop"] / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "traffic": None, "launches_per_slice": conv_n, "ms_per_slice": conv_ms, "avg_launch_us": conv_ms * 1e3 / max(conv_n, 1),
-                "flop_per_slice": cfg["conv_flop"]}
-    roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    # the same FLOPs over the driver-timed wall time of the in-flight graph replay: whole-chip fp32-MFMA utilisation of the
-    # timed mode, a lower bound on the conv family's own rate there (its kernels overlap other families' on other streams)
-    roofline["in_flight"] = {"tflops_lower_bound": cfg["conv_flop"] * slices / world / dt / 1e12,
-                             "frac_lower_bound": cfg["conv_flop"] * slices / world / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                             "mode": ("hipGraph replay" if use_graph else "eager") + f", {S} slices in flight (the timed region)"}
-    # HBM-side bytes per launch of that kernel family: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
-    # summarised by tools/pmc_traffic.py into profiles/ (PMC collection cannot run inside the bench itself)
-    tr, tr_src = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        tpath = os.path.join(ROOT, "profiles", name)
-        if args.config == 2 and os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            tr, tr_src = tj["families"], f"profiles/{name}" + (f" @ {tj['commit']}" if "commit" in tj else "")
-            break
+    roofline = conv_roofline(wl, fam, dt, slices)
+    tr, tr_src = pmc_families(args.config)
     if tr and "conv3x3_mfma" in tr:
         roofline["traffic"] = tr["conv3x3_mfma"]["hbm_MB_per_launch"] * 1e6
         roofline["traffic_unit"] = f"HBM bytes per launch (mean over the launches of a slice), PMC FETCH_SIZE x2 + WRITE_SIZE, {tr_src}"
@@ -421,7 +568,7 @@ def main():
                    "launch": ("hipGraph replay" if use_graph else "eager") + f", {S} independent steps in flight on {S} HIP streams, "
                              f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                    "parallelism": f"slice-sharded x{world}, one all-gather for volume assembly"},
-        "rccl_ranks": world,
+        "rccl_ranks": rccl_ranks, "rccl_initialised": bool(dist.is_initialized()),
         "timed_region_s": dt,
         "repeat_values": [slices / d for d in extra], "repeat_median_value": (slices / extra[len(extra) // 2]) if extra else None,
         "value_with_h2d": slices / dt_h2d,
@@ -436,20 +583,19 @@ def main():
                     "mode": roofline["mode"], "achieved": cfg["fft_bytes"] / (fft_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "algorithmic_bytes": cfg["fft_bytes"], "traffic": None, "ms_per_slice": fft_ms,
                     "note": "achieved = SURVEY 8(d) bytes at the reference's module boundaries / kernel time; the image-space chain "
-                            "moves far fewer bytes than that (traffic), so this is the step's speed in the survey's units, not a bandwidth"}
+                            "moves far fewer bytes than that (traffic), so this is the step's speed in the survey's units, not a bandwidth: "
+                            "achieved_traffic_gbs is the bandwidth (PMC bytes / kernel time)"}
         roof_fft["frac"] = roof_fft["achieved"] / roof_fft["peak"]
         if tr and "fft_col_pass" in tr:
             roof_fft["traffic"] = (tr.get("fft_col_pass", {}).get("hbm_MB_per_slice", 0.0) + tr.get("fft_row_pass", {}).get("hbm_MB_per_slice", 0.0)) * 1e6 or None
             roof_fft["traffic_unit"] = f"HBM bytes per slice over all FFT / DC passes, PMC, {tr_src}"
+            if roof_fft["traffic"]:
+                roof_fft["achieved_traffic_gbs"] = roof_fft["traffic"] / (fft_ms * 1e-3) / 1e9
+                roof_fft["frac_traffic"] = roof_fft["achieved_traffic_gbs"] / HBM_PEAK_GBS
         line["roofline_fft_dc"] = roof_fft
     # ---- parity of a GRAPH-REPLAYED output (stream 0's slice) and the CPU baseline
-    if use_graph:
-        graphs[0].replay()
-        torch.cuda.synchronize()
-        chk = gouts[0][:1].clone()
-    else:
-        chk = forward(0)[:1].clone()
-    ex0 = exs[0][0]
+    chk = wl.replayed_output()
+    ex0 = wl.exs[0][0]
     tgt_d = ex0["target"].to(dev)
     try:
         from cine_hip import ops
@@ -458,8 +604,10 @@ def main():
                         "note": "device kernel (cine_image_metrics), graph-replayed output vs the synthetic target; untrained weights"}
     except (ImportError, AttributeError):
         pass
+    best_threads = 16
     if not args.no_cpu_baseline and world == 1:        # the host-core baseline is timed on rank 0 of the 1-GPU run only
         ref_out, cb = cpu_baseline(cfg, ex0, args.cpu_forwards, args.cpu_threads)
+        best_threads = cb["cores"]
         line["cpu_baseline"] = cb
         from reconstruction.utils import evaluate
         got = chk.cpu()
@@ -472,8 +620,21 @@ def main():
             line["parity_note"] = ("a 10-cascade XPDNet with random weights amplifies rounding: the reference's own fp32 output is 7.0e-4 of the "
                                    "peak (NMSE 2.9e-7) from its fp64 evaluation (tests/golden/xpdnet_cfg3.npz); every cascade alone agrees with "
                                    "the oracle to 1.6e-6 (tests/test_hip_parity.py::test_xpdnet_cfg3_every_cascade_vs_oracle)")
+    # ---- the default 1-GPU line also carries the other BASELINE configurations and the training step (shorter runs)
+    if world == 1 and args.config == 2 and not args.headline_only:
+        wl.release()
+        line["other_configs"] = {}
+        for cid in (3, 4, 5):
+            try:
+                line["other_configs"][str(cid)] = measure_other_config(cid, args, dev, best_threads)
+            except Exception as e:                                        # pragma: no cover
+                line["other_configs"][str(cid)] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            line["train_step"] = measure_training_step(args, dev, best_threads)
+        except Exception as e:                                            # pragma: no cover
+            line["train_step"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

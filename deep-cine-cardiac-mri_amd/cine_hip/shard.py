@@ -10,6 +10,10 @@ import torch
 import torch.distributed as dist
 
 
+# bench.py --force-dist: run the collective even in a world of one rank (hardware rehearsal of the RCCL path on a 1-GPU box)
+FORCE_COLLECTIVE = False
+
+
 def slice_indices(n_slices: int, rank: int, world: int) -> List[int]:
     """Round-robin ownership: slice i belongs to rank i % world."""
     return list(range(rank, n_slices, world))
@@ -23,7 +27,7 @@ def padded_count(n_slices: int, world: int) -> int:
 def assemble_volume(local: torch.Tensor, n_slices: int) -> torch.Tensor:
     """local: (padded_count, ...) outputs of this rank's slices in ownership order (rows past the
     rank's real share are ignored).  Returns (n_slices, ...) in slice order on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not FORCE_COLLECTIVE):
         return local[:n_slices]
     world = dist.get_world_size()
     per = padded_count(n_slices, world)

@@ -545,7 +545,62 @@ def g_varnet_grad_cfg2():
     save("varnet_grad_cfg2", **a)
 
 
-GENERATORS = dict(varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def g_lightning():
+    """Lightning-style checkpoints of the reference's pl_modules (VarNetModule / CineNetModule / XPDNetModule: the state-dict keys
+    carry the `varnet.` / `cinenet.` / `xpdnet.` prefixes plus the loss window and the metric accumulators) for the tiny models,
+    and what the lines of traintest_scripts/run_inference.py:53-78 (InferenceTransform.forward) make of one slice: target, output
+    and zero-filled reconstruction after the center crops.  pytorch_lightning / torchmetrics / skimage are absent from the image:
+    import-time stand-ins (a LightningModule is an nn.Module here; nothing of them is on the path)."""
+    import pathlib
+    for name in ("torchmetrics", "skimage", "skimage.metrics"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["skimage.metrics"].peak_signal_noise_ratio = None
+    sys.modules["skimage.metrics"].structural_similarity = None
+    pl = types.ModuleType("pytorch_lightning")
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k): pass
+
+    class Metric(torch.nn.Module):
+        def __init__(self, dist_sync_on_step=True): super().__init__()
+        def add_state(self, name, default, dist_reduce_fx=None): self.register_buffer(name, default)
+    pl.LightningModule, pl.LightningDataModule = LightningModule, type("LightningDataModule", (), {})
+    pl.metrics = types.ModuleType("pytorch_lightning.metrics"); pl.metrics.Metric = Metric
+    sys.modules["pytorch_lightning"] = pl; sys.modules["pytorch_lightning.metrics"] = pl.metrics
+    import reconstruction.pl_modules as P
+    import reconstruction.pl_modules.mri_module as MM
+    MM.fetch_dir = lambda key, cfg=None: pathlib.Path("/tmp")      # MriModule.__init__ writes a yaml next to the scripts otherwise
+    t, c, h, w = 5, 3, 24, 20
+    ex = synth.make_cine_slice(t, c, h, w, accel=4, center_lines=4, seed=11, noise_std=0.01)
+    mk, mask, sens = ex["masked_kspace"], ex["mask"], ex["sens_maps"]
+    target = ex["target"][:, :, 2:-2, 1:-1].contiguous()
+    a = dict(masked_kspace=mk, mask=mask, sens_maps=sens, target=target)
+    mods = dict(varnet=P.VarNetModule(num_cascades=2, pools=2, chans=4, sens_pools=2, sens_chans=4, dynamic_type="XF"),
+                cinenet=P.CineNetModule(num_cascades=2, CG_iters=3, pools=2, chans=4, dynamic_type="XF"),
+                xpdnet=P.XPDNetModule(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
+                                      n_convs_per_scale=[1, 1], first_conv_n_filters=8, n_primal=2, dynamic_type="XF"))
+    for kind, mod in mods.items():
+        mod.eval()
+        synth.fill_parameters_(getattr(mod, kind), 61, keep=("lambda",) if kind != "xpdnet" else ())
+        a.update(sd_np(mod, f"{kind}::ckpt::"))
+        # ---- run_inference.py:53-78 (device = cpu here)
+        if kind == "cinenet":
+            output = mod(mk, mask, sens)
+        else:
+            output = mod(mk, mask)
+        scaling_factor = torch.sqrt(torch.prod(torch.as_tensor(mk.shape[-3:-1])))
+        images = RU.ifft2c(mk, norm=None) * scaling_factor
+        zero_filled = RU.rss_complex(images, dim=2)
+        tgt, output = r_tf.center_crop_to_smallest(target, output)
+        tgt, zero_filled = r_tf.center_crop_to_smallest(tgt, zero_filled)
+        a[f"{kind}_target"] = tgt.numpy().astype("float32")[0]
+        a[f"{kind}_output"] = output.numpy().astype("float32")[0]
+        a[f"{kind}_zero_filled"] = zero_filled.numpy().astype("float32")[0]
+        print("   ", kind, len(mod.state_dict()), "keys; non-model:", [k for k in mod.state_dict() if not k.startswith(kind + ".")])
+    save("lightning_ckpt", **a)
+
+
+GENERATORS = dict(lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)

@@ -230,8 +230,11 @@ def test_varnet_cfg2_training_step_vs_reference_fingerprint(dev, golden):
     """cfg 2 at full size (XF-VarNet, 6 cascades, 15 coils x 15 frames x 200 x 200): strided fingerprints of the reference's
     parameter gradients (varnet_grad_cfg2.npz).  At this size the reference's own float32 gradients move by 1e-3 (median over
     the parameters; up to 9e-3) when the k-space changes by 1e-6 -- tens of thousands of InstanceNorm planes sit on LeakyReLU's
-    kink (make_golden.py:_kink_stability) -- and the fixture stores that movement per parameter (selfmax / selfnorm).  Bar: the
-    larger of 1e-3 and 3x the reference's own movement, on the largest entry and on the L2 norm of every gradient tensor."""
+    kink (make_golden.py:_kink_stability) -- and the fixture stores that movement per parameter (selfmax / selfnorm).  Float32
+    summation over 10^7 pixels per weight adds to that: for the sensitivity network alone at this size the CPU's float32 autograd
+    is 2e-3 .. 7e-3 (max) / 1e-3 .. 3.5e-3 (L2) from its float64 run, the HIP kernels 1e-3 .. 4e-3 / 0.8e-3 .. 2.6e-3
+    (tools/grad_check_sens.py, profiles/r03_grad_floor_sensnet_cfg2.txt).  Bar: the larger of 5e-3 (max) / 3e-3 (L2) and 3x the
+    reference's own movement, on every gradient tensor."""
     import reconstruction.models as M
     from cine_hip import synth
     g = golden("varnet_grad_cfg2")
@@ -249,7 +252,7 @@ def test_varnet_cfg2_training_step_vs_reference_fingerprint(dev, golden):
         got = flat[::max(1, flat.numel() // 512)].cpu()
         e = float((got.double() - torch.from_numpy(g[f"grad::{k}"]).double()).abs().max() / float(g[f"gmax::{k}"]))
         en = abs(float(grads[k].double().norm()) - float(g[f"gnorm::{k}"])) / float(g[f"gnorm::{k}"])
-        if e > max(1e-3, 3 * float(g[f"selfmax::{k}"])) or en > max(1e-3, 3 * float(g[f"selfnorm::{k}"])):
+        if e > max(5e-3, 3 * float(g[f"selfmax::{k}"])) or en > max(3e-3, 3 * float(g[f"selfnorm::{k}"])):
             bad[k] = (e, en)
     assert not bad, bad
 

@@ -1,0 +1,48 @@
+"""Diagnostic: time of one cfg-2 training step (forward + SSIMLoss + backward + Adam) on the HIP path, per kernel family."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-cine-cardiac-mri_amd")]
+import ctypes
+import torch
+import reconstruction.models as M
+from reconstruction.utils import SSIMLoss
+from cine_hip import synth
+from cine_hip._lib import lib
+
+dev = torch.device("cuda:0")
+ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+net = M.VarNet(6, 8, 3, 16, 3, "XF"); synth.fill_parameters_(net, 1); net = net.to(dev).train()
+mk, mask, target = ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev)
+lossf = SSIMLoss().to(dev)
+opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    out = net(mk, mask)
+    loss = lossf(out.unsqueeze(1), target.unsqueeze(1), target.max())
+    loss.backward()
+    opt.step()
+    return loss
+
+for _ in range(2): step()
+torch.cuda.synchronize()
+t0 = time.time()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for _ in range(n): l = step()
+torch.cuda.synchronize()
+print(f"training step: {(time.time() - t0) / n * 1e3:.1f} ms   loss {float(l):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+with torch.no_grad():
+    for _ in range(2): net(mk, mask)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(n): net(mk, mask)
+    torch.cuda.synchronize()
+print(f"inference forward (eager): {(time.time() - t0) / n * 1e3:.1f} ms")
+L = lib()
+nf = L.cine_profile_families()
+L.cine_profile_begin()
+step()
+ms = (ctypes.c_double * nf)(); cnt = (ctypes.c_long * nf)()
+L.cine_profile_end(ms, cnt, nf)
+for i in range(nf):
+    print(f"  {L.cine_profile_family_name(i).decode():12s} {ms[i]:8.2f} ms  {cnt[i]:5d} launches")
+print(f"  sum {sum(ms):.2f} ms")
