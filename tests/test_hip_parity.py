@@ -3,6 +3,8 @@
 Tolerances (fp32 path): op level rel 1e-5 of the output peak, block level 5e-5,
 model level max|d|/peak <= 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1204,3 +1206,26 @@ def test_lightning_checkpoint_and_inference_lines_vs_reference_golden(golden, de
     assert torch.equal(target[0], torch.from_numpy(g[f"{kind}_target"]))
     assert rel_err(output[0], g[f"{kind}_output"]) < MODEL_TOL
     assert rel_err(zero_filled[0].cpu(), g[f"{kind}_zero_filled"]) < 1e-5
+
+
+def test_bench_force_dist_initialises_rccl_on_hardware(dev):
+    """bench.py --gpus 1 --force-dist under torch.distributed.run (one rank): init_process_group("nccl") = RCCL, the device
+    barrier and the all_gather_into_tensor of the volume assembly run on the GPU at world size 1 (SURVEY 8 e readiness; the
+    8-GPU scaling runs are the driver's).  A child process, started as such -- never an exec of this GPU process."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("NCCL_DEBUG", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "1", "--force-dist",
+           "--headline-only", "--no-cpu-baseline", "--repeats", "0"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    line = json.loads(lines[-1])
+    assert line["rccl_initialised"] is True and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
+    assert line["value"] > 50 and line["steps"] == 6
