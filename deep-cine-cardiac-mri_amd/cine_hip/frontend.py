@@ -90,7 +90,13 @@ def prepare_slice(kspace_txyc: torch.Tensor, crop_shape=(200, 200), n_slices: in
     k = _c2r((kspace_txyc.to(torch.complex64) * scaling).permute(0, 3, 1, 2).contiguous())
     images = ops.fft2c(k, inverse=True)                                      # ifftn(norm=None) * sqrt(N) == ortho (:288-289)
     _, filt = filtered_crop_center_and_slices(images, crop_shape, n_slices, filter_size)
-    return ops.fft2c(filt), filt                                             # fftn(norm=None) / sqrt(N) == ortho (:291-292)
+    # :291 transforms back with the shifts the other way round -- ifftshift(fftn(fftshift(x))) -- which differs from fft2c
+    # (fftshift(fftn(ifftshift(x)))) along axes of ODD length by one sample on either side: fftshift(x) = roll(ifftshift(x), -1)
+    # and ifftshift(y) = roll(fftshift(y), +1) there.  Even lengths (the reference's 200 x 200 crop): no difference.
+    odd = [d for d, n in ((-3, filt.shape[-3]), (-2, filt.shape[-2])) if n % 2]
+    x = torch.roll(filt, shifts=[-1] * len(odd), dims=odd).contiguous() if odd else filt
+    kk = ops.fft2c(x)                                                        # fftn(norm=None) / sqrt(N) == ortho (:291-292)
+    return (torch.roll(kk, shifts=[1] * len(odd), dims=odd).contiguous() if odd else kk), filt
 
 
 def espirit_maps(kspace: torch.Tensor, r: int = 24, k: int = 6, thresh: float = 1e-3, crop: float = 0.8,
@@ -126,8 +132,9 @@ def espirit_maps(kspace: torch.Tensor, r: int = 24, k: int = 6, thresh: float = 
     return maps, lam
 
 
-def ecalib(time_avg_kspace, r: int = 24):
-    """Stand-in for ``bart.bart(2, 'ecalib -r N', time_avg_kspace)[0][..., 0]`` at the reference's call sites
+def ecalib(time_avg_kspace, *, r: int):
+    """``r`` is required: the reference's two call sites differ (`-r 200`, mri_data.py:296; `-r 15`, transforms.py:429).
+    Stand-in for ``bart.bart(2, 'ecalib -r N', time_avg_kspace)[0][..., 0]`` at the reference's call sites
     (mri_data.py:295-297, transforms.py:427-430): (1, x, y, coil) complex (numpy or tensor) -> (x, y, coil) complex of
     the same kind; the calibration itself runs on the GPU."""
     import numpy as np
@@ -140,3 +147,33 @@ def ecalib(time_avg_kspace, r: int = 24):
     maps, _ = espirit_maps(k, r=r)
     out = torch.view_as_complex(maps).permute(1, 2, 0).contiguous()
     return out.cpu().numpy() if is_np else out.to(t.device)
+
+
+def prepare_example(source, mask=None, sens=None, fname: str = "", crop_shape=(200, 200), crop_target=(180, 180), n_slices: int = 15,
+                    filter_size=(0.7, 0.0, 0.3, 0.3), scaling: float = 1e6, ecalib_r: int = 200):
+    """``SliceDataset.__getitem__`` of the reference (data/mri_data.py:267-311) in one piece, on the device: scale -> IFFT2 -> crop +
+    frame selection + Gaussian filter -> FFT2 (k-space of the filtered crop) -> sensitivity maps from the time-averaged k-space
+    (ESPIRiT, where the reference shells out to ``bart ecalib -r 200``; pass ``sens`` (coil, X, Y) complex to use given maps) ->
+    coil-combined magnitude target -> center crop.  ``source``: the raw (t, x, y, coil) complex array / tensor, or an already-open
+    h5py-like mapping holding it under ``"y"`` (and optionally ``"mask"``): the reader stays the caller's.
+    Returns the reference's sample tuple (kspace (t, coil, X, Y) complex64, mask, target (t, cx, cy) float32, attrs, fname, dataslice)
+    as numpy arrays, like the reference (the ``*DataTransform`` classes take it from there, data/transforms.py:300-352)."""
+    import numpy as np
+    if hasattr(source, "keys") and "y" in source:
+        raw = np.asarray(source["y"])
+        if mask is None and "mask" in source:
+            mask = np.asarray(source["mask"])
+    else:
+        raw = source
+    if not torch.cuda.is_available():
+        raise CineHipError("prepare_example: the front-end kernels need a GPU (no CPU fallback)")
+    y = torch.as_tensor(raw).to(torch.complex64).cuda()
+    kspace, filt = prepare_slice(y, crop_shape, n_slices, filter_size, scaling)            # (t, c, X, Y, 2) each
+    if sens is None:
+        time_avg = torch.view_as_complex(kspace.mean(dim=0, keepdim=True).contiguous()).permute(0, 2, 3, 1)     # (1, X, Y, coil), :295
+        smaps = ecalib(time_avg, r=ecalib_r).permute(2, 0, 1).contiguous()                  # (coil, X, Y), :297-298
+    else:
+        smaps = torch.as_tensor(sens).to(torch.complex64).cuda()
+    target = combine_target(filt, torch.view_as_real(smaps).contiguous(), crop_target)      # :302-303
+    k_np = torch.view_as_complex(kspace.contiguous()).cpu().numpy()
+    return k_np, mask, target.cpu().numpy(), {}, fname, 0

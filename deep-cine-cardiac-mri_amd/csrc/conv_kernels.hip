@@ -1092,18 +1092,21 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
 }
 
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is per device: raise it once per (kernel, device), and report a failure
+// hipFuncAttributeMaxDynamicSharedMemorySize is per device: raise it once per (kernel, device) and KEEP the result -- a failed
+// first call must fail every later launch with its own message instead of a generic launch error
 template <typename K>
 static int allow_big_lds(K kern, std::once_flag (&once)[64], const char* what) {
+    static hipError_t status[64];                 // per template instance = per kernel
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    hipError_t err = hipSuccess;
-    std::call_once(once[dev & 63], [&] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "%s: device index %d", what, dev);
+    std::call_once(once[dev], [&] {
+        status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    CINE_REQUIRE(err == hipSuccess, CINE_EHIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(err));
+    CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(status[dev]));
     return CINE_OK;
 }
+
 
 // ---------------------------------------------------------------- launch recorder (plane-persistent U-Net)
 struct RecStep {

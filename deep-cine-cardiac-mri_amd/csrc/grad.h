@@ -39,7 +39,7 @@ size_t wgrad_ws_floats(int rows, int cin, int taps, int n);
 int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1, float* ws, size_t ws_floats, hipStream_t st);
 
 // gb[co] += sum_{n in set, pixels} g[n][co][p]   (bias of the final 1x1 conv, unet.py:69)
-int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, hipStream_t st);
+int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, float* ws, size_t ws_floats, hipStream_t st);   // ws: n * cout floats
 
 // dgrad entry points of conv_kernels.hip
 extern "C" int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,

@@ -103,6 +103,7 @@ struct WgLaunch {
     int chunk, nchunks;        // samples per chunk, chunks per weight set
     int rowsp, cinp;           // padded to 16
     float* part;               // [2][nchunks][rowsp][cinp][TAPS]
+    int fast_in, fast_g;       // vectorised + prefetched staging of the input / output-gradient tiles (see launch_wgrad)
 };
 
 template <int TAPS, int TW, int CT, int WM, int NPIX>
@@ -110,31 +111,39 @@ struct WgCfg {
     static constexpr int HALO = TAPS == 9 ? 1 : 0;
     static constexpr int TH = NPIX / TW;
     static constexpr int ROWS = TH + 2 * HALO, COLS = TW + 2 * HALO;
+    // LDS row of the input tile: interior columns [0, TW), then (3x3 only) the right halo at TW and the left halo at COLS - 1,
+    // so that interior pieces are written with aligned 8-byte stores; image column x of the tile lives at (x + COLS) % COLS
     static constexpr int pad2(int v) { return ((v + 29) / 32) * 32 + 2; }       // smallest >= v with == 2 (mod 32)
     static constexpr int PSI = pad2(ROWS * COLS), PSG = pad2(NPIX);
     static constexpr int COB = 16 * CT * WM, WK = 4 / WM;
     static constexpr int IN_FLOATS = 16 * PSI, G_FLOATS = COB * PSG;
     static constexpr int RED_FLOATS = WK > 1 ? TAPS * CT * WM * 256 : 0;       // the accumulators of one K-split slice
-    static constexpr int LDS_FLOATS = (IN_FLOATS + G_FLOATS > RED_FLOATS ? IN_FLOATS + G_FLOATS : RED_FLOATS) + 32;
-    static_assert(NPIX % TW == 0 && NPIX % 4 == 0, "tile shape");
+    static constexpr int LDS_FLOATS = (IN_FLOATS + G_FLOATS > RED_FLOATS ? IN_FLOATS + G_FLOATS : RED_FLOATS) + 64;
+    static constexpr int PW = TW >= 4 ? 4 : 2, PR = TW / PW;                    // floats per staging piece, pieces per row
+    static constexpr int NIU = 16 * ROWS * PR, NIP = (NIU + 255) / 256;         // input pieces per tile / per thread
+    static constexpr int NGU = COB * NPIX / PW, NGP = (NGU + 255) / 256;        // output-gradient pieces
+    static_assert(NPIX % TW == 0 && NPIX % 4 == 0 && COLS % 2 == 0, "tile shape");
 };
+
+template <int PW> struct WgPiece;
+template <> struct WgPiece<4> { typedef float4 T; };
+template <> struct WgPiece<2> { typedef float2 T; };
 
 template <int TAPS, int TW, int CT, int WM, int NPIX>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     using C = WgCfg<TAPS, TW, CT, WM, NPIX>;
-    constexpr int HALO = C::HALO;
+    constexpr int HALO = C::HALO, PW = C::PW, PR = C::PR;
+    typedef typename WgPiece<PW>::T piece_t;
     extern __shared__ __align__(16) float smem_g[];
     float* in_lds = smem_g;
     float* g_lds = smem_g + C::IN_FLOATS;
-    float* st_lds = smem_g + C::LDS_FLOATS - 32;      // {scale, shift} of the chunk's 16 input channels
+    float* st_lds = smem_g + C::LDS_FLOATS - 64;      // two tables (sample parity) of {scale, shift} of the chunk's 16 input channels
     const WgArgs& a = L.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const int wm = wave % WM, wk = wave / WM;
     const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * C::COB;
     const int set = blockIdx.z / L.nchunks, ch = blockIdx.z - set * L.nchunks;
-    const int sbeg = (set ? a.set_split : 0) + ch * L.chunk;
-    const int send = min(sbeg + L.chunk, set ? a.n : a.set_split);
     const int c0n = src_cin(a.s0);
 
     f32x4 acc[TAPS][CT];
@@ -144,11 +153,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
         for (int ct = 0; ct < CT; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tiles_w = (a.W + TW - 1) / TW, tiles_h = (a.H + C::TH - 1) / C::TH;
-    // my chunk-channel's source (threads 0..15 own the statistics table; everyone needs the source of the channels it stages)
+    const int ntile = tiles_w * tiles_h;
+    // this workgroup's share: `chunk` consecutive (sample, tile) work items of its weight set
+    const int sbase = set ? a.set_split : 0;
+    const int items = ((set ? a.n : a.set_split) - sbase) * ntile;
+    const int ibeg = min(ch * L.chunk, items), iend = min(ibeg + L.chunk, items);
+    const int total = iend - ibeg;
     const Src gs{a.g, nullptr, a.g_c, a.g_mode, a.g_h, a.g_w, 0, 0, 1};
 
-    for (int n = sbeg; n < send; ++n) {
-        __syncthreads();                                        // previous sample's sweeps are done with st_lds
+    // statistics table of one sample's 16 chunk channels (threads 0..15)
+    auto table = [&](int n, float* st) {
         if (tid < 16) {
             const int cg = ci0 + tid;
             float2 mr = make_float2(0.f, 1.f);
@@ -158,26 +172,110 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 const int cl = f0 ? cg : cg - c0n;
                 if (s.mode == 1 || s.mode == 2) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
             }
-            st_lds[2 * tid] = mr.y; st_lds[2 * tid + 1] = -mr.x * mr.y;
+            st[2 * tid] = mr.y; st[2 * tid + 1] = -mr.x * mr.y;
         }
-        for (int tile = 0; tile < tiles_w * tiles_h; ++tile) {
-            const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
-            const int r0 = ty * C::TH, c0 = tx * TW;
-            __syncthreads();                                    // table ready / previous tile's sweeps done
-            // ---- stage the input tile (+ halo), re-activated like the forward's operand staging
+    };
+    // ---- the tile pipeline: issue(it) puts the raw pieces of tile `it` in flight into registers, commit(it) transforms them and
+    // writes LDS, the sweep of tile `it` runs with the loads of tile it + 1 in flight
+    piece_t xin[C::NIP], gin[C::NGP];
+    auto issue = [&](int it) {
+        const int n = sbase + (ibeg + it) / ntile, tile = (ibeg + it) % ntile;
+        const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+        const int r0 = ty * C::TH, c0 = tx * TW;
+        if (L.fast_in) {
+#pragma unroll
+            for (int i = 0; i < C::NIP; ++i) {
+                const int e = min(tid + i * 256, C::NIU - 1);
+                const int k = e / (C::ROWS * PR), rem = e - k * (C::ROWS * PR);
+                const int row = rem / PR, j = rem - row * PR;
+                const int cg = min(ci0 + k, a.cin - 1);
+                const bool f0 = cg < c0n;
+                const Src& s = f0 ? a.s0 : a.s1;
+                const int cl = f0 ? cg : cg - c0n;
+                const int gy = min(max(r0 - HALO + row, 0), s.h - 1), gx = min(c0 + PW * j, a.W - PW);
+                xin[i] = *reinterpret_cast<const piece_t*>(s.x + (((long)n * s.c + cl) * s.h + gy) * a.W + gx);
+            }
+        }
+        if (L.fast_g) {
+#pragma unroll
+            for (int i = 0; i < C::NGP; ++i) {
+                const int e = min(tid + i * 256, C::NGU - 1);
+                const int co = min(co0 + e / (NPIX / PW), a.rows - 1), pp = (e % (NPIX / PW)) * PW;
+                const int gy = min(r0 + pp / TW, a.H - 1), gx = min(c0 + pp % TW, a.W - PW);
+                gin[i] = *reinterpret_cast<const piece_t*>(a.g + (((long)n * a.rows + co) * a.H + gy) * a.W + gx);
+            }
+        }
+    };
+    auto commit = [&](int it) {
+        const int n = sbase + (ibeg + it) / ntile, tile = (ibeg + it) % ntile;
+        const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
+        const int r0 = ty * C::TH, c0 = tx * TW;
+        const float* st = st_lds + 32 * (((ibeg + it) / ntile) & 1);
+        if (L.fast_in) {
+#pragma unroll
+            for (int i = 0; i < C::NIP; ++i) {
+                const int e = tid + i * 256;
+                if (e >= C::NIU) break;
+                const int k = e / (C::ROWS * PR), rem = e - k * (C::ROWS * PR);
+                const int row = rem / PR, j = rem - row * PR;
+                const int cg = ci0 + k;
+                const bool f0 = cg < c0n;
+                const Src& s = f0 ? a.s0 : a.s1;
+                const int gy = r0 - HALO + row, gx = c0 + PW * j;
+                const bool ok = cg < a.cin && gy >= 0 && gy < s.h && gx < a.W;
+                piece_t o = xin[i];
+                float* ov = reinterpret_cast<float*>(&o);
+                const float sc = st[2 * k], sh = st[2 * k + 1];
+#pragma unroll
+                for (int u = 0; u < PW; ++u) ov[u] = ok ? (s.mode == 0 ? ov[u] : act(ov[u], sc, sh, a.slope)) : 0.f;
+                float* dst = in_lds + k * C::PSI + row * C::COLS + PW * j;
+#pragma unroll
+                for (int u = 0; u < PW; u += 2) *reinterpret_cast<float2*>(dst + u) = make_float2(ov[u], ov[u + 1]);
+            }
+            if (HALO) {       // the two halo columns: data only when the image is wider than the tile
+                for (int e = tid; e < 16 * C::ROWS * 2; e += 256) {
+                    const int k = e / (C::ROWS * 2), rem = e - k * (C::ROWS * 2);
+                    const int row = rem >> 1, side = rem & 1;
+                    const int gy = r0 - 1 + row, gx = side ? c0 + TW : c0 - 1, cg = ci0 + k;
+                    float v = 0.f;
+                    if (a.W > TW && cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+                        const bool f0 = cg < c0n;
+                        const int cl = f0 ? cg : cg - c0n;
+                        v = fetch_scalar(f0 ? a.s0 : a.s1, n, cl, 0, gy, gx, st + 2 * k - 2 * cl, a.slope);
+                    }
+                    in_lds[k * C::PSI + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
+                }
+            }
+        } else {
+            // generic staging (pooled sources, odd widths): element by element, re-activated like the forward's operand staging
             for (int e = tid; e < 16 * C::ROWS * C::COLS; e += 256) {
                 const int k = e / (C::ROWS * C::COLS), rem = e - k * (C::ROWS * C::COLS);
-                const int row = rem / C::COLS, col = rem - row * C::COLS;
-                const int gy = r0 - HALO + row, gx = c0 - HALO + col, cg = ci0 + k;
+                const int row = rem / C::COLS, xc = rem - row * C::COLS;          // xc: tile column + HALO
+                const int gy = r0 - HALO + row, gx = c0 - HALO + xc, cg = ci0 + k;
                 float v = 0.f;
                 if (cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
                     const bool f0 = cg < c0n;
                     const int cl = f0 ? cg : cg - c0n;
-                    v = fetch_scalar(f0 ? a.s0 : a.s1, n, cl, 0, gy, gx, st_lds + 2 * k - 2 * cl, a.slope);
+                    v = fetch_scalar(f0 ? a.s0 : a.s1, n, cl, 0, gy, gx, st + 2 * k - 2 * cl, a.slope);
                 }
-                in_lds[k * C::PSI + rem] = v;
+                in_lds[k * C::PSI + row * C::COLS + (xc - HALO + C::COLS) % C::COLS] = v;
             }
-            // ---- stage the output-gradient tile
+        }
+        if (L.fast_g) {
+#pragma unroll
+            for (int i = 0; i < C::NGP; ++i) {
+                const int e = tid + i * 256;
+                if (e >= C::NGU) break;
+                const int co = e / (NPIX / PW), pp = (e % (NPIX / PW)) * PW;
+                const int gy = r0 + pp / TW, gx = c0 + pp % TW;
+                const bool ok = co0 + co < a.rows && gy < a.H && gx < a.W;
+                const piece_t o = gin[i];
+                const float* ov = reinterpret_cast<const float*>(&o);
+                float* dst = g_lds + co * C::PSG + pp;
+#pragma unroll
+                for (int u = 0; u < PW; u += 2) *reinterpret_cast<float2*>(dst + u) = ok ? make_float2(ov[u], ov[u + 1]) : make_float2(0.f, 0.f);
+            }
+        } else {
             for (int e = tid; e < C::COB * NPIX; e += 256) {
                 const int co = e / NPIX, p = e - co * NPIX;
                 const int gy = r0 + p / TW, gx = c0 + p % TW;
@@ -187,22 +285,33 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                                       : a.g[(((long)n * a.rows + co0 + co) * a.H + gy) * a.W + gx];
                 g_lds[co * C::PSG + p] = v;
             }
-            __syncthreads();
-            // ---- sweep: K = pixel groups of 4
-            for (int g = wk; g < NPIX / 4; g += C::WK) {
-                const int p = 4 * g + kk;
-                const int prow = p / TW, pcol = p % TW;
-                float gv[CT];
+        }
+    };
+
+    if (total > 0) { table(sbase + ibeg / ntile, st_lds + 32 * ((ibeg / ntile) & 1)); issue(0); }
+    for (int it = 0; it < total; ++it) {
+        __syncthreads();                                        // previous sweep done with LDS; this sample's table written
+        if ((ibeg + it + 1) % ntile == 0 && it + 1 < total)     // the next item starts a new sample: its table goes into the other buffer
+            table(sbase + (ibeg + it + 1) / ntile, st_lds + 32 * (((ibeg + it + 1) / ntile) & 1));
+        commit(it);
+        __syncthreads();
+        if (it + 1 < total) issue(it + 1);
+        // ---- sweep: K = pixel groups of 4
+        for (int g = wk; g < NPIX / 4; g += C::WK) {
+            const int p = 4 * g + kk;
+            const int prow = p / TW, pcol = p % TW;
+            float gv[CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) gv[ct] = g_lds[(16 * (wm * CT + ct) + q) * C::PSG + p];
-                const float* ib = in_lds + q * C::PSI + prow * C::COLS + pcol;
+            for (int ct = 0; ct < CT; ++ct) gv[ct] = g_lds[(16 * (wm * CT + ct) + q) * C::PSG + p];
+            const float* ib = in_lds + q * C::PSI + prow * C::COLS;
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const float xv = ib[(TAPS == 9 ? (t / 3) * C::COLS + (t % 3) : 0)];
+            for (int t = 0; t < TAPS; ++t) {
+                int xc = pcol;
+                if (TAPS == 9) { xc = pcol + (t % 3) - 1; xc = xc < 0 ? C::COLS - 1 : xc; }
+                const float xv = ib[(TAPS == 9 ? (t / 3) * C::COLS : 0) + xc];
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct)
-                        acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, gv[ct], acc[t][ct], 0, 0, 0);
-                }
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, gv[ct], acc[t][ct], 0, 0, 0);
             }
         }
     }
@@ -242,7 +351,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     }
 }
 
-// grad (+)= sum over the sample chunks of one weight set, in chunk order
+// grad += sum over the partial sums of one weight set: one wave per weight, lanes stride over the chunks, then a fixed butterfly
+// (the same order on every run: deterministic)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nchunks, int rows, int cin, int rowsp, int cinp,
                                                            int taps, int kind, float* grad0, float* grad1) {
     const int set = blockIdx.y;
@@ -251,35 +361,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, in
     const long total = (long)rows * cin * taps;
     const long pstride = (long)rowsp * cinp * taps;
     const float* p0 = part + (long)set * nchunks * pstride;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (long)gridDim.x * 4) {
         const int t = (int)(e % taps);
         const long r2 = e / taps;
         const int ci = (int)(r2 % cin), row = (int)(r2 / cin);
         const float* p = p0 + ((long)row * cinp + ci) * taps + t;
         float s = 0.f;
-        for (int c = 0; c < nchunks; ++c) s += p[c * pstride];
-        long o;
-        if (kind == 1) o = (long)ci * rows + row;                // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
-        else o = e;                                               // (rows, cin, taps)
-        grad[o] += s;
+        for (int c = lane; c < nchunks; c += 64) s += p[c * pstride];
+        s = wave_sum_g(s);
+        if (lane == 0) {
+            const long o = kind == 1 ? (long)ci * rows + row : e;     // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
+            grad[o] += s;
+        }
     }
 }
 
-static int wgrad_chunks(int rows, int cin, int n_set) {
-    // enough workgroups to fill the chip a few times over, at least a handful of samples' worth of work each
+// partial sums per weight set: enough workgroups to fill the chip twice over (1024 resident slots of 4 waves)
+constexpr int kWgTarget = 2048;
+static int wgrad_chunks(int rows, int cin) {
     const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
     const long wgs = (long)ceil_div(cin, 16) * ceil_div(rows, cob);
-    long nch = ceil_div(1024L, wgs);
-    if (nch > n_set) nch = n_set;
-    if (nch < 1) nch = 1;
-    return (int)nch;
+    const long per_chunk = (long)ceil_div(rows, cob) * cob * ceil_div(cin, 16) * 16 * 9 * 4;     // bytes of one partial (3x3)
+    const long cap = std::max(8L, (32L << 20) / per_chunk);                                        // <= 32 MB of partials per weight set
+    return (int)std::max(1L, std::min(cap, ceil_div((long)kWgTarget, wgs)));
 }
 
 size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
     const int rowsp = ceil_div(rows, 16) * 16, cinp = ceil_div(cin, 16) * 16;
     const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
     const int rowsb = ceil_div(rowsp, cob) * cob;
-    return (size_t)2 * wgrad_chunks(rows, cin, n) * rowsb * cinp * taps;
+    (void)n;
+    return (size_t)2 * wgrad_chunks(rows, cin) * rowsb * cinp * taps;
 }
 
 template <int TAPS, int TW, int CT, int WM, int NPIX>
@@ -308,20 +421,32 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     CINE_REQUIRE(a.set_split >= 0 && a.set_split <= a.n && (a.set_split == a.n || grad1), CINE_EINVAL, "wgrad: second weight set without a gradient");
     WgLaunch L{};
     L.a = a;
+    const int TW = a.W > 8 ? 16 : a.W > 4 ? 8 : a.W > 2 ? 4 : 2;
     L.rowsp = ceil_div(a.rows, 16) * 16; L.cinp = ceil_div(a.cin, 16) * 16;
     const int cob = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : a.rows <= 64 ? 64 : 128;
     const int rowsb = ceil_div(L.rowsp, cob) * cob;
     L.rowsp = rowsb;                                      // partial rows padded to whole row blocks
     const int n0 = a.set_split, n1 = a.n - a.set_split;
-    L.nchunks = wgrad_chunks(a.rows, a.cin, std::max(n0, n1));
-    L.chunk = ceil_div(std::max(n0, n1), L.nchunks);
+    {   // work items = (sample, tile); the tile shape follows the row block (launch_wg_tw)
+        const int npix = cob == 16 ? 256 : cob == 128 ? 64 : 128;
+        const long items = (long)std::max(n0, n1) * ceil_div(a.W, TW) * ceil_div(a.H, npix / TW);
+        L.nchunks = (int)std::min<long>(wgrad_chunks(a.rows, a.cin), items);
+        L.chunk = (int)ceil_div(items, (long)L.nchunks);
+        L.nchunks = (int)ceil_div(items, (long)L.chunk);
+    }
     L.part = ws;
+    // vectorised staging: rows of whole 16 / 8-byte pieces at aligned addresses, sources addressed with the conv's row stride
+    const int PW = TW >= 4 ? 4 : 2;
+    auto src_fast = [&](const Src& s) {
+        return s.c == 0 || (s.mode <= 1 && s.w == a.W && s.h <= a.H && reinterpret_cast<uintptr_t>(s.x) % 16 == 0);
+    };
+    L.fast_in = a.W % PW == 0 && a.W >= PW && src_fast(a.s0) && src_fast(a.s1);
+    L.fast_g = a.g_mode == 0 && a.W % PW == 0 && a.W >= PW && reinterpret_cast<uintptr_t>(a.g) % 16 == 0;
     const int nsets = n1 > 0 ? 2 : 1;
     CINE_REQUIRE(ws_floats >= (size_t)nsets * L.nchunks * L.rowsp * L.cinp * taps, CINE_EWORKSPACE, "wgrad: workspace too small");
     const dim3 grid(L.cinp / 16, rowsb / cob, nsets * L.nchunks);
     ProfScope prof(taps == 9 ? F_CONV3 : (kind == 1 ? F_TCONV : F_CONV1), st);
     int e;
-    const int TW = a.W > 8 ? 16 : a.W > 4 ? 8 : a.W > 2 ? 4 : 2;
     if (taps == 9) {
         if (TW == 16) e = launch_wg_tw<9, 16>(L, cob, grid, st);
         else if (TW == 8) e = launch_wg_tw<9, 8>(L, cob, grid, st);
@@ -335,36 +460,42 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     }
     if (e) return e;
     const long total = (long)a.rows * a.cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256L), 1024), nsets), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 4L), 4096), nsets), dim3(256), 0, st,
                        ws, L.nchunks, a.rows, a.cin, L.rowsp, L.cinp, taps, kind, grad0, grad1);
     return check_launch("wgrad_reduce_kernel");
 }
 
 // ---------------------------------------------------------------- bias gradient
-// one workgroup per (set, channel): fixed-order sum over the set's samples and pixels
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1) {
+// one workgroup per (channel, sample): the sample's pixel sum into ws[co][n]; then one wave per (set, channel) adds the samples of
+// its set in a fixed order
+__global__ __launch_bounds__(256) void bias_partial_kernel(const float* g, int cout, long hw, float* ws, int n) {
     __shared__ float red[4];
+    const int co = blockIdx.x, i = blockIdx.y;
+    const float* p = g + ((long)i * cout + co) * hw;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < hw; e += 256) s += p[e];
+    s = wave_sum_g(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[(long)co * n + i] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(64) void bias_final_kernel(const float* ws, int n, int set_split, float* gb0, float* gb1) {
     const int co = blockIdx.x, set = blockIdx.y;
     float* gb = set ? gb1 : gb0;
     const int nb = set ? set_split : 0, ne = set ? n : set_split;
     if (!gb || ne <= nb) return;
     float s = 0.f;
-    for (int i = nb; i < ne; ++i) {
-        const float* p = g + ((long)i * cout + co) * hw;
-        float t = 0.f;
-        for (long e = threadIdx.x; e < hw; e += 256) t += p[e];
-        s += t;
-    }
+    for (int i = nb + (int)threadIdx.x; i < ne; i += 64) s += ws[(long)co * n + i];
     s = wave_sum_g(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) gb[co] += red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) gb[co] += s;
 }
 
-int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, hipStream_t st) {
-    CINE_REQUIRE(g && gb0 && n > 0 && cout > 0 && hw > 0, CINE_EINVAL, "bias_grad: bad arguments");
+int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, float* ws, size_t ws_floats, hipStream_t st) {
+    CINE_REQUIRE(g && gb0 && ws && n > 0 && n <= 65535 && cout > 0 && hw > 0, CINE_EINVAL, "bias_grad: bad arguments");
+    CINE_REQUIRE(ws_floats >= (size_t)n * cout, CINE_EWORKSPACE, "bias_grad: workspace too small");
     ProfScope prof(F_STATS, st);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(cout, set_split < n ? 2 : 1), dim3(256), 0, st, g, n, cout, hw, set_split, gb0, gb1);
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(cout, n), dim3(256), 0, st, g, cout, hw, ws, n);
+    hipLaunchKernelGGL(bias_final_kernel, dim3(cout, set_split < n ? 2 : 1), dim3(64), 0, st, ws, n, set_split, gb0, gb1);
     return check_launch("bias_grad_kernel");
 }
 

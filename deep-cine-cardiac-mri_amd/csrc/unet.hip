@@ -282,6 +282,7 @@ void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch)
         }
     }
     wg = std::max(wg, wgrad_ws_floats(out_ch, p.ch[0], 1, n));
+    wg = std::max(wg, (size_t)n * out_ch);                  // bias-gradient partial sums
     q.wg_floats = wg;
     q.wg = b.take(wg);
 }
@@ -347,7 +348,7 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
 
     // ---- final 1x1 conv + bias (unet.py:69): y = W act(cb_0) + b
     const long hw0 = (long)h * w;
-    if ((e = launch_bias_grad(gy, n, out_ch, hw0, sp, gr(i_bias, 0), gr(i_bias, 1), st))) return e;
+    if ((e = launch_bias_grad(gy, n, out_ch, hw0, sp, gr(i_bias, 0), gr(i_bias, 1), q.wg, q.wg_floats, st))) return e;
     {
         WgArgs a{}; a.s0 = src(p.cb[0], p.pcb[0], chans, 1, h, w, p.np_conv[0]); a.s1 = none; a.cin = chans;
         a.g = gy; a.g_mode = 0; a.rows = out_ch; a.n = n; a.H = h; a.W = w; a.set_split = sp; a.eps = kEps; a.slope = kSlope;

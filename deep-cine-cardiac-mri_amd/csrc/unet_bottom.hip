@@ -516,12 +516,13 @@ int launch_unet_bottom(const BottomArgs& a, int n, hipStream_t st) {
     static_assert(lds <= 160 * 1024, "unet_bottom_kernel LDS");
     int dev = 0;
     (void)hipGetDevice(&dev);
+    CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "unet_bottom_kernel: device index %d", dev);
     static std::once_flag once[64];
-    hipError_t err = hipSuccess;
-    std::call_once(once[dev & 63], [&] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(unet_bottom_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static hipError_t status[64];       // kept per device: a failed first call fails every later launch with its own message
+    std::call_once(once[dev], [&] {
+        status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(unet_bottom_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
-    CINE_REQUIRE(err == hipSuccess, CINE_EHIP, "unet_bottom_kernel: %s", hipGetErrorString(err));
+    CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "unet_bottom_kernel: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", hipGetErrorString(status[dev]));
     ProfScope prof(F_CONV3, st);
     hipLaunchKernelGGL(unet_bottom_kernel, dim3(n), dim3(ub::NT), lds, st, a);
     return check_launch("unet_bottom_kernel");

@@ -123,6 +123,7 @@ class CineNet(nn.Module):
 
     @torch.no_grad()
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
         image_pred = ops.sens_reduce(masked_kspace, sens_maps)
         image_ref = image_pred.clone()
         for cascade in self.cascades:

@@ -23,6 +23,7 @@ class CineNet_RNN(CRNNBody):
 
     @torch.no_grad()
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
+        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
         b, t, _, h, w, _ = ref_kspace.shape
         if b != 1:
             raise NotImplementedError("the CRNN models assume batch 1, like the reference")

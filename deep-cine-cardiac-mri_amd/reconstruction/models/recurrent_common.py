@@ -17,6 +17,22 @@ from torch import nn
 from cine_hip import ops
 
 
+_zeros = {}
+
+
+def zeros_ro(shape, like: torch.Tensor) -> torch.Tensor:
+    """A READ-ONLY zero tensor, shared by every caller on the device (initial hidden states, recurrent_varnet.py:236, 118-121): no
+    fill kernel per forward / per replayed graph.  Created outside hipGraph capture (the first eager forward); inside a capture
+    with nothing cached yet it falls back to a fresh tensor."""
+    key = (like.device, like.dtype, tuple(shape))
+    z = _zeros.get(key)
+    if z is None:
+        z = torch.zeros(shape, device=like.device, dtype=like.dtype)
+        if not torch.cuda.is_current_stream_capturing():
+            _zeros[key] = z
+    return z
+
+
 class CRNNcell(nn.Module):
     def __init__(self, input_size: int, hidden_size: int, kernel_size: int):
         super().__init__()
@@ -58,7 +74,7 @@ class BCRNNlayer(nn.Module):
         w_in, w_hh, bias = self._packed()
         p = ops.conv3x3_sum([hidden_iteration.reshape(t * b, c, h, w), input.reshape(t * b, ch, h, w)], w_in, bias, c)
         p = p.view(t, b, c, h, w)
-        zero = torch.zeros((b, c, h, w), device=p.device, dtype=p.dtype)       # hid_init (:236)
+        zero = zeros_ro((b, c, h, w), p)                                       # hid_init (:236)
         out = torch.empty_like(p)
         # The forward pass over time (:241-245) and the backward pass (:247-252, same cell) are independent chains; only their
         # sum couples them (:254).  Step s advances both in ONE launch: frame s of the forward chain, frame t-1-s of the
@@ -117,7 +133,7 @@ class CRNNBody(nn.Module):
         return self._pairs, self._w4, self._b4
 
     def zero_state(self, t: int, b: int, h: int, w: int, like: torch.Tensor):
-        return [torch.zeros(t * b, self.chans, h, w, device=like.device, dtype=like.dtype) for _ in range(4)]
+        return [zeros_ro((t * b, self.chans, h, w), like) for _ in range(4)]     # read only: sources of the first cascade
 
     def body(self, x: torch.Tensor, state, residual: torch.Tensor):
         """x (t, b, ch, h, w); state [x0..x3] of the previous cascade; returns (residual + conv4(x3), new state)."""

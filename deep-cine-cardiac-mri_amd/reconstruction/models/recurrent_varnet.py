@@ -20,6 +20,7 @@ class VarNet_RNN(CRNNBody):
 
     @torch.no_grad()
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
+        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         b, t, _, h, w, _ = ref_kspace.shape
         if b != 1:

@@ -144,6 +144,7 @@ class XPDNet(nn.Module):
     @torch.no_grad()
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
         n = self.i_buffer_size
+        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
         sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ops.sens_reduce(masked_kspace, sens_maps)                       # unmasked backward op (:303)
         image_buffer = ops.repeat_complex(image, n)                             # (:307)

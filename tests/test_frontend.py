@@ -163,3 +163,34 @@ def test_cinenet_on_espirit_maps(dev):
     keep = (lam >= 0.8).cpu() & (ex["target"][0].mean(0) > 0.1 * ex["target"].max())
     d = (out_e - out_a).abs().cpu()[0][:, keep]
     assert keep.sum() > 500 and float(d.mean()) < 0.05 * float(out_a.abs().max())
+
+
+@pytest.mark.gpu
+def test_prepare_example_vs_reference_golden(golden, dev):
+    """cine_hip.frontend.prepare_example = SliceDataset.__getitem__ (reference data/mri_data.py:267-311) in one piece, fed through
+    an h5py-like mapping: k-space of the filtered crop and the coil-combined target against the reference's arrays, with the
+    stored maps standing in for `bart ecalib` (frontend.npz).  With sens=None the maps come from the build's ESPIRiT -- PARITY
+    UNPINNED (BART is not in the reference tree nor in this image): only shapes and finiteness are asserted for that leg."""
+    from cine_hip import frontend as FE
+    g = golden("frontend")
+    hf = {"y": g["raw"], "mask": np.arange(5)}
+    kw = dict(crop_shape=tuple(int(v) for v in g["crop_shape"]), crop_target=tuple(int(v) for v in g["crop_target"]),
+              n_slices=int(g["n_slices"]), filter_size=tuple(float(v) for v in g["filter_size"]))
+    k, mask, target, attrs, fname, dataslice = FE.prepare_example(hf, sens=g["sens"], fname="slice_0.h5", **kw)
+    assert k.dtype == np.complex64 and k.shape == g["kspace"].shape and rel_err(_cplx(k), _cplx(g["kspace"])) < 1e-5
+    assert target.dtype == np.float32 and rel_err(target, g["target"]) < 1e-5
+    assert (mask == np.arange(5)).all() and attrs == {} and fname == "slice_0.h5" and dataslice == 0
+    k2, _, target2, *_ = FE.prepare_example(g["raw"], ecalib_r=16, **kw)                   # the ESPIRiT leg (unpinned)
+    assert rel_err(_cplx(k2), _cplx(g["kspace"])) < 1e-5 and target2.shape == g["target"].shape and np.isfinite(target2).all()
+
+
+@pytest.mark.gpu
+def test_prepare_slice_odd_crop_uses_the_reference_shift_order(dev):
+    """mri_data.py:291 returns to k-space with ifftshift(fftn(fftshift(x))), which differs from fft2c for odd sizes."""
+    from cine_hip import frontend as FE
+    rs = np.random.RandomState(3)
+    raw = (rs.standard_normal((4, 30, 28, 2)) + 1j * rs.standard_normal((4, 30, 28, 2))).astype(np.complex64)
+    k, filt = FE.prepare_slice(torch.from_numpy(raw).to(dev), (21, 17), 3, (0.7, 0.0, 0.3, 0.3))
+    f = torch.view_as_complex(filt.cpu().contiguous()).numpy()
+    want = np.fft.ifftshift(np.fft.fftn(np.fft.fftshift(f, axes=(-2, -1)), axes=(-2, -1), norm=None), axes=(-2, -1)) / np.sqrt(21 * 17)
+    assert rel_err(k.cpu(), _cplx(want.astype(np.complex64))) < 1e-5
