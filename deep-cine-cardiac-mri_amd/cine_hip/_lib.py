@@ -134,6 +134,9 @@ _SIGS = {
     "cine_rss_normalise_bwd": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_complex_abs_bwd": (c_int, [P, P, P, c_long, P]),
     "cine_axpby_lam": (c_int, [P, P, P, c_long, P, c_int, c_float, P]),
+    "cine_ssim_loss_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cine_ssim_loss": (c_int, [P, P, c_int, c_int, c_int, c_int, c_double, c_double, P, P, c_size_t, P]),
+    "cine_ssim_loss_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P, P]),
     "cine_profile_begin": (c_int, []),
     "cine_profile_end": (c_int, [P, P, c_int]),
     "cine_profile_families": (c_int, []),

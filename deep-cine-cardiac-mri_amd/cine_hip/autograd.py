@@ -320,6 +320,35 @@ class AbsFn(Function):
         return gx
 
 
+class SsimLossFn(Function):
+    """SSIMLoss.forward (utils/losses.py:25-58) on GPU tensors: x = reconstruction, y = target, both (t, h, w)."""
+
+    @staticmethod
+    def forward(ctx, x, y, win, k1, k2):
+        x = ops._dev(x, "SSIMLoss reconstruction"); y = ops._dev(y.detach(), "SSIMLoss target")
+        t, h, w = x.shape
+        nbytes = lib().cine_ssim_loss_ws_bytes(t, h, w, win)
+        if nbytes == 0:
+            raise ValueError(f"SSIMLoss: frames {tuple(x.shape)} too small for a {win} x {win} window")
+        ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(lib().cine_ssim_loss(x.data_ptr(), y.data_ptr(), t, h, w, win, k1, k2, loss.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+              "cine_ssim_loss")
+        ctx.save_for_backward(x, y, ws)
+        ctx.win = win
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        x, y, ws = ctx.saved_tensors
+        t, h, w = x.shape
+        gl = ops._dev(gloss.reshape(1).to(torch.float32), "SSIMLoss upstream gradient")
+        gx = torch.empty_like(x)
+        check(lib().cine_ssim_loss_bwd(x.data_ptr(), y.data_ptr(), t, h, w, ctx.win, gl.data_ptr(), ws.data_ptr(), ws.numel(), gx.data_ptr(),
+                                       _stream()), "cine_ssim_loss_bwd")
+        return gx, None, None, None, None
+
+
 def grad_mode(module: torch.nn.Module) -> bool:
     """True when the call should build an autograd graph (what ``loss.backward()`` in a training_step needs)."""
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())

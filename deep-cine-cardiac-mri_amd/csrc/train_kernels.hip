@@ -411,3 +411,147 @@ extern "C" int cine_axpby_lam(float* out, const float* a, const float* b, long n
     hipLaunchKernelGGL(axpby_lam_kernel, dim3(grid_t(n, 256, 2048)), dim3(256), 0, as_stream(stream), out, a, b, n, lambda_dev, kind, sign);
     return check_launch("axpby_lam_kernel");
 }
+
+// ---------------------------------------------------------------- SSIMLoss forward + backward (utils/losses.py:25-58)
+// loss = mean_t (1 - mean_windows S_t), S from win x win uniform windows (valid region), sample covariance, data range = max of the
+// TARGET frame (losses.py:34).  The window sums run in float64 (the reference's float32 conv2d cancels catastrophically in
+// uxx - ux^2; double keeps the loss and its gradient at float32 resolution).  Forward keeps dS/d(ux), dS/d(uxx), dS/d(uxy) per window;
+// backward spreads them back over the windows that contain a pixel.
+namespace cine {
+constexpr int kSsimTile = 16;          // windows per tile side
+constexpr int kSsimMaxWin = 11;
+
+__global__ __launch_bounds__(256) void ssim_frame_max_kernel(const float* y, long hw, float* fmax) {
+    __shared__ float red[4];
+    const float* p = y + (long)blockIdx.x * hw;
+    float m = -INFINITY;
+    for (long e = threadIdx.x; e < hw; e += 256) m = fmaxf(m, p[e]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) fmax[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// one workgroup = one 16 x 16 tile of windows of one frame; part[frame][tile] = sum of S over the tile's windows
+__global__ __launch_bounds__(256) void ssim_loss_fwd_kernel(const float* x, const float* y, int H, int W, int win, double k1, double k2,
+                                                            const float* fmax, float* da, float* db, float* dc, double* part) {
+    __shared__ float sx[(kSsimTile + kSsimMaxWin - 1) * (kSsimTile + kSsimMaxWin - 1)];
+    __shared__ float sy[(kSsimTile + kSsimMaxWin - 1) * (kSsimTile + kSsimMaxWin - 1)];
+    __shared__ double red[4];
+    const int Ho = H - win + 1, Wo = W - win + 1;
+    const int tiles_w = (Wo + kSsimTile - 1) / kSsimTile;
+    const int t = blockIdx.y, ty = blockIdx.x / tiles_w, tx = blockIdx.x % tiles_w;
+    const int y0 = ty * kSsimTile, x0 = tx * kSsimTile;
+    const int PS = kSsimTile + win - 1;
+    const float* xp = x + (long)t * H * W;
+    const float* yp = y + (long)t * H * W;
+    for (int e = threadIdx.x; e < PS * PS; e += 256) {
+        const int r = e / PS, c = e - r * PS;
+        const int gy = min(y0 + r, H - 1), gx = min(x0 + c, W - 1);
+        sx[e] = xp[(long)gy * W + gx]; sy[e] = yp[(long)gy * W + gx];
+    }
+    __syncthreads();
+    const int wy = threadIdx.x / kSsimTile, wx = threadIdx.x % kSsimTile;
+    double S = 0.0;
+    if (y0 + wy < Ho && x0 + wx < Wo) {
+        double a = 0, b = 0, aa = 0, bb = 0, ab = 0;
+        for (int i = 0; i < win; ++i)
+            for (int j = 0; j < win; ++j) {
+                const double u = sx[(wy + i) * PS + wx + j], v = sy[(wy + i) * PS + wx + j];
+                a += u; b += v; aa += u * u; bb += v * v; ab += u * v;
+            }
+        const double np = (double)win * win, cn = np / (np - 1.0);
+        const double ux = a / np, uy = b / np, uxx = aa / np, uyy = bb / np, uxy = ab / np;
+        const double L = fmax[t], C1 = (k1 * L) * (k1 * L), C2 = (k2 * L) * (k2 * L);
+        const double vx = cn * (uxx - ux * ux), vy = cn * (uyy - uy * uy), vxy = cn * (uxy - ux * uy);
+        const double A1 = 2 * ux * uy + C1, A2 = 2 * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+        S = (A1 * A2) / (B1 * B2);
+        const long o = ((long)t * Ho + y0 + wy) * Wo + x0 + wx;
+        da[o] = (float)(S * (2 * uy / A1 - 2 * cn * uy / A2 - 2 * ux / B1 + 2 * cn * ux / B2));
+        db[o] = (float)(-S * cn / B2);
+        dc[o] = (float)(S * 2 * cn / A2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = S;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(long)t * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(64) void ssim_loss_final_kernel(const double* part, int T, int ntiles, long nwin, float* loss) {
+    double acc = 0.0;
+    for (int t = 0; t < T; ++t) {               // fixed order: frames, then tiles lane-strided + butterfly
+        double s = 0.0;
+        for (int i = threadIdx.x; i < ntiles; i += 64) s += part[(long)t * ntiles + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        acc += 1.0 - s / (double)nwin;
+    }
+    if (threadIdx.x == 0) *loss = (float)(acc / T);
+}
+
+// gx[t][p] = gloss * (-1 / (T Nw)) / win^2 * sum over the windows containing p of (da + 2 x_p db + y_p dc)
+__global__ __launch_bounds__(256) void ssim_loss_bwd_kernel(const float* x, const float* y, int T, int H, int W, int win, const float* gloss,
+                                                            const float* da, const float* db, const float* dc, float* gx) {
+    const int Ho = H - win + 1, Wo = W - win + 1;
+    const long total = (long)T * H * W;
+    const double k = -(double)*gloss / ((double)T * Ho * Wo) / ((double)win * win);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int px = (int)(e % W); const long r = e / W;
+        const int py = (int)(r % H), t = (int)(r / H);
+        const int wy0 = max(py - win + 1, 0), wy1 = min(py, Ho - 1), wx0 = max(px - win + 1, 0), wx1 = min(px, Wo - 1);
+        double sa = 0, sb = 0, sc = 0;
+        for (int wy = wy0; wy <= wy1; ++wy)
+            for (int wx = wx0; wx <= wx1; ++wx) {
+                const long o = ((long)t * Ho + wy) * Wo + wx;
+                sa += da[o]; sb += db[o]; sc += dc[o];
+            }
+        gx[e] = (float)(k * (sa + 2.0 * x[e] * sb + y[e] * sc));
+    }
+}
+}  // namespace cine
+
+extern "C" size_t cine_ssim_loss_ws_bytes(int t, int h, int w, int win) {
+    if (t <= 0 || h < win || w < win || win < 1 || win > kSsimMaxWin) return 0;
+    const long nw = (long)t * (h - win + 1) * (w - win + 1);
+    const long ntiles = (long)ceil_div(h - win + 1, kSsimTile) * ceil_div(w - win + 1, kSsimTile);
+    return (size_t)(3 * nw + t + 16) * sizeof(float) + (size_t)(t * ntiles + 2) * sizeof(double);
+}
+
+static void ssim_ws_layout(void* ws, int t, int h, int w, int win, float*& fmax, float*& da, float*& db, float*& dc, double*& part) {
+    const long nw = (long)t * (h - win + 1) * (w - win + 1);
+    part = reinterpret_cast<double*>(ws);
+    const long ntiles = (long)ceil_div(h - win + 1, kSsimTile) * ceil_div(w - win + 1, kSsimTile);
+    float* f = reinterpret_cast<float*>(part + (long)t * ntiles + 2);
+    fmax = f; da = f + t; db = da + nw; dc = db + nw;
+}
+
+extern "C" int cine_ssim_loss(const float* x, const float* y, int t, int h, int w, int win, double k1, double k2,
+                              float* loss_dev, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(x && y && loss_dev && ws, CINE_EINVAL, "cine_ssim_loss: null pointer");
+    CINE_REQUIRE(t > 0 && t <= 65535 && win >= 1 && win <= kSsimMaxWin && h >= win && w >= win, CINE_EINVAL, "cine_ssim_loss: bad sizes");
+    CINE_REQUIRE(ws_bytes >= cine_ssim_loss_ws_bytes(t, h, w, win), CINE_EWORKSPACE, "cine_ssim_loss: workspace too small");
+    float *fmax, *da, *db, *dc; double* part;
+    ssim_ws_layout(ws, t, h, w, win, fmax, da, db, dc, part);
+    hipStream_t st = as_stream(stream);
+    const int ntiles = ceil_div(h - win + 1, kSsimTile) * ceil_div(w - win + 1, kSsimTile);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(ssim_frame_max_kernel, dim3(t), dim3(256), 0, st, y, (long)h * w, fmax);
+    hipLaunchKernelGGL(ssim_loss_fwd_kernel, dim3(ntiles, t), dim3(256), 0, st, x, y, h, w, win, k1, k2, fmax, da, db, dc, part);
+    hipLaunchKernelGGL(ssim_loss_final_kernel, dim3(1), dim3(64), 0, st, part, t, ntiles, (long)(h - win + 1) * (w - win + 1), loss_dev);
+    return check_launch("ssim_loss kernels");
+}
+
+extern "C" int cine_ssim_loss_bwd(const float* x, const float* y, int t, int h, int w, int win, const float* gloss_dev,
+                                  const void* ws, size_t ws_bytes, float* gx, void* stream) {
+    CINE_REQUIRE(x && y && gloss_dev && ws && gx, CINE_EINVAL, "cine_ssim_loss_bwd: null pointer");
+    CINE_REQUIRE(t > 0 && win >= 1 && win <= kSsimMaxWin && h >= win && w >= win, CINE_EINVAL, "cine_ssim_loss_bwd: bad sizes");
+    CINE_REQUIRE(ws_bytes >= cine_ssim_loss_ws_bytes(t, h, w, win), CINE_EWORKSPACE, "cine_ssim_loss_bwd: workspace too small");
+    float *fmax, *da, *db, *dc; double* part;
+    ssim_ws_layout(const_cast<void*>(ws), t, h, w, win, fmax, da, db, dc, part);
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(ssim_loss_bwd_kernel, dim3(grid_t((long)t * h * w, 256)), dim3(256), 0, as_stream(stream), x, y, t, h, w, win, gloss_dev,
+                       da, db, dc, gx);
+    return check_launch("ssim_loss_bwd_kernel");
+}

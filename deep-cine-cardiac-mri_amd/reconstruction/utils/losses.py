@@ -2,9 +2,9 @@
 
 Time-averaged ``1 - SSIM`` over dim 2 of (b, 1, t, h, w) tensors: 7x7 uniform window (valid region only), sample
 covariance (N / (N-1)), K1 = 0.01, K2 = 0.03, and -- as the reference does (:34) -- the data range of every frame is
-the maximum of that TARGET frame, whatever ``data_range`` was passed.  Differentiable torch ops (a training loss needs
-autograd, which the inference-only HIP path does not provide); the fused no-grad metric kernel is
-``reconstruction.utils.evaluate.ssim_device`` / ``cine_hip.ops.ssim_frames``.
+the maximum of that TARGET frame, whatever ``data_range`` was passed.  GPU tensors of the shape ``training_step`` passes
+((1, 1, t, h, w), pl_modules/varnet_module.py:110-112) go through the HIP kernels (cine_ssim_loss / cine_ssim_loss_bwd: window
+sums in float64, hand-written backward); anything else -- CPU tensors in the host-side tests -- through the same formula in torch ops.
 """
 import torch
 import torch.nn as nn
@@ -21,6 +21,9 @@ class SSIMLoss(nn.Module):
         self.cov_norm = npix / (npix - 1)
 
     def forward(self, Xt: torch.Tensor, Yt: torch.Tensor, data_range: torch.Tensor = None) -> torch.Tensor:
+        if Xt.is_cuda and Xt.dim() == 5 and Xt.shape[0] == 1 and Xt.shape[1] == 1 and Xt.dtype == torch.float32 and Yt.shape == Xt.shape:
+            from cine_hip.autograd import SsimLossFn
+            return SsimLossFn.apply(Xt[0, 0], Yt[0, 0], self.win_size, self.k1, self.k2)
         w = self.w.to(device=Xt.device, dtype=Xt.dtype)
         total = 0.0
         frames = Xt.shape[2]

@@ -509,6 +509,16 @@ int cine_complex_abs_bwd(const float* gy, const float* x, float* gx, long n, voi
  * 3 f = 1 / (1 + v).  a == NULL: out = sign * f(v) * b. */
 int cine_axpby_lam(float* out, const float* a, const float* b, long n, const float* lambda_dev, int kind, float sign, void* stream);
 
+/* SSIMLoss (utils/losses.py:25-58): loss = mean over frames of (1 - mean SSIM over the win x win windows of the valid region), sample
+ * covariance, K1 / K2, the data range of every frame = the maximum of that TARGET frame (losses.py:34).  x = reconstruction, y = target,
+ * both (t, h, w) float32; *loss_dev one float.  The forward keeps the per-window derivatives in `ws` (cine_ssim_loss_ws_bytes) for
+ * cine_ssim_loss_bwd: gx (t, h, w) = d loss / d x scaled by the upstream gradient *gloss_dev.  Window sums in float64. */
+size_t cine_ssim_loss_ws_bytes(int t, int h, int w, int win);
+int cine_ssim_loss(const float* x, const float* y, int t, int h, int w, int win, double k1, double k2,
+                   float* loss_dev, void* ws, size_t ws_bytes, void* stream);
+int cine_ssim_loss_bwd(const float* x, const float* y, int t, int h, int w, int win, const float* gloss_dev,
+                       const void* ws, size_t ws_bytes, float* gx, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * measurement aid (no reference counterpart; the reference only wraps time.time() around the
  * model call, traintest_scripts/run_inference.py:53-61)

@@ -274,3 +274,33 @@ def test_inference_path_untouched_by_grad_mode(dev, golden):
     assert torch.equal(a, b) and not a.requires_grad and c.requires_grad
     assert rel_err(c.detach().cpu(), a.cpu()) < 1e-5
     assert rel_err(net(mk, mask.float()).cpu(), a.cpu()) == 0.0           # a float 0/1 mask (apply_mask's return) is accepted
+
+
+@pytest.mark.parametrize("t,h,w", [(15, 180, 180), (3, 20, 18), (2, 7, 9)])
+def test_ssim_loss_kernels_vs_torch_formula(dev, t, h, w):
+    """cine_ssim_loss / cine_ssim_loss_bwd (reference utils/losses.py:25-58) against the same formula in float64 torch ops on the
+    CPU: loss and d loss / d reconstruction; through SSIMLoss.forward's (1, 1, t, h, w) calling convention."""
+    from reconstruction.utils import SSIMLoss
+    rs = np.random.RandomState(t * 100 + h)
+    tgt = torch.from_numpy(rs.uniform(0, 1.5, size=(t, h, w)).astype(np.float32))
+    rec = (tgt + torch.from_numpy((0.1 * rs.standard_normal((t, h, w))).astype(np.float32))).clamp_min(0)
+    with torch.enable_grad():
+        r64 = rec.double().requires_grad_(True)
+        want = SSIMLoss().double()(r64[None, None], tgt.double()[None, None], tgt.max())
+        want.backward()
+        rd = rec.to(dev).requires_grad_(True)
+        got = SSIMLoss().to(dev)(rd[None, None], tgt.to(dev)[None, None], tgt.max())
+        (3.0 * got).backward()
+    assert abs(float(got) - float(want)) < 2e-6
+    assert rel_err(rd.grad.cpu() / 3.0, r64.grad) < 1e-5
+
+
+def test_ssim_loss_kernel_vs_reference_golden(golden, dev):
+    """The reference's SSIMLoss value on a (1, 1, 15, 180, 180) pair (metrics.npz)."""
+    from reconstruction.utils import SSIMLoss
+    g = golden("metrics")
+    rs = np.random.RandomState(int(g["seed"]))
+    tgt = torch.from_numpy(rs.uniform(0, 1.5, size=(15, 180, 180)).astype(np.float32))
+    rec = (tgt + torch.from_numpy((0.1 * rs.standard_normal((15, 180, 180))).astype(np.float32))).clamp_min(0)
+    got = SSIMLoss().to(dev)(rec.to(dev)[None, None], tgt.to(dev)[None, None], torch.tensor([1.0]))
+    assert abs(float(got) - float(g["ssim_loss"])) < 2e-6
