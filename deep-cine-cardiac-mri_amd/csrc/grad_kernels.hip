@@ -196,13 +196,27 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 xin[i] = *reinterpret_cast<const piece_t*>(s.x + (((long)n * s.c + cl) * s.h + gy) * a.W + gx);
             }
         }
-        if (L.fast_g) {
+        if (L.fast_g == 1) {
 #pragma unroll
             for (int i = 0; i < C::NGP; ++i) {
                 const int e = min(tid + i * 256, C::NGU - 1);
                 const int co = min(co0 + e / (NPIX / PW), a.rows - 1), pp = (e % (NPIX / PW)) * PW;
                 const int gy = min(r0 + pp / TW, a.H - 1), gx = min(c0 + pp % TW, a.W - PW);
                 gin[i] = *reinterpret_cast<const piece_t*>(a.g + (((long)n * a.rows + co) * a.H + gy) * a.W + gx);
+            }
+        } else if (L.fast_g == 2) {
+            // space-to-depth view (g_mode 5): rows 4 c + 2 a + b.  One unit = (c, a, PW pixels) = 2 PW consecutive floats of row 2 y + a
+            // of channel c, which hold both column parities b: register pieces 2 u and 2 u + 1 (NGP is even)
+#pragma unroll
+            for (int i = 0; i < C::NGP / 2; ++i) {
+                const int e = min(tid + i * 256, C::NGU / 2 - 1);
+                const int ca = e / (NPIX / PW), pp = (e % (NPIX / PW)) * PW;       // ca = 2 c + a relative to the row block
+                const int row0 = min(co0 + 2 * ca, a.rows - 2);                     // GEMM row of (c, a, b = 0)
+                const int c = row0 >> 2, sa = (row0 >> 1) & 1;
+                const int gy = min(r0 + pp / TW, a.H - 1), gx = min(c0 + pp % TW, a.W - PW);
+                const float* src = a.g + (((long)n * a.g_c + c) * a.g_h + 2 * gy + sa) * a.g_w + 2 * gx;
+                gin[2 * i] = *reinterpret_cast<const piece_t*>(src);
+                gin[2 * i + 1] = *reinterpret_cast<const piece_t*>(src + PW);
             }
         }
     };
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 in_lds[k * C::PSI + row * C::COLS + (xc - HALO + C::COLS) % C::COLS] = v;
             }
         }
-        if (L.fast_g) {
+        if (L.fast_g == 1) {
 #pragma unroll
             for (int i = 0; i < C::NGP; ++i) {
                 const int e = tid + i * 256;
@@ -274,6 +288,25 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 float* dst = g_lds + co * C::PSG + pp;
 #pragma unroll
                 for (int u = 0; u < PW; u += 2) *reinterpret_cast<float2*>(dst + u) = ok ? make_float2(ov[u], ov[u + 1]) : make_float2(0.f, 0.f);
+            }
+        } else if (L.fast_g == 2) {
+#pragma unroll
+            for (int i = 0; i < C::NGP / 2; ++i) {
+                const int e = tid + i * 256;
+                if (e >= C::NGU / 2) break;
+                const int ca = e / (NPIX / PW), pp = (e % (NPIX / PW)) * PW;
+                const int gy = r0 + pp / TW, gx = c0 + pp % TW;
+                const bool ok = co0 + 2 * ca + 1 < a.rows && gy < a.H && gx < a.W;
+                float t[2 * PW];
+                *reinterpret_cast<piece_t*>(t) = gin[2 * i];
+                *reinterpret_cast<piece_t*>(t + PW) = gin[2 * i + 1];
+                float* d0 = g_lds + (2 * ca) * C::PSG + pp;         // column parity 0
+                float* d1 = d0 + C::PSG;                            // column parity 1
+#pragma unroll
+                for (int u = 0; u < PW; u += 2) {
+                    *reinterpret_cast<float2*>(d0 + u) = ok ? make_float2(t[2 * u], t[2 * u + 2]) : make_float2(0.f, 0.f);
+                    *reinterpret_cast<float2*>(d1 + u) = ok ? make_float2(t[2 * u + 1], t[2 * u + 3]) : make_float2(0.f, 0.f);
+                }
             }
         } else {
             for (int e = tid; e < C::COB * NPIX; e += 256) {
@@ -296,23 +329,33 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
         commit(it);
         __syncthreads();
         if (it + 1 < total) issue(it + 1);
-        // ---- sweep: K = pixel groups of 4
-        for (int g = wk; g < NPIX / 4; g += C::WK) {
-            const int p = 4 * g + kk;
+        // ---- sweep: K = pixel groups of 4, software-pipelined one group ahead (the operands of group i + 1 are read from LDS
+        // while the MFMAs of group i issue)
+        constexpr int NSTEP = NPIX / 4 / C::WK;
+        float gv[2][CT], xv[2][TAPS];
+        auto load_step = [&](int i, float (&gq)[CT], float (&xq)[TAPS]) {
+            const int p = 4 * (wk + i * C::WK) + kk;
             const int prow = p / TW, pcol = p % TW;
-            float gv[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) gv[ct] = g_lds[(16 * (wm * CT + ct) + q) * C::PSG + p];
+            for (int ct = 0; ct < CT; ++ct) gq[ct] = g_lds[(16 * (wm * CT + ct) + q) * C::PSG + p];
             const float* ib = in_lds + q * C::PSI + prow * C::COLS;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 int xc = pcol;
                 if (TAPS == 9) { xc = pcol + (t % 3) - 1; xc = xc < 0 ? C::COLS - 1 : xc; }
-                const float xv = ib[(TAPS == 9 ? (t / 3) * C::COLS : 0) + xc];
+                xq[t] = ib[(TAPS == 9 ? (t / 3) * C::COLS : 0) + xc];
+            }
+        };
+        load_step(0, gv[0], xv[0]);
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            if (i + 1 < NSTEP) load_step(i + 1, gv[(i + 1) & 1], xv[(i + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
-                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv, gv[ct], acc[t][ct], 0, 0, 0);
-            }
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i & 1][t], gv[i & 1][ct], acc[t][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- the partial goes out.  lane (q, kk), register j of acc[t][ct]: D[ci = 4 kk + j][co = 16 (wm CT + ct) + q]
@@ -351,29 +394,36 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     }
 }
 
-// grad += sum over the partial sums of one weight set: one wave per weight, lanes stride over the chunks, then a fixed butterfly
-// (the same order on every run: deterministic)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* part, int nchunks, int rows, int cin, int rowsp, int cinp,
-                                                           int taps, int kind, float* grad0, float* grad1) {
+// grad += sum over the partial sums of one weight set.  A workgroup owns 64 consecutive weights (coalesced 256-byte reads of
+// every partial) and splits the chunks over its 16 waves; the 16 wave sums are added in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* part, int nchunks, int rows, int cin, int rowsp, int cinp,
+                                                            int taps, int kind, float* grad0, float* grad1) {
+    __shared__ float red[16][64];
     const int set = blockIdx.y;
     float* grad = set ? grad1 : grad0;
     if (!grad) return;
     const long total = (long)rows * cin * taps;
     const long pstride = (long)rowsp * cinp * taps;
     const float* p0 = part + (long)set * nchunks * pstride;
-    const int lane = threadIdx.x & 63;
-    for (long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6); e < total; e += (long)gridDim.x * 4) {
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    long o = 0;
+    if (e < total) {
         const int t = (int)(e % taps);
         const long r2 = e / taps;
         const int ci = (int)(r2 % cin), row = (int)(r2 / cin);
         const float* p = p0 + ((long)row * cinp + ci) * taps + t;
-        float s = 0.f;
-        for (int c = lane; c < nchunks; c += 64) s += p[c * pstride];
-        s = wave_sum_g(s);
-        if (lane == 0) {
-            const long o = kind == 1 ? (long)ci * rows + row : e;     // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
-            grad[o] += s;
-        }
+        for (int c = sub; c < nchunks; c += 16) s += p[c * pstride];
+        o = kind == 1 ? (long)ci * rows + row : e;            // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
+    }
+    red[sub][lane] = s;
+    __syncthreads();
+    if (sub == 0 && e < total) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tsum += red[i][lane];
+        grad[o] += tsum;
     }
 }
 
@@ -442,6 +492,10 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     };
     L.fast_in = a.W % PW == 0 && a.W >= PW && src_fast(a.s0) && src_fast(a.s1);
     L.fast_g = a.g_mode == 0 && a.W % PW == 0 && a.W >= PW && reinterpret_cast<uintptr_t>(a.g) % 16 == 0;
+    // the transpose conv's space-to-depth view: whole 2 x 2 blocks (exact 2:1 extents), rows in whole row blocks of 4 c + 2 a + b
+    if (a.g_mode == 5 && a.W % PW == 0 && a.W >= PW && a.g_w == 2 * a.W && a.g_h == 2 * a.H && a.rows == 4 * a.g_c && a.rows % 4 == 0 &&
+        (a.rows >= cob || a.rows % 4 == 0) && reinterpret_cast<uintptr_t>(a.g) % 16 == 0)
+        L.fast_g = 2;
     const int nsets = n1 > 0 ? 2 : 1;
     CINE_REQUIRE(ws_floats >= (size_t)nsets * L.nchunks * L.rowsp * L.cinp * taps, CINE_EWORKSPACE, "wgrad: workspace too small");
     const dim3 grid(L.cinp / 16, rowsb / cob, nsets * L.nchunks);
@@ -460,7 +514,7 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     }
     if (e) return e;
     const long total = (long)a.rows * a.cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 4L), 4096), nsets), dim3(256), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 64L), nsets), dim3(1024), 0, st,
                        ws, L.nchunks, a.rows, a.cin, L.rowsp, L.cinp, taps, kind, grad0, grad1);
     return check_launch("wgrad_reduce_kernel");
 }
