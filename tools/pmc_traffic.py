@@ -6,7 +6,7 @@ algorithmic bytes are known (85.2 MB read, 10.6 MB written per launch at cfg 2).
 import csv, re, collections, json, sys
 
 def fam(k):
-    if "conv_mfma" in k and re.search(r", 9(, \d)?>", k): return "conv3x3_mfma"
+    if "conv_mfma" in k and re.search(r", (9|27)(, \d)?>", k): return "conv3x3_mfma"
     if "conv_mfma" in k: return "tconv_conv1x1_mfma"
     if "conv1x1_stream" in k: return "conv1x1_stream"
     if "col200" in k or "col_pass" in k or "imgdc" in k: return "fft_col_pass"
