@@ -11,6 +11,8 @@ forward + ``SSIMLoss``) is differentiated here by the gradient entry points of `
                  sensitivity maps, the zero-filled term and lambda_reg)
   CoilReduceFn : models/varnet.py:187-194 with respect to the maps
   RssNormFn    : models/varnet.py:58-59;  AbsFn: utils/math.py:48-62
+  ConjGradFn   : models/cinenet.py:136-171 (the adjoint recurrence of the CG iteration with the recorded step sizes),
+                 AxpbyLamFn: cinenet.py:255-257;  SsimLossFn: utils/losses.py:25-58
 
 Gradient convention for complex tensors: the trailing (re, im) pair carries (dL/dre, dL/dim), as torch does for real
 views.  Every reduction in the kernels runs in a fixed order: repeated backward passes are bit-identical.
@@ -108,38 +110,39 @@ class NormUnetFn(Function):
     """NormUnet.forward (norm_unet.py:98-114) on x (n, h, w, 2)."""
 
     @staticmethod
-    def forward(ctx, x, weights, *params):
+    def forward(ctx, x, weights, norm, *params):
         x = ops._dev(x, "normunet input")
         n, h, w, _ = x.shape
-        planes, stats = ops.normunet_pack(x)
+        planes, stats = ops.normunet_pack(x, norm=norm)          # norm False: the plain repack around CineNet's bare Unet (cinenet.py:242-244)
         q, ws = unet2d_forward_train(planes, weights)
         y = ops.normunet_unpack(q, stats, h, w)
-        ctx.weights, ctx.ws, ctx.params, ctx.hw = weights, ws, params, (h, w)
-        ctx.save_for_backward(planes, q, stats)
+        ctx.weights, ctx.ws, ctx.params, ctx.hw, ctx.norm = weights, ws, params, (h, w), norm
+        ctx.save_for_backward(planes, q, *([stats] if norm else []))
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        planes, q, stats = ctx.saved_tensors
+        planes, q = ctx.saved_tensors[:2]
+        stats = ctx.saved_tensors[2] if ctx.norm else None
         h, w = ctx.hw
         n = planes.shape[0]
         gy = ops._dev(_c(gy), "normunet output gradient")
         gq = torch.empty_like(q)
-        dstats = torch.empty_like(stats)
-        check(lib().cine_normunet_unpack_bwd(gy.data_ptr(), q.data_ptr(), stats.data_ptr(), gq.data_ptr(), dstats.data_ptr(),
-                                             n, h, w, _stream()), "cine_normunet_unpack_bwd")
+        dstats = torch.empty_like(stats) if ctx.norm else None
+        check(lib().cine_normunet_unpack_bwd(gy.data_ptr(), q.data_ptr(), _p(stats), gq.data_ptr(), _p(dstats), n, h, w, _stream()),
+              "cine_normunet_unpack_bwd")
         need_gx = ctx.needs_input_grad[0]
         gp, grads = unet2d_backward(planes, gq, ctx.weights, ctx.ws, need_gx)
         gx = None
         if need_gx:
             gx = torch.empty((n, h, w, 2), device=gy.device, dtype=gy.dtype)
-            check(lib().cine_normunet_pack_bwd(gp.data_ptr(), planes.data_ptr(), stats.data_ptr(), dstats.data_ptr(), gx.data_ptr(),
-                                               n, h, w, _stream()), "cine_normunet_pack_bwd")
-        return (gx, None) + _param_grads(ctx.weights, grads, ctx.params)
+            check(lib().cine_normunet_pack_bwd(gp.data_ptr(), planes.data_ptr(), _p(stats), _p(dstats), gx.data_ptr(), n, h, w, _stream()),
+                  "cine_normunet_pack_bwd")
+        return (gx, None, None) + _param_grads(ctx.weights, grads, ctx.params)
 
 
-def norm_unet(x: torch.Tensor, weights: "ops.UnetWeights") -> torch.Tensor:
-    return NormUnetFn.apply(x, weights, *weights.distinct_params())
+def norm_unet(x: torch.Tensor, weights: "ops.UnetWeights", norm: bool = True) -> torch.Tensor:
+    return NormUnetFn.apply(x, weights, norm, *weights.distinct_params())
 
 
 # ------------------------------------------------------------------ x-f / y-f regulariser (both NormUnets)
@@ -148,10 +151,10 @@ class XfyfFn(Function):
     ``wboth`` holds both U-Nets (x-f first); ``wx`` / ``wy`` the single ones for plane sets of different shapes."""
 
     @staticmethod
-    def forward(ctx, image, xf, wboth, wx, wy, *params):
+    def forward(ctx, image, xf, norm, wboth, wx, wy, *params):
         image = ops._dev(image, "image")
         b, t, h, w, _ = image.shape
-        pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image, xf)
+        pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image, xf, norm=norm)     # norm False: CineNet's bare U-Nets (cinenet.py:181-219)
         joint = pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr()
         if joint:
             planes = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
@@ -163,15 +166,16 @@ class XfyfFn(Function):
             oyf, ws1 = unet2d_forward_train(pyf, wy)
             ctx.ws = (ws0, ws1)
         out = ops.xfyf_unpack(oxf, oyf, sxf, syf, mean, b, t, h, w, xf)
-        ctx.cfg = (b, t, h, w, bool(xf), joint)
+        ctx.cfg = (b, t, h, w, bool(xf), joint, bool(norm))
         ctx.weights, ctx.params = (wboth, wx, wy), params
-        ctx.save_for_backward(pxf, pyf, oxf, oyf, sxf, syf)
+        ctx.save_for_backward(pxf, pyf, oxf, oyf, *([sxf, syf] if norm else []))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        pxf, pyf, oxf, oyf, sxf, syf = ctx.saved_tensors
-        b, t, h, w, xf, joint = ctx.cfg
+        pxf, pyf, oxf, oyf = ctx.saved_tensors[:4]
+        b, t, h, w, xf, joint, norm = ctx.cfg
+        sxf, syf = (ctx.saved_tensors[4], ctx.saved_tensors[5]) if norm else (None, None)
         wboth, wx, wy = ctx.weights
         gout = ops._dev(_c(gout), "xfyf output gradient")
         dev, dt = gout.device, gout.dtype
@@ -182,10 +186,10 @@ class XfyfFn(Function):
             gqx, gqy = gq[:pxf.shape[0]], gq[pxf.shape[0]:]
         else:
             gqx, gqy = torch.empty_like(oxf), torch.empty_like(oyf)
-        dsx, dsy = torch.empty_like(sxf), torch.empty_like(syf)
+        dsx, dsy = (torch.empty_like(sxf), torch.empty_like(syf)) if norm else (None, None)
         gmean = torch.empty((b, h, w, 2), device=dev, dtype=dt)
-        check(lib().cine_xfyf_unpack_bwd(gout.data_ptr(), oxf.data_ptr(), oyf.data_ptr(), sxf.data_ptr(), syf.data_ptr(),
-                                         gqx.data_ptr(), gqy.data_ptr(), dsx.data_ptr(), dsy.data_ptr(), gmean.data_ptr(),
+        check(lib().cine_xfyf_unpack_bwd(gout.data_ptr(), oxf.data_ptr(), oyf.data_ptr(), _p(sxf), _p(syf),
+                                         gqx.data_ptr(), gqy.data_ptr(), _p(dsx), _p(dsy), gmean.data_ptr(),
                                          b, t, h, w, int(xf), wsb.data_ptr(), nbytes, _stream()), "cine_xfyf_unpack_bwd")
         if joint:
             planes = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
@@ -200,14 +204,14 @@ class XfyfFn(Function):
         gimg = None
         if ctx.needs_input_grad[0]:
             gimg = torch.empty((b, t, h, w, 2), device=dev, dtype=dt)
-            check(lib().cine_xfyf_pack_bwd(gpx.data_ptr(), gpy.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), sxf.data_ptr(), syf.data_ptr(),
-                                           dsx.data_ptr(), dsy.data_ptr(), gmean.data_ptr(), gimg.data_ptr(), b, t, h, w, int(xf),
+            check(lib().cine_xfyf_pack_bwd(gpx.data_ptr(), gpy.data_ptr(), pxf.data_ptr(), pyf.data_ptr(), _p(sxf), _p(syf),
+                                           _p(dsx), _p(dsy), gmean.data_ptr(), gimg.data_ptr(), b, t, h, w, int(xf),
                                            wsb.data_ptr(), nbytes, _stream()), "cine_xfyf_pack_bwd")
-        return (gimg, None, None, None, None) + pg
+        return (gimg, None, None, None, None, None) + pg
 
 
-def xfyf(image: torch.Tensor, xf: bool, wboth, wx, wy) -> torch.Tensor:
-    return XfyfFn.apply(image, xf, wboth, wx, wy, *wboth.distinct_params())
+def xfyf(image: torch.Tensor, xf: bool, wboth, wx, wy, norm: bool = True) -> torch.Tensor:
+    return XfyfFn.apply(image, xf, norm, wboth, wx, wy, *wboth.distinct_params())
 
 
 # ------------------------------------------------------------------ coil operators
@@ -318,6 +322,94 @@ class AbsFn(Function):
         gx = torch.empty_like(x)
         check(lib().cine_complex_abs_bwd(gy.data_ptr(), x.data_ptr(), gx.data_ptr(), gy.numel(), _stream()), "cine_complex_abs_bwd")
         return gx
+
+
+def _axpby_lam(a, b, lam, kind, sign=1.0):
+    out = torch.empty_like(b)
+    check(lib().cine_axpby_lam(out.data_ptr(), _p(a), b.data_ptr(), b.numel(), lam.detach().data_ptr(), kind, float(sign), _stream()),
+          "cine_axpby_lam")
+    return out
+
+
+def _lam_grad(dot: torch.Tensor, lam: torch.Tensor) -> torch.Tensor:
+    """d/d lambda of softplus(lambda) times a device scalar."""
+    return (dot * torch.sigmoid(lam.detach())).view(lam.shape)
+
+
+class AxpbyLamFn(Function):
+    """a + softplus(lambda) * b: CineNet's right-hand side x_ref + v x_reg (cinenet.py:255-257)."""
+
+    @staticmethod
+    def forward(ctx, a, b, lam):
+        a = ops._dev(a, "axpby a"); b = ops._dev(b, "axpby b")
+        ctx.save_for_backward(b, lam)
+        return _axpby_lam(a, b, lam, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        b, lam = ctx.saved_tensors
+        g = ops._dev(_c(g), "axpby gradient")
+        ga = g if ctx.needs_input_grad[0] else None
+        gb = _axpby_lam(None, g, lam, 0) if ctx.needs_input_grad[1] else None
+        gl = _lam_grad(ops.dot(g, b), lam) if ctx.needs_input_grad[2] else None
+        return ga, gb, gl
+
+
+class ConjGradFn(Function):
+    """CineNetBlock.ConjGrad (cinenet.py:136-171): K iterations of conjugate gradients on H x = b, H = A^H M A + softplus(lambda) I,
+    from the start value x0.  The reference takes alpha and beta out of the graph (``.item()``, :159-169), so the iteration it
+    differentiates is LINEAR in (x0, b) with the recorded step sizes; H is self-adjoint, so the adjoint recurrence is K + 1 more
+    applications of the same image-space kernel (cine_normal_op), run backwards:
+        gp_k = beta_k gp_{k+1} + alpha_k gx - alpha_k H(gr_{k+1} + gp_{k+1}),   gr_k = gr_{k+1} + gp_{k+1}
+        gb = gr_0 + gp_0,  gx0 = gx - H(gb),  d/d v = -sum_k alpha_k <gr_{k+1} + gp_{k+1}, p_k> - <gb, x0>."""
+
+    @staticmethod
+    def forward(ctx, x0, b, lam, mask, sens, iters):
+        x0 = ops._dev(x0, "CG start value"); b = ops._dev(b, "CG right-hand side")
+        one = torch.ones(1, device=x0.device, dtype=torch.float32)
+        r = ops.axpby_dev(b, ops.normal_op(x0, sens, mask, lam), num=one, sign=-1.0)
+        p = r.clone()
+        x = x0.clone()
+        rr = ops.dot(r, r)
+        ps, scal = [], []
+        for _ in range(iters):
+            d = ops.normal_op(p, sens, mask, lam)
+            pd = ops.dot(p, d)
+            ps.append(p)
+            x = ops.axpby_dev(x, p, num=rr, den=pd)                   # x + alpha p
+            r = ops.axpby_dev(r, d, num=rr, den=pd, sign=-1.0)        # r - alpha d
+            rr_new = ops.dot(r, r)
+            p = ops.axpby_dev(r, p, num=rr_new, den=rr)               # r + beta p
+            scal.append((rr, pd, rr_new))
+            rr = rr_new
+        ctx.save_for_backward(x0, lam, mask, sens, *ps)
+        ctx.scal = scal
+        return x
+
+    @staticmethod
+    def backward(ctx, gx):
+        x0, lam, mask, sens = ctx.saved_tensors[:4]
+        ps = ctx.saved_tensors[4:]
+        gx = ops._dev(_c(gx), "CG output gradient")
+        gr = torch.zeros_like(gx)
+        gp = torch.zeros_like(gx)
+        gv = torch.zeros(1, device=gx.device, dtype=torch.float32)
+        for k in reversed(range(len(ps))):
+            rr, pd, rr_new = ctx.scal[k]
+            grp = gr + gp                                             # gradient reaching r_{k+1} (through p_{k+1} = r_{k+1} + beta p_k too)
+            hg = ops.normal_op(grp, sens, mask, lam)
+            gv = gv - ops.dot(grp, ps[k]) * (rr / pd)
+            gp_new = ops.axpby_dev(ops.axpby_dev(torch.zeros_like(gx), gp, num=rr_new, den=rr), gx, num=rr, den=pd)     # beta gp + alpha gx
+            gp = ops.axpby_dev(gp_new, hg, num=rr, den=pd, sign=-1.0)                                                   # - alpha H(grp)
+            gr = grp
+        gb = gr + gp
+        need = ctx.needs_input_grad
+        gx0 = None
+        if need[0]:
+            one = torch.ones(1, device=gx.device, dtype=torch.float32)
+            gx0 = ops.axpby_dev(gx, ops.normal_op(gb, sens, mask, lam), num=one, sign=-1.0)
+        glam = _lam_grad(gv - ops.dot(gb, x0), lam) if need[2] else None
+        return gx0, (gb if need[1] else None), glam, None, None, None
 
 
 class SsimLossFn(Function):

@@ -5,13 +5,16 @@ Drop-in for the reference's models/cinenet.py (CineNet :14, CineNetBlock :77): s
 A^H M A (HOperator :121-133) is one row-FFT kernel, one fused column FFT -> hard mask -> column IFFT
 kernel and one row-IFFT + coil-sum kernel; the CG scalars (alpha, beta, :159-169) stay in device
 memory, so the solve has no host synchronisation and can be captured in a hipGraph.
-Inference only; GPU tensors only.
+GPU tensors only.  With gradients enabled (2D / XT / XF) the forward builds an autograd graph of ``cine_hip.autograd``
+Functions: the bare U-Nets through the HIP backward kernels, the conjugate-gradient solve through its adjoint recurrence
+(the reference detaches the step sizes, cinenet.py:159-169), lambda_reg through both.
 """
 import math
 
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 from .denoisers.unet import Unet
 
@@ -68,8 +71,10 @@ class CineNetBlock(nn.Module):
         """(b, t, h, w, 2) -> (b, t, 1, h, w, 2); planes go to the bare U-Nets unnormalised and unpadded."""
         b, t, h, w, _ = image_combined.shape
         xf = self.dynamic_type == 'XF'
-        pxf, pyf, _, _, mean = ops.xfyf_pack(image_combined, xf, norm=False)
         both, wx, wy = self._xfyf_weights()
+        if ag.grad_mode(self):
+            return ag.xfyf(image_combined, xf, both, wx, wy, norm=False)
+        pxf, pyf, _, _, mean = ops.xfyf_pack(image_combined, xf, norm=False)
         if pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr():
             joint = torch.as_strided(pxf, (2 * pxf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
             out = ops.unet2d_forward(joint, both)
@@ -83,6 +88,8 @@ class CineNetBlock(nn.Module):
         if self.dynamic_type in ['XF', 'XT']:
             return self.xfyf_transform(image_pred.squeeze(2))
         if self.dynamic_type == '2D':
+            if ag.grad_mode(self):
+                return ag.norm_unet(image_pred.reshape(b * t, h, w, 2), self.model.hip_weights(), norm=False).view(b, t, 1, h, w, 2)
             planes, _ = ops.normunet_pack(image_pred.reshape(b * t, h, w, 2), norm=False)
             return ops.normunet_unpack(self.model(planes), None, h, w).view(b, t, 1, h, w, 2)
         if self.dynamic_type == '3D':
@@ -92,6 +99,14 @@ class CineNetBlock(nn.Module):
         raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
 
     def forward(self, image_pred, image_ref, mask, sens_maps):
+        if ag.grad_mode(self):
+            if self.dynamic_type == '3D':
+                raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet (XF / XT / 2D are)")
+            if not ops.is_row_mask(mask, sens_maps.expand(-1, image_pred.shape[1], -1, -1, -1, -1)):
+                raise NotImplementedError("training through the HIP path needs the reference's (b, t, 1, h, 1, 1) row mask")
+            model_out = self.regularise(image_pred)
+            rhs = ag.AxpbyLamFn.apply(image_ref, model_out, self.lambda_reg)
+            return ag.ConjGradFn.apply(model_out, rhs, self.lambda_reg, mask, sens_maps, self.CG_iters)
         model_out = self.regularise(image_pred)
         rhs = ops.axpby_dev(image_ref, model_out, lambda_reg=self.lambda_reg)       # x_ref + v x_reg
         return self.ConjGrad(model_out, rhs, mask, sens_maps, self.CG_iters)
@@ -121,9 +136,19 @@ class CineNet(nn.Module):
         self.cascades = nn.ModuleList(
             [CineNetBlock(self.model, CG_iters, dynamic_type, weight_sharing) for _ in range(num_cascades)])
 
-    @torch.no_grad()
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
         mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        if ag.grad_mode(self):               # k-space and maps are data: the graph starts at the first regulariser
+            with torch.no_grad():
+                image_pred = ops.sens_reduce(masked_kspace, sens_maps)
+                image_ref = image_pred.clone()
+            for cascade in self.cascades:
+                image_pred = cascade(image_pred, image_ref, mask, sens_maps)
+            return ag.AbsFn.apply(image_pred.squeeze(2))
+        with torch.no_grad():
+            return self._forward_infer(masked_kspace, mask, sens_maps)
+
+    def _forward_infer(self, masked_kspace, mask, sens_maps):
         image_pred = ops.sens_reduce(masked_kspace, sens_maps)
         image_ref = image_pred.clone()
         for cascade in self.cascades:

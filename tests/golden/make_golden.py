@@ -411,7 +411,7 @@ def g_frontend():
          time_avg_kspace=time_avg[0].transpose(2, 0, 1).astype(np.complex64))
 
 
-def _training_step(net, mk, mask, target, lr=0.0003, dtype=None):
+def _training_step(net, mk, mask, target, lr=0.0003, dtype=None, extra=()):
     """The body of reference pl_modules/varnet_module.py:97-113 (forward, center_crop_to_smallest, SSIMLoss) followed by
     loss.backward() and one step of the optimiser of :151-154 (Adam, lr 0.0003, weight_decay 0).  Returns (loss, {name: grad},
     {name: updated weight}, output).  dtype float64 re-runs the same reference code in double precision (the reproducibility
@@ -422,13 +422,13 @@ def _training_step(net, mk, mask, target, lr=0.0003, dtype=None):
     try:
         with torch.enable_grad():
             if dtype is not None:
-                net = net.to(dtype); mk = mk.to(dtype); target = target.to(dtype)
+                net = net.to(dtype); mk = mk.to(dtype); target = target.to(dtype); extra = tuple(e.to(dtype) for e in extra)
             lossf = SSIMLoss()
             if dtype is not None:
                 lossf = lossf.to(dtype)
             opt = torch.optim.Adam(net.parameters(), lr=lr, weight_decay=0.0)
             opt.zero_grad()
-            output = net(mk, mask)
+            output = net(mk, mask, *extra)
             tgt, out = r_tf.center_crop_to_smallest(target, output)
             if dtype is not None:       # losses.py:34 builds the data range with torch.Tensor(...) (float32): keep the module's dtype
                 loss = _ssim_loss_any_dtype(lossf, out.unsqueeze(1), tgt.unsqueeze(1))
@@ -461,18 +461,18 @@ def _ssim_loss_any_dtype(lossf, Xt, Yt):
     return ssims / Nt
 
 
-def _kink_stability(net, mk, mask, target, trials=6):
+def _kink_stability(net, mk, mask, target, trials=6, extra=()):
     """LeakyReLU has a kink at 0 and InstanceNorm planes whose mean is zero up to rounding (the first conv of every NormUnet on a
     zero-padded, mean-normalised plane) put whole groups of activations within rounding of it: the reference's OWN float32
     gradient then jumps by ~1e-3 when the input changes by 1e-6.  A fixture can pin an implementation only where that does not
     happen: largest relative change of any parameter gradient of the reference's training step under `trials` random relative
     input perturbations of 1e-6."""
     import copy
-    base = _training_step(copy.deepcopy(net), mk, mask, target)[1]
+    base = _training_step(copy.deepcopy(net), mk, mask, target, extra=extra)[1]
     worst = 0.0
     for i in range(trials):
         pert = mk * (1 + 1e-6 * rnd(900 + i, *mk.shape))
-        gi = _training_step(copy.deepcopy(net), pert, mask, target)[1]
+        gi = _training_step(copy.deepcopy(net), pert, mask, target, extra=extra)[1]
         worst = max(worst, max(float((gi[k] - base[k]).abs().max() / base[k].abs().max().clamp_min(1e-30)) for k in base))
     return worst
 
@@ -600,7 +600,46 @@ def g_lightning():
     save("lightning_ckpt", **a)
 
 
-GENERATORS = dict(lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def g_cinenet_grad():
+    """Gradients of the reference's training step for the tiny CineNets (pl_modules/cinenet_module.py:98-114: forward(masked_kspace,
+    mask, sens_maps) + SSIMLoss; conjugate gradient with detached step sizes, cinenet.py:159-169): XF, XT, 2D, XF with weight sharing.
+    Same contents and the same kink-stable seed selection as varnet_grad.npz."""
+    import copy
+    t, c, h, w = 5, 3, 24, 20
+    mask = tiny_mask(t, h)
+    mk = rnd(64, 1, t, c, h, w, 2) * mask
+    sens = rnd(66, 1, 1, c, h, w, 2)
+    sens = sens / RU.rss_complex(sens, dim=2).unsqueeze(-1).unsqueeze(2)
+    target = rnd(65, 1, t, 20, 18).abs() + 0.1
+    a = dict(masked_kspace=mk, mask=mask, target=target, sens_maps=sens)
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)):
+        for seed in range(43, 143):
+            net = RM.CineNet(2, 3, 4, 2, dyn, ws)
+            synth.fill_parameters_(net, seed)
+            with torch.no_grad():
+                for i, cas in enumerate(net.cascades):
+                    cas.lambda_reg.fill_(0.2 + 0.5 * i)
+            stab = _kink_stability(net, mk, mask, target, extra=(sens,))
+            print(f"    {tag}: weight seed {seed}: gradient change under 1e-6 input perturbations {stab:.2e}")
+            if stab <= 2e-5:
+                break
+        else:
+            raise RuntimeError("no kink-stable seed")
+        a[f"{tag}_seed"] = seed; a[f"{tag}_stability"] = stab
+        a.update(sd_np(copy.deepcopy(net), f"{tag}::sd::"))
+        net64 = copy.deepcopy(net)
+        loss, grads, new, out = _training_step(net, mk, mask, target, extra=(sens,))
+        loss64, grads64, _, _ = _training_step(net64, mk, mask, target, dtype=torch.float64, extra=(sens,))
+        a[f"{tag}_loss"] = loss; a[f"{tag}_out"] = out; a[f"{tag}_loss64"] = loss64
+        for k, g in grads.items():
+            a[f"{tag}::grad::{k}"] = g
+            a[f"{tag}::new::{k}"] = new[k]
+            g64 = grads64[k]
+            a[f"{tag}::floor::{k}"] = float((g.double() - g64).abs().max() / g64.abs().max().clamp_min(1e-300))
+    save("cinenet_grad", **a)
+
+
+GENERATORS = dict(cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)

@@ -226,6 +226,44 @@ def test_varnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+def test_cinenet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
+    """The training step of pl_modules/cinenet_module.py:98-114 on the drop-in CineNet: bare U-Nets through the HIP backward kernels,
+    conjugate gradients through the adjoint recurrence (the reference detaches alpha / beta, cinenet.py:159-169), lambda_reg through
+    both; loss, gradients and the Adam-updated weights against the reference's own (cinenet_grad.npz)."""
+    import reconstruction.models as M
+    from reconstruction.data import transforms
+    from reconstruction.utils import SSIMLoss
+    g = golden("cinenet_grad")
+    net = M.CineNet(2, 3, 4, 2, dyn, share)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net = net.to(dev).train()
+    mk, mask, target, sens = (torch.from_numpy(g[k]).to(dev) for k in ("masked_kspace", "mask", "target", "sens_maps"))
+    with torch.enable_grad():
+        opt = torch.optim.Adam(net.parameters(), lr=0.0003, weight_decay=0.0)
+        opt.zero_grad()
+        output = net(mk, mask, sens)
+        tgt, out = transforms.center_crop_to_smallest(target, output)
+        loss = SSIMLoss().to(dev)(out.unsqueeze(1), tgt.unsqueeze(1), data_range=tgt.max())
+        loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        opt.step()
+    assert rel_err(output.detach().cpu(), g[f"{tag}_out"]) < TOL
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5
+    new = dict(net.named_parameters())
+    bad = {}
+    for k in (k[len(tag) + 8:] for k in g if k.startswith(f"{tag}::grad::")):
+        floor = float(g[f"{tag}::floor::{k}"])
+        e = rel_err(grads[k].cpu(), g[f"{tag}::grad::{k}"])
+        if e > max(TOL, 20 * floor):
+            bad[k] = (e, floor)
+        want_new, gref = torch.from_numpy(g[f"{tag}::new::{k}"]), torch.from_numpy(g[f"{tag}::grad::{k}"])
+        sel = gref.abs() > 1e-5
+        if sel.any():
+            assert (new[k].detach().cpu() - want_new)[sel].abs().max() <= 0.02 * 0.0003, k
+    assert not bad, bad
+
+
 def test_varnet_cfg2_training_step_vs_reference_fingerprint(dev, golden):
     """cfg 2 at full size (XF-VarNet, 6 cascades, 15 coils x 15 frames x 200 x 200): strided fingerprints of the reference's
     parameter gradients (varnet_grad_cfg2.npz).  At this size the reference's own float32 gradients move by 1e-3 (median over

@@ -228,3 +228,25 @@ def test_oracle_training_step_gradients_vs_reference_golden(golden, tag, dyn, sh
     for k, p in net.named_parameters():
         floor = float(g[f"{tag}::floor::{k}"])
         assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
+
+
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("2D", "2D", False)])
+def test_oracle_cinenet_training_gradients_vs_reference_golden(golden, tag, dyn, share):
+    """The CineNet oracle under autograd (conjugate gradients with detached step sizes, cinenet.py:159-169) reproduces the
+    reference's training-step gradients (cinenet_grad.npz)."""
+    from oracle import cinenet_ref as C
+    from reconstruction.utils.losses import SSIMLoss
+    g = golden("cinenet_grad")
+    net = C.CineNet(2, 3, 4, 2, dyn, share)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    mk, mask, target, sens = (torch.from_numpy(g[k]) for k in ("masked_kspace", "mask", "target", "sens_maps"))
+    with torch.enable_grad():
+        out = net(mk, mask, sens)
+        h0, w0 = (out.shape[-2] - target.shape[-2]) // 2, (out.shape[-1] - target.shape[-1]) // 2
+        crop = out[..., h0:h0 + target.shape[-2], w0:w0 + target.shape[-1]]
+        loss = SSIMLoss()(crop.unsqueeze(1), target.unsqueeze(1), data_range=target.max())
+        loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-6
+    for k, p in net.named_parameters():
+        floor = float(g[f"{tag}::floor::{k}"])
+        assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
