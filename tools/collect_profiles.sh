@@ -18,13 +18,13 @@ if [ "$PART" != others ]; then
 python3 bench.py --steps 30 --warmup 3 > $O/bench.json 2> $O/bench.err
 cd /tmp
 # kernel traces of the default command in BOTH modes: the timed one (3 graphs in flight) and one slice in flight
-rocprofv3 --kernel-trace --stats -d $O/trace_inflight -o t --output-format csv -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --repeats 0 > $O/trace_inflight.log 2>&1
-rocprofv3 --kernel-trace --stats -d $O/trace_isolated -o t --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --repeats 0 --inflight 1 > $O/trace_isolated.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace_inflight -o t --output-format csv -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --repeats 0 --headline-only > $O/trace_inflight.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/trace_isolated -o t --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --repeats 0 --inflight 1 --headline-only > $O/trace_isolated.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph > $O/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph --headline-only > $O/pmc_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE \
-  -d $O/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph > $O/pmc_mfma.log 2>&1
+  -d $O/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph --headline-only > $O/pmc_mfma.log 2>&1
 cd $R
 python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv 7 $O/pmc_traffic.json $COMMIT > $O/pmc_traffic.txt
 python3 tools/pmc_mfma.py $O/pmc_mfma/p_counter_collection.csv 7 $O/pmc_mfma.json $COMMIT > $O/pmc_mfma.txt
