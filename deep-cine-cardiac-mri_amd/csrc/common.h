@@ -81,5 +81,6 @@ int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev);   // pro
 size_t plane_program_bytes();
 bool plane_kernel_enabled();   // CINE_PLANE_KERNEL=1 in the environment
 void plane_record_abort(PlaneRecorder* r);
+int plane_record_end_pair(PlaneRecorder* r, hipStream_t st);          // two steps (3x3 conv, transpose conv on its output): fused when one workgroup owns the plane in both
 
 }  // namespace cine

@@ -924,6 +924,8 @@ constexpr int plane_cfg_id() {
         if (CT == 2 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 3;
     }
     if (CK == 16 && TAPS == 1) {
+        if (CT == 4 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 7;        // all 4 x cout rows of the 128 -> 64 transpose conv in one workgroup
+        if (CT == 2 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 8;       // ... of the 64 -> 32 one
         if (CT == 2 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 4;
         if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 5;
         if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 8) return 6;
@@ -1162,6 +1164,51 @@ int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
     hipLaunchKernelGGL(plane_program_write_kernel, dim3(1), dim3(256), 0, st, pp, dprog);
     hipLaunchKernelGGL(unet_plane_kernel, dim3(n), dim3(256), lds, st, dprog);
     return check_launch("unet_plane_kernel");
+}
+
+// ---------------------------------------------------------------- conv + transpose conv of a plane-owning level in one kernel
+// At the two lowest levels of the cfg-2 U-Net one workgroup owns a whole plane in BOTH the second conv of the level and the
+// transpose conv that follows (unet.py:99-104, 212-218): the statistics of the conv's output are workgroup-local (one record per
+// channel), so the transpose conv can run right behind it in the same workgroup -- a barrier orders the plane's stores before its
+// re-load (same CU: L1 / L2 hits) -- without a launch boundary or a grid-wide drain in between.
+template <int CKA, int CTA, int WMA, int WNA, int MTA, int TWA, int CKB, int CTB, int WMB, int WNB, int MTB, int TWB>
+__global__ __launch_bounds__(256, 2) void conv_tconv_fused_kernel(ConvArgs a, ConvArgs b) {
+    extern __shared__ __align__(16) float smem_f[];
+    static_assert(64 * WMA * WNA == 256 && 64 * WMB * WNB == 256, "both steps use 256 threads");
+    const int n = blockIdx.x;
+    conv_tile<CKA, CTA, WMA, WNA, MTA, TWA, 9>(a, 0, 0, n, smem_f);
+    __syncthreads();                         // the plane's raw output and its statistics records are visible to the whole workgroup
+    conv_tile<CKB, CTB, WMB, WNB, MTB, TWB, 1>(b, 0, 0, n, smem_f);
+}
+
+// Issue two recorded steps (a 3x3 conv and the transpose conv reading its output) as one fused kernel when both are
+// one-workgroup-per-plane launches of a known configuration pair; else one after the other.
+int plane_record_end_pair(PlaneRecorder* r, hipStream_t st) {
+    g_rec = nullptr;
+    std::unique_ptr<PlaneRecorder> own(r);
+    bool ok = r->steps.size() == 2 && !r->steps[0].is_c1 && !r->steps[1].is_c1;
+    if (ok) {
+        const RecStep &s0 = r->steps[0], &s1 = r->steps[1];
+        ok = s0.grid.x == 1 && s0.grid.y == 1 && s1.grid.x == 1 && s1.grid.y == 1 && s0.grid.z == s1.grid.z && !s0.a.vol && !s1.a.vol &&
+             s1.a.s0.x == s0.a.y && s1.a.s0.part == s0.a.ypart && s1.a.tconv_cout > 0;
+        if (ok) {
+            const size_t lds = std::max(s0.lds, s1.lds);
+            const dim3 grid(s0.grid.z);
+            auto launch = [&](auto kern, const char* what) -> int {
+                static std::once_flag once[64];
+                if (lds > 64 * 1024) if (int e = allow_big_lds(kern, once, what)) return e;
+                ProfScope prof(F_CONV3, st);
+                hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, s0.a, s1.a);
+                return check_launch(what);
+            };
+#ifndef CINE_FAST_BUILD
+            if (s0.cfg == 3 && s1.cfg == 7) return launch(conv_tconv_fused_kernel<8, 2, 4, 1, 4, 2, 16, 4, 4, 1, 4, 2>, "conv_tconv_fused_kernel");
+            if (s0.cfg == 2 && s1.cfg == 8) return launch(conv_tconv_fused_kernel<8, 1, 4, 1, 13, 4, 16, 2, 4, 1, 13, 4>, "conv_tconv_fused_kernel");
+#endif
+        }
+    }
+    for (const RecStep& q : r->steps) if (int e = q.launch(q, st)) return e;
+    return CINE_OK;
 }
 
 // ---------------------------------------------------------------- host dispatch

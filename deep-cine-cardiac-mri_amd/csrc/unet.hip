@@ -6,6 +6,7 @@
 // cascade, varnet.py:224-226) run in the SAME launches: samples [0, n/2) use set 0, the rest set 1.
 // Workspace: one raw buffer per skip level plus three rotating scratch buffers.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "grad.h"
 
@@ -183,6 +184,16 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
     // plane when the planes are cfg 2's 52 x 4 with 64 channels (unet_bottom.hip); its output carries ONE statistics record
     const bool fuse = pools >= 2 && !train && !plane_kernel_enabled() && unet_bottom_applies(p.ch[pools - 1], p.hs[pools - 1], p.wsz[pools - 1]) &&
                       p.ch[pools - 2] * 2 == p.ch[pools - 1] && p.hs[pools - 2] == 2 * p.hs[pools - 1] && p.wsz[pools - 2] == 2 * p.wsz[pools - 1];
+    // Opt-in (CINE_PAIR_FUSE=1): the second conv of a level and the transpose conv that reads its output issued as ONE kernel where one
+    // workgroup owns the plane in both (plane_record_end_pair: the two lowest levels of the cfg-2 U-Net).  Measured on cfg 2: 14 fewer
+    // launches per slice, transpose-conv family 0.84 -> 0.36 ms per slice, 3x3 family 7.96 -> 8.36 ms, 154.5 / 154.7 vs 154.7 / 155.1
+    // slices/s in flight -- the time moves, it does not shrink (the launch boundary was never the cost), so it stays off by default.
+    struct PairGuard {
+        PlaneRecorder* r = nullptr;
+        ~PairGuard() { if (r) plane_record_abort(r); }
+    } pair;
+    static const bool pair_env = [] { const char* v = getenv("CINE_PAIR_FUSE"); return v && atoi(v) != 0; }();
+    const bool pair_ok = pair_env && !train && !plane_kernel_enabled() && !fuse;
     // ---- down path (unet.py:94-97) + bottleneck (:99)
     for (int d = 0; d <= pools; ++d) {
         if (fuse && d >= pools - 1) { wi += 2; continue; }
@@ -200,6 +211,7 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
                                 mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
         next();
+        if (last && pair_ok) pair.r = plane_record_begin();          // bottleneck output -> first transpose conv
         e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                             w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
@@ -228,12 +240,18 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
         e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
                              p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
         if (e) return e;
+        if (pair.r) {                                                 // issue the recorded (conv, transpose conv) pair
+            PlaneRecorder* r = pair.r;
+            pair.r = nullptr;
+            if ((e = plane_record_end_pair(r, as_stream(stream)))) return e;
+        }
         next();   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
         e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
                             p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
                             p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
         next();
+        if (d >= 1 && pair_ok) pair.r = plane_record_begin();        // this level's output -> the next transpose conv
         e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                             w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
