@@ -104,6 +104,8 @@ _SIGS = {
     "cine_dot_ws_bytes": (c_size_t, []),
     "cine_cg_ws_bytes": (c_size_t, []),
     "cine_cg_step": (c_int, [P, P, P, P, c_long, P, P, P, P]),
+    "cine_cg_step_pd": (c_int, [P, P, P, P, c_long, P, P, P, P]),
+    "cine_normal_op_pd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_dot": (c_int, [P, P, c_long, P, P, P]),
     "cine_axpby_dev": (c_int, [P, P, P, c_long, P, P, P, c_float, P]),
     "cine_crop_select": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),

@@ -363,6 +363,30 @@ def cg_step(x: torch.Tensor, r: torch.Tensor, p: torch.Tensor, d: torch.Tensor, 
     return rr_new
 
 
+def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new) -> torch.Tensor:
+    """One conjugate-gradient iteration of reference cinenet.py:153-169 for a row mask: d = H p with the partial sums of p.d produced by
+    the operator's last kernel (cine_normal_op_pd), then the alpha / x / r / r.r / beta / p updates (cine_cg_step_pd).  Falls back to
+    normal_op + cg_step where the operator has no partial-sum kernel."""
+    b, _, c, h, w, _ = sens.shape
+    t = p.shape[1]
+    nbytes = lib().cine_image_dc_ws_bytes(b, t, c, h, w)
+    if nbytes == 0:
+        return cg_step(x, r, p, normal_op(p, sens, mask, lambda_reg), rr_old, rr_new)
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _cg_ws.get(key)
+    if ws is None:
+        _no_capture("the conjugate-gradient workspace of this stream")
+        ws = _cg_ws[key] = torch.empty(lib().cine_cg_ws_bytes(), device=x.device, dtype=torch.uint8)
+    d = torch.empty((b, t, 1, h, w, 2), device=p.device, dtype=p.dtype)
+    dws = torch.empty(nbytes, device=p.device, dtype=torch.uint8)
+    lam = _dev(lambda_reg.detach(), "lambda_reg")
+    check(lib().cine_normal_op_pd(p.data_ptr(), sens.data_ptr(), mask.data_ptr(), lam.data_ptr(), d.data_ptr(), ws.data_ptr(), b, t, c, h, w,
+                                  dws.data_ptr(), nbytes, _stream()), "cine_normal_op_pd")
+    check(lib().cine_cg_step_pd(x.data_ptr(), r.data_ptr(), p.data_ptr(), d.data_ptr(), x.numel(), rr_old.data_ptr(), rr_new.data_ptr(),
+                                ws.data_ptr(), _stream()), "cine_cg_step_pd")
+    return rr_new
+
+
 def axpby_dev(a: torch.Tensor, b: torch.Tensor, num: Optional[torch.Tensor] = None, den: Optional[torch.Tensor] = None,
               lambda_reg: Optional[torch.Tensor] = None, sign: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = a + sign * s * b, s = num/den (device scalars) or softplus(lambda_reg)."""

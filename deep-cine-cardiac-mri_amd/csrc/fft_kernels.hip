@@ -566,6 +566,7 @@ struct ImgDcArgs {
     cf* out; float* out_abs;
     int T, C, H, W;
     cf* partial; long part_stride;   // H == 200 with more than one coil group: per-group partial sums (workspace)
+    float* pd_part;                  // optional: 256 partial sums of <img, out> (the p.d of a conjugate-gradient step, cinenet.py:155), one per workgroup of imgdc_sum_kernel
     int BT, ntx, nz;                 // H == 200: frames x batch, column tiles, coil groups
 };
 
@@ -715,12 +716,27 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
 
 // out = sum_z partial[z] (fixed order) + beta * zf
 __global__ __launch_bounds__(256) void imgdc_sum_kernel(ImgDcArgs a, int nz, long n) {
+    __shared__ float red[4];
     float w1, w0, beta;
     imgdc_weights(a, w1, w0, beta);
+    float pd = 0.f;
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (long)gridDim.x * blockDim.x) {
         cf s = a.partial[o];
         for (int z = 1; z < nz; ++z) { const cf u = a.partial[z * a.part_stride + o]; s.x += u.x; s.y += u.y; }
+        if (a.pd_part) {        // the value imgdc_store writes (complex output only), times the operator's input
+            cf v = s;
+            if (a.zf) { const cf zz = a.zf[o]; v.x = fmaf(beta, zz.x, v.x); v.y = fmaf(beta, zz.y, v.y); }
+            const cf p = a.img[o];
+            pd += p.x * v.x + p.y * v.y;
+        }
         imgdc_store(a, o, s, beta);
+    }
+    if (a.pd_part) {            // uniform
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pd += __shfl_xor(pd, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pd;
+        __syncthreads();
+        if (threadIdx.x == 0) a.pd_part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -1022,7 +1038,7 @@ extern "C" size_t cine_image_dc_ws_bytes(int b, int t, int c, int h, int w) {
 static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                          const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
                          float* out, int b, int t, int c, int h, int w, int magnitude,
-                         void* ws, size_t ws_bytes, void* stream);
+                         void* ws, size_t ws_bytes, void* stream, float* pd_part = nullptr);
 
 extern "C" int cine_image_dc(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                              const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
@@ -1037,11 +1053,20 @@ extern "C" int cine_normal_op(const float* img, const float* sens, const uint8_t
     CINE_REQUIRE(lambda_dev, CINE_EINVAL, "cine_normal_op: null lambda");
     return image_dc_impl(img, sens, img, mask, lambda_dev, 1, 1.f, 0.f, 0.f, out, b, t, c, h, w, 0, ws, ws_bytes, stream);
 }
+// cine_normal_op that also leaves the 256 partial sums of <img, out> in pd_part (device, 256 floats): the p.d of the conjugate-gradient
+// step that follows (cinenet.py:155-159), computed where out is produced instead of by a separate pass over both vectors.  Returns
+// CINE_EUNSUPPORTED for shapes whose operator does not end in the partial-sum kernel (h != 200 or <= 5 coils): use cine_cg_step then.
+extern "C" int cine_normal_op_pd(const float* img, const float* sens, const uint8_t* mask, const float* lambda_dev,
+                                 float* out, float* pd_part, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(lambda_dev && pd_part, CINE_EINVAL, "cine_normal_op_pd: null pointer");
+    CINE_REQUIRE(cine_image_dc_ws_bytes(b, t, c, h, w) > 0, CINE_EUNSUPPORTED, "cine_normal_op_pd: this shape has no partial-sum kernel");
+    return image_dc_impl(img, sens, img, mask, lambda_dev, 1, 1.f, 0.f, 0.f, out, b, t, c, h, w, 0, ws, ws_bytes, stream, pd_part);
+}
 
 static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                          const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
                          float* out, int b, int t, int c, int h, int w, int magnitude,
-                         void* ws, size_t ws_bytes, void* stream) {
+                         void* ws, size_t ws_bytes, void* stream, float* pd_part) {
     CINE_REQUIRE(img && sens && mask && out, CINE_EINVAL, "cine_image_dc: null pointer");
     CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_image_dc: bad sizes");
     CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_image_dc: b*t > 65535");
@@ -1068,7 +1093,8 @@ static int image_dc_impl(const float* img, const float* sens, const float* zf, c
         if (int e = check_launch("imgdc200_kernel")) return e;
         if (nz > 1) {
             const long n = a.part_stride;
-            hipLaunchKernelGGL(imgdc_sum_kernel, dim3((unsigned)std::min<long>(ceil_div(n, 256L), 2048)), dim3(256), 0, st, a, nz, n);
+            a.pd_part = pd_part;        // 256 workgroups when the p.d partial sums ride along (what cg_update_kernel adds up)
+            hipLaunchKernelGGL(imgdc_sum_kernel, dim3(pd_part ? 256u : (unsigned)std::min<long>(ceil_div(n, 256L), 2048)), dim3(256), 0, st, a, nz, n);
         }
     } else {
         hipLaunchKernelGGL(imgdc_generic_kernel, dim3(ceil_div(w, kLinesGen), b * t), dim3(kThreadsGen),

@@ -531,6 +531,19 @@ extern "C" int cine_cg_step(float* x, float* r, float* p, const float* d, long n
     return check_launch("cine_cg_step");
 }
 
+// cine_cg_step without its first launch: ws[0..256) already holds the partial sums of p.d (cine_normal_op_pd)
+extern "C" int cine_cg_step_pd(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
+                               void* ws, void* stream) {
+    CINE_REQUIRE(x && r && p && d && rr_old_dev && rr_new_dev && ws && n > 0, CINE_EINVAL, "cine_cg_step_pd: bad arguments");
+    CINE_REQUIRE(rr_old_dev != rr_new_dev, CINE_EINVAL, "cine_cg_step_pd: rr_old and rr_new must be different scalars");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks);
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, r, n, part + kDotBlocks, rr_old_dev, rr_new_dev);
+    return check_launch("cine_cg_step_pd");
+}
+
 extern "C" int cine_dot(const float* a, const float* b, long n, float* out_dev, void* ws, void* stream) {
     CINE_REQUIRE(a && b && out_dev && ws && n > 0, CINE_EINVAL, "cine_dot: bad arguments");
     hipStream_t st = as_stream(stream);

@@ -55,9 +55,11 @@ class CineNetBlock(nn.Module):
         x = x.clone()
         rr_new = torch.empty_like(rr_old)
         for _ in range(CG_iters):
-            d = self.HOperator(p, mask, sens_maps, hyb)
-            # alpha = rr / p.d; x += alpha p; r -= alpha d; rr' = r.r; p = r + (rr' / rr) p   (:155-169), scalars on the device
-            ops.cg_step(x, r, p, d, rr_old, rr_new)
+            # d = H p; alpha = rr / p.d; x += alpha p; r -= alpha d; rr' = r.r; p = r + (rr' / rr) p   (:153-169), scalars on the device
+            if rowmask:     # the p.d partial sums come out of the operator's own last kernel: four launches per iteration
+                ops.normal_op_cg_step(x, r, p, sens_maps, mask, self.lambda_reg, rr_old, rr_new)
+            else:
+                ops.cg_step(x, r, p, self.HOperator(p, mask, sens_maps, hyb), rr_old, rr_new)
             rr_old, rr_new = rr_new, rr_old
         return x
 

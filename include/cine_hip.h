@@ -118,6 +118,11 @@ int cine_image_dc(const float* img, const float* sens, const float* zf, const ui
  * shapes / workspace as cine_image_dc. */
 int cine_normal_op(const float* img, const float* sens, const uint8_t* mask, const float* lambda_dev,
                    float* out, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
+/* cine_normal_op that also leaves 256 partial sums of <img, out> in pd_part (device floats): the p.d of the conjugate-gradient step that
+ * follows (models/cinenet.py:155-159), produced where `out` is produced instead of by a separate pass over both vectors; feed them to
+ * cine_cg_step_pd (pd_part = the first 256 floats of its workspace).  CINE_EUNSUPPORTED where cine_image_dc_ws_bytes() is 0. */
+int cine_normal_op_pd(const float* img, const float* sens, const uint8_t* mask, const float* lambda_dev,
+                      float* out, float* pd_part, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
 
 /* cine_kspace_to_hybrid of (mask * k) without reading the rows the mask drops: the hybrid-space image of the
  * measured lines only (the zero-filled term zf above: cine_hybrid_reduce of it).  k, hyb (bt, c, h, w, 2); mask (bt, h). */
@@ -394,6 +399,9 @@ int cine_axpby_dev(float* out, const float* a, const float* b, long n, const flo
 size_t cine_cg_ws_bytes(void);
 int cine_cg_step(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                  void* ws, void* stream);
+/* cine_cg_step without its p.d pass: ws[0..256) floats already hold the partial sums (cine_normal_op_pd).  Two launches. */
+int cine_cg_step_pd(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
+                    void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * data front-end + sensitivity calibration (the step BEFORE the path)
