@@ -1212,6 +1212,9 @@ int plane_record_end_pair(PlaneRecorder* r, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------- host dispatch
+#ifndef CINE_MT16
+#define CINE_MT16 13         // pixel fragments per wave of the <= 16-row configurations (variant builds: 7 fits four waves per SIMD)
+#endif
 #ifndef CINE_WN16
 #define CINE_WN16 4
 #endif
@@ -1291,7 +1294,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
 static int regular_nf(int rowsp, long frags, bool plane3x3 = false) {
     if (plane3x3 && rowsp > 16 && rowsp <= 32 && frags <= 14) return 14;
     if (plane3x3 && rowsp > 32 && rowsp <= 64 && frags <= 4) return 4;
-    if (rowsp <= 16) return 13 * CINE_WN16;
+    if (rowsp <= 16) return CINE_MT16 * CINE_WN16;
     if (rowsp <= 32) return 26;
     if (rowsp <= 64 || frags > 8) return 13;
     return 4;
@@ -1334,9 +1337,9 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     if constexpr (TAPS == 9 && CK == 8) {
         // the first layer of every U-Net (2 -> chans, unet.py:51): a 4-channel chunk and one k-step per tap instead of an 8-channel
         // chunk that is three quarters zeros (half the MFMAs and half the staging of that layer)
-        if (a.rowsp <= 16 && !a.vol && a.cin <= 4 && a.s1.c == 0 && a.nchunks == 1) return launch_cfg<4, 1, 1, kWN16, 13, TW, 9>(a, st);
+        if (a.rowsp <= 16 && !a.vol && a.cin <= 4 && a.s1.c == 0 && a.nchunks == 1) return launch_cfg<4, 1, 1, kWN16, CINE_MT16, TW, 9>(a, st);
     }
-    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, 13, TW, TAPS>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, CINE_MT16, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
     // workgroups per CU): a touch slower than one 4-wave workgroup per plane in isolation, but it packs better with the
     // kernels of the other slices in flight (134.8 -> 138.0 slices/s on cfg 2)
@@ -1366,7 +1369,7 @@ static bool conv3d_v3_ok(const ConvArgs& a) {
 static int dispatch_v3(const ConvArgs& a, hipStream_t st) {
     if (vol_small_tiles(a.rowsp, a.H, a.W, a.D)) return launch_cfg<kCK3, 1, 4, 1, 4, 16, 9, false, 1>(a, st);    // 64 rows per workgroup
     const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
-    if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, 13, 16, 9, false, 1>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, CINE_MT16, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 32) return launch_cfg<kCK3, 1, 2, 2, 13, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK3, 1, 4, 1, 13, 16, 9, false, 1>(a, st);
     return launch_cfg<kCK3, 2, 4, 1, 4, 16, 9, false, 1>(a, st);
@@ -1379,7 +1382,7 @@ static bool vol1x1_fast_ok(const ConvArgs& a) {
 }
 static int dispatch_vol1x1(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
-    if (a.rowsp <= 16) return launch_cfg<kCK1, 1, 1, kWN16, 13, 16, 1, false, 2>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<kCK1, 1, 1, kWN16, CINE_MT16, 16, 1, false, 2>(a, st);
     if (a.rowsp <= 32) return launch_cfg<kCK1, 1, 2, 2, 13, 16, 1, false, 2>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK1, 1, 4, 1, 13, 16, 1, false, 2>(a, st);
     return launch_cfg<kCK1, 2, 4, 1, 4, 16, 1, false, 2>(a, st);

@@ -5,7 +5,7 @@ CFG=${CFG:-2}
 for v in "$@"; do
   if [ $v = base ]; then unset CINE_HIP_LIB; else export CINE_HIP_LIB=$V/libcine_hip_$v.so; fi
   for inf in 0 1; do
-    timeout -k 10 200 python3 bench.py --config $CFG --steps 24 --warmup 3 --no-cpu-baseline --repeats 1 --inflight $inf > gpurun_out/var_${v}_$inf.json 2> gpurun_out/var_${v}_$inf.err || { echo "$v $inf failed"; tail -3 gpurun_out/var_${v}_$inf.err; }
+    timeout -k 10 200 python3 bench.py --config $CFG --steps 24 --warmup 3 --no-cpu-baseline --repeats 1 --headline-only --inflight $inf > gpurun_out/var_${v}_$inf.json 2> gpurun_out/var_${v}_$inf.err || { echo "$v $inf failed"; tail -3 gpurun_out/var_${v}_$inf.err; }
     python3 - <<P
 import json
 try:
