@@ -214,6 +214,66 @@ def xfyf(image: torch.Tensor, xf: bool, wboth, wx, wy, norm: bool = True) -> tor
     return XfyfFn.apply(image, xf, norm, wboth, wx, wy, *wboth.distinct_params())
 
 
+# ------------------------------------------------------------------ MWCNN
+class MwcnnFn(Function):
+    """MWCNN.forward (denoisers/mwcnn.py:135-179) on (n, in_ch, h, w) planes.  ``w2`` / ``split``: samples [split, n) go through a second
+    network of the same topology in the same launches (XPDNet's x-t / y-t networks); ``params`` = the parameters of both, for autograd."""
+
+    @staticmethod
+    def forward(ctx, x, w, w2, split, *params):
+        x = ops._dev(x, "mwcnn input")
+        net = w.net
+        n, cin, h, wd = x.shape
+        two = w2 is not None and w2 is not w
+        L = lib()
+        need = L.cine_mwcnn_train_ws_bytes(n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters)
+        ws = torch.empty(max(need, 1), device=x.device, dtype=torch.uint8)
+        y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
+        check(L.cine_mwcnn_forward_train(x.data_ptr(), y.data_ptr(), w.pointers(), w2.pointers() if two else None, int(split) if two else n,
+                                         n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters,
+                                         int(net.res), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
+        ctx.cfg = (w, w2 if two else None, int(split) if two else n)
+        ctx.ws, ctx.params = ws, params
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        w, w2, split = ctx.cfg
+        net = w.net
+        gy = ops._dev(_c(gy), "mwcnn output gradient")
+        n, cin, h, wd = x.shape
+        L = lib()
+        need = L.cine_mwcnn_backward_ws_bytes(n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters)
+        ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+
+        def grads_of(wt):
+            pl = wt.param_list()
+            gl = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in pl]
+            return pl, gl, (ctypes.c_void_p * len(gl))(*[g.data_ptr() for g in gl])
+        p1, g1, gp1 = grads_of(w)
+        p2, g2, gp2 = grads_of(w2) if w2 is not None else (None, None, None)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(L.cine_mwcnn_backward(x.data_ptr(), gy.data_ptr(), w.dgrad_pointers(), w2.dgrad_pointers() if w2 is not None else None, gp1, gp2,
+                                    split, n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters,
+                                    ctx.ws.data_ptr(), ctx.ws.numel(), ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_mwcnn_backward")
+        out = {}
+        for pl, gl in ((p1, g1),) + (((p2, g2),) if w2 is not None else ()):
+            for p, g in zip(pl, gl):
+                out[id(p)] = g if id(p) not in out else out[id(p)] + g
+        return (gx, None, None, None) + tuple(out.get(id(p)) for p in ctx.params)
+
+
+def mwcnn(x: torch.Tensor, w, w2=None, split: int = 0) -> torch.Tensor:
+    params, seen = [], set()
+    for wt in (w,) + ((w2,) if w2 is not None and w2 is not w else ()):
+        for p in wt.param_list():
+            if id(p) not in seen:
+                seen.add(id(p)); params.append(p)
+    return MwcnnFn.apply(x, w, w2, split, *params)
+
+
 # ------------------------------------------------------------------ coil operators
 class ImageDcFn(Function):
     """cine_image_dc with the soft-DC weights of softplus(lambda) (varnet.py:181-194, 281-282):

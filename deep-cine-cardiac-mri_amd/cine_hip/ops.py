@@ -751,6 +751,25 @@ class MwcnnWeights:
     def release_old(self) -> None:
         self._old = []
 
+    # ---- training (cine_mwcnn_backward)
+    def param_list(self):
+        return [p for _, p in self._params()]
+
+    def dgrad_pointers(self):
+        params = self._params()
+        key = tuple((p.data_ptr(), p._version) for _, p in params)
+        if key != getattr(self, "_dkey", None):
+            _no_capture("packed MWCNN gradient weights")
+            keep, ptrs = [], []
+            for kind, p in params:
+                if kind == "raw":
+                    ptrs.append(None); continue
+                t = _pack("c3d", p)
+                keep.append(t); ptrs.append(t.data_ptr())
+            self._dkeep, self._dkey = keep, key
+            self._dptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        return self._dptrs
+
 
 def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights, w2: Optional[MwcnnWeights] = None, split: int = 0) -> torch.Tensor:
     """reference denoisers/mwcnn.py:135-179 on (n, in_ch, h, w), h and w multiples of 2^n_scales.  ``w2`` / ``split``: samples

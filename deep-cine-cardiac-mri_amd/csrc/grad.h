@@ -7,27 +7,33 @@ namespace cine {
 
 // InstanceNorm + LeakyReLU backward of one raw tensor r (n, c, h, w) with statistics records `part`:
 //   gr = d loss / d r   from   g = d loss / d act(r),   act = LeakyReLU((r - mean) * rstd)
-// g is the sum of up to two pieces: `ga`, a (n, ca_total, ha, wa) tensor of which channels [ca_off, ca_off + c) and the
-// top-left (h, w) window belong to this tensor (the input gradient of a conv over a channel concat / a zero-padded source,
-// unet.py:106-122), and `gb`, the gradient of the 2x2 average pool of act(r) (n, c, hb, wb) (unet.py:97).
+// g is the sum of up to two pieces, each the input gradient of one consumer of act(r), gathered on load:
+//   type 1  window : a (n, c_total, gh, gw) tensor of which channels [c_off, c_off + c) and the top-left (h, w) window belong to this
+//                    tensor (a conv over a channel concat / a zero-padded source, unet.py:106-122; an added skip, mwcnn.py:164,172)
+//   type 2  pool   : the consumer read the 2x2 average pool of act(r) (unet.py:97): g (n, c, gh, gw), 0.25 g[y/2][x/2]
+//   type 3  DWT    : the consumer read the Haar DWT of act(r) (mwcnn.py:224-236): g (n, c_total >= 4 c, h/2, w/2), bands [LL, HL, LH, HH]
+//                    of channel ch at c_off + band * c + ch -- the adjoint is the inverse transform of the four band gradients
+//   type 4  IWT    : the consumer read the Haar IWT of act(r) (mwcnn.py:252-261): g (n, c_total >= c / 4, 2 h, 2 w); channel ch = k c/4 + cc
+//                    collects the 2x2 block of output channel c_off + cc with the signs of sub-band k
+struct GradPiece { const float* g; int type, c_total, c_off, gh, gw; };
 struct InBwdArgs {
     const float* r; const float* part; int np;
-    const float* ga; int ca_total, ca_off, ha, wa;
-    const float* gb; int hb, wb;
+    GradPiece a, b;
     float* gr;
     int n, c, h, w;
     float eps, slope;
 };
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st);
 
-// Weight gradient of a convolution y = conv(X) whose input X is described like the forward's sources (modes 0 / 1 / 2,
-// channel concat of two sources):  dW[row][ci][tap] += sum_{n, pixels} G[n][row][p] * X[n][ci][p + tap offset].
+// Weight gradient of a convolution y = conv(X) whose input X is described like the forward's sources (modes 0 / 1 / 2 vectorised; the
+// Haar modes 3 / 4 and added sources element by element; channel concat or sum of two sources):  dW[row][ci][tap] += sum_{n, pixels} G[n][row][p] * X[n][ci][p + tap offset].
 //   taps 9: 3x3 pad 1; taps 1: 1x1 (also the k2 s2 transpose conv, whose rows are the 4 sub-positions x cout of G's
 //   space-to-depth view: g_mode 5, g (n, g_c, 2H, 2W), rows = 4 g_c).
 // Samples [0, set_split) accumulate into grad0, the rest into grad1 (two networks in one launch).  grad layouts (natural,
 // `+=`): kind 0 (rows, cin, 3, 3); kind 1 transpose conv (cin, rows / 4, 2, 2); kind 2 (rows, cin).
 struct WgArgs {
     Src s0, s1;
+    int add_src1;          // 1: source 1 is ADDED to source 0 channel-wise (the MWCNN skips) instead of concatenated
     int cin;
     const float* g; int g_mode, g_c, g_h, g_w;
     int rows;

@@ -23,12 +23,36 @@ __device__ __forceinline__ float wave_sum_g(float v) {
 }
 
 // ---------------------------------------------------------------- InstanceNorm + LeakyReLU backward
-// g(y, x) of the plane: concat / crop piece + pooled piece
-__device__ __forceinline__ float in_bwd_g(const InBwdArgs& a, const float* ga, const float* gb, int y, int x) {
-    float g = 0.f;
-    if (ga) g = ga[(long)y * a.wa + x];
-    if (gb) { const int py = y >> 1, px = x >> 1; if (py < a.hb && px < a.wb) g = fmaf(0.25f, gb[(long)py * a.wb + px], g); }
-    return g;
+// one consumer's share of g(y, x) for channel ch of sample n (see grad.h)
+__device__ __forceinline__ float grad_piece(const GradPiece& p, int n, int c, int ch, int y, int x) {
+    if (p.type == 1) return p.g[(((long)n * p.c_total + p.c_off + ch) * p.gh + y) * p.gw + x];
+    if (p.type == 2) {
+        const int py = y >> 1, px = x >> 1;
+        return (py < p.gh && px < p.gw) ? 0.25f * p.g[(((long)n * p.c_total + p.c_off + ch) * p.gh + py) * p.gw + px] : 0.f;
+    }
+    if (p.type == 3) {
+        const int Y = y >> 1, X = x >> 1;
+        if (Y >= p.gh || X >= p.gw) return 0.f;
+        const long plane = (long)p.gh * p.gw;
+        const float* q = p.g + (((long)n * p.c_total + p.c_off + ch) * p.gh + Y) * p.gw + X;
+        const float ll = q[0], hl = q[(long)c * plane], lh = q[2L * c * plane], hh = q[3L * c * plane];
+        const bool ry = y & 1, rx = x & 1;
+        // forward: LL = x1+x2+x3+x4, HL = -x1-x2+x3+x4, LH = -x1+x2-x3+x4, HH = x1-x2-x3+x4 (x1 even/even, x2 odd row, x3 odd column), all / 2
+        const float v = !ry && !rx ? ll - hl - lh + hh : (ry && !rx ? ll - hl + lh - hh : (!ry && rx ? ll + hl - lh - hh : ll + hl + lh + hh));
+        return 0.5f * v;
+    }
+    if (p.type == 4) {
+        const int cq = c >> 2, k = ch / cq, cc = ch - k * cq;
+        if (2 * y + 1 >= p.gh || 2 * x + 1 >= p.gw) return 0.f;
+        const float* q = p.g + (((long)n * p.c_total + p.c_off + cc) * p.gh + 2 * y) * p.gw + 2 * x;
+        const float g00 = q[0], g01 = q[1], g10 = q[p.gw], g11 = q[p.gw + 1];      // g[row parity][column parity]
+        const float v = k == 0 ? g00 + g10 + g01 + g11 : (k == 1 ? -g00 - g10 + g01 + g11 : (k == 2 ? -g00 + g10 - g01 + g11 : g00 - g10 - g01 + g11));
+        return 0.5f * v;
+    }
+    return 0.f;
+}
+__device__ __forceinline__ float in_bwd_g(const InBwdArgs& a, int n, int ch, int y, int x) {
+    return grad_piece(a.a, n, a.c, ch, y, x) + (a.b.type ? grad_piece(a.b, n, a.c, ch, y, x) : 0.f);
 }
 
 // WAVE = true: one wave per plane (small planes), else one workgroup per plane
@@ -45,15 +69,13 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
     const float2 mr = merge_partials(a.part + pl * a.np * 3, a.np, a.eps);
     const float scale = mr.y, shift = -mr.x * mr.y;
     const float* r = a.r + pl * pe;
-    const float* ga = a.ga ? a.ga + ((long)n * a.ca_total + a.ca_off + c) * a.ha * a.wa : nullptr;
-    const float* gb = a.gb ? a.gb + pl * a.hb * a.wb : nullptr;
     float* gr = a.gr + pl * pe;
     const int t0 = WAVE ? lane : threadIdx.x, ts = WAVE ? 64 : 256;
     float s1 = 0.f, s2 = 0.f;
     for (int e = t0; e < pe; e += ts) {
         const int y = e / a.w, x = e - y * a.w;
         const float xh = fmaf(r[e], scale, shift);
-        float g = in_bwd_g(a, ga, gb, y, x);
+        float g = in_bwd_g(a, n, c, y, x);
         g = xh > 0.f ? g : g * a.slope;
         s1 += g; s2 = fmaf(g, xh, s2);
     }
@@ -69,17 +91,23 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
     for (int e = t0; e < pe; e += ts) {
         const int y = e / a.w, x = e - y * a.w;
         const float xh = fmaf(r[e], scale, shift);
-        float g = in_bwd_g(a, ga, gb, y, x);
+        float g = in_bwd_g(a, n, c, y, x);
         g = xh > 0.f ? g : g * a.slope;
         gr[e] = scale * (g - m1 - xh * m2);
     }
 }
 
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st) {
-    CINE_REQUIRE(a.r && a.part && a.gr && (a.ga || a.gb) && a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.np > 0, CINE_EINVAL,
+    CINE_REQUIRE(a.r && a.part && a.gr && a.a.g && a.a.type >= 1 && a.a.type <= 4 && a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.np > 0, CINE_EINVAL,
                  "in_lrelu_bwd: bad arguments");
-    CINE_REQUIRE(!a.ga || (a.ha >= a.h && a.wa >= a.w && a.ca_off >= 0 && a.ca_off + a.c <= a.ca_total), CINE_EINVAL,
-                 "in_lrelu_bwd: gradient window (%d, %d) smaller than the tensor (%d, %d)", a.ha, a.wa, a.h, a.w);
+    for (const GradPiece* p : {&a.a, &a.b}) {
+        if (!p->type) continue;
+        CINE_REQUIRE(p->g && p->type >= 1 && p->type <= 4 && p->c_off >= 0, CINE_EINVAL, "in_lrelu_bwd: bad gradient piece");
+        const int need_c = p->type == 3 ? 3 * a.c + a.c : (p->type == 4 ? a.c / 4 : a.c);
+        CINE_REQUIRE(p->c_off + need_c <= p->c_total && (p->type != 4 || a.c % 4 == 0), CINE_EINVAL, "in_lrelu_bwd: gradient piece channels");
+        CINE_REQUIRE(p->type != 1 || (p->gh >= a.h && p->gw >= a.w), CINE_EINVAL,
+                     "in_lrelu_bwd: gradient window (%d, %d) smaller than the tensor (%d, %d)", p->gh, p->gw, a.h, a.w);
+    }
     const long planes = (long)a.n * a.c;
     ProfScope prof(F_STATS, st);
     if ((long)a.h * a.w <= 1024) {
@@ -118,7 +146,7 @@ struct WgCfg {
     static constexpr int COB = 16 * CT * WM, WK = 4 / WM;
     static constexpr int IN_FLOATS = 16 * PSI, G_FLOATS = COB * PSG;
     static constexpr int RED_FLOATS = WK > 1 ? TAPS * CT * WM * 256 : 0;       // the accumulators of one K-split slice
-    static constexpr int LDS_FLOATS = (IN_FLOATS + G_FLOATS > RED_FLOATS ? IN_FLOATS + G_FLOATS : RED_FLOATS) + 64;
+    static constexpr int LDS_FLOATS = (IN_FLOATS + G_FLOATS > RED_FLOATS ? IN_FLOATS + G_FLOATS : RED_FLOATS);   // + the statistics tables (launch_wg_cfg)
     static constexpr int PW = TW >= 4 ? 4 : 2, PR = TW / PW;                    // floats per staging piece, pieces per row
     static constexpr int NIU = 16 * ROWS * PR, NIP = (NIU + 255) / 256;         // input pieces per tile / per thread
     static constexpr int NGU = COB * NPIX / PW, NGP = (NGU + 255) / 256;        // output-gradient pieces
@@ -137,8 +165,9 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     extern __shared__ __align__(16) float smem_g[];
     float* in_lds = smem_g;
     float* g_lds = smem_g + C::IN_FLOATS;
-    float* st_lds = smem_g + C::LDS_FLOATS - 64;      // two tables (sample parity) of {scale, shift} of the chunk's 16 input channels
+    float* st_lds = smem_g + C::LDS_FLOATS;           // two tables (sample parity) of {scale, shift} of ALL source channels (source 0's, then source 1's)
     const WgArgs& a = L.a;
+    const int nch = a.s0.c + a.s1.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, kk = lane >> 4;
     const int wm = wave % WM, wk = wave / WM;
@@ -161,19 +190,24 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     const int total = iend - ibeg;
     const Src gs{a.g, nullptr, a.g_c, a.g_mode, a.g_h, a.g_w, 0, 0, 1};
 
-    // statistics table of one sample's 16 chunk channels (threads 0..15)
+    // statistics table of one sample: {scale, shift} of every source channel
+    auto src_stats = [](const Src& s) { return s.mode == 1 || s.mode == 2 || (s.mode >= 3 && (s.act & 1)); };
     auto table = [&](int n, float* st) {
-        if (tid < 16) {
-            const int cg = ci0 + tid;
+        for (int ci = tid; ci < nch; ci += 256) {
+            const bool f0 = ci < a.s0.c;
+            const Src& s = f0 ? a.s0 : a.s1;
+            const int cl = f0 ? ci : ci - a.s0.c;
             float2 mr = make_float2(0.f, 1.f);
-            if (cg < a.cin) {
-                const bool f0 = cg < c0n;
-                const Src& s = f0 ? a.s0 : a.s1;
-                const int cl = f0 ? cg : cg - c0n;
-                if (s.mode == 1 || s.mode == 2) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
-            }
-            st[2 * tid] = mr.y; st[2 * tid + 1] = -mr.x * mr.y;
+            if (src_stats(s)) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+            st[2 * ci] = mr.y; st[2 * ci + 1] = -mr.x * mr.y;
         }
+    };
+    // one transformed input value of concat / summed channel cg (any source mode), st = this sample's table
+    auto fetch_in = [&](int n, int cg, int gy, int gx, const float* st) -> float {
+        if (a.add_src1)
+            return fetch_scalar(a.s0, n, cg, 0, gy, gx, st, a.slope) + fetch_scalar(a.s1, n, cg, 0, gy, gx, st + 2 * a.s0.c, a.slope);
+        const bool f0 = cg < c0n;
+        return fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? cg : cg - c0n, 0, gy, gx, st + (f0 ? 0 : 2 * a.s0.c), a.slope);
     };
     // ---- the tile pipeline: issue(it) puts the raw pieces of tile `it` in flight into registers, commit(it) transforms them and
     // writes LDS, the sweep of tile `it` runs with the loads of tile it + 1 in flight
@@ -224,7 +258,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
         const int n = sbase + (ibeg + it) / ntile, tile = (ibeg + it) % ntile;
         const int ty = tile / tiles_w, tx = tile - ty * tiles_w;
         const int r0 = ty * C::TH, c0 = tx * TW;
-        const float* st = st_lds + 32 * (((ibeg + it) / ntile) & 1);
+        const float* st = st_lds + 2 * nch * (((ibeg + it) / ntile) & 1);
         if (L.fast_in) {
 #pragma unroll
             for (int i = 0; i < C::NIP; ++i) {
@@ -239,7 +273,8 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 const bool ok = cg < a.cin && gy >= 0 && gy < s.h && gx < a.W;
                 piece_t o = xin[i];
                 float* ov = reinterpret_cast<float*>(&o);
-                const float sc = st[2 * k], sh = st[2 * k + 1];
+                const int cgc = min(cg, a.cin - 1);
+                const float sc = st[2 * cgc], sh = st[2 * cgc + 1];
 #pragma unroll
                 for (int u = 0; u < PW; ++u) ov[u] = ok ? (s.mode == 0 ? ov[u] : act(ov[u], sc, sh, a.slope)) : 0.f;
                 float* dst = in_lds + k * C::PSI + row * C::COLS + PW * j;
@@ -252,11 +287,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                     const int row = rem >> 1, side = rem & 1;
                     const int gy = r0 - 1 + row, gx = side ? c0 + TW : c0 - 1, cg = ci0 + k;
                     float v = 0.f;
-                    if (a.W > TW && cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                        const bool f0 = cg < c0n;
-                        const int cl = f0 ? cg : cg - c0n;
-                        v = fetch_scalar(f0 ? a.s0 : a.s1, n, cl, 0, gy, gx, st + 2 * k - 2 * cl, a.slope);
-                    }
+                    if (a.W > TW && cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = fetch_in(n, cg, gy, gx, st);
                     in_lds[k * C::PSI + row * C::COLS + (side ? TW : C::COLS - 1)] = v;
                 }
             }
@@ -267,11 +298,7 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 const int row = rem / C::COLS, xc = rem - row * C::COLS;          // xc: tile column + HALO
                 const int gy = r0 - HALO + row, gx = c0 - HALO + xc, cg = ci0 + k;
                 float v = 0.f;
-                if (cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-                    const bool f0 = cg < c0n;
-                    const int cl = f0 ? cg : cg - c0n;
-                    v = fetch_scalar(f0 ? a.s0 : a.s1, n, cl, 0, gy, gx, st + 2 * k - 2 * cl, a.slope);
-                }
+                if (cg < a.cin && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = fetch_in(n, cg, gy, gx, st);
                 in_lds[k * C::PSI + row * C::COLS + (xc - HALO + C::COLS) % C::COLS] = v;
             }
         }
@@ -321,11 +348,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
         }
     };
 
-    if (total > 0) { table(sbase + ibeg / ntile, st_lds + 32 * ((ibeg / ntile) & 1)); issue(0); }
+    if (total > 0) { table(sbase + ibeg / ntile, st_lds + 2 * nch * ((ibeg / ntile) & 1)); issue(0); }
     for (int it = 0; it < total; ++it) {
         __syncthreads();                                        // previous sweep done with LDS; this sample's table written
         if ((ibeg + it + 1) % ntile == 0 && it + 1 < total)     // the next item starts a new sample: its table goes into the other buffer
-            table(sbase + (ibeg + it + 1) / ntile, st_lds + 32 * (((ibeg + it + 1) / ntile) & 1));
+            table(sbase + (ibeg + it + 1) / ntile, st_lds + 2 * nch * (((ibeg + it + 1) / ntile) & 1));
         commit(it);
         __syncthreads();
         if (it + 1 < total) issue(it + 1);
@@ -448,8 +475,9 @@ size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
 template <int TAPS, int TW, int CT, int WM, int NPIX>
 static int launch_wg_cfg(const WgLaunch& L, dim3 grid, hipStream_t st) {
     using C = WgCfg<TAPS, TW, CT, WM, NPIX>;
-    const size_t lds = (size_t)C::LDS_FLOATS * sizeof(float);
-    static_assert(C::LDS_FLOATS * sizeof(float) <= 64 * 1024, "wgrad tile exceeds the default LDS limit");
+    const size_t lds = (size_t)(C::LDS_FLOATS + 4 * (L.a.s0.c + L.a.s1.c)) * sizeof(float);
+    static_assert(C::LDS_FLOATS * sizeof(float) <= 60 * 1024, "wgrad tile exceeds the default LDS limit");
+    CINE_REQUIRE(lds <= 64 * 1024, CINE_EUNSUPPORTED, "wgrad: %d source channels need %zu bytes of LDS", L.a.s0.c + L.a.s1.c, lds);
     hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX>), grid, dim3(256), lds, st, L);
     return check_launch("wgrad_mfma_kernel");
 }
@@ -466,8 +494,9 @@ static int launch_wg_tw(const WgLaunch& L, int cob, dim3 grid, hipStream_t st) {
 int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1, float* ws, size_t ws_floats, hipStream_t st) {
     CINE_REQUIRE(a.g && a.s0.x && ws && grad0 && a.n > 0 && a.rows > 0 && a.cin > 0 && a.H > 0 && a.W > 0, CINE_EINVAL, "wgrad: bad arguments");
     CINE_REQUIRE(taps == 9 || taps == 1, CINE_EINVAL, "wgrad: taps %d", taps);
-    CINE_REQUIRE(a.s0.mode <= 2 && (a.s1.c == 0 || a.s1.mode <= 2), CINE_EUNSUPPORTED, "wgrad: source modes 0..2 only");
-    CINE_REQUIRE(src_cin(a.s0) + src_cin(a.s1) == a.cin, CINE_EINVAL, "wgrad: channel counts");
+    CINE_REQUIRE(a.s0.mode <= 4 && (a.s1.c == 0 || a.s1.mode <= 4), CINE_EUNSUPPORTED, "wgrad: source modes 0..4 only");
+    CINE_REQUIRE((a.add_src1 && a.s1.c > 0) ? (src_cin(a.s0) == a.cin && src_cin(a.s1) == a.cin) : (src_cin(a.s0) + src_cin(a.s1) == a.cin), CINE_EINVAL,
+                 "wgrad: channel counts");
     CINE_REQUIRE(a.set_split >= 0 && a.set_split <= a.n && (a.set_split == a.n || grad1), CINE_EINVAL, "wgrad: second weight set without a gradient");
     WgLaunch L{};
     L.a = a;
@@ -490,7 +519,7 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     auto src_fast = [&](const Src& s) {
         return s.c == 0 || (s.mode <= 1 && s.w == a.W && s.h <= a.H && reinterpret_cast<uintptr_t>(s.x) % 16 == 0);
     };
-    L.fast_in = a.W % PW == 0 && a.W >= PW && src_fast(a.s0) && src_fast(a.s1);
+    L.fast_in = !a.add_src1 && a.W % PW == 0 && a.W >= PW && src_fast(a.s0) && src_fast(a.s1);
     L.fast_g = a.g_mode == 0 && a.W % PW == 0 && a.W >= PW && reinterpret_cast<uintptr_t>(a.g) % 16 == 0;
     // the transpose conv's space-to-depth view: whole 2 x 2 blocks (exact 2:1 extents), rows in whole row blocks of 4 c + 2 a + b
     if (a.g_mode == 5 && a.W % PW == 0 && a.W >= PW && a.g_w == 2 * a.W && a.g_h == 2 * a.H && a.rows == 4 * a.g_c && a.rows % 4 == 0 &&

@@ -189,3 +189,228 @@ static int mwcnn_impl(const float* x, float* y, const void* const* weights, cons
     const float* bl = reinterpret_cast<const float*>(weights[woff[p.S] + 1]);
     return conv(cur, M_IWT_ACT, &p.first_feat, M_ACT, 1, wl, bl, y, nullptr, out_ch, h, w);
 }
+
+// ---------------------------------------------------------------- training: forward that keeps every feature map, and the backward pass
+// Same launch sequence as mwcnn_impl, but every conv output owns its memory (the backward pass reads all of them).  One weight set or
+// two (samples >= set_split through the second network).
+#include "grad.h"
+extern "C" int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
+                                  float* gx, int n, int cout, int cin, int h, int w, void* stream);
+namespace {
+struct TrainPlan {
+    Plan p;
+    Feat first_feat, feat[kMaxScales][kMaxConvs];
+};
+void build_train(TrainPlan& t, Bump& b, int n, int h, int w) {
+    const Plan& p = t.p;
+    t.first_feat = alloc(b, n, p.first, h, w);
+    for (int s = 0; s < p.S; ++s)
+        for (int i = 0; i < 2 * p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            t.feat[s][i] = alloc(b, n, co, h >> (s + 1), w >> (s + 1));
+        }
+}
+int plan_from(Plan& p, int in_ch, int out_ch, int n_scales, const int* nf, const int* nc, int first) {
+    p = Plan{}; p.S = n_scales; p.first = first; p.out_ch = out_ch; p.in_ch = in_ch;
+    for (int s = 0; s < n_scales; ++s) { p.nf[s] = nf[s]; p.nc[s] = nc[s]; }
+    return 0;
+}
+int woffsets(const Plan& p, int* woff) { woff[0] = 1; for (int s = 0; s < p.S; ++s) woff[s + 1] = woff[s] + 2 * p.nc[s]; return woff[p.S] + 2; }
+// what conv (s, i) reads: source 0 (+ mode), optional added source 1
+struct ConvIn { Feat s0; int m0; Feat s1; int m1; int add; };
+ConvIn conv_input(const TrainPlan& t, int s, int i) {
+    const Plan& p = t.p;
+    ConvIn c{}; c.add = 0;
+    if (i == 0) { c.s0 = s == 0 ? t.first_feat : t.feat[s - 1][p.nc[s - 1] - 1]; c.m0 = M_DWT_ACT; return c; }
+    if (i == p.nc[s] && s != p.S - 1) {        // IWT of the coarser scale's last feature + this scale's last analysis feature (:162-164)
+        c.s0 = t.feat[s + 1][2 * p.nc[s + 1] - 1]; c.m0 = M_IWT_ACT; c.s1 = t.feat[s][p.nc[s] - 1]; c.m1 = M_ACT; c.add = 1; return c;
+    }
+    c.s0 = t.feat[s][i - 1]; c.m0 = M_ACT; return c;
+}
+}  // namespace
+
+extern "C" size_t cine_mwcnn_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
+                                            const int* n_convs, int first_filters) {
+    if (n <= 0 || h <= 0 || w <= 0 || n_scales < 1 || n_scales > kMaxScales || !n_filters || !n_convs) return 0;
+    TrainPlan t{}; plan_from(t.p, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters);
+    Bump b{nullptr, 0};
+    build_train(t, b, n, h, w);
+    return b.off;
+}
+
+extern "C" int cine_mwcnn_forward_train(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
+                                        int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                                        int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(x && y && weights && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_forward_train: null pointer");
+    CINE_REQUIRE(n > 0 && h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && first_filters > 0, CINE_EINVAL, "cine_mwcnn_forward_train: bad sizes");
+    if (int e = check_topology(n_scales, n_filters, n_convs, n_first_convs, res)) return e;
+    CINE_REQUIRE(h % (1 << n_scales) == 0 && w % (1 << n_scales) == 0, CINE_EINVAL, "cine_mwcnn_forward_train: %dx%d is not a multiple of 2^%d", h, w, n_scales);
+    CINE_REQUIRE(ws_bytes >= cine_mwcnn_train_ws_bytes(n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters), CINE_EWORKSPACE,
+                 "cine_mwcnn_forward_train: workspace too small");
+    CINE_REQUIRE(!weights2 || (set_split > 0 && set_split < n), CINE_EINVAL, "cine_mwcnn_forward_train: set_split");
+    TrainPlan t{}; plan_from(t.p, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters);
+    const Plan& p = t.p;
+    Bump b{reinterpret_cast<char*>(ws), 0};
+    build_train(t, b, n, h, w);
+    int woff[kMaxScales + 1];
+    const int nptr = woffsets(p, woff);
+    for (int i = 0; i < nptr; ++i) CINE_REQUIRE(weights[i] && (!weights2 || weights2[i]), CINE_EINVAL, "cine_mwcnn_forward_train: weights[%d] is null", i);
+    auto W = [&](int idx, int set) { return reinterpret_cast<const float*>((set && weights2 ? weights2 : weights)[idx]); };
+    const int sp = weights2 ? set_split : n;
+    auto conv = [&](const Feat& s0, int mode0, const Feat* s1, int mode1, int add, int widx, bool bias, float* yo, float* po, int cout, int ho, int wo) {
+        return cine_conv3x3_ex2(s0.x, s0.part, s0.np, s0.c, mode0, s0.h, s0.w,
+                                s1 ? s1->x : nullptr, s1 ? s1->part : nullptr, s1 ? s1->np : 0, s1 ? s1->c : 0, mode1, s1 ? s1->h : 0, s1 ? s1->w : 0, add,
+                                W(widx, 0), bias ? W(widx + 1, 0) : nullptr, weights2 ? W(widx, 1) : nullptr, (bias && weights2) ? W(widx + 1, 1) : nullptr, sp,
+                                nullptr, 0, yo, po, n, cout, ho, wo, kEps, kSlope, stream);
+    };
+    int e;
+    Feat in{const_cast<float*>(x), nullptr, in_ch, h, w, 0};
+    if ((e = conv(in, M_PLAIN, nullptr, 0, 0, 0, false, t.first_feat.x, t.first_feat.part, p.first, h, w))) return e;
+    for (int s = 0; s < p.S; ++s)                                     // analysis
+        for (int i = 0; i < p.nc[s]; ++i) {
+            const ConvIn c = conv_input(t, s, i);
+            const Feat& o = t.feat[s][i];
+            if ((e = conv(c.s0, c.m0, nullptr, 0, 0, woff[s] + i, false, o.x, o.part, o.c, o.h, o.w))) return e;
+        }
+    for (int s = p.S - 1; s >= 0; --s)                                // synthesis
+        for (int i = p.nc[s]; i < 2 * p.nc[s]; ++i) {
+            const ConvIn c = conv_input(t, s, i);
+            const Feat& o = t.feat[s][i];
+            if ((e = conv(c.s0, c.m0, c.add ? &c.s1 : nullptr, c.m1, c.add, woff[s] + i, false, o.x, o.part, o.c, o.h, o.w))) return e;
+        }
+    const Feat& last = t.feat[0][2 * p.nc[0] - 1];
+    return conv(last, M_IWT_ACT, &t.first_feat, M_ACT, 1, woff[p.S], true, y, nullptr, out_ch, h, w);
+}
+
+extern "C" size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
+                                               const int* n_convs, int first_filters) {
+    if (n <= 0 || h <= 0 || w <= 0 || n_scales < 1 || n_scales > kMaxScales || !n_filters || !n_convs) return 0;
+    Plan p; plan_from(p, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters);
+    Bump b{nullptr, 0};
+    size_t big = (size_t)n * p.first * h * w, wg = wgrad_ws_floats(p.first, in_ch, 9, n);
+    b.take((size_t)n * p.first * h * w);                              // input gradient of the final conv
+    wg = std::max(wg, std::max(wgrad_ws_floats(out_ch, p.first, 9, n), (size_t)n * out_ch));
+    for (int s = 0; s < p.S; ++s)
+        for (int i = 0; i < 2 * p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            const size_t hw = (size_t)(h >> (s + 1)) * (w >> (s + 1));
+            b.take((size_t)n * ci * hw);                              // input gradient of conv (s, i)
+            big = std::max(big, (size_t)n * co * hw);
+            wg = std::max(wg, wgrad_ws_floats(co, ci, 9, n));
+        }
+    b.take(big);                                                      // d/d(raw) of the tensor in hand
+    b.take(wg);
+    return b.off;
+}
+
+// Gradients of cine_mwcnn_forward_train.  wdgrad / grads as for cine_unet2d_backward, in the order of `weights` (first conv, the conv blocks in
+// module order, the final conv's weight and bias); weights2-style second lists for the second network when set_split < n.
+extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* const* wdgrad, const void* const* wdgrad2, void* const* grads,
+                                   void* const* grads2, int set_split, int n, int h, int w, int in_ch, int out_ch, int n_scales,
+                                   const int* n_filters, const int* n_convs, int first_filters, const void* fwd_ws, size_t fwd_ws_bytes,
+                                   void* ws, size_t ws_bytes, float* gx, void* stream) {
+    CINE_REQUIRE(x && gy && wdgrad && grads && fwd_ws && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_backward: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && h > 0 && w > 0, CINE_EINVAL, "cine_mwcnn_backward: bad sizes");
+    if (int e = check_topology(n_scales, n_filters, n_convs, 1, 0)) return e;
+    const bool two = wdgrad2 != nullptr;
+    CINE_REQUIRE(!two || (grads2 && set_split > 0 && set_split < n), CINE_EINVAL, "cine_mwcnn_backward: second weight set");
+    CINE_REQUIRE(fwd_ws_bytes >= cine_mwcnn_train_ws_bytes(n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters) &&
+                 ws_bytes >= cine_mwcnn_backward_ws_bytes(n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters), CINE_EWORKSPACE,
+                 "cine_mwcnn_backward: workspace too small");
+    TrainPlan t{}; plan_from(t.p, in_ch, out_ch, n_scales, n_filters, n_convs, first_filters);
+    const Plan& p = t.p;
+    Bump bf{const_cast<char*>(reinterpret_cast<const char*>(fwd_ws)), 0};
+    build_train(t, bf, n, h, w);
+    int woff[kMaxScales + 1];
+    const int nptr = woffsets(p, woff);
+    for (int i = 0; i < nptr; ++i) {
+        CINE_REQUIRE(grads[i] && (!two || grads2[i]), CINE_EINVAL, "cine_mwcnn_backward: grads[%d] is null", i);
+        CINE_REQUIRE(i == nptr - 1 || (wdgrad[i] && (!two || wdgrad2[i])), CINE_EINVAL, "cine_mwcnn_backward: wdgrad[%d] is null", i);
+    }
+    // scratch (same order as cine_mwcnn_backward_ws_bytes)
+    Bump bb{reinterpret_cast<char*>(ws), 0};
+    float* g_final = bb.take((size_t)n * p.first * h * w);
+    float* gin[kMaxScales][kMaxConvs];
+    size_t big = (size_t)n * p.first * h * w, wgf = wgrad_ws_floats(p.first, in_ch, 9, n);
+    wgf = std::max(wgf, std::max(wgrad_ws_floats(out_ch, p.first, 9, n), (size_t)n * out_ch));
+    for (int s = 0; s < p.S; ++s)
+        for (int i = 0; i < 2 * p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            const size_t hw = (size_t)(h >> (s + 1)) * (w >> (s + 1));
+            gin[s][i] = bb.take((size_t)n * ci * hw);
+            big = std::max(big, (size_t)n * co * hw);
+            wgf = std::max(wgf, wgrad_ws_floats(co, ci, 9, n));
+        }
+    float* gr = bb.take(big);
+    float* wgs = bb.take(wgf);
+    hipStream_t st = as_stream(stream);
+    const int sp = two ? set_split : n;
+    auto WD = [&](int idx, int set) { return reinterpret_cast<const float*>((set ? wdgrad2 : wdgrad)[idx]); };
+    auto GR = [&](int idx, int set) { return set ? (two ? reinterpret_cast<float*>(grads2[idx]) : nullptr) : reinterpret_cast<float*>(grads[idx]); };
+    auto src_of = [&](const Feat& f, int mode) { return Src{f.x, f.part, f.c, mode & 7, f.h, f.w, f.np, (mode >> 3) & 1, 1}; };
+    const Src none{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    auto wgrad = [&](const ConvIn& c, const float* g, int rows, int cin, int hh, int ww, int widx) {
+        WgArgs a{}; a.s0 = src_of(c.s0, c.m0); a.s1 = c.add ? src_of(c.s1, c.m1) : none; a.add_src1 = c.add; a.cin = cin;
+        a.g = g; a.g_mode = 0; a.rows = rows; a.n = n; a.H = hh; a.W = ww; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
+        return launch_wgrad(a, 9, 0, GR(widx, 0), GR(widx, 1), wgs, wgf, st);
+    };
+    auto inbwd = [&](const Feat& f, GradPiece pa, GradPiece pb) {
+        InBwdArgs a{f.x, f.part, f.np, pa, pb, gr, n, f.c, f.h, f.w, kEps, kSlope};
+        return launch_in_lrelu_bwd(a, st);
+    };
+    const GradPiece nopiece{nullptr, 0, 0, 0, 0, 0};
+    int e;
+    // ---- final conv: y = conv(IWT(act(last)) + act(first_feat)) + b  (:170-174)
+    const Feat& last = t.feat[0][2 * p.nc[0] - 1];
+    if ((e = launch_bias_grad(gy, n, out_ch, (long)h * w, sp, GR(woff[p.S] + 1, 0), GR(woff[p.S] + 1, 1), wgs, wgf, st))) return e;
+    { ConvIn c{last, M_IWT_ACT, t.first_feat, M_ACT, 1};
+      if ((e = wgrad(c, gy, out_ch, p.first, h, w, woff[p.S]))) return e; }
+    if ((e = cine_conv3x3_dgrad(gy, WD(woff[p.S], 0), two ? WD(woff[p.S], 1) : nullptr, sp, g_final, n, out_ch, p.first, h, w, stream))) return e;
+    // the gradient piece the consumer(s) of feature (s, i) hand back
+    auto consumer_piece = [&](int s, int i) -> GradPiece {
+        const int hs = h >> (s + 1), ws2 = w >> (s + 1);
+        if (i == 2 * p.nc[s] - 1) {                                   // read through an IWT by scale s - 1's first synthesis conv, or by the final conv
+            if (s == 0) return GradPiece{g_final, 4, p.first, 0, h, w};
+            int ci, co; chans(p, s - 1, p.nc[s - 1], ci, co);
+            return GradPiece{gin[s - 1][p.nc[s - 1]], 4, ci, 0, 2 * hs, 2 * ws2};
+        }
+        int ci, co; chans(p, s, i + 1, ci, co);                       // the next conv of the same scale reads it plainly
+        return GradPiece{gin[s][i + 1], 1, ci, 0, hs, ws2};
+    };
+    // ---- synthesis path, reversed: scale 0 first
+    for (int s = 0; s < p.S; ++s)
+        for (int i = 2 * p.nc[s] - 1; i >= p.nc[s]; --i) {
+            const Feat& f = t.feat[s][i];
+            int ci, co; chans(p, s, i, ci, co);
+            if ((e = inbwd(f, consumer_piece(s, i), nopiece))) return e;
+            const ConvIn c = conv_input(t, s, i);
+            if ((e = wgrad(c, gr, co, ci, f.h, f.w, woff[s] + i))) return e;
+            if ((e = cine_conv3x3_dgrad(gr, WD(woff[s] + i, 0), two ? WD(woff[s] + i, 1) : nullptr, sp, gin[s][i], n, co, ci, f.h, f.w, stream))) return e;
+        }
+    // ---- analysis path, reversed: the coarsest scale first
+    for (int s = p.S - 1; s >= 0; --s)
+        for (int i = p.nc[s] - 1; i >= 0; --i) {
+            const Feat& f = t.feat[s][i];
+            int ci, co; chans(p, s, i, ci, co);
+            GradPiece pa, pb = nopiece;
+            if (i == p.nc[s] - 1 && s != p.S - 1) {                   // the scale's last analysis feature: DWT of the next scale + the synthesis skip
+                int c2, o2; chans(p, s + 1, 0, c2, o2);
+                pa = GradPiece{gin[s + 1][0], 3, c2, 0, f.h / 2, f.w / 2};
+                int c3, o3; chans(p, s, p.nc[s], c3, o3);
+                pb = GradPiece{gin[s][p.nc[s]], 1, c3, 0, f.h, f.w};
+            } else pa = consumer_piece(s, i);
+            if ((e = inbwd(f, pa, pb))) return e;
+            const ConvIn c = conv_input(t, s, i);
+            if ((e = wgrad(c, gr, co, ci, f.h, f.w, woff[s] + i))) return e;
+            if ((e = cine_conv3x3_dgrad(gr, WD(woff[s] + i, 0), two ? WD(woff[s] + i, 1) : nullptr, sp, gin[s][i], n, co, ci, f.h, f.w, stream))) return e;
+        }
+    // ---- first conv block: consumers = scale 0's DWT conv and the final conv's skip
+    {
+        int c2, o2; chans(p, 0, 0, c2, o2);
+        if ((e = inbwd(t.first_feat, GradPiece{gin[0][0], 3, c2, 0, h / 2, w / 2}, GradPiece{g_final, 1, p.first, 0, h, w}))) return e;
+        ConvIn c{}; c.s0 = Feat{const_cast<float*>(x), nullptr, in_ch, h, w, 0}; c.m0 = M_PLAIN;
+        if ((e = wgrad(c, gr, p.first, in_ch, h, w, 0))) return e;
+        if (gx && (e = cine_conv3x3_dgrad(gr, WD(0, 0), two ? WD(0, 1) : nullptr, sp, gx, n, p.first, in_ch, h, w, stream))) return e;
+    }
+    return CINE_OK;
+}

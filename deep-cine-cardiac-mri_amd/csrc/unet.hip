@@ -360,7 +360,7 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
     };
     auto inbwd = [&](const float* r, const float* part, int np, int c, int hh, int ww, const float* ga, int ca_total, int ca_off,
                      int ha, int wa, const float* gb, int hb, int wb, float* out) {
-        InBwdArgs a{r, part, np, ga, ca_total, ca_off, ha, wa, gb, hb, wb, out, n, c, hh, ww, kEps, kSlope};
+        InBwdArgs a{r, part, np, GradPiece{ga, 1, ca_total, ca_off, ha, wa}, GradPiece{gb, gb ? 2 : 0, c, 0, hb, wb}, out, n, c, hh, ww, kEps, kSlope};
         return launch_in_lrelu_bwd(a, st);
     };
 

@@ -94,4 +94,7 @@ class MWCNN(nn.Module):
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         if self.dims != 2:
             raise NotImplementedError("3-D MWCNN is not on the HIP path")
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from cine_hip import autograd as ag          # training: forward keeps every feature map, backward = cine_mwcnn_backward
+            return ag.mwcnn(inputs, self.hip_weights())
         return ops.mwcnn_forward(inputs, self.hip_weights())

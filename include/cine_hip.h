@@ -478,6 +478,23 @@ int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdg
                          int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                          const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream);
 
+/* The same for the wavelet CNN (denoisers/mwcnn.py:135-179): a forward that keeps every feature map, and the backward pass -- InstanceNorm +
+ * LeakyReLU backward with the Haar DWT / IWT adjoints (the transforms are orthogonal: each one's adjoint is the other) and the additive
+ * skips gathered on load, input gradients on the forward conv kernel, weight gradients with the wavelet / summed sources re-staged.
+ * weights / weights2, set_split as cine_mwcnn_forward2 (weights2 NULL: one network); wdgrad*: the cine_pack_conv3x3_dgrad packings in the
+ * order of `weights` (bias slot ignored); grads*: the parameters' own layouts, accumulated into. */
+size_t cine_mwcnn_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
+                                 const int* n_convs, int first_filters);
+int cine_mwcnn_forward_train(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
+                             int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
+                             int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
+                                    const int* n_convs, int first_filters);
+int cine_mwcnn_backward(const float* x, const float* gy, const void* const* wdgrad, const void* const* wdgrad2, void* const* grads,
+                        void* const* grads2, int set_split, int n, int h, int w, int in_ch, int out_ch, int n_scales,
+                        const int* n_filters, const int* n_convs, int first_filters, const void* fwd_ws, size_t fwd_ws_bytes,
+                        void* ws, size_t ws_bytes, float* gx, void* stream);
+
 /* Adjoints of cine_normunet_unpack / cine_normunet_pack (norm_unet.py:59-96).
  *   unpack_bwd: gout (n, h, w, 2), the U-Net output planes_q -> gq (planes, zero on the pad frame) and dstats (n, 2, 2) =
  *               {d/d mean, d/d std} per (sample, re|im) from the un-normalisation x * std + mean.

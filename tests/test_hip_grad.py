@@ -379,3 +379,27 @@ def test_training_loop_tracks_the_oracle_and_learns(dev):
     assert lh[-1] < lh[0] - 1e-3, lh                       # it learns
     for a, b in zip(lh, lr_):
         assert abs(a - b) < 2e-3 * max(abs(b), 1e-3), (lh, lr_)
+
+
+@pytest.mark.parametrize("n,in_ch,out_ch,scales,nf,nc,first,h,w", [(3, 6, 4, 2, [8, 16], [2, 1], 8, 16, 8), (4, 12, 10, 3, [16, 32, 64], [2, 2, 2], 16, 32, 16)])
+def test_mwcnn_backward_vs_oracle(dev, n, in_ch, out_ch, scales, nf, nc, first, h, w):
+    """cine_mwcnn_backward (reference denoisers/mwcnn.py:135-179 under autograd): every weight / bias gradient and the input gradient,
+    incl. the Haar DWT / IWT adjoints and the additive skips; the second case is XPDNet's default topology."""
+    from reconstruction.models.denoisers import MWCNN
+    from oracle import xpdnet_ref as R
+    from cine_hip import synth
+    kw = dict(in_chans=in_ch, out_chans=out_ch, n_scales=scales, n_filters_per_scale=nf, n_convs_per_scale=nc, first_conv_n_filters=first)
+    hip = MWCNN(**kw).to(dev)
+    synth.fill_parameters_(hip, 51, keep=())
+    ref = R.MWCNN(**kw)
+    ref.load_state_dict(hip.state_dict())
+    x, gy = rnd(16, n, in_ch, h, w), rnd(17, n, out_ch, h, w)
+    with torch.enable_grad():
+        xr = x.clone().requires_grad_(True)
+        want = _grads(ref, (ref(xr) * gy).sum())
+        xh = x.to(dev).requires_grad_(True)
+        yh = hip(xh)
+        got = _grads(hip, (yh * gy.to(dev)).sum())
+    assert rel_err(yh.detach().cpu(), ref(x)) < 1e-5
+    _cmp(got, want, "mwcnn weight gradients")
+    assert rel_err(xh.grad.cpu(), xr.grad) < TOL
