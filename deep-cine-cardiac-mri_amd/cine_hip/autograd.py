@@ -11,6 +11,8 @@ forward + ``SSIMLoss``) is differentiated here by the gradient entry points of `
                  sensitivity maps, the zero-filled term and lambda_reg)
   CoilReduceFn : models/varnet.py:187-194 with respect to the maps
   RssNormFn    : models/varnet.py:58-59;  AbsFn: utils/math.py:48-62
+  MwcnnFn      : denoisers/mwcnn.py:135-179 (Haar DWT / IWT adjoints, additive skips);  XpdRegFn: models/xpdnet.py:424-509 (XPDNet's I-step
+                 network: buffer pack with its own temporal transform, both MWCNNs, unpack);  ImageDcFixedFn: xpdnet.py:128-167
   ConjGradFn   : models/cinenet.py:136-171 (the adjoint recurrence of the CG iteration with the recorded step sizes),
                  AxpbyLamFn: cinenet.py:255-257;  SsimLossFn: utils/losses.py:25-58
 
@@ -315,6 +317,138 @@ class ImageDcFn(Function):
             v = torch.nn.functional.softplus(lv)
             glam = (dot * torch.sigmoid(lv) / ((1 + v) * (1 + v))).view(lam.shape)
         return gm, gs, gzf, None, glam
+
+
+class ImageDcFixedFn(Function):
+    """cine_image_dc with fixed weights: sum_c conj(S_c) IFFT_h[(mask ? w1 : w0) FFT_h(S_c m)] + beta zf -- XPDNet's K step + masked backward
+    operator A^H M (A x - k_ref) is (1, 0, -1) (xpdnet.py:128-131, 161-167, 295-298)."""
+
+    @staticmethod
+    def forward(ctx, m, sens, zf, mask, w1, w0, beta):
+        out = ops.image_dc(m, sens, zf, mask, None, weights=(w1, w0, beta))
+        ctx.save_for_backward(m, sens, mask)
+        ctx.wts = (float(w1), float(w0), float(beta))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        m, sens, mask = ctx.saved_tensors
+        w1, w0, beta = ctx.wts
+        gout = ops._dev(_c(gout), "image_dc output gradient")
+        m = ops._dev(m, "image")
+        b, _, c, h, w, _ = sens.shape
+        t = m.shape[1]
+        need = ctx.needs_input_grad
+        gm = ops.image_dc(gout, sens, None, mask, None, weights=(w1, w0, 0.0)).view(m.shape) if need[0] else None
+        gs = None
+        if need[1]:
+            part = torch.empty((b, t, c, h, w, 2), device=m.device, dtype=m.dtype)
+            check(lib().cine_image_dc_sens_grad(m.data_ptr(), gout.data_ptr(), ops._dev(sens, "sens_maps").data_ptr(), mask.data_ptr(), None,
+                                                w1, w0, part.data_ptr(), b, t, c, h, w, _stream()), "cine_image_dc_sens_grad")
+            gs = coil_accum(None, part)
+        gzf = (gout * beta) if need[2] else None
+        return gm, gs, gzf, None, None, None, None
+
+
+class XpdRegFn(Function):
+    """XPDNetBlock's I-step network (xpdnet.py:424-509) for the XT / XF dynamic types: buffer (b, t, 1, h, w, 2n) + backward-operator image
+    -> new buffer, through cine_xpd_pack, the two MWCNNs (one launch sequence when the plane sets have one shape) and cine_xpd_unpack."""
+
+    @staticmethod
+    def forward(ctx, buf, extra, n, n_scales, xf, wx, wy, *params):
+        buf = ops._dev(buf, "image buffer"); extra = ops._dev(extra, "backward-op image")
+        b, t, _, h, w, _ = buf.shape
+        pxf, pyf, mean = ops.xpd_pack(buf, extra, n, n_scales, xf)
+        joint = pxf.shape[1:] == pyf.shape[1:] and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr()
+        L = lib()
+
+        def run(planes, w1, w2, split):
+            net = w1.net
+            nn_, cin, hh, ww = planes.shape
+            need = L.cine_mwcnn_train_ws_bytes(nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc, net.first_conv_n_filters)
+            ws = torch.empty(max(need, 1), device=planes.device, dtype=torch.uint8)
+            y = torch.empty((nn_, net.out_chans, hh, ww), device=planes.device, dtype=planes.dtype)
+            two = w2 is not None and w2 is not w1
+            check(L.cine_mwcnn_forward_train(planes.data_ptr(), y.data_ptr(), w1.pointers(), w2.pointers() if two else None, split if two else nn_,
+                                             nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc, net.n_first_convs,
+                                             net.first_conv_n_filters, int(net.res), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
+            return y, ws
+        if joint:
+            planes = torch.as_strided(pxf, (pxf.shape[0] + pyf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+            q, ws = run(planes, wx, wy, pxf.shape[0])
+            oxf, oyf = q[:pxf.shape[0]], q[pxf.shape[0]:]
+            ctx.ws = (ws,)
+        else:
+            oxf, ws0 = run(pxf, wx, None, 0)
+            oyf, ws1 = run(pyf, wy, None, 0)
+            ctx.ws = (ws0, ws1)
+        out = ops.xpd_unpack(oxf, oyf, mean, b, t, h, w, n, n_scales, xf)
+        ctx.cfg = (b, t, h, w, int(n), int(n_scales), bool(xf), joint)
+        ctx.weights, ctx.params = (wx, wy), params
+        ctx.save_for_backward(pxf, pyf)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pxf, pyf = ctx.saved_tensors
+        b, t, h, w, n, n_scales, xf, joint = ctx.cfg
+        wx, wy = ctx.weights
+        gout = ops._dev(_c(gout), "I-step output gradient")
+        dev, dt = gout.device, gout.dtype
+        L = lib()
+        oc = 2 * n
+        if joint:
+            gq = torch.empty((pxf.shape[0] + pyf.shape[0], oc) + tuple(pxf.shape[2:]), device=dev, dtype=dt)
+            gqx, gqy = gq[:pxf.shape[0]], gq[pxf.shape[0]:]
+        else:
+            gqx = torch.empty((pxf.shape[0], oc) + tuple(pxf.shape[2:]), device=dev, dtype=dt)
+            gqy = torch.empty((pyf.shape[0], oc) + tuple(pyf.shape[2:]), device=dev, dtype=dt)
+        gmean = torch.empty((b, h, w, n + 1, 2), device=dev, dtype=dt)
+        check(L.cine_xpd_unpack_bwd(gout.data_ptr(), gqx.data_ptr(), gqy.data_ptr(), gmean.data_ptr(), b, t, h, w, n, n_scales, int(xf), _stream()),
+              "cine_xpd_unpack_bwd")
+        out = {}
+
+        def back(planes, gy, w1, w2, split, fws):
+            net = w1.net
+            nn_, cin, hh, ww = planes.shape
+            need = L.cine_mwcnn_backward_ws_bytes(nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc, net.first_conv_n_filters)
+            ws = torch.empty(need, device=dev, dtype=torch.uint8)
+            two = w2 is not None and w2 is not w1
+            lists = []
+            for wt in (w1,) + ((w2,) if two else ()):
+                pl = wt.param_list()
+                gl = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in pl]
+                lists.append((pl, gl, (ctypes.c_void_p * len(gl))(*[g.data_ptr() for g in gl])))
+            gx = torch.empty_like(planes)
+            check(L.cine_mwcnn_backward(planes.data_ptr(), gy.data_ptr(), w1.dgrad_pointers(), w2.dgrad_pointers() if two else None, lists[0][2],
+                                        lists[1][2] if two else None, split if two else nn_, nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc,
+                                        net.first_conv_n_filters, fws.data_ptr(), fws.numel(), ws.data_ptr(), ws.numel(), gx.data_ptr(), _stream()),
+                  "cine_mwcnn_backward")
+            for pl, gl, _ in lists:
+                for p, g in zip(pl, gl):
+                    out[id(p)] = g if id(p) not in out else out[id(p)] + g
+            return gx
+        if joint:
+            planes = torch.as_strided(pxf, (pxf.shape[0] + pyf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
+            gp = back(planes, gq, wx, wy, pxf.shape[0], ctx.ws[0])
+            gpx, gpy = gp[:pxf.shape[0]], gp[pxf.shape[0]:]
+        else:
+            gpx = back(pxf, gqx, wx, None, 0, ctx.ws[0])
+            gpy = back(pyf, gqy, wy, None, 0, ctx.ws[1])
+        gbuf = torch.empty((b, t, 1, h, w, 2 * n), device=dev, dtype=dt)
+        gextra = torch.empty((b, t, 1, h, w, 2), device=dev, dtype=dt)
+        check(L.cine_xpd_pack_bwd(gpx.data_ptr(), gpy.data_ptr(), gmean.data_ptr(), gbuf.data_ptr(), gextra.data_ptr(), b, t, h, w, n, n_scales,
+                                  int(xf), _stream()), "cine_xpd_pack_bwd")
+        return (gbuf, gextra, None, None, None, None, None) + tuple(out.get(id(p)) for p in ctx.params)
+
+
+def xpd_regularise(buf, extra, n, n_scales, xf, wx, wy):
+    params, seen = [], set()
+    for wt in (wx, wy):
+        for p in wt.param_list():
+            if id(p) not in seen:
+                seen.add(id(p)); params.append(p)
+    return XpdRegFn.apply(buf, extra, n, n_scales, xf, wx, wy, *params)
 
 
 def coil_accum(g: Optional[torch.Tensor], z: torch.Tensor) -> torch.Tensor:

@@ -555,3 +555,156 @@ extern "C" int cine_ssim_loss_bwd(const float* x, const float* y, int t, int h, 
                        da, db, dc, gx);
     return check_launch("ssim_loss_bwd_kernel");
 }
+
+// ---------------------------------------------------------------- XPDNet I-step halves, adjoint (models/xpdnet.py:424-509)
+namespace cine {
+constexpr int kXPixT = 32;
+// centered ortho DFT over the T values tile[g * cols + r] with explicit shifts: sum_g x[g] W^(+-(i - s_out)(g + s_in))
+template <int DIR>
+__device__ __forceinline__ cf shifted_dft(const cf* tile, const cf* tw, int T, int cols, int r, int i, int s_in, int s_out) {
+    int k = i - s_out; if (k < 0) k += T;
+    float ax = 0.f, ay = 0.f;
+    int idx = (s_in * k) % T;
+    for (int g = 0; g < T; ++g) {
+        const cf w = tw[idx], x = tile[g * cols + r];
+        if (DIR > 0) { ax += x.x * w.x - x.y * w.y; ay += x.x * w.y + x.y * w.x; }
+        else { ax += x.x * w.x + x.y * w.y; ay += x.y * w.x - x.x * w.y; }
+        idx += k; if (idx >= T) idx -= T;
+    }
+    return mk(ax, ay);
+}
+
+struct XpdUnpackBwdArgs {
+    const float* gout; float* gpxf; float* gpyf; cf* gmean;
+    int n, T, H, W, Wpx, Tp, pad_wx, pad_t, Hpy, pad_hy, xf;
+};
+// adjoint of xpd_unpack_kernel: gout (b, t, h, w, 2n) -> 0.5 * T2^H(gout) scattered into both plane sets (their pad frames are zeroed
+// beforehand); gmean[b][pix][k < n] = sum_t gout (the temporal mean of channels 0..n-1 is added to every frame, :504-509), channel n: 0.
+// T2 = fftshift(ifft(ifftshift(.))) (:500) is unitary: its adjoint is the forward transform with the same shifts.
+__global__ __launch_bounds__(256) void xpd_unpack_bwd_kernel(XpdUnpackBwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_x[];
+    const int n = a.n, T = a.T, H = a.H, W = a.W;
+    cf* tile = reinterpret_cast<cf*>(smem_x);          // [T][kXPixT * n]
+    cf* tw = tile + (size_t)T * kXPixT * n;
+    const int b = blockIdx.z, h = blockIdx.y, w0 = blockIdx.x * kXPixT;
+    const int np = min(kXPixT, W - w0);
+    const int cols = kXPixT * n;
+    const long HW = (long)H * W;
+    if (a.xf) temporal_table_t(tw, T);
+    for (int e = threadIdx.x; e < T * np * n; e += blockDim.x) {
+        const int t = e / (np * n), r = e - t * (np * n), p = r / n, k = r - p * n;
+        const float* g = a.gout + (((long)b * T + t) * HW + (long)h * W + w0 + p) * 2 * n;
+        tile[t * cols + r] = mk(g[k], g[n + k]);
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < np * (n + 1); r += blockDim.x) {
+        const int p = r / (n + 1), k = r - p * (n + 1);
+        float sx = 0.f, sy = 0.f;
+        if (k < n) for (int t = 0; t < T; ++t) { sx += tile[t * cols + p * n + k].x; sy += tile[t * cols + p * n + k].y; }
+        a.gmean[((long)b * HW + (long)h * W + w0 + p) * (n + 1) + k] = mk(sx, sy);
+    }
+    float* px = a.gpxf + ((long)b * H + h) * 2 * n * a.Wpx * a.Tp;
+    const long chx = (long)a.Wpx * a.Tp, chy = (long)a.Hpy * a.Tp;
+    for (int e = threadIdx.x; e < np * n * T; e += blockDim.x) {
+        const int r = e / T, i = e - r * T, p = r / n, k = r - p * n;
+        const cf v = a.xf ? shifted_dft<1>(tile, tw, T, cols, r, i, (T + 1) / 2, T / 2) : tile[i * cols + r];
+        const int w = w0 + p;
+        const long qx = (long)(w + a.pad_wx) * a.Tp + i + a.pad_t;
+        float* py = a.gpyf + ((long)b * W + w) * 2 * n * a.Hpy * a.Tp;
+        const long qy = (long)(h + a.pad_hy) * a.Tp + i + a.pad_t;
+        px[k * chx + qx] = 0.5f * v.x; px[(n + k) * chx + qx] = 0.5f * v.y;
+        py[k * chy + qy] = 0.5f * v.x; py[(n + k) * chy + qy] = 0.5f * v.y;
+    }
+}
+
+struct XpdPackBwdArgs {
+    const float* gpxf; const float* gpyf; const cf* gmean; float* gbuf; cf* gextra;
+    int n, T, H, W, Wpx, Tp, pad_wx, pad_t, Hpy, pad_hy, xf;
+};
+// adjoint of cine_xpd_pack: the gradients of the two plane sets (2 (n + 1) channels each) gathered per pixel, T1^H over the frames
+// (T1 = ifftshift(fft(fftshift(.))), :466: the inverse transform with the same shifts), the temporal-mean subtraction's adjoint, then split
+// into the buffer's gradient (channels < n) and the backward-operator image's (channel n).
+__global__ __launch_bounds__(256) void xpd_pack_bwd_kernel(XpdPackBwdArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_x[];
+    const int n = a.n, nc = n + 1, T = a.T, H = a.H, W = a.W;
+    const int cols = kXPixT * nc;
+    cf* tile = reinterpret_cast<cf*>(smem_x);          // [T][cols]
+    cf* out = tile + (size_t)T * cols;                 // [T][cols]
+    cf* tw = out + (size_t)T * cols;
+    const int b = blockIdx.y;
+    const long HW = (long)H * W, p0 = (long)blockIdx.x * kXPixT;
+    const int np = (int)min((long)kXPixT, HW - p0);
+    if (a.xf) temporal_table_t(tw, T);
+    const long chx = (long)a.Wpx * a.Tp, chy = (long)a.Hpy * a.Tp;
+    for (int e = threadIdx.x; e < np * nc * T; e += blockDim.x) {
+        const int r = e / T, i = e - r * T, p = r / nc, k = r - p * nc;
+        const long pix = p0 + p;
+        const int h = (int)(pix / W), w = (int)(pix - (long)h * W);
+        const float* px = a.gpxf + ((long)b * H + h) * 2 * nc * chx + (long)(w + a.pad_wx) * a.Tp + i + a.pad_t;
+        const float* py = a.gpyf + ((long)b * W + w) * 2 * nc * chy + (long)(h + a.pad_hy) * a.Tp + i + a.pad_t;
+        tile[i * cols + r] = mk(px[k * chx] + py[k * chy], px[(nc + k) * chx] + py[(nc + k) * chy]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * np * nc; e += blockDim.x) {
+        const int i = e / (np * nc), r = e - i * (np * nc);
+        out[i * cols + r] = a.xf ? shifted_dft<-1>(tile, tw, T, cols, r, i, T / 2, (T + 1) / 2) : tile[i * cols + r];
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < np * nc; r += blockDim.x) {
+        const int p = r / nc, k = r - p * nc;
+        float sx = 0.f, sy = 0.f;
+        for (int t = 0; t < T; ++t) { sx += out[t * cols + r].x; sy += out[t * cols + r].y; }
+        const cf gm = a.gmean[((long)b * HW + p0 + p) * nc + k];
+        tile[r] = mk((gm.x - sx) / T, (gm.y - sy) / T);               // row 0 of `tile` is free again: per (pixel, channel) correction
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < T * np * nc; e += blockDim.x) {
+        const int t = e / (np * nc), r = e - t * (np * nc), p = r / nc, k = r - p * nc;
+        const cf v = cadd(out[t * cols + r], tile[r]);
+        const long bt_pix = ((long)b * T + t) * HW + p0 + p;
+        if (k < n) { float* q = a.gbuf + bt_pix * 2 * n; q[k] = v.x; q[n + k] = v.y; }
+        else a.gextra[bt_pix] = v;
+    }
+}
+}  // namespace cine
+
+static void xpd_pads(int t, int h, int w, int n_scales, int& tp, int& lt, int& wp, int& lw, int& hp, int& lh) {
+    int r;
+    tp = cine_mwcnn_pad(t, n_scales, &lt, &r); wp = cine_mwcnn_pad(w, n_scales, &lw, &r); hp = cine_mwcnn_pad(h, n_scales, &lh, &r);
+}
+
+extern "C" int cine_xpd_unpack_bwd(const float* gout, float* gplanes_xf, float* gplanes_yf, float* gmean,
+                                   int b, int t, int h, int w, int n_primal, int n_scales, int xf, void* stream) {
+    CINE_REQUIRE(gout && gplanes_xf && gplanes_yf && gmean, CINE_EINVAL, "cine_xpd_unpack_bwd: null pointer");
+    CINE_REQUIRE(b > 0 && t > 1 && t <= 64 && h > 0 && w > 0 && n_primal >= 1 && n_primal <= 15 && h <= 65535 && b <= 65535, CINE_EINVAL,
+                 "cine_xpd_unpack_bwd: bad sizes");
+    XpdUnpackBwdArgs a{};
+    a.gout = gout; a.gpxf = gplanes_xf; a.gpyf = gplanes_yf; a.gmean = reinterpret_cast<cf*>(gmean);
+    a.n = n_primal; a.T = t; a.H = h; a.W = w; a.xf = xf;
+    xpd_pads(t, h, w, n_scales, a.Tp, a.pad_t, a.Wpx, a.pad_wx, a.Hpy, a.pad_hy);
+    hipStream_t st = as_stream(stream);
+    const size_t lds = ((size_t)t * kXPixT * n_primal + t) * sizeof(cf);
+    CINE_REQUIRE(lds <= 64 * 1024, CINE_EUNSUPPORTED, "cine_xpd_unpack_bwd: tile does not fit LDS");
+    ProfScope prof(F_PACK, st);
+    CINE_REQUIRE(hipMemsetAsync(gplanes_xf, 0, (size_t)b * h * 2 * n_primal * a.Wpx * a.Tp * sizeof(float), st) == hipSuccess &&
+                 hipMemsetAsync(gplanes_yf, 0, (size_t)b * w * 2 * n_primal * a.Hpy * a.Tp * sizeof(float), st) == hipSuccess, CINE_EHIP,
+                 "cine_xpd_unpack_bwd: hipMemsetAsync failed");
+    hipLaunchKernelGGL(xpd_unpack_bwd_kernel, dim3(ceil_div(w, kXPixT), h, b), dim3(256), lds, st, a);
+    return check_launch("xpd_unpack_bwd_kernel");
+}
+
+extern "C" int cine_xpd_pack_bwd(const float* gplanes_xf, const float* gplanes_yf, const float* gmean, float* gbuf, float* gextra,
+                                 int b, int t, int h, int w, int n_primal, int n_scales, int xf, void* stream) {
+    CINE_REQUIRE(gplanes_xf && gplanes_yf && gmean && gbuf && gextra, CINE_EINVAL, "cine_xpd_pack_bwd: null pointer");
+    CINE_REQUIRE(b > 0 && t > 1 && t <= 64 && h > 0 && w > 0 && n_primal >= 1 && n_primal <= 15 && b <= 65535, CINE_EINVAL,
+                 "cine_xpd_pack_bwd: bad sizes");
+    XpdPackBwdArgs a{};
+    a.gpxf = gplanes_xf; a.gpyf = gplanes_yf; a.gmean = reinterpret_cast<const cf*>(gmean); a.gbuf = gbuf; a.gextra = reinterpret_cast<cf*>(gextra);
+    a.n = n_primal; a.T = t; a.H = h; a.W = w; a.xf = xf;
+    xpd_pads(t, h, w, n_scales, a.Tp, a.pad_t, a.Wpx, a.pad_wx, a.Hpy, a.pad_hy);
+    const size_t lds = ((size_t)2 * t * kXPixT * (n_primal + 1) + t) * sizeof(cf);
+    CINE_REQUIRE(lds <= 64 * 1024, CINE_EUNSUPPORTED, "cine_xpd_pack_bwd: tile does not fit LDS");
+    ProfScope prof(F_PACK, as_stream(stream));
+    hipLaunchKernelGGL(xpd_pack_bwd_kernel, dim3((unsigned)ceil_div((long)h * w, (long)kXPixT), b), dim3(256), lds, as_stream(stream), a);
+    return check_launch("xpd_pack_bwd_kernel");
+}

@@ -8,13 +8,16 @@ and state-dict keys (``sens_net.unet_model.*``, ``image_net.N[.{0,1}].*`` and th
   I step : row IFFT + conj(S) + coil sum; buffer pack (temporal mean / XPDNet's own temporal transform /
            x-f, y-f rotation / left-heavy zero pad); two MWCNNs; unpack
 and never materialises the k-space buffer.  ``primal_only=False`` adds the KSpaceCNN dual update (Conv3d on the MFMA kernel) and materialises
-the k-space buffer.  Inference only; GPU tensors only.
+the k-space buffer.  GPU tensors only.  With gradients enabled (primal-only, XT / XF, row masks) the forward builds an autograd graph of
+``cine_hip.autograd`` Functions: the sensitivity network, the K step + masked backward operator (image-space, with respect to image and maps),
+the I-step network (buffer pack / both MWCNNs / unpack) -- all with hand-written HIP backward kernels.
 """
 from typing import Dict, List, Union
 
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 from .denoisers.unet import Unet
 from .denoisers.mwcnn import MWCNN
@@ -33,6 +36,12 @@ class SensitivityModel(nn.Module):
         pad, n_low = _VarnetSens.acs_window(mask) if acs is None else acs
         x = ops.sens_prologue(masked_kspace, pad, pad + n_low)                 # (b, c, h, w, 2)
         b, c, h, w, _ = x.shape
+        if ag.grad_mode(self):
+            # unpack(unet(planes) + planes) = unpack(unet(planes)) + x: the repacks are linear and x is data (no gradient)
+            y = ag.norm_unet(x.view(b * c, h, w, 2), self.unet_model.hip_weights(), norm=False)
+            if self.res_connection:
+                y = y + x.view(b * c, h, w, 2)
+            return ag.RssNormFn.apply(y.view(b, c, h, w, 2)).unsqueeze(1)
         planes, _ = ops.normunet_pack(x.view(b * c, h, w, 2), norm=False)      # xpdnet.py:55-59
         y = self.unet_model(planes)
         if self.res_connection:
@@ -80,8 +89,12 @@ class XPDNetBlock(nn.Module):
         nets = self.image_net[i_domain // 2]
         if self.dynamic_type in ['XF', 'XT']:
             xf = self.dynamic_type == 'XF'
-            pxf, pyf, mean = ops.xpd_pack(image_buffer, backward_img, n, self.n_scales, xf)
             net_x, net_y = (nets, nets) if self.weight_sharing else (nets[0], nets[1])
+            if ag.grad_mode(self):
+                if getattr(net_x, "dims", 2) != 2:
+                    raise NotImplementedError("training through the 3-D MWCNN is not on the HIP path")
+                return ag.xpd_regularise(image_buffer, backward_img, n, self.n_scales, xf, net_x.hip_weights(), net_y.hip_weights())
+            pxf, pyf, mean = ops.xpd_pack(image_buffer, backward_img, n, self.n_scales, xf)
             if pxf.shape[1:] == pyf.shape[1:] and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr() and getattr(net_x, "dims", 2) == 2:
                 # x-t and y-t planes of one shape, adjacent in memory: both networks in the same launches (two weight sets)
                 joint = torch.as_strided(pxf, (pxf.shape[0] + pyf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
@@ -141,10 +154,30 @@ class XPDNet(nn.Module):
     def measurements_residual(concat_kspace: torch.Tensor) -> torch.Tensor:
         return concat_kspace[..., [0, 2]] - concat_kspace[..., [1, 3]]
 
-    @torch.no_grad()
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
-        n = self.i_buffer_size
         mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        if ag.grad_mode(self):
+            return self._forward_train(masked_kspace, mask, acs)
+        with torch.no_grad():
+            return self._forward_infer(masked_kspace, mask, acs)
+
+    def _forward_train(self, masked_kspace, mask, acs):
+        """The primal-only chain of ``_forward_infer`` (reference xpdnet.py:301-326) as an autograd graph."""
+        n = self.i_buffer_size
+        if self.k_buffer_mode or self.dynamic_type not in ['XF', 'XT'] or not ops.is_row_mask(mask, masked_kspace):
+            raise NotImplementedError("training through the HIP path: primal-only XPDNet, dynamic_type XF / XT, the reference's row mask")
+        sens_maps = self.sens_net(masked_kspace, mask, acs)
+        image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)           # unmasked backward op (:303)
+        image_buffer = image.repeat_interleave(n, dim=-1)                        # (:307): [re x n, im x n]
+        zf = ag.CoilReduceFn.apply(masked_kspace, sens_maps, mask)              # A^H M k_ref
+        for i_domain in range(1, len(self.domain_sequence), 2):
+            x0 = image_buffer[..., [0, n]]                                       # channel 0 of the buffer (:128)
+            backward_img = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)     # A^H M (A x0 - k_ref)
+            image_buffer = self.cascades[i_domain].regularise(i_domain, image_buffer, backward_img)
+        return ag.AbsFn.apply(image_buffer[..., [0, n]].squeeze(2))               # (:321-326)
+
+    def _forward_infer(self, masked_kspace, mask, acs):
+        n = self.i_buffer_size
         sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ops.sens_reduce(masked_kspace, sens_maps)                       # unmasked backward op (:303)
         image_buffer = ops.repeat_complex(image, n)                             # (:307)

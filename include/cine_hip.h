@@ -517,6 +517,15 @@ int cine_xfyf_pack_bwd(const float* gp_xf, const float* gp_yf, const float* p_xf
                        const float* gmean, float* gimg, int b, int t, int h, int w, int xf,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Adjoints of cine_xpd_unpack / cine_xpd_pack (models/xpdnet.py:424-509): gout (b, t, 1, h, w, 2n) -> the gradients of the two MWCNNs' output
+ * planes (2n channels, zero on the pad frames) and gmean (b, h, w, n + 1, 2) (the temporal mean of channels < n is added back, :504-509); then
+ * from the gradients of the MWCNNs' input planes (2 (n + 1) channels) -> gbuf (b, t, 1, h, w, 2n) and gextra (b, t, 1, h, w, 2) (the
+ * backward-operator image).  XPDNet's temporal transforms (:466, :500) are unitary: each adjoint is the inverse with the same shifts. */
+int cine_xpd_unpack_bwd(const float* gout, float* gplanes_xf, float* gplanes_yf, float* gmean,
+                        int b, int t, int h, int w, int n_primal, int n_scales, int xf, void* stream);
+int cine_xpd_pack_bwd(const float* gplanes_xf, const float* gplanes_yf, const float* gmean, float* gbuf, float* gextra,
+                      int b, int t, int h, int w, int n_primal, int n_scales, int xf, void* stream);
+
 /* cine_image_dc is self-adjoint in the image (T = IFFT_h W FFT_h is Hermitian): its image gradient is cine_image_dc of the output
  * gradient (zf = NULL).  With respect to the maps it gives, per frame, part (b, t, c, h, w) = conj(g) T(S_c img) + T(S_c g) conj(img)
  * (varnet.py:181-194, 281-282); add the frames with cine_coil_accum(NULL, part, ...).  Weights as cine_image_dc. */

@@ -264,6 +264,54 @@ def test_cinenet_training_step_vs_reference_golden(dev, golden, tag, dyn, share)
     assert not bad, bad
 
 
+_XPD_GRAD_KW = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1],
+                    first_conv_n_filters=8, n_primal=2)
+
+
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True)])
+def test_xpdnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
+    """The training step of pl_modules/xpdnet_module.py on the drop-in primal-only XPDNet: sensitivity network (residual U-Net, RSS
+    normalisation), K step + masked backward operator with respect to image and maps, the I-step network (buffer pack with XPDNet's own
+    temporal transform, both MWCNNs through the HIP backward kernels, unpack); loss, gradients and the Adam-updated weights against the
+    reference's own (xpdnet_grad.npz)."""
+    import reconstruction.models as M
+    g = golden("xpdnet_grad")
+    net = M.XPDNet(dynamic_type=dyn, weight_sharing=share, primal_only=True, **_XPD_GRAD_KW)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net = net.to(dev).train()
+    mk, mask, target = (torch.from_numpy(g[k]).to(dev) for k in ("masked_kspace", "mask", "target"))
+    with torch.enable_grad():
+        loss, grads, out = _training_step(net, mk, mask, target)
+    assert rel_err(out.cpu(), g[f"{tag}_out"]) < TOL
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5
+    new = dict(net.named_parameters())
+    bad = {}
+    for k in (k[len(tag) + 8:] for k in g if k.startswith(f"{tag}::grad::")):
+        floor = float(g[f"{tag}::floor::{k}"])
+        e = rel_err(grads[k].cpu(), g[f"{tag}::grad::{k}"])
+        if e > max(TOL, 20 * floor):
+            bad[k] = (e, floor)
+        want_new, gref = torch.from_numpy(g[f"{tag}::new::{k}"]), torch.from_numpy(g[f"{tag}::grad::{k}"])
+        sel = gref.abs() > 1e-5
+        if sel.any():
+            assert (new[k].detach().cpu() - want_new)[sel].abs().max() <= 0.02 * 0.0003, k
+    assert not bad, bad
+
+
+def test_xpdnet_training_rejects_what_is_not_on_the_hip_path(dev):
+    """Dual (k-space net) and 2-D XPDNets train only in the reference; the HIP path says so instead of returning wrong gradients."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    t, c, h, w = 3, 2, 16, 16
+    mk = torch.randn(1, t, c, h, w, 2, device=dev)
+    mask = torch.zeros(1, t, 1, h, 1, 1, device=dev); mask[:, :, :, ::2] = 1
+    for kw in (dict(dynamic_type="2D"), dict(dynamic_type="XF", primal_only=False)):
+        net = M.XPDNet(num_cascades=1, sens_chans=2, sens_pools=1, n_scales=1, n_filters_per_scale=[4], n_convs_per_scale=[1],
+                       first_conv_n_filters=4, n_primal=2, **kw).to(dev).train()
+        with torch.enable_grad(), pytest.raises(NotImplementedError):
+            net(mk * mask, mask)
+
+
 def test_varnet_cfg2_training_step_vs_reference_fingerprint(dev, golden):
     """cfg 2 at full size (XF-VarNet, 6 cascades, 15 coils x 15 frames x 200 x 200): strided fingerprints of the reference's
     parameter gradients (varnet_grad_cfg2.npz).  At this size the reference's own float32 gradients move by 1e-3 (median over

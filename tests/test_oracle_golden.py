@@ -250,3 +250,28 @@ def test_oracle_cinenet_training_gradients_vs_reference_golden(golden, tag, dyn,
     for k, p in net.named_parameters():
         floor = float(g[f"{tag}::floor::{k}"])
         assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
+
+
+_XPD_GRAD_KW = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1],
+                    first_conv_n_filters=8, n_primal=2)
+
+
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False)])
+def test_oracle_xpdnet_training_gradients_vs_reference_golden(golden, tag, dyn, share):
+    """The XPDNet oracle under autograd reproduces the reference's training-step gradients (xpdnet_grad.npz)."""
+    from oracle import xpdnet_ref as X
+    from reconstruction.utils.losses import SSIMLoss
+    g = golden("xpdnet_grad")
+    net = X.XPDNet(dynamic_type=dyn, weight_sharing=share, primal_only=True, **_XPD_GRAD_KW)
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    mk, mask, target = (torch.from_numpy(g[k]) for k in ("masked_kspace", "mask", "target"))
+    with torch.enable_grad():
+        out = net(mk, mask)
+        h0, w0 = (out.shape[-2] - target.shape[-2]) // 2, (out.shape[-1] - target.shape[-1]) // 2
+        crop = out[..., h0:h0 + target.shape[-2], w0:w0 + target.shape[-1]]
+        loss = SSIMLoss()(crop.unsqueeze(1), target.unsqueeze(1), data_range=target.max())
+        loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-6
+    for k, p in net.named_parameters():
+        floor = float(g[f"{tag}::floor::{k}"])
+        assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
