@@ -47,6 +47,30 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
 // gb[co] += sum_{n in set, pixels} g[n][co][p]   (bias of the final 1x1 conv, unet.py:69)
 int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, float* ws, size_t ws_floats, hipStream_t st);   // ws: n * cout floats
 
+// Weight gradients beside the input-gradient chain.  Per conv layer the backward pass is in_lrelu_bwd (writes g) -> {wgrad(g), dgrad(g)}:
+// the two consumers are independent, and a backward pass on ONE stream pays every launch's half-empty last round.  SideLane
+// puts the weight gradients on a second, per-device stream: fork() after the producer of g has been enqueued, launched() after the wgrad;
+// g alternates between two buffers and before_write(slot) makes the main stream wait for the wgrad that still reads that slot; join()
+// before the call returns.  The weight gradients stay serial among themselves (they share the partial-sum workspace), and nothing about
+// the results depends on timing.  CINE_WGRAD_OVERLAP=0 keeps everything on the caller's stream.
+class SideLane {
+public:
+    explicit SideLane(hipStream_t main);
+    ~SideLane();
+    SideLane(const SideLane&) = delete;
+    SideLane& operator=(const SideLane&) = delete;
+    int slot() const { return k_ & 1; }
+    void before_write();            // main: wait for the wgrad that read buffer slot()
+    hipStream_t fork();             // main: record "g ready"; side: wait for it.  Returns the stream for the wgrad
+    void launched();                // side: record "wgrad done" for slot(); advances to the other slot
+    void join();                    // main: wait for everything on the side lane
+private:
+    hipStream_t main_, side_ = nullptr;
+    hipEvent_t ready_ = nullptr, done_[2] = {nullptr, nullptr};
+    bool rec_[2] = {false, false};
+    int k_ = 0;
+};
+
 // dgrad entry points of conv_kernels.hip
 extern "C" int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
                                   float* gx, int n, int cout, int cin, int h, int w, void* stream);

@@ -13,6 +13,8 @@
 // Reference: reconstruction/models/denoisers/unet.py:73-125 (what autograd differentiates there).
 #include <algorithm>
 #include "grad.h"
+#include <mutex>
+#include <cstdlib>
 
 namespace cine {
 
@@ -54,9 +56,18 @@ __device__ __forceinline__ float grad_piece(const GradPiece& p, int n, int c, in
 __device__ __forceinline__ float in_bwd_g(const InBwdArgs& a, int n, int ch, int y, int x) {
     return grad_piece(a.a, n, a.c, ch, y, x) + (a.b.type ? grad_piece(a.b, n, a.c, ch, y, x) : 0.f);
 }
+// window / pooled pieces (the U-Net's): the plane's base pointer once, then one multiply-add per element
+__device__ __forceinline__ const float* piece_plane(const GradPiece& p, int n, int ch) {
+    return p.type ? p.g + ((long)n * p.c_total + p.c_off + ch) * p.gh * p.gw : nullptr;
+}
+__device__ __forceinline__ float piece_at(const GradPiece& p, const float* q, int y, int x) {
+    if (p.type == 1) return q[y * p.gw + x];
+    const int py = y >> 1, px = x >> 1;
+    return (py < p.gh && px < p.gw) ? 0.25f * q[py * p.gw + px] : 0.f;
+}
 
-// WAVE = true: one wave per plane (small planes), else one workgroup per plane
-template <bool WAVE>
+// WAVE = true: one wave per plane (small planes), else one workgroup per plane.  HAAR: a piece is a wavelet adjoint (MWCNN)
+template <bool WAVE, bool HAAR>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
     __shared__ float red[2][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -70,12 +81,18 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
     const float scale = mr.y, shift = -mr.x * mr.y;
     const float* r = a.r + pl * pe;
     float* gr = a.gr + pl * pe;
+    const float* qa = HAAR ? nullptr : piece_plane(a.a, n, c);
+    const float* qb = HAAR ? nullptr : piece_plane(a.b, n, c);
+    auto grad_at = [&](int y, int x) -> float {
+        if constexpr (HAAR) return in_bwd_g(a, n, c, y, x);
+        else return piece_at(a.a, qa, y, x) + (qb ? piece_at(a.b, qb, y, x) : 0.f);
+    };
     const int t0 = WAVE ? lane : threadIdx.x, ts = WAVE ? 64 : 256;
     float s1 = 0.f, s2 = 0.f;
     for (int e = t0; e < pe; e += ts) {
         const int y = e / a.w, x = e - y * a.w;
         const float xh = fmaf(r[e], scale, shift);
-        float g = in_bwd_g(a, n, c, y, x);
+        float g = grad_at(y, x);
         g = xh > 0.f ? g : g * a.slope;
         s1 += g; s2 = fmaf(g, xh, s2);
     }
@@ -91,7 +108,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
     for (int e = t0; e < pe; e += ts) {
         const int y = e / a.w, x = e - y * a.w;
         const float xh = fmaf(r[e], scale, shift);
-        float g = in_bwd_g(a, n, c, y, x);
+        float g = grad_at(y, x);
         g = xh > 0.f ? g : g * a.slope;
         gr[e] = scale * (g - m1 - xh * m2);
     }
@@ -109,13 +126,17 @@ int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st) {
                      "in_lrelu_bwd: gradient window (%d, %d) smaller than the tensor (%d, %d)", p->gh, p->gw, a.h, a.w);
     }
     const long planes = (long)a.n * a.c;
+    const bool haar = a.a.type >= 3 || a.b.type >= 3;
+    CINE_REQUIRE(haar || ((long)a.a.gh * a.a.gw < (1L << 31) && (long)a.b.gh * a.b.gw < (1L << 31)), CINE_EUNSUPPORTED, "in_lrelu_bwd: plane too large");
     ProfScope prof(F_STATS, st);
     if ((long)a.h * a.w <= 1024) {
         CINE_REQUIRE(ceil_div(planes, 4L) <= 0x7fffffffL, CINE_EUNSUPPORTED, "in_lrelu_bwd: too many planes");
-        hipLaunchKernelGGL(in_lrelu_bwd_kernel<true>, dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, st, a);
+        if (haar) hipLaunchKernelGGL((in_lrelu_bwd_kernel<true, true>), dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((in_lrelu_bwd_kernel<true, false>), dim3((unsigned)ceil_div(planes, 4L)), dim3(256), 0, st, a);
     } else {
         CINE_REQUIRE(planes <= 0x7fffffffL, CINE_EUNSUPPORTED, "in_lrelu_bwd: too many planes");
-        hipLaunchKernelGGL(in_lrelu_bwd_kernel<false>, dim3((unsigned)planes), dim3(256), 0, st, a);
+        if (haar) hipLaunchKernelGGL((in_lrelu_bwd_kernel<false, true>), dim3((unsigned)planes), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((in_lrelu_bwd_kernel<false, false>), dim3((unsigned)planes), dim3(256), 0, st, a);
     }
     return check_launch("in_lrelu_bwd_kernel");
 }
@@ -157,7 +178,9 @@ template <int PW> struct WgPiece;
 template <> struct WgPiece<4> { typedef float4 T; };
 template <> struct WgPiece<2> { typedef float2 T; };
 
-template <int TAPS, int TW, int CT, int WM, int NPIX>
+// ADD: the conv input is the SUM of the two sources (MWCNN's additive skips); its own instantiation, because the second inlined fetch per value
+// costs the plain kernels their registers (the compiler then keeps the kernel arguments in scratch: 187 -> 212 us per level-0 layer)
+template <int TAPS, int TW, int CT, int WM, int NPIX, bool ADD>
 __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     using C = WgCfg<TAPS, TW, CT, WM, NPIX>;
     constexpr int HALO = C::HALO, PW = C::PW, PR = C::PR;
@@ -190,24 +213,27 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     const int total = iend - ibeg;
     const Src gs{a.g, nullptr, a.g_c, a.g_mode, a.g_h, a.g_w, 0, 0, 1};
 
-    // statistics table of one sample: {scale, shift} of every source channel
-    auto src_stats = [](const Src& s) { return s.mode == 1 || s.mode == 2 || (s.mode >= 3 && (s.act & 1)); };
-    auto table = [&](int n, float* st) {
-        for (int ci = tid; ci < nch; ci += 256) {
-            const bool f0 = ci < a.s0.c;
-            const Src& s = f0 ? a.s0 : a.s1;
-            const int cl = f0 ? ci : ci - a.s0.c;
+    // the fields the vectorised staging selects per lane, as values (a per-lane choice between the two structs themselves makes the compiler
+    // keep a copy of the kernel arguments in scratch and re-load from it in the staging loops)
+    const float* const s0x = a.s0.x; const float* const s1x = a.s1.x;
+    const int s0c = a.s0.c, s1c = a.s1.c, s0h = a.s0.h, s1h = a.s1.h, s0mode = a.s0.mode, s1mode = a.s1.mode;
+    // statistics table of one sample: {scale, shift} of every source channel (one loop per source: the source is uniform in each)
+    auto table_of = [&](const Src& s, int n, float* st) {
+        const bool stats = s.mode == 1 || s.mode == 2 || (s.mode >= 3 && (s.act & 1));
+        for (int cl = tid; cl < s.c; cl += 256) {
             float2 mr = make_float2(0.f, 1.f);
-            if (src_stats(s)) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
-            st[2 * ci] = mr.y; st[2 * ci + 1] = -mr.x * mr.y;
+            if (stats) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+            st[2 * cl] = mr.y; st[2 * cl + 1] = -mr.x * mr.y;
         }
     };
+    auto table = [&](int n, float* st) { table_of(a.s0, n, st); table_of(a.s1, n, st + 2 * a.s0.c); };
     // one transformed input value of concat / summed channel cg (any source mode), st = this sample's table
     auto fetch_in = [&](int n, int cg, int gy, int gx, const float* st) -> float {
-        if (a.add_src1)
+        if constexpr (ADD)
             return fetch_scalar(a.s0, n, cg, 0, gy, gx, st, a.slope) + fetch_scalar(a.s1, n, cg, 0, gy, gx, st + 2 * a.s0.c, a.slope);
-        const bool f0 = cg < c0n;
-        return fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? cg : cg - c0n, 0, gy, gx, st + (f0 ? 0 : 2 * a.s0.c), a.slope);
+        // (a source chosen per lane by reference or by value makes the compiler keep a copy of the kernel arguments in scratch)
+        if (cg < c0n) return fetch_scalar(a.s0, n, cg, 0, gy, gx, st, a.slope);
+        return fetch_scalar(a.s1, n, cg - c0n, 0, gy, gx, st + 2 * a.s0.c, a.slope);
     };
     // ---- the tile pipeline: issue(it) puts the raw pieces of tile `it` in flight into registers, commit(it) transforms them and
     // writes LDS, the sweep of tile `it` runs with the loads of tile it + 1 in flight
@@ -224,10 +250,11 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 const int row = rem / PR, j = rem - row * PR;
                 const int cg = min(ci0 + k, a.cin - 1);
                 const bool f0 = cg < c0n;
-                const Src& s = f0 ? a.s0 : a.s1;
+                const float* sx = f0 ? s0x : s1x;
+                const int sc_ = f0 ? s0c : s1c, sh_ = f0 ? s0h : s1h;
                 const int cl = f0 ? cg : cg - c0n;
-                const int gy = min(max(r0 - HALO + row, 0), s.h - 1), gx = min(c0 + PW * j, a.W - PW);
-                xin[i] = *reinterpret_cast<const piece_t*>(s.x + (((long)n * s.c + cl) * s.h + gy) * a.W + gx);
+                const int gy = min(max(r0 - HALO + row, 0), sh_ - 1), gx = min(c0 + PW * j, a.W - PW);
+                xin[i] = *reinterpret_cast<const piece_t*>(sx + (((long)n * sc_ + cl) * sh_ + gy) * a.W + gx);
             }
         }
         if (L.fast_g == 1) {
@@ -268,15 +295,15 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
                 const int row = rem / PR, j = rem - row * PR;
                 const int cg = ci0 + k;
                 const bool f0 = cg < c0n;
-                const Src& s = f0 ? a.s0 : a.s1;
+                const int smode = f0 ? s0mode : s1mode, sh_ = f0 ? s0h : s1h;
                 const int gy = r0 - HALO + row, gx = c0 + PW * j;
-                const bool ok = cg < a.cin && gy >= 0 && gy < s.h && gx < a.W;
+                const bool ok = cg < a.cin && gy >= 0 && gy < sh_ && gx < a.W;
                 piece_t o = xin[i];
                 float* ov = reinterpret_cast<float*>(&o);
                 const int cgc = min(cg, a.cin - 1);
                 const float sc = st[2 * cgc], sh = st[2 * cgc + 1];
 #pragma unroll
-                for (int u = 0; u < PW; ++u) ov[u] = ok ? (s.mode == 0 ? ov[u] : act(ov[u], sc, sh, a.slope)) : 0.f;
+                for (int u = 0; u < PW; ++u) ov[u] = ok ? (smode == 0 ? ov[u] : act(ov[u], sc, sh, a.slope)) : 0.f;
                 float* dst = in_lds + k * C::PSI + row * C::COLS + PW * j;
 #pragma unroll
                 for (int u = 0; u < PW; u += 2) *reinterpret_cast<float2*>(dst + u) = make_float2(ov[u], ov[u + 1]);
@@ -478,7 +505,14 @@ static int launch_wg_cfg(const WgLaunch& L, dim3 grid, hipStream_t st) {
     const size_t lds = (size_t)(C::LDS_FLOATS + 4 * (L.a.s0.c + L.a.s1.c)) * sizeof(float);
     static_assert(C::LDS_FLOATS * sizeof(float) <= 60 * 1024, "wgrad tile exceeds the default LDS limit");
     CINE_REQUIRE(lds <= 64 * 1024, CINE_EUNSUPPORTED, "wgrad: %d source channels need %zu bytes of LDS", L.a.s0.c + L.a.s1.c, lds);
-    hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX>), grid, dim3(256), lds, st, L);
+    if constexpr (TAPS == 9) {
+        if (L.a.add_src1) {
+            hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX, true>), grid, dim3(256), lds, st, L);
+            return check_launch("wgrad_mfma_kernel");
+        }
+    }
+    CINE_REQUIRE(!L.a.add_src1, CINE_EUNSUPPORTED, "wgrad: summed sources only for 3x3 convs");
+    hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX, false>), grid, dim3(256), lds, st, L);
     return check_launch("wgrad_mfma_kernel");
 }
 
@@ -580,6 +614,52 @@ int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, fl
     hipLaunchKernelGGL(bias_partial_kernel, dim3(cout, n), dim3(256), 0, st, g, cout, hw, ws, n);
     hipLaunchKernelGGL(bias_final_kernel, dim3(cout, set_split < n ? 2 : 1), dim3(64), 0, st, ws, n, set_split, gb0, gb1);
     return check_launch("bias_grad_kernel");
+}
+
+// ---- SideLane -------------------------------------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_side_mu;
+hipStream_t g_side[64] = {};
+hipStream_t side_stream_of_device() {
+    const char* env = getenv("CINE_WGRAD_OVERLAP");
+    if (env && env[0] == '0') return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    if (!g_side[dev] && hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking) != hipSuccess) g_side[dev] = nullptr;
+    return g_side[dev];
+}
+}  // namespace
+
+SideLane::SideLane(hipStream_t main) : main_(main) {
+    side_ = side_stream_of_device();
+    if (!side_) return;
+    bool ok = hipEventCreateWithFlags(&ready_, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&done_[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) side_ = nullptr;       // everything on the caller's stream
+}
+SideLane::~SideLane() {
+    join();
+    if (ready_) (void)hipEventDestroy(ready_);
+    for (auto e : done_) if (e) (void)hipEventDestroy(e);
+}
+void SideLane::before_write() {
+    if (side_ && rec_[slot()]) { (void)hipStreamWaitEvent(main_, done_[slot()], 0); rec_[slot()] = false; }
+}
+hipStream_t SideLane::fork() {
+    if (!side_) return main_;
+    (void)hipEventRecord(ready_, main_);
+    (void)hipStreamWaitEvent(side_, ready_, 0);
+    return side_;
+}
+void SideLane::launched() {
+    if (side_) { (void)hipEventRecord(done_[slot()], side_); rec_[slot()] = true; }
+    ++k_;
+}
+void SideLane::join() {
+    if (!side_) return;
+    for (int i = 0; i < 2; ++i)
+        if (rec_[i]) { (void)hipStreamWaitEvent(main_, done_[i], 0); rec_[i] = false; }
 }
 
 }  // namespace cine

@@ -298,7 +298,7 @@ extern "C" size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, i
             big = std::max(big, (size_t)n * co * hw);
             wg = std::max(wg, wgrad_ws_floats(co, ci, 9, n));
         }
-    b.take(big);                                                      // d/d(raw) of the tensor in hand
+    b.take(big); b.take(big);                                         // d/d(raw) of the tensor in hand, two alternating buffers (SideLane)
     b.take(wg);
     return b.off;
 }
@@ -341,9 +341,13 @@ extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* 
             big = std::max(big, (size_t)n * co * hw);
             wgf = std::max(wgf, wgrad_ws_floats(co, ci, 9, n));
         }
-    float* gr = bb.take(big);
+    float* grb[2] = {bb.take(big), nullptr};
+    grb[1] = bb.take(big);
     float* wgs = bb.take(wgf);
     hipStream_t st = as_stream(stream);
+    SideLane lane(st);              // weight gradients on the side stream (grad.h)
+    float* gr = nullptr;
+    auto next_g = [&]() { lane.before_write(); gr = grb[lane.slot()]; };
     const int sp = two ? set_split : n;
     auto WD = [&](int idx, int set) { return reinterpret_cast<const float*>((set ? wdgrad2 : wdgrad)[idx]); };
     auto GR = [&](int idx, int set) { return set ? (two ? reinterpret_cast<float*>(grads2[idx]) : nullptr) : reinterpret_cast<float*>(grads[idx]); };
@@ -352,9 +356,13 @@ extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* 
     auto wgrad = [&](const ConvIn& c, const float* g, int rows, int cin, int hh, int ww, int widx) {
         WgArgs a{}; a.s0 = src_of(c.s0, c.m0); a.s1 = c.add ? src_of(c.s1, c.m1) : none; a.add_src1 = c.add; a.cin = cin;
         a.g = g; a.g_mode = 0; a.rows = rows; a.n = n; a.H = hh; a.W = ww; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
-        return launch_wgrad(a, 9, 0, GR(widx, 0), GR(widx, 1), wgs, wgf, st);
+        hipStream_t sw = lane.fork();
+        const int err = launch_wgrad(a, 9, 0, GR(widx, 0), GR(widx, 1), wgs, wgf, sw);
+        lane.launched();
+        return err;
     };
     auto inbwd = [&](const Feat& f, GradPiece pa, GradPiece pb) {
+        next_g();
         InBwdArgs a{f.x, f.part, f.np, pa, pb, gr, n, f.c, f.h, f.w, kEps, kSlope};
         return launch_in_lrelu_bwd(a, st);
     };
@@ -412,5 +420,6 @@ extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* 
         if ((e = wgrad(c, gr, p.first, in_ch, h, w, 0))) return e;
         if (gx && (e = cine_conv3x3_dgrad(gr, WD(0, 0), two ? WD(0, 1) : nullptr, sp, gx, n, p.first, in_ch, h, w, stream))) return e;
     }
+    lane.join();
     return CINE_OK;
 }

@@ -276,7 +276,7 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
 // gradient, and the partial sums of the weight-gradient kernel.
 namespace {
 struct BwdPlan {
-    float *A, *B, *cat[8], *pool, *wg;
+    float *A, *B[2], *cat[8], *pool, *wg;
     size_t wg_floats;
 };
 void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch) {
@@ -285,7 +285,7 @@ void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch)
     size_t big = 0;
     for (int d = 0; d <= P; ++d) big = std::max(big, elems(d));
     big = std::max(big, (size_t)n * std::max(in_ch, 16) * p.hs[0] * p.wsz[0]);
-    q.A = b.take(big); q.B = b.take(big);
+    q.A = b.take(big); q.B[0] = b.take(big); q.B[1] = b.take(big);
     for (int d = 0; d < P; ++d) q.cat[d] = b.take(2 * elems(d));
     q.pool = b.take(P > 0 ? elems(1) / 2 + 16 : 16);          // (n, ch[d], hs[d+1], wsz[d+1]) <= elems(d) / 4
     for (int d = 0; d < P; ++d) (void)0;
@@ -353,10 +353,13 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
     const int i_fin = 5 * P + 2, i_bias = 5 * P + 3;
     auto src = [&](const float* t, const float* part, int c, int mode, int hh, int ww, int np) { return Src{t, part, c, mode, hh, ww, np, 0, 1}; };
     const Src none{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    SideLane lane(st);              // weight gradients on the side stream (grad.h); g alternates between q.B[0] / q.B[1]
+    auto next_g = [&]() { lane.before_write(); return q.B[lane.slot()]; };
+    auto on_side = [&](auto&& launch) { hipStream_t sw = lane.fork(); const int err = launch(sw); lane.launched(); return err; };
     auto wgrad3 = [&](const Src& s0, const Src& s1, const float* g, int rows, int hh, int ww, int wi) {
         WgArgs a{}; a.s0 = s0; a.s1 = s1; a.cin = src_cin(s0) + src_cin(s1); a.g = g; a.g_mode = 0; a.rows = rows;
         a.n = n; a.H = hh; a.W = ww; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
-        return launch_wgrad(a, 9, 0, gr(wi, 0), gr(wi, 1), q.wg, q.wg_floats, st);
+        return on_side([&](hipStream_t sw) { return launch_wgrad(a, 9, 0, gr(wi, 0), gr(wi, 1), q.wg, q.wg_floats, sw); });
     };
     auto inbwd = [&](const float* r, const float* part, int np, int c, int hh, int ww, const float* ga, int ca_total, int ca_off,
                      int ha, int wa, const float* gb, int hb, int wb, float* out) {
@@ -370,7 +373,7 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
     {
         WgArgs a{}; a.s0 = src(p.cb[0], p.pcb[0], chans, 1, h, w, p.np_conv[0]); a.s1 = none; a.cin = chans;
         a.g = gy; a.g_mode = 0; a.rows = out_ch; a.n = n; a.H = h; a.W = w; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
-        if ((e = launch_wgrad(a, 1, 2, gr(i_fin, 0), gr(i_fin, 1), q.wg, q.wg_floats, st))) return e;
+        if ((e = on_side([&](hipStream_t sw) { return launch_wgrad(a, 1, 2, gr(i_fin, 0), gr(i_fin, 1), q.wg, q.wg_floats, sw); }))) return e;
     }
     if ((e = cine_conv1x1_dgrad(gy, wd(i_fin, 0), wd2(i_fin), sp, q.A, n, out_ch, chans, h, w, stream))) return e;   // A = d/d act(cb_0)
 
@@ -379,48 +382,54 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
         const int c = p.ch[d], hh = p.hs[d], ww = p.wsz[d], npc = p.np_conv[d];
         const int hu = 2 * p.hs[d + 1], wu = 2 * p.wsz[d + 1];           // extent of the transpose-conv output
         // second conv of the block: cb = conv(act(ca))
-        if ((e = inbwd(p.cb[d], p.pcb[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
-        if ((e = wgrad3(src(p.ca[d], p.pca[d], c, 1, hh, ww, npc), none, q.B, c, hh, ww, i_up(d, 2)))) return e;
-        if ((e = cine_conv3x3_dgrad(q.B, wd(i_up(d, 2), 0), wd2(i_up(d, 2)), sp, q.A, n, c, c, hh, ww, stream))) return e;
+        float* B = next_g();
+        if ((e = inbwd(p.cb[d], p.pcb[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
+        if ((e = wgrad3(src(p.ca[d], p.pca[d], c, 1, hh, ww, npc), none, B, c, hh, ww, i_up(d, 2)))) return e;
+        if ((e = cine_conv3x3_dgrad(B, wd(i_up(d, 2), 0), wd2(i_up(d, 2)), sp, q.A, n, c, c, hh, ww, stream))) return e;
         // first conv: ca = conv(cat(act(up) zero-padded, act(skip)))
-        if ((e = inbwd(p.ca[d], p.pca[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
-        if ((e = wgrad3(src(p.up[d], p.pup[d], c, 1, hu, wu, p.np_tconv[d]), src(p.skip[d], p.pskip[d], c, 1, hh, ww, npc), q.B, c, hh, ww, i_up(d, 1)))) return e;
-        if ((e = cine_conv3x3_dgrad(q.B, wd(i_up(d, 1), 0), wd2(i_up(d, 1)), sp, q.cat[d], n, c, 2 * c, hh, ww, stream))) return e;
+        B = next_g();
+        if ((e = inbwd(p.ca[d], p.pca[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
+        if ((e = wgrad3(src(p.up[d], p.pup[d], c, 1, hu, wu, p.np_tconv[d]), src(p.skip[d], p.pskip[d], c, 1, hh, ww, npc), B, c, hh, ww, i_up(d, 1)))) return e;
+        if ((e = cine_conv3x3_dgrad(B, wd(i_up(d, 1), 0), wd2(i_up(d, 1)), sp, q.cat[d], n, c, 2 * c, hh, ww, stream))) return e;
         // transpose conv: up = tconv(act(cur)), cur = cb[d+1] or the bottleneck output
-        if ((e = inbwd(p.up[d], p.pup[d], p.np_tconv[d], c, hu, wu, q.cat[d], 2 * c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        B = next_g();
+        if ((e = inbwd(p.up[d], p.pup[d], p.np_tconv[d], c, hu, wu, q.cat[d], 2 * c, 0, hh, ww, nullptr, 0, 0, B))) return e;
         const bool bott = d + 1 == P;
         const float* cur = bott ? p.bott : p.cb[d + 1];
         const float* pcur = bott ? p.pbott : p.pcb[d + 1];
         const int c1 = p.ch[d + 1], h1 = p.hs[d + 1], w1 = p.wsz[d + 1];
         {
             WgArgs a{}; a.s0 = src(cur, pcur, c1, 1, h1, w1, p.np_conv[d + 1]); a.s1 = none; a.cin = c1;
-            a.g = q.B; a.g_mode = 5; a.g_c = c; a.g_h = hu; a.g_w = wu; a.rows = 4 * c;
+            a.g = B; a.g_mode = 5; a.g_c = c; a.g_h = hu; a.g_w = wu; a.rows = 4 * c;
             a.n = n; a.H = h1; a.W = w1; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
-            if ((e = launch_wgrad(a, 1, 1, gr(i_up(d, 0), 0), gr(i_up(d, 0), 1), q.wg, q.wg_floats, st))) return e;
+            if ((e = on_side([&](hipStream_t sw) { return launch_wgrad(a, 1, 1, gr(i_up(d, 0), 0), gr(i_up(d, 0), 1), q.wg, q.wg_floats, sw); }))) return e;
         }
-        if ((e = cine_tconv2x2_dgrad(q.B, wd(i_up(d, 0), 0), wd2(i_up(d, 0)), sp, q.A, n, c1, c, h1, w1, stream))) return e;   // A = d/d act(cur)
+        if ((e = cine_tconv2x2_dgrad(B, wd(i_up(d, 0), 0), wd2(i_up(d, 0)), sp, q.A, n, c1, c, h1, w1, stream))) return e;   // A = d/d act(cur)
     }
     // ---- bottleneck and down path (reverse of unet.py:94-99)
     for (int d = P; d >= 0; --d) {
         const int c = p.ch[d], hh = p.hs[d], ww = p.wsz[d], npc = p.np_conv[d];
         const float* out = d == P ? p.bott : p.skip[d];
         const float* pout = d == P ? p.pbott : p.pskip[d];
+        float* B = next_g();
         if (d == P) {
-            if ((e = inbwd(out, pout, npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+            if ((e = inbwd(out, pout, npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
         } else {    // the skip tensor feeds the concat (second half of cat[d]) and the 2x2 average pool
-            if ((e = inbwd(out, pout, npc, c, hh, ww, q.cat[d], 2 * c, c, hh, ww, q.pool, p.hs[d + 1], p.wsz[d + 1], q.B))) return e;
+            if ((e = inbwd(out, pout, npc, c, hh, ww, q.cat[d], 2 * c, c, hh, ww, q.pool, p.hs[d + 1], p.wsz[d + 1], B))) return e;
         }
-        if ((e = wgrad3(src(p.mid[d], p.pmid[d], c, 1, hh, ww, npc), none, q.B, c, hh, ww, i_down(d, 1)))) return e;
-        if ((e = cine_conv3x3_dgrad(q.B, wd(i_down(d, 1), 0), wd2(i_down(d, 1)), sp, q.A, n, c, c, hh, ww, stream))) return e;
-        if ((e = inbwd(p.mid[d], p.pmid[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, q.B))) return e;
+        if ((e = wgrad3(src(p.mid[d], p.pmid[d], c, 1, hh, ww, npc), none, B, c, hh, ww, i_down(d, 1)))) return e;
+        if ((e = cine_conv3x3_dgrad(B, wd(i_down(d, 1), 0), wd2(i_down(d, 1)), sp, q.A, n, c, c, hh, ww, stream))) return e;
+        B = next_g();
+        if ((e = inbwd(p.mid[d], p.pmid[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
         if (d > 0) {
             const int cp = p.ch[d - 1];
-            if ((e = wgrad3(src(p.skip[d - 1], p.pskip[d - 1], cp, 2, p.hs[d - 1], p.wsz[d - 1], p.np_conv[d - 1]), none, q.B, c, hh, ww, i_down(d, 0)))) return e;
-            if ((e = cine_conv3x3_dgrad(q.B, wd(i_down(d, 0), 0), wd2(i_down(d, 0)), sp, q.pool, n, c, cp, hh, ww, stream))) return e;
+            if ((e = wgrad3(src(p.skip[d - 1], p.pskip[d - 1], cp, 2, p.hs[d - 1], p.wsz[d - 1], p.np_conv[d - 1]), none, B, c, hh, ww, i_down(d, 0)))) return e;
+            if ((e = cine_conv3x3_dgrad(B, wd(i_down(d, 0), 0), wd2(i_down(d, 0)), sp, q.pool, n, c, cp, hh, ww, stream))) return e;
         } else {
-            if ((e = wgrad3(src(x, nullptr, in_ch, 0, h, w, 0), none, q.B, c, hh, ww, i_down(0, 0)))) return e;
-            if (gx && (e = cine_conv3x3_dgrad(q.B, wd(i_down(0, 0), 0), wd2(i_down(0, 0)), sp, gx, n, c, in_ch, hh, ww, stream))) return e;
+            if ((e = wgrad3(src(x, nullptr, in_ch, 0, h, w, 0), none, B, c, hh, ww, i_down(0, 0)))) return e;
+            if (gx && (e = cine_conv3x3_dgrad(B, wd(i_down(0, 0), 0), wd2(i_down(0, 0)), sp, gx, n, c, in_ch, hh, ww, stream))) return e;
         }
     }
+    lane.join();
     return CINE_OK;
 }

@@ -1,4 +1,5 @@
-"""Diagnostic: time of one cfg-2 training step (forward + SSIMLoss + backward + Adam) on the HIP path, per kernel family."""
+"""Diagnostic: time of one training step (forward + SSIMLoss + backward + Adam) on the HIP path, per kernel family.
+usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-cine-cardiac-mri_amd")]
@@ -10,8 +11,10 @@ from cine_hip import synth
 from cine_hip._lib import lib
 
 dev = torch.device("cuda:0")
-ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
-net = M.VarNet(6, 8, 3, 16, 3, "XF"); synth.fill_parameters_(net, 1); net = net.to(dev).train()
+cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+ex = synth.make_cine_slice(15, 15, 200, 200, accel=4 if cfg == 2 else 8, seed=0)
+net = M.VarNet(6, 8, 3, 16, 3, "XF") if cfg == 2 else M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
+synth.fill_parameters_(net, 1); net = net.to(dev).train()
 mk, mask, target = ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev)
 lossf = SSIMLoss().to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=3e-4)
