@@ -481,14 +481,18 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* part, i
     }
 }
 
-// partial sums per weight set: enough workgroups to fill the chip twice over (1024 resident slots of 4 waves)
-constexpr int kWgTarget = 2048;
-static int wgrad_chunks(int rows, int cin) {
+// Runs of work items per launch: ONE resident round of workgroups.  The kernel is register-bound to two workgroups per CU for row blocks of
+// 16 / 32 and one for 64 / 128; a run that covers ~10 tiles amortises its prologue and its K-split reduction, and every extra run is another
+// partial sum to write and re-read (measured on the cfg-2 step, conv family: 2048 runs per set 32.7 ms, 512: 30.4, 256: 28.6, 128: 29.5,
+// 64: 40.0).  CINE_WG_TARGET overrides the total.
+static int wgrad_runs(int rows, int cin, int nsets) {
+    static const int env = [] { const char* e = getenv("CINE_WG_TARGET"); return e ? atoi(e) : 0; }();
     const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
-    const long wgs = (long)ceil_div(cin, 16) * ceil_div(rows, cob);
-    const long per_chunk = (long)ceil_div(rows, cob) * cob * ceil_div(cin, 16) * 16 * 9 * 4;     // bytes of one partial (3x3)
-    const long cap = std::max(8L, (32L << 20) / per_chunk);                                        // <= 32 MB of partials per weight set
-    return (int)std::max(1L, std::min(cap, ceil_div((long)kWgTarget, wgs)));
+    const long slots = env > 0 ? env : 256L * (cob <= 32 ? 2 : 1);
+    const long wgs = (long)ceil_div(cin, 16) * ceil_div(rows, cob) * nsets;
+    const long per_run = (long)ceil_div(rows, cob) * cob * ceil_div(cin, 16) * 16 * 9 * 4;       // bytes of one partial (3x3)
+    const long cap = std::max(8L, (32L << 20) / per_run);                                          // <= 32 MB of partials per weight set
+    return (int)std::max(1L, std::min(cap, ceil_div(slots, wgs)));
 }
 
 size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
@@ -496,7 +500,7 @@ size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
     const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
     const int rowsb = ceil_div(rowsp, cob) * cob;
     (void)n;
-    return (size_t)2 * wgrad_chunks(rows, cin) * rowsb * cinp * taps;
+    return (size_t)std::max(wgrad_runs(rows, cin, 1), 2 * wgrad_runs(rows, cin, 2)) * rowsb * cinp * taps;
 }
 
 template <int TAPS, int TW, int CT, int WM, int NPIX>
@@ -543,7 +547,7 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     {   // work items = (sample, tile); the tile shape follows the row block (launch_wg_tw)
         const int npix = cob == 16 ? 256 : cob == 128 ? 64 : 128;
         const long items = (long)std::max(n0, n1) * ceil_div(a.W, TW) * ceil_div(a.H, npix / TW);
-        L.nchunks = (int)std::min<long>(wgrad_chunks(a.rows, a.cin), items);
+        L.nchunks = (int)std::min<long>(wgrad_runs(a.rows, a.cin, n1 > 0 ? 2 : 1), items);
         L.chunk = (int)ceil_div(items, (long)L.nchunks);
         L.nchunks = (int)ceil_div(items, (long)L.chunk);
     }
