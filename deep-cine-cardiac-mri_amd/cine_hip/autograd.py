@@ -59,6 +59,19 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
     return y, ws
 
 
+def _zero_grads(plists, device):
+    """Zeroed gradient buffers shaped like the parameters of every list, carved out of ONE zero fill (the C entry points accumulate)."""
+    sizes = [(p.numel() + 3) // 4 * 4 for pl in plists for p in pl]          # 16-byte aligned pieces
+    flat = torch.zeros(sum(sizes), device=device, dtype=torch.float32)
+    out, off, k = [], 0, 0
+    for pl in plists:
+        gl = []
+        for p in pl:
+            gl.append(flat[off:off + p.numel()].view(p.shape)); off += sizes[k]; k += 1
+        out.append(gl)
+    return out
+
+
 def unet2d_backward(x: torch.Tensor, gy: torch.Tensor, weights: "ops.UnetWeights", fwd_ws: torch.Tensor, need_gx: bool):
     """cine_unet2d_backward: returns (gx | None, [per-set list of parameter gradients in ``weights.param_list()`` order])."""
     x = ops._dev(x, "unet input"); gy = ops._dev(gy, "unet output gradient")
@@ -67,7 +80,7 @@ def unet2d_backward(x: torch.Tensor, gy: torch.Tensor, weights: "ops.UnetWeights
     need = lib().cine_unet2d_backward_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     plists = weights.param_lists()
-    grads = [[torch.zeros_like(p, memory_format=torch.contiguous_format) for p in pl] for pl in plists]
+    grads = _zero_grads(plists, x.device)
     gptr = (ctypes.c_void_p * (nsets * len(plists[0])))(*[g.data_ptr() for gl in grads for g in gl])
     gx = torch.empty_like(x) if need_gx else None
     check(lib().cine_unet2d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, nsets, n, h, w, cin,
@@ -252,7 +265,7 @@ class MwcnnFn(Function):
 
         def grads_of(wt):
             pl = wt.param_list()
-            gl = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in pl]
+            gl = _zero_grads([pl], x.device)[0]
             return pl, gl, (ctypes.c_void_p * len(gl))(*[g.data_ptr() for g in gl])
         p1, g1, gp1 = grads_of(w)
         p2, g2, gp2 = grads_of(w2) if w2 is not None else (None, None, None)
@@ -415,9 +428,8 @@ class XpdRegFn(Function):
             ws = torch.empty(need, device=dev, dtype=torch.uint8)
             two = w2 is not None and w2 is not w1
             lists = []
-            for wt in (w1,) + ((w2,) if two else ()):
-                pl = wt.param_list()
-                gl = [torch.zeros_like(p, memory_format=torch.contiguous_format) for p in pl]
+            pls = [wt.param_list() for wt in (w1,) + ((w2,) if two else ())]
+            for pl, gl in zip(pls, _zero_grads(pls, dev)):
                 lists.append((pl, gl, (ctypes.c_void_p * len(gl))(*[g.data_ptr() for g in gl])))
             gx = torch.empty_like(planes)
             check(L.cine_mwcnn_backward(planes.data_ptr(), gy.data_ptr(), w1.dgrad_pointers(), w2.dgrad_pointers() if two else None, lists[0][2],

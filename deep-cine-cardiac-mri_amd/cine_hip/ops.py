@@ -612,6 +612,10 @@ class UnetWeights:
         self._dkeep = []
         self._dptrs = None
 
+    def __reduce__(self):
+        # copies / pickles carry the modules only; the packed device buffers and pointer tables are rebuilt on first use
+        return (type(self), (self.unets,))
+
     def _params(self):
         out = []
         for u in self.unets:
@@ -723,6 +727,9 @@ class MwcnnWeights:
         self._ptrs = None
         self.nf = (ctypes.c_int * net.n_scales)(*net.n_filters_per_scale)
         self.nc = (ctypes.c_int * net.n_scales)(*net.n_convs_per_scale)
+
+    def __reduce__(self):
+        return (type(self), (self.net,))
 
     def _params(self):
         n = self.net

@@ -64,10 +64,12 @@ class CineNetBlock(nn.Module):
         return x
 
     def _xfyf_weights(self):
-        if self._uw is None:
+        # kept on the shared model object: every cascade holds the same networks, one set of packed weights serves all
+        uw = self.model.__dict__.get("_hip_uw")
+        if uw is None:
             nets = [self.model, self.model] if self.weight_sharing else [self.model[0], self.model[1]]
-            self._uw = (ops.UnetWeights(nets), ops.UnetWeights([nets[0]]), ops.UnetWeights([nets[1]]))
-        return self._uw
+            uw = self.model.__dict__["_hip_uw"] = (ops.UnetWeights(nets), ops.UnetWeights([nets[0]]), ops.UnetWeights([nets[1]]))
+        return uw
 
     def xfyf_transform(self, image_combined):
         """(b, t, h, w, 2) -> (b, t, 1, h, w, 2); planes go to the bare U-Nets unnormalised and unpadded."""

@@ -76,11 +76,13 @@ class VarNetBlock(nn.Module):
         return ops.sens_reduce(x, sens_maps)
 
     def _xfyf_weights(self):
-        if self._uw is None:
+        # kept on the shared model object: every cascade holds the same networks (varnet.py:138-140), one set of packed weights serves all
+        uw = self.model.__dict__.get("_hip_uw")
+        if uw is None:
             nets = [self.model, self.model] if self.weight_sharing else [self.model[0], self.model[1]]
-            self._uw = (ops.UnetWeights([nets[0].unet, nets[1].unet]),
-                        ops.UnetWeights([nets[0].unet]), ops.UnetWeights([nets[1].unet]))
-        return self._uw
+            uw = self.model.__dict__["_hip_uw"] = (ops.UnetWeights([nets[0].unet, nets[1].unet]),
+                                                    ops.UnetWeights([nets[0].unet]), ops.UnetWeights([nets[1].unet]))
+        return uw
 
     def xfyf_transform(self, image_combined: torch.Tensor) -> torch.Tensor:
         """(b, t, h, w, 2) -> (b, t, 1, h, w, 2)."""
