@@ -453,15 +453,15 @@ def measure_other_config(cfg_id, args, dev, threads):
     return res
 
 
-def measure_training_step(args, dev, threads):
-    """One training step of BASELINE configs[1] through the HIP backward kernels: the body of reference
+def measure_training_step(args, dev, threads, cfg_id=2, cpu=True):
+    """One training step of a BASELINE configuration (default configs[1]) through the HIP backward kernels: the body of reference
     pl_modules/varnet_module.py:97-113 (forward + SSIMLoss), loss.backward() and one Adam step (:151-154), k-space resident in HBM;
     and the same step of the CPU oracle on the host cores (ONE step: it takes tens of seconds)."""
     import reconstruction.models as M
     from reconstruction.utils import SSIMLoss
     from cine_hip import synth
-    cfg = CONFIGS[2]()
-    ex = synth.make_cine_slice(FRAMES, COILS, H, W, accel=cfg["accel"], seed=0)
+    cfg = CONFIGS[cfg_id]()
+    ex = synth.make_cine_slice(FRAMES, COILS, H, W, accel=cfg["accel"], seed=0, noise_std=cfg["noise"])
 
     def make(model, device):
         synth.fill_parameters_(model, cfg["wseed"], keep=cfg["keep"])
@@ -491,11 +491,12 @@ def measure_training_step(args, dev, threads):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         fam = profile_families(step, iters=1)
-        res = {"what": "forward + SSIMLoss + backward (hand-written HIP gradient kernels) + Adam, one cfg-2 slice per step, eager launches",
+        res = {"what": f"forward + SSIMLoss + backward (hand-written HIP gradient kernels) + Adam, one cfg-{cfg_id} slice per step, eager launches, "
+                       "weight gradients on a side stream",
                "ms_per_step": ms, "steps_per_sec": 1e3 / ms, "loss_after_7_steps": float(loss),
                "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
                "kernel_ms_per_step": {k: round(v[0], 3) for k, v in fam.items() if v[1]}}
-        if not args.no_cpu_baseline:
+        if cpu and not args.no_cpu_baseline:
             torch.set_num_threads(threads)
             cstep = make(cfg["ref"](), torch.device("cpu"))
             t0 = time.perf_counter()
@@ -633,6 +634,10 @@ def main():
             line["train_step"] = measure_training_step(args, dev, best_threads)
         except Exception as e:                                            # pragma: no cover
             line["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+        try:                                                              # XT-XPDNet (cfg 3): MWCNN backward; GPU only (the CPU oracle's step takes a minute)
+            line["train_step_cfg3"] = measure_training_step(args, dev, best_threads, cfg_id=3, cpu=False)
+        except Exception as e:                                            # pragma: no cover
+            line["train_step_cfg3"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -130,6 +130,9 @@ _SIGS = {
     "cine_mwcnn_forward_train": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_mwcnn_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
     "cine_mwcnn_backward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P, c_size_t, P, P]),
+    "cine_relu_mask": (c_int, [P, P, c_long, P]),
+    "cine_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "cine_conv3x3_wgrad": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_xpd_unpack_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_xpd_pack_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_unpack_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),

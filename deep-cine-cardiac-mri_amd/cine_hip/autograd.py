@@ -463,6 +463,139 @@ def xpd_regularise(buf, extra, n, n_scales, xf, wx, wy):
     return XpdRegFn.apply(buf, extra, n, n_scales, xf, wx, wy, *params)
 
 
+# ---- convolutional-RNN cells (models/recurrent_varnet.py:153-259) --------------------------------------------------------------------
+def _relu_mask_(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    check(lib().cine_relu_mask(g.data_ptr(), y.data_ptr(), g.numel(), _stream()), "cine_relu_mask")
+    return g
+
+
+def _conv_wgrad_(gw, gb, x0, x1, g):
+    """gw (cout, c0 + c1, 3, 3) += weight gradient of conv3x3(cat(x0, x1)) from g; gb (cout) += bias gradient when not None."""
+    n, c0, h, w = x0.shape
+    c1 = 0 if x1 is None else x1.shape[1]
+    cout = g.shape[1]
+    L = lib()
+    ws = torch.empty(L.cine_conv3x3_wgrad_ws_bytes(cout, c0 + c1, n), device=g.device, dtype=torch.uint8)
+    check(L.cine_conv3x3_wgrad(x0.data_ptr(), c0, _p(x1), c1, g.data_ptr(), gw.data_ptr(), _p(gb), n, cout, h, w,
+                               ws.data_ptr(), ws.numel(), _stream()), "cine_conv3x3_wgrad")
+
+
+def _conv_dgrad(g, weight):
+    """(n, cout, h, w) -> (n, cin, h, w) through the forward conv kernel on the flipped / transposed packing."""
+    n, cout, h, w = g.shape
+    cin = weight.shape[1]
+    gx = torch.empty((n, cin, h, w), device=g.device, dtype=g.dtype)
+    check(lib().cine_conv3x3_dgrad(g.data_ptr(), ops._pack("c3d", weight).data_ptr(), None, n, gx.data_ptr(), n, cout, cin, h, w, _stream()),
+          "cine_conv3x3_dgrad")
+    return gx
+
+
+class ConvSumFn(Function):
+    """y = [ReLU](conv3x3(cat(x0, x1); W) + bias + addend): the "conv_x(a) + conv_h(b)" pairs of the CRNN body (recurrent_varnet.py:122-134)
+    as one convolution over the concatenated inputs; W (cout, c0 + c1, 3, 3) in the module's own layout."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, addend, relu):
+        x0 = ops._dev(x0, "conv input")
+        x1 = None if x1 is None else ops._dev(x1, "conv input 1")
+        cout = weight.shape[0]
+        y = ops.conv3x3_sum([x0] + ([x1] if x1 is not None else []), ops.pack_conv3x3(weight), None if bias is None else ops._dev(bias.detach(), "bias"),
+                            cout, addend=None if addend is None else ops._dev(addend, "addend"), relu=bool(relu))
+        ctx.relu = bool(relu)
+        ctx.has = (x1 is not None, bias is not None, addend is not None)
+        ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0), weight, y if relu else torch.empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x0, x1, weight, y = ctx.saved_tensors
+        has_x1, has_bias, has_add = ctx.has
+        x1 = x1 if has_x1 else None
+        g = ops._dev(_c(gy), "conv output gradient")
+        if ctx.relu:
+            g = _relu_mask_(g.clone(), y)
+        need = ctx.needs_input_grad
+        c0 = x0.shape[1]
+        gx0 = gx1 = gw = gb = None
+        if need[0] or (has_x1 and need[1]):
+            gx = _conv_dgrad(g, weight)
+            gx0 = gx[:, :c0] if need[0] else None
+            gx1 = gx[:, c0:] if has_x1 and need[1] else None
+        if need[2] or (has_bias and need[3]):
+            gw = torch.zeros_like(weight, memory_format=torch.contiguous_format)
+            gb = torch.zeros(weight.shape[0], device=g.device, dtype=g.dtype) if has_bias and need[3] else None
+            _conv_wgrad_(gw, gb, x0, x1, g)
+        return gx0, gx1, gw if need[2] else None, gb, g if has_add and need[4] else None, None
+
+
+class BcrnnFn(Function):
+    """BCRNNlayer.forward (recurrent_varnet.py:220-259) for batch 1: P_t = conv([hid_iter_t, x_t]; [W_ih2ih | W_i2h]) + the three biases for
+    all frames in one launch, then both time sweeps h_t = ReLU(conv(h_prev; W_h2h) + P_t) step by step (both directions in one launch
+    per step), output = forward + backward hidden states.  Every hidden state is kept; the backward pass is back-propagation through
+    time on the same conv kernel (the flipped / transposed packing of W_h2h, the gradient of the frame riding in as the addend), then
+    ONE weight-gradient launch per weight over all frames."""
+
+    @staticmethod
+    def forward(ctx, x, hid_iter, w_in, w_hh, bias):
+        x = ops._dev(x, "BCRNN input"); hid_iter = ops._dev(hid_iter, "BCRNN iteration state")
+        T, ch, h, w = x.shape
+        c = w_hh.shape[0]
+        wpi, wph = ops.pack_conv3x3(w_in), ops.pack_conv3x3(w_hh)
+        P = ops.conv3x3_sum([hid_iter, x], wpi, ops._dev(bias.detach(), "bias"), c)
+        hf, hb, out = torch.empty_like(P), torch.empty_like(P), torch.empty_like(P)
+        zero = torch.zeros((1, c, h, w), device=x.device, dtype=x.dtype)
+        hid_f = hid_b = zero
+        for s in range(T):
+            i_f, i_b = s, T - 1 - s
+            first = i_f < i_b
+            if i_f == i_b:
+                ops.crnn_step2(wph, (hid_f, P[i_f:i_f + 1], hf[i_f:i_f + 1], out[i_f:i_f + 1], True))
+                ops.crnn_step2(wph, (hid_b, P[i_b:i_b + 1], hb[i_b:i_b + 1], out[i_b:i_b + 1], False))
+            else:
+                ops.crnn_step2(wph, (hid_f, P[i_f:i_f + 1], hf[i_f:i_f + 1], out[i_f:i_f + 1], first),
+                               (hid_b, P[i_b:i_b + 1], hb[i_b:i_b + 1], out[i_b:i_b + 1], first))
+            hid_f, hid_b = hf[i_f:i_f + 1], hb[i_b:i_b + 1]
+        ctx.save_for_backward(x, hid_iter, w_in, w_hh, hf, hb)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, hid_iter, w_in, w_hh, hf, hb = ctx.saved_tensors
+        gout = ops._dev(_c(gout), "BCRNN output gradient")
+        T, ch, h, w = x.shape
+        c = w_hh.shape[0]
+        wdh = ops._pack("c3d", w_hh)
+        gf, gb = torch.empty_like(gout), torch.empty_like(gout)       # d loss / d (pre-activation) of the two chains
+        for t in range(T - 1, -1, -1):                                 # forward-in-time chain, walked backwards
+            if t == T - 1:
+                gf[t:t + 1].copy_(gout[t:t + 1])
+            else:
+                ops.conv3x3_sum([gf[t + 1:t + 2]], wdh, None, c, addend=gout[t:t + 1], out=gf[t:t + 1])
+            _relu_mask_(gf[t:t + 1], hf[t:t + 1])
+        for t in range(T):                                             # backward-in-time chain
+            if t == 0:
+                gb[t:t + 1].copy_(gout[t:t + 1])
+            else:
+                ops.conv3x3_sum([gb[t - 1:t]], wdh, None, c, addend=gout[t:t + 1], out=gb[t:t + 1])
+            _relu_mask_(gb[t:t + 1], hb[t:t + 1])
+        gP = gf + gb
+        need = ctx.needs_input_grad
+        gx = ghid = gw_in = gw_hh = gbias = None
+        if need[0] or need[1]:
+            gcat = _conv_dgrad(gP, w_in)
+            ghid, gx = (gcat[:, :c] if need[1] else None), (gcat[:, c:] if need[0] else None)
+        if need[2] or need[4]:
+            gw_in = torch.zeros_like(w_in, memory_format=torch.contiguous_format)
+            gbias = torch.zeros(c, device=gP.device, dtype=gP.dtype) if need[4] else None
+            _conv_wgrad_(gw_in, gbias, hid_iter, x, gP)
+        if need[3]:
+            gw_hh = torch.zeros_like(w_hh, memory_format=torch.contiguous_format)
+            if T > 1:       # h_{t-1} -> h_t (the first frame of each chain starts from zeros)
+                _conv_wgrad_(gw_hh, None, hf[:T - 1], None, gf[1:])
+                _conv_wgrad_(gw_hh, None, hb[1:], None, gb[:T - 1])
+        return gx, ghid, gw_in if need[2] else None, gw_hh, gbias
+
+
 def coil_accum(g: Optional[torch.Tensor], z: torch.Tensor) -> torch.Tensor:
     """sum_t conj(g[b, t]) z[b, t, c] -> (b, 1, c, h, w, 2) (g None: sum_t z)."""
     b, t, c, h, w, _ = z.shape

@@ -884,14 +884,19 @@ def expand_resid_hybrid(img: torch.Tensor, sens: torch.Tensor, kref: torch.Tenso
 
 # ------------------------------------------------------------------ convolutional-RNN cells
 def conv3x3_sum(srcs: Sequence, wpacked: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
-                addend: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+                addend: Optional[torch.Tensor] = None, relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = [ReLU](conv3x3(cat(srcs)) + bias + addend): a sum of convolutions of different inputs
     (reference recurrent_varnet.py:172-178, 122-134) as ONE convolution over the concatenated inputs;
     `wpacked` = pack_conv3x3(cat(weights, dim=1)).  srcs: one or two (n, c, h, w) tensors, used as is."""
     x0 = _dev(srcs[0], "conv source 0")
     n, _, h, w = x0.shape
     x1 = _dev(srcs[1], "conv source 1") if len(srcs) > 1 else None
-    y = torch.empty((n, cout, h, w), device=x0.device, dtype=x0.dtype)
+    if out is None:
+        y = torch.empty((n, cout, h, w), device=x0.device, dtype=x0.dtype)
+    else:
+        y = _dev(out, "conv output")
+        if tuple(y.shape) != (n, cout, h, w):
+            raise ValueError("conv3x3_sum: out has the wrong shape")
     check(lib().cine_conv3x3_ex(x0.data_ptr(), None, 0, x0.shape[1], 0, h, w,
                                 _p(x1), None, 0, 0 if x1 is None else x1.shape[1], 0, h, w, 0,
                                 wpacked.data_ptr(), _p(bias), _p(addend), int(relu),

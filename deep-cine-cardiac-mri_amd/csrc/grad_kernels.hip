@@ -620,6 +620,64 @@ int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, fl
     return check_launch("bias_grad_kernel");
 }
 
+// ---- plain convolutions with bias / ReLU epilogues (the convolutional-RNN cells, recurrent_varnet.py:153-259) -------------------------
+__global__ __launch_bounds__(256) void relu_mask_kernel(float4* __restrict__ g, const float4* __restrict__ y, long n4, float* gs, const float* ys, long tail0, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        float4 a = g[i]; const float4 b = y[i];
+        a.x = b.x > 0.f ? a.x : 0.f; a.y = b.y > 0.f ? a.y : 0.f; a.z = b.z > 0.f ? a.z : 0.f; a.w = b.w > 0.f ? a.w : 0.f;
+        g[i] = a;
+    }
+    if (i == 0) for (long k = tail0; k < n; ++k) gs[k] = ys[k] > 0.f ? gs[k] : 0.f;
+}
+__global__ __launch_bounds__(256) void relu_mask_scalar_kernel(float* __restrict__ g, const float* __restrict__ y, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) g[i] = y[i] > 0.f ? g[i] : 0.f;
+}
+
+}  // namespace cine
+using namespace cine;
+
+// g *= (y > 0): the gradient of y = ReLU(pre) with respect to pre, from the stored output (in place)
+extern "C" int cine_relu_mask(float* g, const float* y, long n, void* stream) {
+    CINE_REQUIRE(g && y && n > 0, CINE_EINVAL, "cine_relu_mask: bad arguments");
+    if (reinterpret_cast<uintptr_t>(g) % 16 || reinterpret_cast<uintptr_t>(y) % 16) {
+        CINE_REQUIRE(ceil_div(n, 256L) <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_relu_mask: too large");
+        hipLaunchKernelGGL(relu_mask_scalar_kernel, dim3((unsigned)ceil_div(n, 256L)), dim3(256), 0, as_stream(stream), g, y, n);
+        return check_launch("relu_mask_scalar_kernel");
+    }
+    const long n4 = n / 4;
+    CINE_REQUIRE(ceil_div(std::max(n4, 1L), 256L) <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_relu_mask: too large");
+    hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)ceil_div(std::max(n4, 1L), 256L)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<float4*>(g), reinterpret_cast<const float4*>(y), n4, g, y, n4 * 4, n);
+    return check_launch("relu_mask_kernel");
+}
+
+extern "C" size_t cine_conv3x3_wgrad_ws_bytes(int cout, int cin, int n) {
+    if (cout <= 0 || cin <= 0 || n <= 0) return 0;
+    return std::max(wgrad_ws_floats(cout, cin, 9, n), (size_t)n * cout) * sizeof(float);
+}
+
+// gw (cout, c0 + c1, 3, 3) += d loss / d W of y = conv3x3(cat(x0, x1); W) from g = d loss / d y; x0 (n, c0, h, w), x1 (n, c1, h, w) or NULL
+// (the summed convolutions of the CRNN cells are one convolution over concatenated inputs, recurrent_varnet.py:172-178, 122-134);
+// gb (cout) += sum of g over samples and pixels when not NULL.
+extern "C" int cine_conv3x3_wgrad(const float* x0, int c0, const float* x1, int c1, const float* g, float* gw, float* gb,
+                                  int n, int cout, int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(x0 && g && gw && ws && c0 > 0 && c1 >= 0 && (c1 == 0 || x1) && n > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL,
+                 "cine_conv3x3_wgrad: bad arguments");
+    CINE_REQUIRE(ws_bytes >= cine_conv3x3_wgrad_ws_bytes(cout, c0 + c1, n), CINE_EWORKSPACE, "cine_conv3x3_wgrad: workspace too small");
+    hipStream_t st = as_stream(stream);
+    WgArgs a{};
+    a.s0 = Src{x0, nullptr, c0, 0, h, w, 0, 0, 1};
+    a.s1 = c1 ? Src{x1, nullptr, c1, 0, h, w, 0, 0, 1} : Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    a.cin = c0 + c1; a.g = g; a.g_mode = 0; a.rows = cout; a.n = n; a.H = h; a.W = w; a.set_split = n; a.eps = 1e-5f; a.slope = 0.2f;
+    float* wsf = reinterpret_cast<float*>(ws);
+    const size_t wsn = ws_bytes / sizeof(float);
+    if (gb) if (int e = launch_bias_grad(g, n, cout, (long)h * w, n, gb, nullptr, wsf, wsn, st)) return e;
+    return launch_wgrad(a, 9, 0, gw, nullptr, wsf, wsn, st);
+}
+
+namespace cine {
 // ---- SideLane -------------------------------------------------------------------------------------------------------------------------
 namespace {
 std::mutex g_side_mu;

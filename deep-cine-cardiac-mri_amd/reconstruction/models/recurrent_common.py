@@ -14,6 +14,7 @@ the MFMA kernel's epilogue.
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 
 
@@ -134,6 +135,22 @@ class CRNNBody(nn.Module):
 
     def zero_state(self, t: int, b: int, h: int, w: int, like: torch.Tensor):
         return [zeros_ro((t * b, self.chans, h, w), like) for _ in range(4)]     # read only: sources of the first cascade
+
+    def body_train(self, x: torch.Tensor, state, residual: torch.Tensor):
+        """``body`` as an autograd graph (batch 1): the BCRNN layer is one Function (back-propagation through time inside), every
+        "conv_x(a) + conv_h(b) -> ReLU" pair one ConvSumFn on the concatenated weights; torch only concatenates / adds the parameters."""
+        t, b, ch, h, w = x.shape
+        cell = self.bcrnn.CRNN_model
+        x0 = ag.BcrnnFn.apply(x.reshape(t * b, ch, h, w), state[0], torch.cat([cell.ih2ih.weight, cell.i2h.weight], dim=1), cell.h2h.weight,
+                              cell.i2h.bias + cell.h2h.bias + cell.ih2ih.bias)
+        feats = [x0]
+        cur = x0
+        for k in (1, 2, 3):
+            cx, chh = getattr(self, f"conv{k}_x"), getattr(self, f"conv{k}_h")
+            cur = ag.ConvSumFn.apply(cur, state[k], torch.cat([cx.weight, chh.weight], dim=1), cx.bias + chh.bias, None, True)
+            feats.append(cur)
+        out = ag.ConvSumFn.apply(cur, None, self.conv4_x.weight, self.conv4_x.bias, residual, False)
+        return out, feats
 
     def body(self, x: torch.Tensor, state, residual: torch.Tensor):
         """x (t, b, ch, h, w); state [x0..x3] of the previous cascade; returns (residual + conv4(x3), new state)."""

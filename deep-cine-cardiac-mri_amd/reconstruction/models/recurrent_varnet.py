@@ -4,6 +4,7 @@ import math
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 from .recurrent_common import BCRNNlayer, CRNNBody, CRNNcell  # noqa: F401  (re-exported like the reference)
 from .varnet import SensitivityModel
@@ -18,9 +19,31 @@ class VarNet_RNN(CRNNBody):
         self.Softplus = nn.Softplus(1.)
         self.lambda_reg = nn.Parameter(torch.full((1,), math.log(math.e - 1.0)))
 
-    @torch.no_grad()
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
         mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        if ag.grad_mode(self):
+            return self._forward_train(ref_kspace, mask, acs)
+        with torch.no_grad():
+            return self._forward_infer(ref_kspace, mask, acs)
+
+    def _forward_train(self, ref_kspace, mask, acs):
+        """The chain of ``_forward_infer`` (reference recurrent_varnet.py:92-150) as an autograd graph: sensitivity network, BCRNN +
+        conv pairs through the HIP backward kernels (hidden states flow across time AND cascades), image-space soft DC."""
+        b, t, _, h, w, _ = ref_kspace.shape
+        if b != 1 or not ops.is_row_mask(mask, ref_kspace):
+            raise NotImplementedError("training through the HIP path: batch 1 and the reference's (b, t, 1, h, 1, 1) row mask")
+        sens_maps = self.sens_net(ref_kspace, mask, acs)
+        img = ag.CoilReduceFn.apply(ref_kspace, sens_maps, None)                  # (1, t, 1, h, w, 2)
+        zf = ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
+        state = self.zero_state(t, b, h, w, img)
+        for _ in range(self.num_cascades):
+            planes = img.view(t, h, w, 2).permute(0, 3, 1, 2).contiguous()        # (t, 2, h, w): frames are the conv batch
+            out, state = self.body_train(planes.view(t, 1, 2, h, w), state, planes)
+            new_img = out.permute(0, 2, 3, 1).reshape(1, t, 1, h, w, 2)
+            img = ag.ImageDcFn.apply(new_img, sens_maps, zf, mask, self.lambda_reg)
+        return ag.AbsFn.apply(img.squeeze(2))
+
+    def _forward_infer(self, ref_kspace, mask, acs):
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         b, t, _, h, w, _ = ref_kspace.shape
         if b != 1:

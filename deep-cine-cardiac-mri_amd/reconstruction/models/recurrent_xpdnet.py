@@ -2,6 +2,7 @@
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 from .denoisers.kspace_net import KSpaceCNN
 from .recurrent_common import BCRNNlayer, CRNNBody, CRNNcell  # noqa: F401
@@ -29,10 +30,36 @@ class XPDNet_RNN(CRNNBody):
     def measurements_residual(concat_kspace: torch.Tensor) -> torch.Tensor:
         return concat_kspace[..., [0, 2]] - concat_kspace[..., [1, 3]]
 
-    @torch.no_grad()
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
-        n = self.i_buffer_size
         mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        if ag.grad_mode(self):
+            return self._forward_train(ref_kspace, mask, acs)
+        with torch.no_grad():
+            return self._forward_infer(ref_kspace, mask, acs)
+
+    def _forward_train(self, ref_kspace, mask, acs):
+        """The primal-only chain of ``_forward_infer`` as an autograd graph: sensitivity network, K step + masked backward operator
+        (image space, with respect to image and maps), CRNN body on the (image buffer, backward image) planes."""
+        n = self.i_buffer_size
+        b, t, _, h, w, _ = ref_kspace.shape
+        if b != 1 or self.k_buffer_mode or not ops.is_row_mask(mask, ref_kspace):
+            raise NotImplementedError("training through the HIP path: primal-only, batch 1, the reference's (b, t, 1, h, 1, 1) row mask")
+        sens_maps = self.sens_net(ref_kspace, mask, acs)
+        image_buffer = ag.CoilReduceFn.apply(ref_kspace, sens_maps, None).repeat_interleave(n, dim=-1)     # (1, t, 1, h, w, 2n)
+        zf = ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
+        state = self.zero_state(t, b, h, w, image_buffer)
+        keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]
+        for _ in range(self.num_cascades):
+            x0 = image_buffer[..., [0, n]]
+            bwd = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)
+            cat = torch.cat([image_buffer[..., :n], bwd[..., :1], image_buffer[..., n:], bwd[..., 1:]], dim=-1)
+            planes = cat.view(t, h, w, 2 * (n + 1)).permute(0, 3, 1, 2).contiguous()                       # (t, 2(n+1), h, w)
+            out, state = self.body_train(planes.view(t, 1, 2 * (n + 1), h, w), state, planes[:, keep].contiguous())
+            image_buffer = out.permute(0, 2, 3, 1).reshape(1, t, 1, h, w, 2 * n)
+        return ag.AbsFn.apply(image_buffer[..., [0, n]].squeeze(2))
+
+    def _forward_infer(self, ref_kspace, mask, acs):
+        n = self.i_buffer_size
         b, t, _, h, w, _ = ref_kspace.shape
         if b != 1:
             raise NotImplementedError("the CRNN models assume batch 1, like the reference")

@@ -517,6 +517,16 @@ int cine_xfyf_pack_bwd(const float* gp_xf, const float* gp_yf, const float* p_xf
                        const float* gmean, float* gimg, int b, int t, int h, int w, int xf,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* Backward pieces of the convolutional-RNN cells (models/recurrent_varnet.py:153-259: sums of plain 3x3 convolutions + bias, ReLU).
+ * cine_relu_mask: g *= (y > 0) in place, y = the stored ReLU output.  cine_conv3x3_wgrad: gw (cout, c0 + c1, 3, 3) += the weight
+ * gradient of y = conv3x3(cat(x0, x1); W) from g = d loss / d y (x1 NULL / c1 0: one input), gb (cout) += the bias gradient when
+ * not NULL; deterministic (partial sums in `ws`, fixed-order reduction).  The input gradient is cine_conv3x3_dgrad, or
+ * cine_conv3x3_ex on the cine_pack_conv3x3_dgrad packing when an addend rides along (the time sweep's chain rule). */
+int cine_relu_mask(float* g, const float* y, long n, void* stream);
+size_t cine_conv3x3_wgrad_ws_bytes(int cout, int cin, int n);
+int cine_conv3x3_wgrad(const float* x0, int c0, const float* x1, int c1, const float* g, float* gw, float* gb,
+                       int n, int cout, int h, int w, void* ws, size_t ws_bytes, void* stream);
+
 /* Adjoints of cine_xpd_unpack / cine_xpd_pack (models/xpdnet.py:424-509): gout (b, t, 1, h, w, 2n) -> the gradients of the two MWCNNs' output
  * planes (2n channels, zero on the pad frames) and gmean (b, h, w, n + 1, 2) (the temporal mean of channels < n is added back, :504-509); then
  * from the gradients of the MWCNNs' input planes (2 (n + 1) channels) -> gbuf (b, t, 1, h, w, 2n) and gextra (b, t, 1, h, w, 2) (the

@@ -419,6 +419,9 @@ def _training_step(net, mk, mask, target, lr=0.0003, dtype=None, extra=()):
     from reconstruction.utils.losses import SSIMLoss
     orig_to = torch.Tensor.to
     torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else orig_to(self, *a, **k)     # losses.py:34 hard-wires 'cuda'
+    orig_default = torch.get_default_dtype()
+    if dtype is not None:
+        torch.set_default_dtype(dtype)       # the CRNN models create their zero hidden states with torch.zeros(size) (recurrent_varnet.py:112, 236)
     try:
         with torch.enable_grad():
             if dtype is not None:
@@ -440,6 +443,7 @@ def _training_step(net, mk, mask, target, lr=0.0003, dtype=None, extra=()):
             new = {k: p.detach().clone() for k, p in net.named_parameters()}
     finally:
         torch.Tensor.to = orig_to
+        torch.set_default_dtype(orig_default)
     return loss.detach(), grads, new, output.detach()
 
 
@@ -675,7 +679,48 @@ def g_xpdnet_grad():
     save("xpdnet_grad", **a)
 
 
-GENERATORS = dict(xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def g_rnn_grad():
+    """Gradients of the reference's training step for the tiny convolutional-RNN hybrids (models/recurrent_*.py: BCRNN over time, hidden
+    states carried across cascades, weights shared by all cascades): VarNet_RNN, CineNet_RNN, XPDNet_RNN.  Same contents and the same
+    kink-stable seed selection as varnet_grad.npz (the sensitivity U-Nets have LeakyReLU kinks; the CRNN's ReLU has its own at 0)."""
+    import copy
+    t, c, h, w = 5, 3, 24, 20
+    mask = tiny_mask(t, h)
+    mk = rnd(94, 1, t, c, h, w, 2) * mask
+    sens = rnd(96, 1, 1, c, h, w, 2)
+    sens = sens / RU.rss_complex(sens, dim=2).unsqueeze(-1).unsqueeze(2)
+    target = rnd(95, 1, t, 20, 18).abs() + 0.1
+    a = dict(masked_kspace=mk, mask=mask, target=target, sens_maps=sens)
+    for tag, make, extra, keep in (("varnet_rnn", lambda: RM.VarNet_RNN(3, 4, 2, 6), (), ("lambda",)),
+                                   ("cinenet_rnn", lambda: RM.CineNet_RNN(3, 3, 6), (sens,), ("lambda",)),
+                                   ("xpdnet_rnn", lambda: RM.XPDNet_RNN(3, 4, 2, 6, True, 2, 1), (), ())):
+        for seed in range(43, 143):
+            net = make()
+            synth.fill_parameters_(net, seed, keep=keep)
+            if keep:
+                with torch.no_grad():
+                    net.lambda_reg.fill_(0.4)
+            stab = _kink_stability(net, mk, mask, target, extra=extra)
+            print(f"    {tag}: weight seed {seed}: gradient change under 1e-6 input perturbations {stab:.2e}")
+            if stab <= 2e-5:
+                break
+        else:
+            raise RuntimeError("no kink-stable seed")
+        a[f"{tag}_seed"] = seed; a[f"{tag}_stability"] = stab
+        a.update(sd_np(copy.deepcopy(net), f"{tag}::sd::"))
+        net64 = copy.deepcopy(net)
+        loss, grads, new, out = _training_step(net, mk, mask, target, extra=extra)
+        loss64, grads64, _, _ = _training_step(net64, mk, mask, target, dtype=torch.float64, extra=extra)
+        a[f"{tag}_loss"] = loss; a[f"{tag}_out"] = out; a[f"{tag}_loss64"] = loss64
+        for k, g in grads.items():
+            a[f"{tag}::grad::{k}"] = g
+            a[f"{tag}::new::{k}"] = new[k]
+            g64 = grads64[k]
+            a[f"{tag}::floor::{k}"] = float((g.double() - g64).abs().max() / g64.abs().max().clamp_min(1e-300))
+    save("rnn_grad", **a)
+
+
+GENERATORS = dict(rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)

@@ -181,14 +181,14 @@ def test_rss_abs_backward_vs_torch(dev):
 
 
 # ------------------------------------------------------------------ whole model against the reference's gradients
-def _training_step(model, mk, mask, target, lr=0.0003):
+def _training_step(model, mk, mask, target, lr=0.0003, extra=()):
     """Body of reference pl_modules/varnet_module.py:97-113 on the drop-in modules, loss.backward(), one Adam step (:151-154)."""
     from reconstruction.data import transforms
     from reconstruction.utils import SSIMLoss
     lossf = SSIMLoss().to(mk.device)
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.0)
     opt.zero_grad()
-    output = model(mk, mask)
+    output = model(mk, mask, *extra)
     tgt, out = transforms.center_crop_to_smallest(target, output)
     loss = lossf(out.unsqueeze(1), tgt.unsqueeze(1), data_range=tgt.max())
     loss.backward()
@@ -296,6 +296,80 @@ def test_xpdnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
         if sel.any():
             assert (new[k].detach().cpu() - want_new)[sel].abs().max() <= 0.02 * 0.0003, k
     assert not bad, bad
+
+
+@pytest.mark.parametrize("tag", ["varnet_rnn", "cinenet_rnn", "xpdnet_rnn"])
+def test_rnn_training_step_vs_reference_golden(dev, golden, tag):
+    """The reference's training step on the drop-in convolutional-RNN hybrids: back-propagation through the BCRNN time sweeps (both
+    directions) and through the hidden states carried across cascades, on the HIP conv / weight-gradient kernels; loss, gradients and
+    Adam-updated weights against the reference's own (rnn_grad.npz)."""
+    import reconstruction.models as M
+    g = golden("rnn_grad")
+    net = {"varnet_rnn": lambda: M.VarNet_RNN(3, 4, 2, 6), "cinenet_rnn": lambda: M.CineNet_RNN(3, 3, 6),
+           "xpdnet_rnn": lambda: M.XPDNet_RNN(3, 4, 2, 6, True, 2, 1)}[tag]()
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    net = net.to(dev).train()
+    mk, mask, target, sens = (torch.from_numpy(g[k]).to(dev) for k in ("masked_kspace", "mask", "target", "sens_maps"))
+    with torch.enable_grad():
+        loss, grads, out = _training_step(net, mk, mask, target, extra=(sens,) if tag == "cinenet_rnn" else ())
+    assert rel_err(out.cpu(), g[f"{tag}_out"]) < TOL
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-5
+    new = dict(net.named_parameters())
+    bad = {}
+    for k in (k[len(tag) + 8:] for k in g if k.startswith(f"{tag}::grad::")):
+        floor = float(g[f"{tag}::floor::{k}"])
+        e = rel_err(grads[k].cpu(), g[f"{tag}::grad::{k}"])
+        if e > max(TOL, 20 * floor):
+            bad[k] = (e, floor)
+        want_new, gref = torch.from_numpy(g[f"{tag}::new::{k}"]), torch.from_numpy(g[f"{tag}::grad::{k}"])
+        sel = gref.abs() > 1e-5
+        if sel.any():
+            assert (new[k].detach().cpu() - want_new)[sel].abs().max() <= 0.02 * 0.0003, k
+    assert not bad, bad
+
+
+def test_conv_sum_and_bcrnn_backward_vs_torch_autograd(dev):
+    """ConvSumFn / BcrnnFn against torch's own autograd of the same formulas in float64 (odd sizes: unaligned frames, ragged tiles)."""
+    from cine_hip import autograd as ag
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    T, ch, c, h, w = 4, 3, 5, 9, 7
+    x = torch.randn(T, ch, h, w); hid = torch.randn(T, c, h, w)
+    w_in = torch.randn(c, c + ch, 3, 3) * 0.2; w_hh = torch.randn(c, c, 3, 3) * 0.2; bias = torch.randn(c) * 0.1
+    gout = torch.randn(T, c, h, w)
+
+    def ref(x, hid, w_in, w_hh, bias):
+        P = F.conv2d(torch.cat([hid, x], 1), w_in, bias, padding=1)
+        hf, hb, hcur = [], [None] * T, torch.zeros(1, c, h, w, dtype=x.dtype)
+        for t in range(T):
+            hcur = F.relu(F.conv2d(hcur, w_hh, padding=1) + P[t:t + 1]); hf.append(hcur)
+        hcur = torch.zeros(1, c, h, w, dtype=x.dtype)
+        for t in range(T - 1, -1, -1):
+            hcur = F.relu(F.conv2d(hcur, w_hh, padding=1) + P[t:t + 1]); hb[t] = hcur
+        return torch.cat(hf) + torch.cat(hb)
+    args64 = [a.double().requires_grad_(True) for a in (x, hid, w_in, w_hh, bias)]
+    with torch.enable_grad():
+        y64 = ref(*args64); y64.backward(gout.double())
+    args = [a.clone().to(dev).requires_grad_(True) for a in (x, hid, w_in, w_hh, bias)]
+    with torch.enable_grad():
+        y = ag.BcrnnFn.apply(*args)
+        y.backward(gout.to(dev))
+    assert rel_err(y.detach().cpu(), y64.detach()) < 1e-5
+    for a, b, name in zip(args, args64, ("x", "hid_iter", "w_in", "w_hh", "bias")):
+        assert rel_err(a.grad.cpu(), b.grad) < 2e-5, name
+    # conv pair + bias + addend + ReLU
+    x0 = torch.randn(T, c, h, w); x1 = torch.randn(T, 2, h, w); wt = torch.randn(4, c + 2, 3, 3) * 0.2; b = torch.randn(4) * 0.1
+    add = torch.randn(T, 4, h, w); gy = torch.randn(T, 4, h, w)
+    a64 = [a.double().requires_grad_(True) for a in (x0, x1, wt, b, add)]
+    with torch.enable_grad():
+        y64 = F.relu(F.conv2d(torch.cat([a64[0], a64[1]], 1), a64[2], a64[3], padding=1) + a64[4]); y64.backward(gy.double())
+    a32 = [a.clone().to(dev).requires_grad_(True) for a in (x0, x1, wt, b, add)]
+    with torch.enable_grad():
+        y = ag.ConvSumFn.apply(*a32, True)
+        y.backward(gy.to(dev))
+    assert rel_err(y.detach().cpu(), y64.detach()) < 1e-5
+    for a, b_, name in zip(a32, a64, ("x0", "x1", "weight", "bias", "addend")):
+        assert rel_err(a.grad.cpu(), b_.grad) < 2e-5, name
 
 
 def test_xpdnet_training_rejects_what_is_not_on_the_hip_path(dev):

@@ -275,3 +275,25 @@ def test_oracle_xpdnet_training_gradients_vs_reference_golden(golden, tag, dyn, 
     for k, p in net.named_parameters():
         floor = float(g[f"{tag}::floor::{k}"])
         assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
+
+
+@pytest.mark.parametrize("tag", ["varnet_rnn", "cinenet_rnn", "xpdnet_rnn"])
+def test_oracle_rnn_training_gradients_vs_reference_golden(golden, tag):
+    """The CRNN oracles under autograd reproduce the reference's training-step gradients (rnn_grad.npz)."""
+    from oracle import recurrent_ref as R
+    from reconstruction.utils.losses import SSIMLoss
+    g = golden("rnn_grad")
+    net = {"varnet_rnn": lambda: R.VarNet_RNN(3, 4, 2, 6), "cinenet_rnn": lambda: R.CineNet_RNN(3, 3, 6),
+           "xpdnet_rnn": lambda: R.XPDNet_RNN(3, 4, 2, 6, True, 2, 1)}[tag]()
+    net.load_state_dict(state_dict_from(g, f"{tag}::sd::"), strict=True)
+    mk, mask, target, sens = (torch.from_numpy(g[k]) for k in ("masked_kspace", "mask", "target", "sens_maps"))
+    with torch.enable_grad():
+        out = net(mk, mask, sens) if tag == "cinenet_rnn" else net(mk, mask)
+        h0, w0 = (out.shape[-2] - target.shape[-2]) // 2, (out.shape[-1] - target.shape[-1]) // 2
+        crop = out[..., h0:h0 + target.shape[-2], w0:w0 + target.shape[-1]]
+        loss = SSIMLoss()(crop.unsqueeze(1), target.unsqueeze(1), data_range=target.max())
+        loss.backward()
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-6
+    for k, p in net.named_parameters():
+        floor = float(g[f"{tag}::floor::{k}"])
+        assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
