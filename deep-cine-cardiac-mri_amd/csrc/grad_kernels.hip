@@ -677,6 +677,35 @@ extern "C" int cine_conv3x3_wgrad(const float* x0, int c0, const float* x1, int 
     return launch_wgrad(a, 9, 0, gw, nullptr, wsf, wsn, st);
 }
 
+// gw (cout, cin) += the weight gradient of a 1x1 (x1) convolution, gb += its bias gradient when not NULL; x (n, cin, h, w), g (n, cout, h, w).
+// Volumes: pass (d h, w) -- a 1x1x1 convolution does not see the shape.
+extern "C" size_t cine_conv1x1_wgrad_ws_bytes(int cout, int cin, int n) {
+    if (cout <= 0 || cin <= 0 || n <= 0) return 0;
+    return std::max(wgrad_ws_floats(cout, cin, 1, n), (size_t)n * cout) * sizeof(float);
+}
+extern "C" int cine_conv1x1_wgrad(const float* x, int cin, const float* g, float* gw, float* gb, int n, int cout, int h, int w,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(x && g && gw && ws && cin > 0 && n > 0 && cout > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv1x1_wgrad: bad arguments");
+    CINE_REQUIRE(ws_bytes >= cine_conv1x1_wgrad_ws_bytes(cout, cin, n), CINE_EWORKSPACE, "cine_conv1x1_wgrad: workspace too small");
+    hipStream_t st = as_stream(stream);
+    WgArgs a{};
+    a.s0 = Src{x, nullptr, cin, 0, h, w, 0, 0, 1};
+    a.s1 = Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    a.cin = cin; a.g = g; a.g_mode = 0; a.rows = cout; a.n = n; a.H = h; a.W = w; a.set_split = n; a.eps = 1e-5f; a.slope = 0.2f;
+    float* wsf = reinterpret_cast<float*>(ws);
+    const size_t wsn = ws_bytes / sizeof(float);
+    if (gb) if (int e = launch_bias_grad(g, n, cout, (long)h * w, n, gb, nullptr, wsf, wsn, st)) return e;
+    return launch_wgrad(a, 1, 2, gw, nullptr, wsf, wsn, st);
+}
+
+// gr = d loss / d raw from g = d loss / d act(raw), act = LeakyReLU(InstanceNorm(raw)) of the planes (n, c) of h * w elements with the
+// statistics records part (n, c, np, 3) (unet.py:159-168); g has the tensor's own shape.  Volumes: pass (d h, w).
+extern "C" int cine_in_lrelu_bwd(const float* r, const float* part, int np, const float* g, float* gr, int n, int c, int h, int w,
+                                 float eps, float slope, void* stream) {
+    InBwdArgs a{r, part, np, GradPiece{g, 1, c, 0, h, w}, GradPiece{nullptr, 0, 0, 0, 0, 0}, gr, n, c, h, w, eps, slope};
+    return launch_in_lrelu_bwd(a, as_stream(stream));
+}
+
 namespace cine {
 // ---- SideLane -------------------------------------------------------------------------------------------------------------------------
 namespace {

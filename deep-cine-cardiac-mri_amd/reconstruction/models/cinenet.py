@@ -5,7 +5,7 @@ Drop-in for the reference's models/cinenet.py (CineNet :14, CineNetBlock :77): s
 A^H M A (HOperator :121-133) is one row-FFT kernel, one fused column FFT -> hard mask -> column IFFT
 kernel and one row-IFFT + coil-sum kernel; the CG scalars (alpha, beta, :159-169) stay in device
 memory, so the solve has no host synchronisation and can be captured in a hipGraph.
-GPU tensors only.  With gradients enabled (2D / XT / XF) the forward builds an autograd graph of ``cine_hip.autograd``
+GPU tensors only.  With gradients enabled the forward builds an autograd graph of ``cine_hip.autograd``
 Functions: the bare U-Nets through the HIP backward kernels, the conjugate-gradient solve through its adjoint recurrence
 (the reference detaches the step sizes, cinenet.py:159-169), lambda_reg through both.
 """
@@ -98,14 +98,15 @@ class CineNetBlock(nn.Module):
             return ops.normunet_unpack(self.model(planes), None, h, w).view(b, t, 1, h, w, 2)
         if self.dynamic_type == '3D':
             # (b, t, 1, h, w, 2) -> (b, 2, t, h, w) volumes for the bare 3-D Unet and back (reference cinenet.py:251-253)
+            if ag.grad_mode(self):
+                vol = image_pred.reshape(b, t, h, w, 2).permute(0, 4, 1, 2, 3).contiguous()
+                return ag.unet3d(vol, self.model.hip_weights()).permute(0, 2, 3, 4, 1).reshape(b, t, 1, h, w, 2)
             planes, _ = ops.normunet3d_pack(image_pred.reshape(b, t, h, w, 2), norm=False)
             return ops.normunet3d_unpack(self.model(planes), None, t, h, w).view(b, t, 1, h, w, 2)
         raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
 
     def forward(self, image_pred, image_ref, mask, sens_maps):
         if ag.grad_mode(self):
-            if self.dynamic_type == '3D':
-                raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet (XF / XT / 2D are)")
             if not ops.is_row_mask(mask, sens_maps.expand(-1, image_pred.shape[1], -1, -1, -1, -1)):
                 raise NotImplementedError("training through the HIP path needs the reference's (b, t, 1, h, 1, 1) row mask")
             model_out = self.regularise(image_pred)

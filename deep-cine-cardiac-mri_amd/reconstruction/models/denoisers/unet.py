@@ -94,8 +94,8 @@ class Unet(nn.Module):
         if self.training and self.drop_prob > 0:
             raise NotImplementedError("dropout > 0 in training mode is not supported by the HIP path")
         if self.dims == 3:
-            if ag.grad_mode(self):
-                raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet")
+            if ag.grad_mode(self) or (torch.is_grad_enabled() and image.requires_grad):
+                return ag.unet3d(image, self.hip_weights())
             return ops.unet3d_forward(image, self.hip_weights())
         if ag.grad_mode(self) or (torch.is_grad_enabled() and image.requires_grad):
             return ag.unet2d(image, self.hip_weights())

@@ -527,6 +527,16 @@ size_t cine_conv3x3_wgrad_ws_bytes(int cout, int cin, int n);
 int cine_conv3x3_wgrad(const float* x0, int c0, const float* x1, int c1, const float* g, float* gw, float* gb,
                        int n, int cout, int h, int w, void* ws, size_t ws_bytes, void* stream);
 
+/* Layer-level backward pieces (the 3-D U-Net's backward pass is composed from these, cine_hip/autograd.py: Unet3dFn).
+ * cine_conv1x1_wgrad: gw (cout, cin) += weight gradient of a 1x1(x1) convolution, gb (cout) += bias gradient when not NULL.
+ * cine_in_lrelu_bwd: d loss / d raw from d loss / d LeakyReLU(InstanceNorm(raw)) (unet.py:159-168) for planes (n, c) of h * w
+ * elements with statistics records part (n, c, np, 3).  Volumes pass (d h, w). */
+size_t cine_conv1x1_wgrad_ws_bytes(int cout, int cin, int n);
+int cine_conv1x1_wgrad(const float* x, int cin, const float* g, float* gw, float* gb, int n, int cout, int h, int w,
+                       void* ws, size_t ws_bytes, void* stream);
+int cine_in_lrelu_bwd(const float* r, const float* part, int np, const float* g, float* gr, int n, int c, int h, int w,
+                      float eps, float slope, void* stream);
+
 /* Adjoints of cine_xpd_unpack / cine_xpd_pack (models/xpdnet.py:424-509): gout (b, t, 1, h, w, 2n) -> the gradients of the two MWCNNs' output
  * planes (2n channels, zero on the pad frames) and gmean (b, h, w, n + 1, 2) (the temporal mean of channels < n is added back, :504-509); then
  * from the gradients of the MWCNNs' input planes (2 (n + 1) channels) -> gbuf (b, t, 1, h, w, 2n) and gextra (b, t, 1, h, w, 2) (the

@@ -616,7 +616,7 @@ def g_cinenet_grad():
     sens = sens / RU.rss_complex(sens, dim=2).unsqueeze(-1).unsqueeze(2)
     target = rnd(65, 1, t, 20, 18).abs() + 0.1
     a = dict(masked_kspace=mk, mask=mask, target=target, sens_maps=sens)
-    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)):
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True), ("3D", "3D", False)):
         for seed in range(43, 143):
             net = RM.CineNet(2, 3, 4, 2, dyn, ws)
             synth.fill_parameters_(net, seed)

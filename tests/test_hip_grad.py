@@ -226,7 +226,7 @@ def test_varnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True), ("3D", "3D", False)])
 def test_cinenet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
     """The training step of pl_modules/cinenet_module.py:98-114 on the drop-in CineNet: bare U-Nets through the HIP backward kernels,
     conjugate gradients through the adjoint recurrence (the reference detaches alpha / beta, cinenet.py:159-169), lambda_reg through
@@ -326,6 +326,34 @@ def test_rnn_training_step_vs_reference_golden(dev, golden, tag):
         if sel.any():
             assert (new[k].detach().cpu() - want_new)[sel].abs().max() <= 0.02 * 0.0003, k
     assert not bad, bad
+
+
+@pytest.mark.parametrize("shape,chans,pools", [((1, 2, 5, 12, 10), 4, 2), ((2, 2, 7, 9, 11), 3, 1)])
+def test_unet3d_backward_vs_oracle_autograd(dev, shape, chans, pools):
+    """Unet3dFn (3x3x3 convs as depth-offset passes of the 2-D weight-gradient kernel, transpose conv through the space-to-depth view, odd
+    extents with the up-path zero pad, 2x2x2 pooling adjoint) against the oracle's float64 autograd."""
+    import reconstruction.models as M
+    from oracle import regularisers as R
+    from cine_hip import synth
+    from reconstruction.models.denoisers.unet import Unet
+    net = Unet(chans, pools, in_chans=shape[1], out_chans=2, dims=3)
+    synth.fill_parameters_(net, 5, keep=())
+    ref = R.Unet(chans, pools, in_chans=shape[1], out_chans=2, dims=3).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    torch.manual_seed(1)
+    x = torch.randn(*shape); gy = torch.randn(shape[0], 2, *shape[2:])
+    x64 = x.double().requires_grad_(True)
+    with torch.enable_grad():
+        y64 = ref(x64); y64.backward(gy.double())
+    net = net.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    with torch.enable_grad():
+        y = net(xg); y.backward(gy.to(dev))
+    assert rel_err(y.detach().cpu(), y64.detach()) < 2e-5
+    assert rel_err(xg.grad.cpu(), x64.grad) < 5e-5
+    want = dict(ref.named_parameters())
+    for k, p in net.named_parameters():
+        assert rel_err(p.grad.cpu(), want[k].grad) < 5e-5, k
 
 
 def test_conv_sum_and_bcrnn_backward_vs_torch_autograd(dev):

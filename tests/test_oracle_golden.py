@@ -230,7 +230,7 @@ def test_oracle_training_step_gradients_vs_reference_golden(golden, tag, dyn, sh
         assert rel_err(p.grad, g[f"{tag}::grad::{k}"]) < max(1e-5, 20 * floor), k
 
 
-@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("2D", "2D", False)])
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("2D", "2D", False), ("3D", "3D", False)])
 def test_oracle_cinenet_training_gradients_vs_reference_golden(golden, tag, dyn, share):
     """The CineNet oracle under autograd (conjugate gradients with detached step sizes, cinenet.py:159-169) reproduces the
     reference's training-step gradients (cinenet_grad.npz)."""

@@ -1,5 +1,5 @@
 """Diagnostic: time of one training step (forward + SSIMLoss + backward + Adam) on the HIP path, per kernel family.
-usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet]"""
+usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet, 5 = CRNN-VarNet]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-cine-cardiac-mri_amd")]
@@ -13,7 +13,8 @@ from cine_hip._lib import lib
 dev = torch.device("cuda:0")
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ex = synth.make_cine_slice(15, 15, 200, 200, accel=4 if cfg == 2 else 8, seed=0)
-net = M.VarNet(6, 8, 3, 16, 3, "XF") if cfg == 2 else M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
+net = {2: lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), 3: lambda: M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT"),
+       5: lambda: M.VarNet_RNN(5, 8, 3, 16)}[cfg]()
 synth.fill_parameters_(net, 1); net = net.to(dev).train()
 mk, mask, target = ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev)
 lossf = SSIMLoss().to(dev)
