@@ -469,10 +469,11 @@ def measure_training_step(args, dev, threads, cfg_id=2, cpu=True):
         lossf = SSIMLoss().to(device)
         opt = torch.optim.Adam(model.parameters(), lr=3e-4)
         mk, mask, target = ex["masked_kspace"].to(device), ex["mask"].to(device), ex["target"].to(device)
+        extra = (ex["sens_maps"].to(device),) if cfg["needs_sens"] else ()
 
         def step():
             opt.zero_grad(set_to_none=True)
-            out = model(mk, mask)
+            out = model(mk, mask, *extra)
             loss = lossf(out.unsqueeze(1), target.unsqueeze(1), target.max())
             loss.backward()
             opt.step()
@@ -634,10 +635,12 @@ def main():
             line["train_step"] = measure_training_step(args, dev, best_threads)
         except Exception as e:                                            # pragma: no cover
             line["train_step"] = {"error": f"{type(e).__name__}: {e}"}
-        try:                                                              # XT-XPDNet (cfg 3): MWCNN backward; GPU only (the CPU oracle's step takes a minute)
-            line["train_step_cfg3"] = measure_training_step(args, dev, best_threads, cfg_id=3, cpu=False)
-        except Exception as e:                                            # pragma: no cover
-            line["train_step_cfg3"] = {"error": f"{type(e).__name__}: {e}"}
+        line["train_step_other_configs"] = {}     # XT-XPDNet (MWCNN backward), 3D CineNet, CRNN-VarNet (back-propagation through time): GPU only
+        for cid in (3, 4, 5):
+            try:
+                line["train_step_other_configs"][str(cid)] = measure_training_step(args, dev, best_threads, cfg_id=cid, cpu=False)
+            except Exception as e:                                        # pragma: no cover
+                line["train_step_other_configs"][str(cid)] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

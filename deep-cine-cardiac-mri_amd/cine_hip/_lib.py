@@ -135,7 +135,8 @@ _SIGS = {
     "cine_conv3x3_wgrad": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_conv1x1_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cine_conv1x1_wgrad": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),
-    "cine_in_lrelu_bwd": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_in_lrelu_bwd_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "cine_in_lrelu_bwd": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P, c_size_t, P]),
     "cine_xpd_unpack_bwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_xpd_pack_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_unpack_bwd": (c_int, [P, P, P, P, P, c_int, c_int, c_int, P]),

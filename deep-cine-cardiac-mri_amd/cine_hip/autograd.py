@@ -558,8 +558,10 @@ class Unet3dFn(Function):
             g = _c(g)
             out = torch.empty_like(raw)
             nn_, c, dd, hh, ww = raw.shape
-            check(L.cine_in_lrelu_bwd(raw.data_ptr(), part.data_ptr(), 1, g.data_ptr(), out.data_ptr(), nn_, c, dd * hh, ww, eps, slope, _stream()),
-                  "cine_in_lrelu_bwd")
+            nb = L.cine_in_lrelu_bwd_ws_bytes(nn_, c, dd * hh, ww)
+            ws = torch.empty(nb, device=dev, dtype=torch.uint8) if nb else None
+            check(L.cine_in_lrelu_bwd(raw.data_ptr(), part.data_ptr(), 1, g.data_ptr(), out.data_ptr(), nn_, c, dd * hh, ww, eps, slope,
+                                      _p(ws), nb, _stream()), "cine_in_lrelu_bwd")
             return out
 
         def dgrad3(g, weight):                                    # (n, cout, d, h, w) -> (n, cin, d, h, w)

@@ -141,6 +141,81 @@ int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st) {
     return check_launch("in_lrelu_bwd_kernel");
 }
 
+// Few, large planes (volumes: 16 channels of 15 x 200 x 200): a plane is cut into chunks of kInBwdChunk elements, one workgroup each.
+// Pass 1 writes the chunk's two sums, pass 2 re-adds the plane's chunk sums in index order (deterministic) and applies.  Window / pooled
+// pieces only.
+constexpr int kInBwdChunk = 8192;
+__global__ __launch_bounds__(256) void in_lrelu_bwd_sums_kernel(InBwdArgs a, float* __restrict__ ws, int nchunk) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long pl = blockIdx.y;
+    const int n = (int)(pl / a.c), c = (int)(pl - (long)n * a.c);
+    const int pe = a.h * a.w;
+    const float2 mr = merge_partials(a.part + pl * a.np * 3, a.np, a.eps);
+    const float scale = mr.y, shift = -mr.x * mr.y;
+    const float* r = a.r + pl * pe;
+    const float* qa = piece_plane(a.a, n, c);
+    const float* qb = piece_plane(a.b, n, c);
+    const int e0 = blockIdx.x * kInBwdChunk, e1 = min(pe, e0 + kInBwdChunk);
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int y = e / a.w, x = e - y * a.w;
+        const float xh = fmaf(r[e], scale, shift);
+        float g = piece_at(a.a, qa, y, x) + (qb ? piece_at(a.b, qb, y, x) : 0.f);
+        g = xh > 0.f ? g : g * a.slope;
+        s1 += g; s2 = fmaf(g, xh, s2);
+    }
+    s1 = wave_sum_g(s1); s2 = wave_sum_g(s2);
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = ws + (pl * nchunk + blockIdx.x) * 2;
+        o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+__global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(InBwdArgs a, const float* __restrict__ ws, int nchunk) {
+    const long pl = blockIdx.y;
+    const int n = (int)(pl / a.c), c = (int)(pl - (long)n * a.c);
+    const int pe = a.h * a.w;
+    const float2 mr = merge_partials(a.part + pl * a.np * 3, a.np, a.eps);
+    const float scale = mr.y, shift = -mr.x * mr.y;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) { s1 += ws[(pl * nchunk + k) * 2]; s2 += ws[(pl * nchunk + k) * 2 + 1]; }
+    const float m1 = s1 / pe, m2 = s2 / pe;
+    const float* r = a.r + pl * pe;
+    float* gr = a.gr + pl * pe;
+    const float* qa = piece_plane(a.a, n, c);
+    const float* qb = piece_plane(a.b, n, c);
+    const int e0 = blockIdx.x * kInBwdChunk, e1 = min(pe, e0 + kInBwdChunk);
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int y = e / a.w, x = e - y * a.w;
+        const float xh = fmaf(r[e], scale, shift);
+        float g = piece_at(a.a, qa, y, x) + (qb ? piece_at(a.b, qb, y, x) : 0.f);
+        g = xh > 0.f ? g : g * a.slope;
+        gr[e] = scale * (g - m1 - xh * m2);
+    }
+}
+size_t in_lrelu_bwd_ws_floats(int n, int c, int h, int w) {
+    const long pe = (long)h * w;
+    return pe > 4 * kInBwdChunk ? (size_t)n * c * ceil_div(pe, (long)kInBwdChunk) * 2 : 0;
+}
+int launch_in_lrelu_bwd_split(const InBwdArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
+    const size_t need = in_lrelu_bwd_ws_floats(a.n, a.c, a.h, a.w);
+    const bool haar = a.a.type >= 3 || a.b.type >= 3;
+    if (!need || !ws || haar || (long)a.n * a.c >= 2048) return launch_in_lrelu_bwd(a, st);
+    CINE_REQUIRE(ws_floats >= need, CINE_EWORKSPACE, "in_lrelu_bwd: workspace too small");
+    CINE_REQUIRE(a.r && a.part && a.gr && a.a.g && a.np > 0 && (long)a.n * a.c <= 65535, CINE_EINVAL, "in_lrelu_bwd: bad arguments");
+    CINE_REQUIRE(a.a.type != 1 || (a.a.gh >= a.h && a.a.gw >= a.w), CINE_EINVAL, "in_lrelu_bwd: gradient window smaller than the tensor");
+    const int nchunk = (int)ceil_div((long)a.h * a.w, (long)kInBwdChunk);
+    ProfScope prof(F_STATS, st);
+    const dim3 grid((unsigned)nchunk, (unsigned)((long)a.n * a.c));
+    hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, grid, dim3(256), 0, st, a, ws, nchunk);
+    hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, grid, dim3(256), 0, st, a, ws, nchunk);
+    return check_launch("in_lrelu_bwd_apply_kernel");
+}
+
+
 // ---------------------------------------------------------------- weight gradient (MFMA)
 // One workgroup = 4 waves = one 16-channel chunk of the conv input x one block of 16*CT*WM output rows x one chunk of
 // samples.  Per tile of NPIX = TH x TW pixels it stages the (re-activated) input tile with its halo and the output-gradient
@@ -700,10 +775,13 @@ extern "C" int cine_conv1x1_wgrad(const float* x, int cin, const float* g, float
 
 // gr = d loss / d raw from g = d loss / d act(raw), act = LeakyReLU(InstanceNorm(raw)) of the planes (n, c) of h * w elements with the
 // statistics records part (n, c, np, 3) (unet.py:159-168); g has the tensor's own shape.  Volumes: pass (d h, w).
+extern "C" size_t cine_in_lrelu_bwd_ws_bytes(int n, int c, int h, int w) {
+    return (n <= 0 || c <= 0 || h <= 0 || w <= 0) ? 0 : in_lrelu_bwd_ws_floats(n, c, h, w) * sizeof(float);
+}
 extern "C" int cine_in_lrelu_bwd(const float* r, const float* part, int np, const float* g, float* gr, int n, int c, int h, int w,
-                                 float eps, float slope, void* stream) {
+                                 float eps, float slope, void* ws, size_t ws_bytes, void* stream) {
     InBwdArgs a{r, part, np, GradPiece{g, 1, c, 0, h, w}, GradPiece{nullptr, 0, 0, 0, 0, 0}, gr, n, c, h, w, eps, slope};
-    return launch_in_lrelu_bwd(a, as_stream(stream));
+    return launch_in_lrelu_bwd_split(a, reinterpret_cast<float*>(ws), ws_bytes / sizeof(float), as_stream(stream));
 }
 
 namespace cine {

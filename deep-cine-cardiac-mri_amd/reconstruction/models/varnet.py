@@ -107,7 +107,7 @@ class VarNetBlock(nn.Module):
         if self.dynamic_type == '2D':
             return self.model(image_combined.squeeze(0)).unsqueeze(0)
         if self.dynamic_type == '3D':
-            return self.model(image_combined.permute(0, 2, 1, 3, 4, 5)).permute(0, 2, 1, 3, 4, 5)
+            return self.model(image_combined.permute(0, 2, 1, 3, 4, 5)).permute(0, 2, 1, 3, 4, 5).contiguous()
         raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
 
     def forward(self, current_kspace, ref_kspace, mask, sens_maps, _destroy_current: bool = False):
@@ -148,8 +148,6 @@ class VarNet(nn.Module):
         """The image-space cascade chain of ``_forward_infer`` as an autograd graph (reference varnet.py:143-151)."""
         if not ops.is_row_mask(mask, masked_kspace):
             raise NotImplementedError("training through the HIP path needs the reference's (b, t, 1, h, 1, 1) row mask")
-        if self.cascades and self.cascades[0].dynamic_type == '3D':
-            raise NotImplementedError("training through the 3-D U-Net is not on the HIP path yet (XF / XT / 2D are)")
         if sens_maps is None:
             sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)          # first cascade's sens_reduce(masked_kspace)

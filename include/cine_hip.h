@@ -534,8 +534,9 @@ int cine_conv3x3_wgrad(const float* x0, int c0, const float* x1, int c1, const f
 size_t cine_conv1x1_wgrad_ws_bytes(int cout, int cin, int n);
 int cine_conv1x1_wgrad(const float* x, int cin, const float* g, float* gw, float* gb, int n, int cout, int h, int w,
                        void* ws, size_t ws_bytes, void* stream);
+size_t cine_in_lrelu_bwd_ws_bytes(int n, int c, int h, int w);      /* 0 for small planes; large ones are cut into chunks (ws may be NULL then: one workgroup per plane) */
 int cine_in_lrelu_bwd(const float* r, const float* part, int np, const float* g, float* gr, int n, int c, int h, int w,
-                      float eps, float slope, void* stream);
+                      float eps, float slope, void* ws, size_t ws_bytes, void* stream);
 
 /* Adjoints of cine_xpd_unpack / cine_xpd_pack (models/xpdnet.py:424-509): gout (b, t, 1, h, w, 2n) -> the gradients of the two MWCNNs' output
  * planes (2n channels, zero on the pad frames) and gmean (b, h, w, n + 1, 2) (the temporal mean of channels < n is added back, :504-509); then

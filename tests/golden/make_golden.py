@@ -492,7 +492,7 @@ def g_varnet_grad():
     mk = rnd(44, 1, t, c, h, w, 2) * mask          # white k-space: every x-f / y-f plane carries signal (well-conditioned InstanceNorms)
     target = rnd(45, 1, t, 20, 18).abs() + 0.1     # (1, t, 20, 18): exercises the center crop
     a = dict(masked_kspace=mk, mask=mask, target=target)
-    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)):
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True), ("3D", "3D", False)):
         # the weight seed is the first whose reference gradients are stable under 1e-6 input perturbations (see _kink_stability):
         # about one fixture in three sits on a LeakyReLU kink and cannot pin any float32 implementation, the reference included
         for seed in range(43, 143):

@@ -197,7 +197,7 @@ def _training_step(model, mk, mask, target, lr=0.0003, extra=()):
     return loss.detach(), grads, output.detach()
 
 
-@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True), ("3D", "3D", False)])
 def test_varnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
     """The reference's training step on the drop-in VarNet: loss, every parameter gradient and the weights after one Adam
     step against the reference's own (varnet_grad.npz)."""

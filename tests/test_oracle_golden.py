@@ -209,7 +209,7 @@ def test_rnn_models(golden):
         assert rel_err(net(mk, mask), g["xpdnet_rnn_out"]) < 1e-4
 
 
-@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True)])
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("2D", "2D", False), ("XFws", "XF", True), ("3D", "3D", False)])
 def test_oracle_training_step_gradients_vs_reference_golden(golden, tag, dyn, share):
     """The oracle under autograd reproduces the reference's training-step gradients (pl_modules/varnet_module.py:97-113 +
     loss.backward(); varnet_grad.npz) -- it is the checker of the HIP backward kernels (tests/test_hip_grad.py)."""

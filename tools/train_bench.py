@@ -1,5 +1,5 @@
 """Diagnostic: time of one training step (forward + SSIMLoss + backward + Adam) on the HIP path, per kernel family.
-usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet, 5 = CRNN-VarNet]"""
+usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet, 4 = 3D-CineNet, 5 = CRNN-VarNet]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-cine-cardiac-mri_amd")]
@@ -12,17 +12,18 @@ from cine_hip._lib import lib
 
 dev = torch.device("cuda:0")
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-ex = synth.make_cine_slice(15, 15, 200, 200, accel=4 if cfg == 2 else 8, seed=0)
+ex = synth.make_cine_slice(15, 15, 200, 200, accel={2: 4, 3: 8, 4: 6, 5: 8}[cfg], seed=0)
 net = {2: lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), 3: lambda: M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT"),
-       5: lambda: M.VarNet_RNN(5, 8, 3, 16)}[cfg]()
+       4: lambda: M.CineNet(6, 6, 16, 3, "3D"), 5: lambda: M.VarNet_RNN(5, 8, 3, 16)}[cfg]()
 synth.fill_parameters_(net, 1); net = net.to(dev).train()
 mk, mask, target = ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev)
+extra = (ex["sens_maps"].to(dev),) if cfg == 4 else ()
 lossf = SSIMLoss().to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=3e-4)
 
 def step():
     opt.zero_grad(set_to_none=True)
-    out = net(mk, mask)
+    out = net(mk, mask, *extra)
     loss = lossf(out.unsqueeze(1), target.unsqueeze(1), target.max())
     loss.backward()
     opt.step()
@@ -36,9 +37,9 @@ for _ in range(n): l = step()
 torch.cuda.synchronize()
 print(f"training step: {(time.time() - t0) / n * 1e3:.1f} ms   loss {float(l):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
 with torch.no_grad():
-    for _ in range(2): net(mk, mask)
+    for _ in range(2): net(mk, mask, *extra)
     torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(n): net(mk, mask)
+    for _ in range(n): net(mk, mask, *extra)
     torch.cuda.synchronize()
 print(f"inference forward (eager): {(time.time() - t0) / n * 1e3:.1f} ms")
 L = lib()
