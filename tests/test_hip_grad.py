@@ -328,7 +328,35 @@ def test_rnn_training_step_vs_reference_golden(dev, golden, tag):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("shape,chans,pools", [((1, 2, 5, 12, 10), 4, 2), ((2, 2, 7, 9, 11), 3, 1)])
+def test_in_lrelu_bwd_large_planes_vs_torch_autograd(dev):
+    """cine_in_lrelu_bwd on few, large planes (the 3-D U-Net's volumes): planes above 32 768 elements are cut into 8 192-element chunks
+    (chunk sums, fixed-order re-add, apply) -- against float64 autograd of LeakyReLU(InstanceNorm(x)); ragged last chunk, odd width."""
+    from cine_hip import ops
+    from cine_hip._lib import lib, check
+    import torch.nn.functional as F
+    torch.manual_seed(2)
+    n, c, h, w = 2, 3, 211, 199                       # 41 989 elements per plane: six chunks, the last one ragged
+    x = torch.randn(n, c, h, w) * 1.7 + 0.3
+    g = torch.randn(n, c, h, w)
+    x64 = x.double().requires_grad_(True)
+    with torch.enable_grad():
+        F.leaky_relu(F.instance_norm(x64, eps=1e-5), 0.2).backward(g.double())
+    xd, gd = x.to(dev), g.to(dev)
+    part = ops.instnorm_partials(xd)
+    out = torch.empty_like(xd)
+    L = lib()
+    nb = L.cine_in_lrelu_bwd_ws_bytes(n, c, h, w)
+    assert nb > 0
+    ws = torch.empty(nb, device=dev, dtype=torch.uint8)
+    st = torch.cuda.current_stream().cuda_stream
+    check(L.cine_in_lrelu_bwd(xd.data_ptr(), part.data_ptr(), 1, gd.data_ptr(), out.data_ptr(), n, c, h, w, 1e-5, 0.2, ws.data_ptr(), nb, st), "cine_in_lrelu_bwd")
+    assert rel_err(out.cpu(), x64.grad) < 2e-5
+    out2 = torch.empty_like(xd)                         # without a workspace: one workgroup per plane, same result up to summation order
+    check(L.cine_in_lrelu_bwd(xd.data_ptr(), part.data_ptr(), 1, gd.data_ptr(), out2.data_ptr(), n, c, h, w, 1e-5, 0.2, None, 0, st), "cine_in_lrelu_bwd")
+    assert rel_err(out2.cpu(), x64.grad) < 2e-5
+
+
+@pytest.mark.parametrize("shape,chans,pools", [((1, 2, 5, 12, 10), 4, 2), ((2, 2, 7, 9, 11), 3, 1), ((1, 2, 6, 88, 80), 2, 1)])
 def test_unet3d_backward_vs_oracle_autograd(dev, shape, chans, pools):
     """Unet3dFn (3x3x3 convs as depth-offset passes of the 2-D weight-gradient kernel, transpose conv through the space-to-depth view, odd
     extents with the up-path zero pad, 2x2x2 pooling adjoint) against the oracle's float64 autograd."""
