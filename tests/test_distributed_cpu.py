@@ -50,6 +50,49 @@ def test_slice_sharding_and_assembly_gloo_world2():
         assert owned == list(range(n_slices))            # every slice reconstructed by exactly one rank
 
 
+def _train_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from cine_hip import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)                                       # the same weights on every rank
+    shared = torch.nn.Conv2d(2, 3, 3, padding=1)
+    net = torch.nn.ModuleList([shared, shared, torch.nn.Conv2d(3, 1, 1)])     # an aliased module, like the cascades' networks
+    sync = shard.GradientAllReduce(net)
+    assert len(sync.params) == 4
+
+    def loss_of(r):
+        g = torch.Generator().manual_seed(50 + r)
+        x = torch.randn(1, 2, 6, 5, generator=g)
+        return net[2](net[1](x) + net[0](x)).square().mean()
+    loss_of(rank).backward()
+    sync()
+    got = [p.grad.clone() for p in sync.params]
+    net.zero_grad()
+    (sum(loss_of(r) for r in range(world)) / world).backward()                 # the same average on one rank
+    ok = all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, sync.params))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_averages_over_ranks_gloo_world2():
+    """Data-parallel training: per-rank gradients -> one flat all-reduce -> the mean over the ranks' slices, aliased parameters once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, 29621, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 def test_single_process_assembly_is_identity():
     from cine_hip import shard
     x = torch.rand(5, 2, 3)
