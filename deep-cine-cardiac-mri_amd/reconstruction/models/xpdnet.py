@@ -8,7 +8,7 @@ and state-dict keys (``sens_net.unet_model.*``, ``image_net.N[.{0,1}].*`` and th
   I step : row IFFT + conj(S) + coil sum; buffer pack (temporal mean / XPDNet's own temporal transform /
            x-f, y-f rotation / left-heavy zero pad); two MWCNNs; unpack
 and never materialises the k-space buffer.  ``primal_only=False`` adds the KSpaceCNN dual update (Conv3d on the MFMA kernel) and materialises
-the k-space buffer.  GPU tensors only.  With gradients enabled (primal-only, XT / XF, row masks) the forward builds an autograd graph of
+the k-space buffer.  GPU tensors only.  With gradients enabled (primal-only, XT / XF / 2D, row masks) the forward builds an autograd graph of
 ``cine_hip.autograd`` Functions: the sensitivity network, the K step + masked backward operator (image-space, with respect to image and maps),
 the I-step network (buffer pack / both MWCNNs / unpack) -- all with hand-written HIP backward kernels.
 """
@@ -104,6 +104,9 @@ class XPDNetBlock(nn.Module):
         if self.dynamic_type == '2D':
             # (b, t, 1, h, w, 2(n+1)) channel-last -> (b*t, 2(n+1), h, w); no padding in 2-D mode (:442-444)
             cat = torch.cat([image_buffer[..., :n], backward_img[..., :1], image_buffer[..., n:], backward_img[..., 1:]], dim=-1)
+            if ag.grad_mode(self):      # the frames are the MWCNN's batch; the module's forward dispatches to the HIP backward kernels
+                planes = cat.reshape(b * t, h, w, 2 * (n + 1)).permute(0, 3, 1, 2).contiguous()
+                return nets(planes).permute(0, 2, 3, 1).reshape(b, t, 1, h, w, 2 * n)
             planes = ops.chanlast_to_planes(cat.reshape(b * t, h, w, 2 * (n + 1)))
             return ops.planes_to_chanlast(nets(planes), h, w).view(b, t, 1, h, w, 2 * n)
         raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
@@ -164,8 +167,8 @@ class XPDNet(nn.Module):
     def _forward_train(self, masked_kspace, mask, acs):
         """The primal-only chain of ``_forward_infer`` (reference xpdnet.py:301-326) as an autograd graph."""
         n = self.i_buffer_size
-        if self.k_buffer_mode or self.dynamic_type not in ['XF', 'XT'] or not ops.is_row_mask(mask, masked_kspace):
-            raise NotImplementedError("training through the HIP path: primal-only XPDNet, dynamic_type XF / XT, the reference's row mask")
+        if self.k_buffer_mode or self.dynamic_type not in ['XF', 'XT', '2D'] or not ops.is_row_mask(mask, masked_kspace):
+            raise NotImplementedError("training through the HIP path: primal-only XPDNet, dynamic_type XF / XT / 2D, the reference's row mask")
         sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)           # unmasked backward op (:303)
         image_buffer = image.repeat_interleave(n, dim=-1)                        # (:307): [re x n, im x n]

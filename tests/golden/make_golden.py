@@ -655,7 +655,7 @@ def g_xpdnet_grad():
     a = dict(masked_kspace=mk, mask=mask, target=target)
     kw = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
               n_convs_per_scale=[2, 1], first_conv_n_filters=8, n_primal=2)
-    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True)):
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True), ("2D", "2D", False)):
         for seed in range(43, 143):
             net = RM.XPDNet(dynamic_type=dyn, weight_sharing=ws, primal_only=True, **kw)
             synth.fill_parameters_(net, seed, keep=())
@@ -720,7 +720,55 @@ def g_rnn_grad():
     save("rnn_grad", **a)
 
 
-GENERATORS = dict(rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def _grad_fingerprint(name, net, ex, extra=(), noise_seed=950, nper=2):
+    """Strided fingerprints of the reference's parameter gradients at a full BASELINE shape + the reference's own movement under 1e-6
+    input perturbations (see g_varnet_grad_cfg2)."""
+    import copy
+    target = ex["target"].contiguous()
+    net0 = copy.deepcopy(net)
+    mk = ex["masked_kspace"]
+    loss, grads, new, out = _training_step(net, mk, ex["mask"], target, extra=extra)
+    a = dict(loss=loss, out_strided=out[:, :, ::4, ::4].contiguous())
+    self_max, self_norm = {k: 0.0 for k in grads}, {k: 0.0 for k in grads}
+    for i in range(nper):
+        gi = _training_step(copy.deepcopy(net0), mk * (1 + 1e-6 * rnd(noise_seed + i, *mk.shape)), ex["mask"], target, extra=extra)[1]
+        for k, g in grads.items():
+            self_max[k] = max(self_max[k], float((gi[k] - g).abs().max() / g.abs().max().clamp_min(1e-30)))
+            self_norm[k] = max(self_norm[k], float((gi[k] - g).double().norm() / g.double().norm().clamp_min(1e-30)))
+    for k, g in grads.items():
+        flat = g.reshape(-1)
+        a[f"grad::{k}"] = flat[::max(1, flat.numel() // 256)].contiguous()
+        a[f"gnorm::{k}"] = g.double().norm()
+        a[f"gmax::{k}"] = g.abs().max()
+        a[f"selfmax::{k}"] = self_max[k]; a[f"selfnorm::{k}"] = self_norm[k]
+    save(name, **a)
+
+
+def g_xpdnet_grad_cfg3():
+    """cfg 3 (XT-XPDNet, 10 cascades, MWCNN defaults, n_primal 5, R = 8, noise 0.01): gradient fingerprints of the reference's training step."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=8, seed=0, noise_std=0.01)
+    net = RM.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
+    synth.fill_parameters_(net, 6, keep=())
+    _grad_fingerprint("xpdnet_grad_cfg3", net, ex, nper=1)
+
+
+def g_cinenet_grad_cfg4():
+    """cfg 4 (3D CineNet, 6 cascades, CG 6, R = 6, analytic sensitivity maps): gradient fingerprints of the reference's training step."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=6, seed=0)
+    net = RM.CineNet(6, 6, 16, 3, "3D")
+    synth.fill_parameters_(net, 7)
+    _grad_fingerprint("cinenet_grad_cfg4", net, ex, extra=(ex["sens_maps"],), nper=4)
+
+
+def g_rnn_grad_cfg5():
+    """cfg 5 (CRNN-VarNet, 5 cascades, 16 hidden channels, R = 8): gradient fingerprints of the reference's training step."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=8, seed=0)
+    net = RM.VarNet_RNN(5, 8, 3, 16)
+    synth.fill_parameters_(net, 9)
+    _grad_fingerprint("rnn_grad_cfg5", net, ex, nper=2)
+
+
+GENERATORS = dict(xpdnet_grad_cfg3=g_xpdnet_grad_cfg3, cinenet_grad_cfg4=g_cinenet_grad_cfg4, rnn_grad_cfg5=g_rnn_grad_cfg5, rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)

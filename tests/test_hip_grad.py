@@ -268,7 +268,7 @@ _XPD_GRAD_KW = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_fi
                     first_conv_n_filters=8, n_primal=2)
 
 
-@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True)])
+@pytest.mark.parametrize("tag,dyn,share", [("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True), ("2D", "2D", False)])
 def test_xpdnet_training_step_vs_reference_golden(dev, golden, tag, dyn, share):
     """The training step of pl_modules/xpdnet_module.py on the drop-in primal-only XPDNet: sensitivity network (residual U-Net, RSS
     normalisation), K step + masked backward operator with respect to image and maps, the I-step network (buffer pack with XPDNet's own
@@ -429,13 +429,13 @@ def test_conv_sum_and_bcrnn_backward_vs_torch_autograd(dev):
 
 
 def test_xpdnet_training_rejects_what_is_not_on_the_hip_path(dev):
-    """Dual (k-space net) and 2-D XPDNets train only in the reference; the HIP path says so instead of returning wrong gradients."""
+    """Dual (k-space net) XPDNets train only in the reference; the HIP path says so instead of returning wrong gradients."""
     import reconstruction.models as M
     from cine_hip import synth
     t, c, h, w = 3, 2, 16, 16
     mk = torch.randn(1, t, c, h, w, 2, device=dev)
     mask = torch.zeros(1, t, 1, h, 1, 1, device=dev); mask[:, :, :, ::2] = 1
-    for kw in (dict(dynamic_type="2D"), dict(dynamic_type="XF", primal_only=False)):
+    for kw in (dict(dynamic_type="XF", primal_only=False),):
         net = M.XPDNet(num_cascades=1, sens_chans=2, sens_pools=1, n_scales=1, n_filters_per_scale=[4], n_convs_per_scale=[1],
                        first_conv_n_filters=4, n_primal=2, **kw).to(dev).train()
         with torch.enable_grad(), pytest.raises(NotImplementedError):
@@ -470,6 +470,43 @@ def test_varnet_cfg2_training_step_vs_reference_fingerprint(dev, golden):
         en = abs(float(grads[k].double().norm()) - float(g[f"gnorm::{k}"])) / float(g[f"gnorm::{k}"])
         if e > max(5e-3, 3 * float(g[f"selfmax::{k}"])) or en > max(3e-3, 3 * float(g[f"selfnorm::{k}"])):
             bad[k] = (e, en)
+    assert not bad, bad
+
+
+_FULL_SIZE = {
+    "xpdnet_grad_cfg3": (lambda M: M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT"), 6, (), 8, 0.01, False),
+    "cinenet_grad_cfg4": (lambda M: M.CineNet(6, 6, 16, 3, "3D"), 7, ("lambda",), 6, 0.0, True),
+    "rnn_grad_cfg5": (lambda M: M.VarNet_RNN(5, 8, 3, 16), 9, ("lambda",), 8, 0.0, False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_FULL_SIZE))
+def test_other_configs_training_step_vs_reference_fingerprint(dev, golden, name):
+    """cfg 3 / 4 / 5 at full size (15 coils x 15 frames x 200 x 200): the training step on the HIP path against strided fingerprints of
+    the reference's parameter gradients, with the same bar as cfg 2 -- the larger of 5e-3 (max) / 3e-3 (L2) and 3x the reference's own
+    movement under a 1e-6 input change.  The full-size code paths (vectorised staging with halo columns, chunked InstanceNorm backward
+    on the 3-D volumes, 15-frame time sweeps) only run here."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    make, wseed, keep, accel, noise, needs_sens = _FULL_SIZE[name]
+    g = golden(name)
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=accel, seed=0, noise_std=noise)
+    net = make(M)
+    synth.fill_parameters_(net, wseed, keep=keep)
+    net = net.to(dev).train()
+    with torch.enable_grad():
+        loss, grads, out = _training_step(net, ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev),
+                                          extra=(ex["sens_maps"].to(dev),) if needs_sens else ())
+    assert rel_err(out[:, :, ::4, ::4].cpu(), g["out_strided"]) < (2e-3 if name == "xpdnet_grad_cfg3" else TOL)    # cfg 3: see bench.py parity_note
+    assert abs(float(loss) - float(g["loss"])) < 1e-4
+    bad = {}
+    for k in (k[6:] for k in g if k.startswith("grad::")):
+        flat = grads[k].reshape(-1)
+        got = flat[::max(1, flat.numel() // 256)].cpu()
+        e = float((got.double() - torch.from_numpy(g[f"grad::{k}"]).double()).abs().max() / max(float(g[f"gmax::{k}"]), 1e-30))
+        en = abs(float(grads[k].double().norm()) - float(g[f"gnorm::{k}"])) / max(float(g[f"gnorm::{k}"]), 1e-30)
+        if e > max(5e-3, 3 * float(g[f"selfmax::{k}"])) or en > max(3e-3, 3 * float(g[f"selfnorm::{k}"])):
+            bad[k] = (e, en, float(g[f"selfmax::{k}"]))
     assert not bad, bad
 
 
