@@ -40,6 +40,8 @@ struct WgArgs {
     int n, H, W;
     int set_split;
     float eps, slope;
+    float* mat; size_t mat_floats;   // optional scratch (n, cin, H, W): sources the vectorised staging cannot read (wavelet modes, summed or pooled
+                                     // sources) are materialised there first and the launch then reads them as one plain tensor
 };
 size_t wgrad_ws_floats(int rows, int cin, int taps, int n);
 int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1, float* ws, size_t ws_floats, hipStream_t st);

@@ -525,6 +525,33 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
 
 // grad += sum over the partial sums of one weight set.  A workgroup owns 64 consecutive weights (coalesced 256-byte reads of
 // every partial) and splits the chunks over its 16 waves; the 16 wave sums are added in a fixed order (deterministic).
+// One plane (sample n, conv-input channel cg) of the transformed conv input -- concat or sum of the two sources, any on-load mode -- written
+// out as a plain tensor (launch_wgrad: sources the vectorised staging cannot read directly).
+__global__ __launch_bounds__(256) void wgrad_materialise_kernel(WgArgs a, float* __restrict__ out) {
+    extern __shared__ float st_m[];                      // {scale, shift} of every source channel of this sample
+    const int n = blockIdx.x / a.cin, cg = blockIdx.x - n * a.cin;
+    auto table_of = [&](const Src& s, float* st) {
+        const bool stats = s.mode == 1 || s.mode == 2 || (s.mode >= 3 && (s.act & 1));
+        for (int cl = threadIdx.x; cl < s.c; cl += 256) {
+            float2 mr = make_float2(0.f, 1.f);
+            if (stats) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+            st[2 * cl] = mr.y; st[2 * cl + 1] = -mr.x * mr.y;
+        }
+    };
+    table_of(a.s0, st_m); table_of(a.s1, st_m + 2 * a.s0.c);
+    __syncthreads();
+    const int c0n = src_cin(a.s0);
+    float* o = out + (long)blockIdx.x * a.H * a.W;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < a.H * a.W; e += gridDim.y * 256) {
+        const int gy = e / a.W, gx = e - gy * a.W;
+        float v;
+        if (a.add_src1) v = fetch_scalar(a.s0, n, cg, 0, gy, gx, st_m, a.slope) + fetch_scalar(a.s1, n, cg, 0, gy, gx, st_m + 2 * a.s0.c, a.slope);
+        else if (cg < c0n) v = fetch_scalar(a.s0, n, cg, 0, gy, gx, st_m, a.slope);
+        else v = fetch_scalar(a.s1, n, cg - c0n, 0, gy, gx, st_m + 2 * a.s0.c, a.slope);
+        o[e] = v;
+    }
+}
+
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* part, int nchunks, int rows, int cin, int rowsp, int cinp,
                                                             int taps, int kind, float* grad0, float* grad1) {
     __shared__ float red[16][64];
@@ -611,9 +638,30 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
     CINE_REQUIRE((a.add_src1 && a.s1.c > 0) ? (src_cin(a.s0) == a.cin && src_cin(a.s1) == a.cin) : (src_cin(a.s0) + src_cin(a.s1) == a.cin), CINE_EINVAL,
                  "wgrad: channel counts");
     CINE_REQUIRE(a.set_split >= 0 && a.set_split <= a.n && (a.set_split == a.n || grad1), CINE_EINVAL, "wgrad: second weight set without a gradient");
+    const int TW = a.W > 8 ? 16 : a.W > 4 ? 8 : a.W > 2 ? 4 : 2;
+    {   // sources the vectorised staging cannot read: materialise the transformed conv input once, then read it as a plain tensor
+        const int PW0 = TW >= 4 ? 4 : 2;
+        auto plain = [&](const Src& s) { return s.c == 0 || (s.mode <= 1 && s.w == a.W && s.h <= a.H); };
+        const size_t elems = (size_t)a.n * a.cin * a.H * a.W;
+        if (a.mat && (a.add_src1 || !plain(a.s0) || !plain(a.s1)) && a.W % PW0 == 0 && a.mat_floats >= elems && elems >= (1u << 16) &&
+            (long)a.n * a.cin <= 0x7fffffffL) {
+            const size_t lds = (size_t)2 * (a.s0.c + a.s1.c) * sizeof(float);
+            CINE_REQUIRE(lds <= 48 * 1024, CINE_EUNSUPPORTED, "wgrad: too many source channels");
+            {
+                ProfScope prof(F_MISC, st);
+                const int gy = std::max(1, std::min(64, (int)ceil_div((long)a.H * a.W, 2048L)));
+                hipLaunchKernelGGL(wgrad_materialise_kernel, dim3((unsigned)(a.n * a.cin), (unsigned)gy), dim3(256), lds, st, a, a.mat);
+                if (int e = check_launch("wgrad_materialise_kernel")) return e;
+            }
+            WgArgs b = a;
+            b.s0 = Src{a.mat, nullptr, a.cin, 0, a.H, a.W, 0, 0, 1};
+            b.s1 = Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+            b.add_src1 = 0; b.mat = nullptr; b.mat_floats = 0;
+            return launch_wgrad(b, taps, kind, grad0, grad1, ws, ws_floats, st);
+        }
+    }
     WgLaunch L{};
     L.a = a;
-    const int TW = a.W > 8 ? 16 : a.W > 4 ? 8 : a.W > 2 ? 4 : 2;
     L.rowsp = ceil_div(a.rows, 16) * 16; L.cinp = ceil_div(a.cin, 16) * 16;
     const int cob = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : a.rows <= 64 ? 64 : 128;
     const int rowsb = ceil_div(L.rowsp, cob) * cob;

@@ -282,6 +282,17 @@ extern "C" int cine_mwcnn_forward_train(const float* x, float* y, const void* co
     return conv(last, M_IWT_ACT, &t.first_feat, M_ACT, 1, woff[p.S], true, y, nullptr, out_ch, h, w);
 }
 
+// the largest conv input (n, cin, h_s, w_s) over the layers: scratch for launch_wgrad's materialised sources
+static size_t mwcnn_mat_floats(const Plan& p, int n, int h, int w, int in_ch) {
+    size_t m = (size_t)n * std::max(p.first, in_ch) * h * w;
+    for (int s = 0; s < p.S; ++s)
+        for (int i = 0; i < 2 * p.nc[s]; ++i) {
+            int ci, co; chans(p, s, i, ci, co);
+            m = std::max(m, (size_t)n * ci * (h >> (s + 1)) * (w >> (s + 1)));
+        }
+    return m;
+}
+
 extern "C" size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
                                                const int* n_convs, int first_filters) {
     if (n <= 0 || h <= 0 || w <= 0 || n_scales < 1 || n_scales > kMaxScales || !n_filters || !n_convs) return 0;
@@ -300,6 +311,7 @@ extern "C" size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, i
         }
     b.take(big); b.take(big);                                         // d/d(raw) of the tensor in hand, two alternating buffers (SideLane)
     b.take(wg);
+    b.take(mwcnn_mat_floats(p, n, h, w, in_ch));                      // materialised conv inputs of the weight gradients
     return b.off;
 }
 
@@ -344,6 +356,8 @@ extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* 
     float* grb[2] = {bb.take(big), nullptr};
     grb[1] = bb.take(big);
     float* wgs = bb.take(wgf);
+    const size_t matf = mwcnn_mat_floats(p, n, h, w, in_ch);
+    float* mat = bb.take(matf);
     hipStream_t st = as_stream(stream);
     SideLane lane(st);              // weight gradients on the side stream (grad.h)
     float* gr = nullptr;
@@ -356,6 +370,7 @@ extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* 
     auto wgrad = [&](const ConvIn& c, const float* g, int rows, int cin, int hh, int ww, int widx) {
         WgArgs a{}; a.s0 = src_of(c.s0, c.m0); a.s1 = c.add ? src_of(c.s1, c.m1) : none; a.add_src1 = c.add; a.cin = cin;
         a.g = g; a.g_mode = 0; a.rows = rows; a.n = n; a.H = hh; a.W = ww; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
+        a.mat = mat; a.mat_floats = matf;
         hipStream_t sw = lane.fork();
         const int err = launch_wgrad(a, 9, 0, GR(widx, 0), GR(widx, 1), wgs, wgf, sw);
         lane.launched();

@@ -276,8 +276,8 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
 // gradient, and the partial sums of the weight-gradient kernel.
 namespace {
 struct BwdPlan {
-    float *A, *B[2], *cat[8], *pool, *wg;
-    size_t wg_floats;
+    float *A, *B[2], *cat[8], *pool, *wg, *mat;
+    size_t wg_floats, mat_floats;
 };
 void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch) {
     const int P = p.P;
@@ -303,6 +303,10 @@ void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch)
     wg = std::max(wg, (size_t)n * out_ch);                  // bias-gradient partial sums
     q.wg_floats = wg;
     q.wg = b.take(wg);
+    size_t mat = 16;                                          // pooled conv inputs (first conv of every level below the top), materialised for the weight gradient
+    for (int d = 1; d <= P; ++d) mat = std::max(mat, (size_t)n * p.ch[d - 1] * p.hs[d] * p.wsz[d]);
+    q.mat_floats = mat;
+    q.mat = b.take(mat);
 }
 }  // namespace
 
@@ -359,6 +363,7 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
     auto wgrad3 = [&](const Src& s0, const Src& s1, const float* g, int rows, int hh, int ww, int wi) {
         WgArgs a{}; a.s0 = s0; a.s1 = s1; a.cin = src_cin(s0) + src_cin(s1); a.g = g; a.g_mode = 0; a.rows = rows;
         a.n = n; a.H = hh; a.W = ww; a.set_split = sp; a.eps = kEps; a.slope = kSlope;
+        a.mat = q.mat; a.mat_floats = q.mat_floats;
         return on_side([&](hipStream_t sw) { return launch_wgrad(a, 9, 0, gr(wi, 0), gr(wi, 1), q.wg, q.wg_floats, sw); });
     };
     auto inbwd = [&](const float* r, const float* part, int np, int c, int hh, int ww, const float* ga, int ca_total, int ca_off,

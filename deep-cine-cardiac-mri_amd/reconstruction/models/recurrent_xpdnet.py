@@ -50,13 +50,13 @@ class XPDNet_RNN(CRNNBody):
         state = self.zero_state(t, b, h, w, image_buffer)
         keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]
         for _ in range(self.num_cascades):
-            x0 = image_buffer[..., [0, n]]
+            x0 = torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1)
             bwd = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)
             cat = torch.cat([image_buffer[..., :n], bwd[..., :1], image_buffer[..., n:], bwd[..., 1:]], dim=-1)
             planes = cat.view(t, h, w, 2 * (n + 1)).permute(0, 3, 1, 2).contiguous()                       # (t, 2(n+1), h, w)
-            out, state = self.body_train(planes.view(t, 1, 2 * (n + 1), h, w), state, planes[:, keep].contiguous())
+            out, state = self.body_train(planes.view(t, 1, 2 * (n + 1), h, w), state, torch.cat([planes[:, :n], planes[:, n + 1:2 * n + 1]], dim=1))
             image_buffer = out.permute(0, 2, 3, 1).reshape(1, t, 1, h, w, 2 * n)
-        return ag.AbsFn.apply(image_buffer[..., [0, n]].squeeze(2))
+        return ag.AbsFn.apply(torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1).squeeze(2))
 
     def _forward_infer(self, ref_kspace, mask, acs):
         n = self.i_buffer_size

@@ -174,10 +174,10 @@ class XPDNet(nn.Module):
         image_buffer = image.repeat_interleave(n, dim=-1)                        # (:307): [re x n, im x n]
         zf = ag.CoilReduceFn.apply(masked_kspace, sens_maps, mask)              # A^H M k_ref
         for i_domain in range(1, len(self.domain_sequence), 2):
-            x0 = image_buffer[..., [0, n]]                                       # channel 0 of the buffer (:128)
+            x0 = torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1)                                       # channel 0 of the buffer (:128)
             backward_img = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)     # A^H M (A x0 - k_ref)
             image_buffer = self.cascades[i_domain].regularise(i_domain, image_buffer, backward_img)
-        return ag.AbsFn.apply(image_buffer[..., [0, n]].squeeze(2))               # (:321-326)
+        return ag.AbsFn.apply(torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1).squeeze(2))               # (:321-326)
 
     def _forward_infer(self, masked_kspace, mask, acs):
         n = self.i_buffer_size
