@@ -574,7 +574,7 @@ class Unet3dFn(Function):
             return gx
 
         def wgrad3(x0, x1, g, weight):                            # weight gradient of a 3x3x3 conv over cat(x0, x1)
-            gw = torch.zeros_like(weight, memory_format=torch.contiguous_format)
+            gwz = torch.zeros((3,) + tuple(weight.shape[:2]) + (3, 3), device=dev, dtype=dt)      # [kz][cout][cin][3][3]: one plain 2-D gradient per depth tap
             dd = g.shape[2]
             for i in range(g.shape[0]):                           # depth slices become the samples of the 2-D weight-gradient kernel
                 xs = [t[i].transpose(0, 1).contiguous() for t in (x0, x1) if t is not None]
@@ -582,12 +582,9 @@ class Unet3dFn(Function):
                 for kz in range(3):
                     dz = kz - 1
                     z0, z1 = max(0, -dz), dd - max(0, dz)
-                    if z1 <= z0:
-                        continue
-                    g2 = torch.zeros(weight.shape[:2] + (3, 3), device=dev, dtype=dt)
-                    _conv_wgrad_(g2, None, xs[0][z0 + dz:z1 + dz], xs[1][z0 + dz:z1 + dz] if len(xs) > 1 else None, gs[z0:z1])
-                    gw[:, :, kz] += g2
-            return gw
+                    if z1 > z0:
+                        _conv_wgrad_(gwz[kz], None, xs[0][z0 + dz:z1 + dz], xs[1][z0 + dz:z1 + dz] if len(xs) > 1 else None, gs[z0:z1])
+            return gwz.permute(1, 2, 0, 3, 4).contiguous()
 
         def wgrad1(xa, g, cout):                                  # (cout, cin) of a 1x1x1 conv; bias gradient too when asked
             nn_, ci = xa.shape[:2]

@@ -712,16 +712,18 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
 // ---------------------------------------------------------------- bias gradient
 // one workgroup per (channel, sample): the sample's pixel sum into ws[co][n]; then one wave per (set, channel) adds the samples of
 // its set in a fixed order
-__global__ __launch_bounds__(256) void bias_partial_kernel(const float* g, int cout, long hw, float* ws, int n) {
+// (large planes with few samples -- volumes -- are cut into `chunks` pieces per plane: ws[co][n][chunk])
+__global__ __launch_bounds__(256) void bias_partial_kernel(const float* g, int cout, long hw, float* ws, int n, int chunks) {
     __shared__ float red[4];
-    const int co = blockIdx.x, i = blockIdx.y;
+    const int co = blockIdx.x, i = blockIdx.y, k = blockIdx.z;
     const float* p = g + ((long)i * cout + co) * hw;
+    const long per = (hw + chunks - 1) / chunks, e0 = k * per, e1 = e0 + per < hw ? e0 + per : hw;
     float s = 0.f;
-    for (long e = threadIdx.x; e < hw; e += 256) s += p[e];
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) s += p[e];
     s = wave_sum_g(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) ws[(long)co * n + i] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) ws[((long)co * n + i) * chunks + k] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ __launch_bounds__(64) void bias_final_kernel(const float* ws, int n, int set_split, float* gb0, float* gb1) {
     const int co = blockIdx.x, set = blockIdx.y;
@@ -738,8 +740,10 @@ int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, fl
     CINE_REQUIRE(g && gb0 && ws && n > 0 && n <= 65535 && cout > 0 && hw > 0, CINE_EINVAL, "bias_grad: bad arguments");
     CINE_REQUIRE(ws_floats >= (size_t)n * cout, CINE_EWORKSPACE, "bias_grad: workspace too small");
     ProfScope prof(F_STATS, st);
-    hipLaunchKernelGGL(bias_partial_kernel, dim3(cout, n), dim3(256), 0, st, g, cout, hw, ws, n);
-    hipLaunchKernelGGL(bias_final_kernel, dim3(cout, set_split < n ? 2 : 1), dim3(64), 0, st, ws, n, set_split, gb0, gb1);
+    const long want = (long)n * cout >= 512 ? 1 : std::min(64L, ceil_div(hw, 8192L));          // few planes: spread each over workgroups
+    const int chunks = (int)std::max(1L, std::min(want, (long)(ws_floats / ((size_t)n * cout))));
+    hipLaunchKernelGGL(bias_partial_kernel, dim3(cout, n, chunks), dim3(256), 0, st, g, cout, hw, ws, n, chunks);
+    hipLaunchKernelGGL(bias_final_kernel, dim3(cout, set_split < n ? 2 : 1), dim3(64), 0, st, ws, n * chunks, set_split * chunks, gb0, gb1);
     return check_launch("bias_grad_kernel");
 }
 
