@@ -10,6 +10,9 @@ if [ "$PART" = train ]; then
 # the training step: kernel trace of tools/train_bench.py (2 warm-up + 2 timed + 1 event-profiled step = 5 steps)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/trace_train -o t --output-format csv -- python3 $R/tools/train_bench.py 2 > $O/trace_train.log 2>&1
+for c in 3 4 5; do   # the other BASELINE configurations' training steps
+  rocprofv3 --kernel-trace --stats -d $O/trace_train_cfg$c -o t --output-format csv -- python3 $R/tools/train_bench.py 2 $c > $O/trace_train_cfg$c.log 2>&1
+done
 cd $R
 find $O -name "*_kernel_trace.csv" -delete
 exit 0
