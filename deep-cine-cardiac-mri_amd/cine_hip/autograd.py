@@ -683,6 +683,107 @@ def unet3d(x: torch.Tensor, weights: "ops.UnetWeights") -> torch.Tensor:
     return Unet3dFn.apply(x, weights, *weights.distinct_params())
 
 
+# ---- k-space networks (XPDNet's dual update, denoisers/kspace_net.py; xpdnet.py:372-403) ----------------------------------------------------
+def _conv3d_dgrad(g, weight):
+    """(n, cout, d, h, w) -> (n, cin, d, h, w): the forward 3x3x3 kernel on the flipped / transposed packing."""
+    wp = ops._pack("c27", weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous())
+    n, cout, d, h, w = g.shape
+    ci = weight.shape[1]
+    gx = torch.empty((n, ci, d, h, w), device=g.device, dtype=g.dtype)
+    check(lib().cine_conv3d_in(g.data_ptr(), None, 0, cout, 0, d, h, w, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(), None, None, 0,
+                               gx.data_ptr(), None, n, ci, d, h, w, ops.IN_EPS, ops.LRELU_SLOPE, _stream()), "cine_conv3d_in")
+    return gx
+
+
+def _conv3d_wgrad(x, g, weight, want_bias):
+    """Weight (and bias) gradient of a 3x3x3 conv: one launch of the 2-D weight-gradient kernel per depth tap, depth slices as samples."""
+    gwz = torch.zeros((3,) + tuple(weight.shape[:2]) + (3, 3), device=g.device, dtype=g.dtype)
+    gb = torch.zeros(weight.shape[0], device=g.device, dtype=g.dtype) if want_bias else None
+    d = g.shape[2]
+    for i in range(g.shape[0]):
+        xs = x[i].transpose(0, 1).contiguous()
+        gs = g[i].transpose(0, 1).contiguous()
+        for kz in range(3):
+            dz = kz - 1
+            z0, z1 = max(0, -dz), d - max(0, dz)
+            if z1 > z0:
+                _conv_wgrad_(gwz[kz], gb if kz == 1 else None, xs[z0 + dz:z1 + dz], None, gs[z0:z1])
+    return gwz.permute(1, 2, 0, 3, 4).contiguous(), gb
+
+
+class Conv3dBiasReluFn(Function):
+    """y = [ReLU](Conv3d(x; W, 3x3x3, 'same') + b) on (n, c, d, h, w) (kspace_net.py:33-46)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x = ops._dev(x, "conv3d input")
+        y = ops.conv3d_bias_relu(x, weight, bias, bool(relu))
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x, weight, y if relu else torch.empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        g = ops._dev(_c(gy), "conv3d output gradient")
+        if ctx.relu:
+            g = _relu_mask_(g.clone(), y)
+        need = ctx.needs_input_grad
+        gx = _conv3d_dgrad(g, weight) if need[0] else None
+        gw = gb = None
+        if need[1] or need[2]:
+            gw, gb = _conv3d_wgrad(x, g, weight, need[2])
+        return gx, gw if need[1] else None, gb, None
+
+
+class SensExpandFn(Function):
+    """k = [M] FFT2(S x) (xpdnet.py:104-131, ForwardOperator): x (b, t, 1, h, w, 2), maps (b, 1, c, h, w, 2) -> (b, t, c, h, w, 2)."""
+
+    @staticmethod
+    def forward(ctx, x, sens, mask):
+        x = ops._dev(x, "image"); sens = ops._dev(sens, "sens_maps")
+        ctx.save_for_backward(x, sens, mask if mask is not None else torch.empty(0))
+        ctx.masked = mask is not None
+        return ops.sens_expand_dc(x, sens, None, mask, None, hard_mask=mask is not None)
+
+    @staticmethod
+    def backward(ctx, gk):
+        x, sens, mask = ctx.saved_tensors
+        gk = ops._dev(_c(gk), "k-space gradient")
+        if ctx.masked:
+            gk = ops.apply_mask(gk, mask)
+        z = ops.fft2c(gk, inverse=True)                       # coil images of the gradient (the FFT is unitary)
+        need = ctx.needs_input_grad
+        gx = ops.sens_reduce(gk, sens) if need[0] else None
+        gs = coil_accum(x, z) if need[1] else None            # sum_t conj(x_t) z_{t, c}
+        return gx, gs, None
+
+
+class SensReduceFn(Function):
+    """x = sum_c conj(S_c) IFFT2([M] k) (xpdnet.py:137-167, BackwardOperator) with gradients for the k-space too (the dual buffer is learned)."""
+
+    @staticmethod
+    def forward(ctx, k, sens, mask):
+        k = ops._dev(k, "k-space"); sens = ops._dev(sens, "sens_maps")
+        if mask is not None:
+            k = ops.apply_mask(k, mask)
+        ctx.save_for_backward(k, sens, mask if mask is not None else torch.empty(0))
+        ctx.masked = mask is not None
+        return ops.sens_reduce(k, sens)
+
+    @staticmethod
+    def backward(ctx, gx):
+        k, sens, mask = ctx.saved_tensors
+        gx = ops._dev(_c(gx), "image gradient")
+        need = ctx.needs_input_grad
+        gk = gs = None
+        if need[0]:
+            gk = ops.sens_expand_dc(gx, sens, None, mask if ctx.masked else None, None, hard_mask=ctx.masked)
+        if need[1]:
+            gs = coil_accum(gx, ops.fft2c(k, inverse=True))
+        return gk, gs, None
+
+
 # ---- convolutional-RNN cells (models/recurrent_varnet.py:153-259) --------------------------------------------------------------------
 def _relu_mask_(g: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     check(lib().cine_relu_mask(g.data_ptr(), y.data_ptr(), g.numel(), _stream()), "cine_relu_mask")

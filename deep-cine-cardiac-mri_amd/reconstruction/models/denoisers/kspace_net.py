@@ -7,6 +7,7 @@ Bias and ReLU ride in the MFMA kernel's epilogue; the layers hold the parameters
 import torch
 from torch import nn
 
+from cine_hip import autograd as ag
 from cine_hip import ops
 
 
@@ -26,6 +27,10 @@ class KSpaceCNN(nn.Module):
         b, t, c, h, w, ch = inputs.shape
         x = inputs.permute(0, 2, 5, 1, 3, 4).reshape(b * c, ch, t, h, w).contiguous()
         convs = [m for m in self.layers if isinstance(m, nn.Conv3d)]
+        train = ag.grad_mode(self) or (torch.is_grad_enabled() and inputs.requires_grad)
         for i, conv in enumerate(convs):
-            x = ops.conv3d_bias_relu(x, conv.weight, conv.bias, relu=i < len(convs) - 1)
+            if train:       # the layer as an autograd node with a HIP backward (cine_hip.autograd.Conv3dBiasReluFn)
+                x = ag.Conv3dBiasReluFn.apply(x, conv.weight, conv.bias, i < len(convs) - 1)
+            else:
+                x = ops.conv3d_bias_relu(x, conv.weight, conv.bias, relu=i < len(convs) - 1)
         return x.reshape(b, c, self.out_chans, t, h, w).permute(0, 3, 1, 4, 5, 2)

@@ -38,25 +38,34 @@ class XPDNet_RNN(CRNNBody):
             return self._forward_infer(ref_kspace, mask, acs)
 
     def _forward_train(self, ref_kspace, mask, acs):
-        """The primal-only chain of ``_forward_infer`` as an autograd graph: sensitivity network, K step + masked backward operator
-        (image space, with respect to image and maps), CRNN body on the (image buffer, backward image) planes."""
-        n = self.i_buffer_size
+        """The chain of ``_forward_infer`` as an autograd graph: sensitivity network, K step + masked backward operator (image space for the
+        primal-only model; forward / k-space net / backward Functions with the dual buffer), CRNN body on the buffer planes."""
+        n, nd = self.i_buffer_size, self.k_buffer_size
         b, t, _, h, w, _ = ref_kspace.shape
-        if b != 1 or self.k_buffer_mode or not ops.is_row_mask(mask, ref_kspace):
-            raise NotImplementedError("training through the HIP path: primal-only, batch 1, the reference's (b, t, 1, h, 1, 1) row mask")
+        if b != 1 or not ops.is_row_mask(mask, ref_kspace):
+            raise NotImplementedError("training through the HIP path: batch 1, the reference's (b, t, 1, h, 1, 1) row mask")
+        pick = lambda buf, k: torch.stack((buf[..., 0], buf[..., k]), dim=-1)
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         image_buffer = ag.CoilReduceFn.apply(ref_kspace, sens_maps, None).repeat_interleave(n, dim=-1)     # (1, t, 1, h, w, 2n)
-        zf = ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
+        if self.k_buffer_mode:
+            kbuf = ref_kspace.repeat_interleave(nd, dim=-1)
+        else:
+            zf = ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
         state = self.zero_state(t, b, h, w, image_buffer)
-        keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]
-        for _ in range(self.num_cascades):
-            x0 = torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1)
-            bwd = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)
+        for i in range(self.num_cascades):
+            x0 = pick(image_buffer, n)
+            if self.k_buffer_mode:
+                fwd = ag.SensExpandFn.apply(x0, sens_maps, mask)
+                cat_k = torch.cat([kbuf[..., :nd], fwd[..., :1], ref_kspace[..., :1], kbuf[..., nd:], fwd[..., 1:], ref_kspace[..., 1:]], dim=-1)
+                kbuf = self.kspace_net[i](cat_k)
+                bwd = ag.SensReduceFn.apply(pick(kbuf, nd).contiguous(), sens_maps, mask)
+            else:
+                bwd = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)
             cat = torch.cat([image_buffer[..., :n], bwd[..., :1], image_buffer[..., n:], bwd[..., 1:]], dim=-1)
             planes = cat.view(t, h, w, 2 * (n + 1)).permute(0, 3, 1, 2).contiguous()                       # (t, 2(n+1), h, w)
             out, state = self.body_train(planes.view(t, 1, 2 * (n + 1), h, w), state, torch.cat([planes[:, :n], planes[:, n + 1:2 * n + 1]], dim=1))
             image_buffer = out.permute(0, 2, 3, 1).reshape(1, t, 1, h, w, 2 * n)
-        return ag.AbsFn.apply(torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1).squeeze(2))
+        return ag.AbsFn.apply(pick(image_buffer, n).squeeze(2))
 
     def _forward_infer(self, ref_kspace, mask, acs):
         n = self.i_buffer_size

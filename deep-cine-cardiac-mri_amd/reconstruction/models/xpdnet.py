@@ -8,7 +8,7 @@ and state-dict keys (``sens_net.unet_model.*``, ``image_net.N[.{0,1}].*`` and th
   I step : row IFFT + conj(S) + coil sum; buffer pack (temporal mean / XPDNet's own temporal transform /
            x-f, y-f rotation / left-heavy zero pad); two MWCNNs; unpack
 and never materialises the k-space buffer.  ``primal_only=False`` adds the KSpaceCNN dual update (Conv3d on the MFMA kernel) and materialises
-the k-space buffer.  GPU tensors only.  With gradients enabled (primal-only, XT / XF / 2D, row masks) the forward builds an autograd graph of
+the k-space buffer.  GPU tensors only.  With gradients enabled (XT / XF / 2D, row masks; with or without the dual net) the forward builds an autograd graph of
 ``cine_hip.autograd`` Functions: the sensitivity network, the K step + masked backward operator (image-space, with respect to image and maps),
 the I-step network (buffer pack / both MWCNNs / unpack) -- all with hand-written HIP backward kernels.
 """
@@ -165,19 +165,31 @@ class XPDNet(nn.Module):
             return self._forward_infer(masked_kspace, mask, acs)
 
     def _forward_train(self, masked_kspace, mask, acs):
-        """The primal-only chain of ``_forward_infer`` (reference xpdnet.py:301-326) as an autograd graph."""
-        n = self.i_buffer_size
-        if self.k_buffer_mode or self.dynamic_type not in ['XF', 'XT', '2D'] or not ops.is_row_mask(mask, masked_kspace):
-            raise NotImplementedError("training through the HIP path: primal-only XPDNet, dynamic_type XF / XT / 2D, the reference's row mask")
+        """The chain of ``_forward_infer`` (reference xpdnet.py:301-326) as an autograd graph.  Primal-only: the K step + masked backward
+        operator is one image-space Function; with the KSpaceCNN dual net the k-space buffer is a learned quantity and the forward / backward
+        operators are Functions with k-space gradients (FFT2 is unitary: each adjoint is the other operator)."""
+        n, nd = self.i_buffer_size, self.k_buffer_size
+        if self.dynamic_type not in ['XF', 'XT', '2D'] or not ops.is_row_mask(mask, masked_kspace):
+            raise NotImplementedError("training through the HIP path: dynamic_type XF / XT / 2D, the reference's row mask")
+        pick = lambda buf, k: torch.stack((buf[..., 0], buf[..., k]), dim=-1)
         sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)           # unmasked backward op (:303)
         image_buffer = image.repeat_interleave(n, dim=-1)                        # (:307): [re x n, im x n]
-        zf = ag.CoilReduceFn.apply(masked_kspace, sens_maps, mask)              # A^H M k_ref
+        if self.k_buffer_mode:
+            kbuf = masked_kspace.repeat_interleave(nd, dim=-1)                   # (:306)
+        else:
+            zf = ag.CoilReduceFn.apply(masked_kspace, sens_maps, mask)          # A^H M k_ref
         for i_domain in range(1, len(self.domain_sequence), 2):
-            x0 = torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1)                                       # channel 0 of the buffer (:128)
-            backward_img = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)     # A^H M (A x0 - k_ref)
+            x0 = pick(image_buffer, n)                                           # channel 0 of the buffer (:128)
+            if self.k_buffer_mode:
+                fwd = ag.SensExpandFn.apply(x0, sens_maps, mask)                 # M A x0 (:385-403)
+                cat = torch.cat([kbuf[..., :nd], fwd[..., :1], masked_kspace[..., :1], kbuf[..., nd:], fwd[..., 1:], masked_kspace[..., 1:]], dim=-1)
+                kbuf = self.kspace_net[i_domain // 2](cat)
+                backward_img = ag.SensReduceFn.apply(pick(kbuf, nd).contiguous(), sens_maps, mask)      # masked backward op (:161-167)
+            else:
+                backward_img = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)         # A^H M (A x0 - k_ref)
             image_buffer = self.cascades[i_domain].regularise(i_domain, image_buffer, backward_img)
-        return ag.AbsFn.apply(torch.stack((image_buffer[..., 0], image_buffer[..., n]), dim=-1).squeeze(2))               # (:321-326)
+        return ag.AbsFn.apply(pick(image_buffer, n).squeeze(2))                   # (:321-326)
 
     def _forward_infer(self, masked_kspace, mask, acs):
         n = self.i_buffer_size

@@ -655,9 +655,9 @@ def g_xpdnet_grad():
     a = dict(masked_kspace=mk, mask=mask, target=target)
     kw = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16],
               n_convs_per_scale=[2, 1], first_conv_n_filters=8, n_primal=2)
-    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True), ("2D", "2D", False)):
+    for tag, dyn, ws in (("XF", "XF", False), ("XT", "XT", False), ("XFws", "XF", True), ("2D", "2D", False), ("XFdual", "XF", False)):
         for seed in range(43, 143):
-            net = RM.XPDNet(dynamic_type=dyn, weight_sharing=ws, primal_only=True, **kw)
+            net = RM.XPDNet(dynamic_type=dyn, weight_sharing=ws, primal_only=tag != "XFdual", **kw)
             synth.fill_parameters_(net, seed, keep=())
             stab = _kink_stability(net, mk, mask, target)
             print(f"    {tag}: weight seed {seed}: gradient change under 1e-6 input perturbations {stab:.2e}")
@@ -693,7 +693,8 @@ def g_rnn_grad():
     a = dict(masked_kspace=mk, mask=mask, target=target, sens_maps=sens)
     for tag, make, extra, keep in (("varnet_rnn", lambda: RM.VarNet_RNN(3, 4, 2, 6), (), ("lambda",)),
                                    ("cinenet_rnn", lambda: RM.CineNet_RNN(3, 3, 6), (sens,), ("lambda",)),
-                                   ("xpdnet_rnn", lambda: RM.XPDNet_RNN(3, 4, 2, 6, True, 2, 1), (), ())):
+                                   ("xpdnet_rnn", lambda: RM.XPDNet_RNN(3, 4, 2, 6, True, 2, 1), (), ()),
+                                   ("xpdnet_rnn_dual", lambda: RM.XPDNet_RNN(3, 4, 2, 6, False, 2, 1), (), ())):
         for seed in range(43, 143):
             net = make()
             synth.fill_parameters_(net, seed, keep=keep)
