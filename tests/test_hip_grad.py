@@ -479,6 +479,69 @@ def test_other_configs_training_step_vs_reference_fingerprint(dev, golden, name)
     assert not bad, bad
 
 
+def _odd_mask(t, h):
+    m = torch.zeros(1, t, 1, h, 1, 1, dtype=torch.uint8)
+    c0 = h // 2 - 2
+    m[:, :, :, c0:c0 + 4] = 1
+    for f in range(t):
+        for r in (1, 6, h - 3):
+            m[:, f, :, (r + 2 * f) % h] = 1
+    m[:, 0, :, c0 - 1] = 0
+    m[:, 0, :, c0 + 4] = 0
+    return m
+
+
+@pytest.mark.parametrize("family", ["varnet_XF", "varnet_XT", "cinenet_XF", "xpdnet_XT", "varnet_3D", "varnet_rnn"])
+def test_training_gradients_on_odd_shapes_vs_oracle_float64(dev, family):
+    """Odd extents everywhere (7 frames, 23 x 19 pixels: ragged tiles, zero pads on both sides, the up-path pad of the 3-D U-Net, unaligned
+    frames in the time sweep): the HIP training gradients against the oracle's float64 autograd of the same model, on three different
+    k-spaces.  A float32 run can sit on a LeakyReLU / ReLU kink the float64 run does not (make_golden.py:_kink_stability: one of five
+    k-spaces moves two XPDNet gradient tensors by 1e-2, the others agree to 1e-5), an indexing mistake is there for every input: the bar
+    is 1e-3 of each tensor's largest gradient on the BEST of the three inputs, and 5e-2 on every one of them."""
+    import reconstruction.models as M
+    from reconstruction.utils import SSIMLoss
+    from cine_hip import synth
+    from oracle import varnet_ref as V, cinenet_ref as C, xpdnet_ref as X, recurrent_ref as R
+    t, c, h, w = 7, 3, 23, 19
+    kwx = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1],
+               first_conv_n_filters=8, n_primal=2, dynamic_type="XT")
+    make = {"varnet_XF": (lambda m: m.VarNet(2, 4, 2, 4, 2, "XF"), V), "varnet_XT": (lambda m: m.VarNet(2, 4, 2, 4, 2, "XT"), V),
+            "varnet_3D": (lambda m: m.VarNet(2, 4, 2, 4, 2, "3D"), V), "cinenet_XF": (lambda m: m.CineNet(2, 3, 4, 2, "XF"), C),
+            "xpdnet_XT": (lambda m: m.XPDNet(**kwx), X), "varnet_rnn": (lambda m: m.VarNet_RNN(2, 4, 2, 5), R)}[family]
+    net = make[0](M)
+    synth.fill_parameters_(net, 11, keep=() if family == "xpdnet_XT" else ("lambda",))
+    ref = make[0](make[1]).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()}, strict=True)
+    net = net.to(dev).train()
+    mask = _odd_mask(t, h)
+    sens = rnd(32, 1, 1, c, h, w, 2)
+    sens = sens / sens.pow(2).sum(dim=(2, 5), keepdim=True).sqrt()
+    target = rnd(33, 1, t, h - 4, w - 2).abs() + 0.1
+    extra = (sens,) if family.startswith("cinenet") else ()
+
+    def loss_of(model, mk, device, dtype):
+        out = model(mk.to(device, dtype), mask.to(device), *(e.to(device, dtype) for e in extra))
+        h0, w0 = (out.shape[-2] - target.shape[-2]) // 2, (out.shape[-1] - target.shape[-1]) // 2
+        crop = out[..., h0:h0 + target.shape[-2], w0:w0 + target.shape[-1]]
+        tg = target.to(device, dtype)
+        lossf = SSIMLoss().to(device)
+        return (lossf.double() if dtype == torch.float64 else lossf)(crop.unsqueeze(1), tg.unsqueeze(1), data_range=tg.max())
+    best, worst = {}, {}
+    for seed in (31, 41, 51):
+        mk = rnd(seed, 1, t, c, h, w, 2) * mask
+        ref.zero_grad(); net.zero_grad()
+        with torch.enable_grad():
+            l64 = loss_of(ref, mk, torch.device("cpu"), torch.float64); l64.backward()
+            l32 = loss_of(net, mk, dev, torch.float32); l32.backward()
+        assert abs(float(l32) - float(l64)) < 1e-4
+        want = dict(ref.named_parameters())
+        for k, p in net.named_parameters():
+            e = rel_err(p.grad.cpu(), want[k].grad.float())
+            best[k] = min(best.get(k, 1e9), e); worst[k] = max(worst.get(k, 0.0), e)
+    bad = {k: (best[k], worst[k]) for k in best if best[k] > 1e-3 or worst[k] > 5e-2}
+    assert not bad, bad
+
+
 def test_inference_path_untouched_by_grad_mode(dev, golden):
     """With autograd off the drop-in model takes the inference path (bit-identical to a no_grad call), and a grad-mode forward
     returns the same values to rounding."""
