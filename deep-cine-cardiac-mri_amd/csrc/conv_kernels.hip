@@ -832,6 +832,20 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     conv_tile<CK, CT, WM, WN, MT, TW, TAPS, V3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
 }
 
+// Experiment (-DCINE_PERSIST=<workgroups>): a fixed grid of workgroups that walk the tiles in launch order (x fastest), one after the other.
+#ifdef CINE_PERSIST
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3 = 0>
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_persist_kernel(ConvArgs a, int gx, int gy, int gz) {
+    extern __shared__ __align__(16) float smem_f[];
+    const long total = (long)gx * gy * gz;
+    for (long t = blockIdx.x; t < total; t += gridDim.x) {
+        const int bx = (int)(t % gx), by = (int)((t / gx) % gy), bz = (int)(t / ((long)gx * gy));
+        conv_tile<CK, CT, WM, WN, MT, TW, TAPS, V3>(a, bx, by, bz, smem_f);
+        __syncthreads();
+    }
+}
+#endif
+
 // Two independent sample sets in one grid: samples [0, pair_n) use the ordinary pointers, samples [pair_n, n) the *_b set.
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
 __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_pair_kernel(ConvArgs a) {
@@ -1284,6 +1298,15 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
         return CINE_OK;
     }
     ProfScope prof(fam, st);
+#ifdef CINE_PERSIST
+    if constexpr (!PAIR) {
+        const long total = (long)grid.x * grid.y * grid.z;
+        if (total > CINE_PERSIST && lds <= 64 * 1024) {
+            hipLaunchKernelGGL((conv_mfma_persist_kernel<CK, CT, WM, WN, MT, TW, TAPS, V3>), dim3(CINE_PERSIST), dim3(C::NT), lds, st, a, (int)grid.x, (int)grid.y, (int)grid.z);
+            return check_launch("conv_mfma_persist_kernel");
+        }
+    }
+#endif
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, a);
     return check_launch("conv_mfma_kernel");
 }
