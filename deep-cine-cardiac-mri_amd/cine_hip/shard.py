@@ -52,7 +52,6 @@ class GradientAllReduce:
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p)); self.params.append(p)
         self.group = group
-        self._flat = None
 
     def __call__(self) -> None:
         if not (dist.is_available() and dist.is_initialized()):
@@ -63,14 +62,7 @@ class GradientAllReduce:
         params = [p for p in self.params if p.grad is not None]
         if len(params) != len(self.params):
             raise RuntimeError("GradientAllReduce: a parameter has no gradient on this rank (every rank must run the same graph)")
-        total = sum(p.numel() for p in params)
-        if self._flat is None or self._flat.numel() != total or self._flat.device != params[0].device:
-            self._flat = torch.empty(total, device=params[0].device, dtype=params[0].dtype)
-        off = 0
-        for p in params:
-            self._flat[off:off + p.numel()].copy_(p.grad.reshape(-1)); off += p.numel()
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        self._flat.mul_(1.0 / world)
-        off = 0
-        for p in params:
-            p.grad.copy_(self._flat[off:off + p.numel()].view_as(p.grad)); off += p.numel()
+        flat = torch.cat([p.grad.reshape(-1) for p in params])                   # one gather kernel, one collective, one scatter
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / world)
+        torch._foreach_copy_([p.grad for p in params], [c.view_as(p.grad) for c, p in zip(flat.split([p.numel() for p in params]), params)])

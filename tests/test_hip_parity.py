@@ -1229,3 +1229,27 @@ def test_bench_force_dist_initialises_rccl_on_hardware(dev):
     line = json.loads(lines[-1])
     assert line["rccl_initialised"] is True and line["rccl_ranks"] == 1 and line["n_gpus"] == 1
     assert line["value"] > 50 and line["steps"] == 6
+
+
+@pytest.mark.gpu
+def test_training_gradient_all_reduce_runs_on_rccl(dev):
+    """Data-parallel training readiness on hardware: tools/train_bench.py under torch.distributed.run (one rank, the collective forced):
+    init_process_group("nccl") = RCCL, cine_hip.shard.GradientAllReduce's flat all-reduce of all gradients every step, and the step does
+    not get slower than the side-stream overlap allows (the package raises GPU_MAX_HW_QUEUES: with four hardware queues RCCL's streams
+    push the weight-gradient stream onto the main stream's queue).  A child process -- never an exec of this GPU process."""
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("NCCL_DEBUG", None)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    env["CINE_FORCE_COLLECTIVE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "tools", "train_bench.py"), "4", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+    m = re.search(r"training step: ([0-9.]+) ms\s+loss ([0-9.]+).*\[1 rank\(s\), RCCL gradient all-reduce of ([0-9.]+) MiB", r.stdout)
+    assert m, r.stdout[-2000:] + "\n" + r.stderr[-2000:]
+    assert float(m.group(1)) < 60.0 and 0.0 < float(m.group(2)) < 1.0 and 3.5 < float(m.group(3)) < 5.0

@@ -1,5 +1,7 @@
 """Diagnostic: time of one training step (forward + SSIMLoss + backward + Adam) on the HIP path, per kernel family.
-usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet, 4 = 3D-CineNet, 5 = CRNN-VarNet]"""
+usage: train_bench.py [steps] [config: 2 = XF-VarNet (default), 3 = XT-XPDNet, 4 = 3D-CineNet, 5 = CRNN-VarNet]
+Under torch.distributed.run (one rank per GPU, RCCL) every rank trains on its own slice and the gradients are averaged with ONE flat
+all-reduce per step (cine_hip.shard.GradientAllReduce); CINE_FORCE_COLLECTIVE=1 runs that all-reduce in a world of one rank too."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "deep-cine-cardiac-mri_amd")]
@@ -10,9 +12,16 @@ from reconstruction.utils import SSIMLoss
 from cine_hip import synth
 from cine_hip._lib import lib
 
-dev = torch.device("cuda:0")
+import torch.distributed as dist
+from cine_hip import shard
+world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+dev = torch.device(f"cuda:{local}")
+torch.cuda.set_device(dev)
+if "WORLD_SIZE" in os.environ:
+    dist.init_process_group("nccl", device_id=dev)
+    shard.FORCE_COLLECTIVE = os.environ.get("CINE_FORCE_COLLECTIVE", "0") == "1"
 cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-ex = synth.make_cine_slice(15, 15, 200, 200, accel={2: 4, 3: 8, 4: 6, 5: 8}[cfg], seed=0)
+ex = synth.make_cine_slice(15, 15, 200, 200, accel={2: 4, 3: 8, 4: 6, 5: 8}[cfg], seed=rank)
 net = {2: lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), 3: lambda: M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT"),
        4: lambda: M.CineNet(6, 6, 16, 3, "3D"), 5: lambda: M.VarNet_RNN(5, 8, 3, 16)}[cfg]()
 synth.fill_parameters_(net, 1); net = net.to(dev).train()
@@ -20,12 +29,14 @@ mk, mask, target = ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"]
 extra = (ex["sens_maps"].to(dev),) if cfg == 4 else ()
 lossf = SSIMLoss().to(dev)
 opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+sync = shard.GradientAllReduce(net)
 
 def step():
     opt.zero_grad(set_to_none=True)
     out = net(mk, mask, *extra)
     loss = lossf(out.unsqueeze(1), target.unsqueeze(1), target.max())
     loss.backward()
+    sync()
     opt.step()
     return loss
 
@@ -35,7 +46,11 @@ t0 = time.time()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for _ in range(n): l = step()
 torch.cuda.synchronize()
-print(f"training step: {(time.time() - t0) / n * 1e3:.1f} ms   loss {float(l):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+dt = (time.time() - t0) / n
+print(f"training step: {dt * 1e3:.1f} ms   loss {float(l):.5f}   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB" +
+      (f"   [{world} rank(s), RCCL gradient all-reduce of {sum(p.numel() for p in sync.params) * 4 / 2**20:.1f} MiB per step: {world / dt:.1f} slices/s]" if dist.is_initialized() else ""))
+if rank != 0:
+    sys.exit(0)
 with torch.no_grad():
     for _ in range(2): net(mk, mask, *extra)
     torch.cuda.synchronize(); t0 = time.time()
