@@ -338,6 +338,10 @@ class Workload:
                 self.use_graph = False
                 self.graphs, self.gouts = [], []
         torch.cuda.synchronize()
+        for i, g in enumerate(self.graphs):                 # part of the set-up: the first replay of an instantiated graph uploads it
+            with torch.cuda.stream(self.streams[i]):
+                g.replay()
+        torch.cuda.synchronize()
         self.outs = torch.empty((steps * B,) + tuple(out.shape[1:]), device=dev)   # this rank's slices
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream())
@@ -540,6 +544,12 @@ def main():
     wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
     cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
     wl.run(args.warmup, False)
+    if dist.is_initialized() and (world > 1 or shard.FORCE_COLLECTIVE):
+        # the warm-up also covers the timed region's collectives: RCCL sets up its channels on the first barrier / all-gather
+        # (measured at world size 1: 151.4 slices/s in a first timed region against 154.3 in every later one)
+        dist.barrier(device_ids=[local])
+        shard.assemble_volume(wl.outs, world * args.steps * B)
+        torch.cuda.synchronize()
     dt = wl.timed(args.steps)                                         # THE timed region: exactly K steps
     extra = sorted(wl.timed(args.steps) for _ in range(max(0, args.repeats)))
     dt_h2d = wl.timed(args.steps, h2d=True)
