@@ -15,12 +15,15 @@ processes BEFORE touching the GPU and relays rank 0's line.  Slices shard over r
 scaling: K slices per GPU); the only exchange is one all-gather of the (K, t, h, w) outputs for volume assembly, inside the
 timed region.  Time = max over ranks, value = N*K / time.
 
-Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel family (3x3 conv on fp32 MFMA): `frac` from the kernels'
-ISOLATED duration (eager launches, one slice in flight, hipEvent pairs on the launch stream -- agrees with
-profiles/r02_rocprofv3_kernel_stats_isolated.csv); `in_flight` = the same FLOPs over the driver-timed wall time of the
-in-flight graph replay (a lower bound on the family's rate in the timed mode, see profiles/r02_..._inflight.csv).
-`roofline_fft_dc` = the HBM-bound FFT + data-consistency family against SURVEY 8(d)'s algorithmic bytes.  `cpu_baseline` =
-the CPU oracle on this host's cores (thread sweep, then >= 3 forwards at the best setting).
+Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel family (3x3 conv on fp32 MFMA).  `roofline.frac` =
+`frac_timed_mode`: the family's algorithmic FLOPs of the K timed slices over the TIMED REGION's wall time (the mode `ms_per_step`
+comes from: graphs of several slices overlap, so this is the whole-chip fp32-MFMA utilisation and a lower bound on the family's
+own rate); `frac_isolated` = the same FLOPs over the kernels' own duration with ONE slice in flight (eager launches, hipEvent
+pairs on the launch stream -- agrees with profiles/rNN_rocprofv3_kernel_stats_isolated.csv).  `roofline_fft_dc` = the FFT +
+data-consistency family, both in SURVEY 8(d)'s algorithmic bytes and in real (PMC) bytes.  `latency_ms_one_slice` = one graph
+replay on one stream (what run_inference.py:53-61 times); `sustained_value` = one >= 10 s region of the same steps with the
+slowest / fastest 1-s window.  `cpu_baseline` = the CPU oracle on this host's cores (thread sweep, then >= 3 forwards at the
+best setting); `oracle/` is imported by that leg (and the parity check it feeds) only.
 """
 import argparse
 import ctypes
@@ -44,6 +47,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+AFFINITY = {"numa_node": None, "cpus": None, "applied": False}      # filled by main() before the first GPU call
 MB = 1e6
 HBM_PEAK_GBS = 8000.0
 MFMA_F32_PEAK_TFLOPS = 157.3
@@ -69,47 +73,59 @@ def unet_conv3_macs(chans, pools, in_ch, h, w):
 
 
 # ---- workloads: BASELINE.json configs[1..4] (SURVEY.md section 8d gives the widths and the conv GFLOP per forward)
+def oracle_model(cfg_id):
+    """The CPU oracle's model of a configuration.  The ONLY place bench.py touches `oracle/`: called by the cpu_baseline leg and
+    by the parity checks that compare a replayed HIP output with it -- never by the workload set-up or the timed region."""
+    if cfg_id == 2:
+        from oracle import varnet_ref as V
+        return V.VarNet(6, 8, 3, 16, 3, "XF")
+    if cfg_id == 3:
+        from oracle import xpdnet_ref as X
+        return X.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
+    if cfg_id == 4:
+        from oracle import cinenet_ref as C
+        return C.CineNet(6, 6, 16, 3, "3D")
+    from oracle import recurrent_ref as R
+    return R.VarNet_RNN(5, 8, 3, 16)
+
+
 def _cfg2():
     import reconstruction.models as M
-    from oracle import varnet_ref as V
     flop = 2.0 * (6 * (H + W) * unet_conv3_macs(16, 3, 2, pad16(W), pad16(FRAMES)) + COILS * unet_conv3_macs(8, 3, 2, pad16(H), pad16(W)))
     k_mb, i_mb, s_mb = 72.0, 4.8, 4.8
     fft_bytes = (6 * ((k_mb + s_mb + i_mb) + (i_mb + s_mb + k_mb + k_mb)) + (k_mb + s_mb + 2.4)) * MB
     return dict(name="BASELINE.json configs[1]: XF-VarNet, 6 cascades, 15 coils x 15 frames x 200x200, R=4 Gaussian-density "
                      "Cartesian mask, sens net 8ch/3 pools, U-Net 16ch/3 pools",
                 metric="cine slices/sec, XF-VarNet R=4 15-coil 200x200x15t", accel=4, noise=0.0, wseed=1, keep=("lambda",),
-                hip=lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), ref=lambda: V.VarNet(6, 8, 3, 16, 3, "XF"), needs_sens=False,
+                hip=lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), ref=lambda: oracle_model(2), needs_sens=False,
                 conv_flop=flop, conv_kernel="cine::conv_mfma_kernel<8, CT, WM, WN, MT, TW, 9, 0> (the 3x3 instantiations)",
                 fft_bytes=fft_bytes)
 
 
 def _cfg3():
     import reconstruction.models as M
-    from oracle import xpdnet_ref as X
     kw = dict(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
     return dict(name="BASELINE.json configs[2]: XT-XPDNet, MWCNN regulariser (script defaults), 10 cascades, n_primal 5, "
                      "15 coils x 15 frames x 200x200, R=8", metric="cine slices/sec, XT-XPDNet R=8 15-coil 200x200x15t",
-                accel=8, noise=0.01, wseed=6, keep=(), hip=lambda: M.XPDNet(**kw), ref=lambda: X.XPDNet(**kw), needs_sens=False,
+                accel=8, noise=0.01, wseed=6, keep=(), hip=lambda: M.XPDNet(**kw), ref=lambda: oracle_model(3), needs_sens=False,
                 conv_flop=416.2e9, conv_kernel="cine::conv_mfma_kernel<8, ..., 9> (MWCNN 3x3 convs with Haar DWT / IWT on load)",
                 fft_bytes=None)
 
 
 def _cfg4():
     import reconstruction.models as M
-    from oracle import cinenet_ref as C
     return dict(name="BASELINE.json configs[3]: 3D CineNet, 6 cascades, CG 6, U-Net3D 16ch/3 pools, 15 coils x 15 frames x 200x200, R=6",
                 metric="cine slices/sec, 3D CineNet R=6 15-coil 200x200x15t", accel=6, noise=0.0, wseed=7, keep=("lambda",),
-                hip=lambda: M.CineNet(6, 6, 16, 3, "3D"), ref=lambda: C.CineNet(6, 6, 16, 3, "3D"), needs_sens=True,
+                hip=lambda: M.CineNet(6, 6, 16, 3, "3D"), ref=lambda: oracle_model(4), needs_sens=True,
                 conv_flop=365.2e9, conv_kernel="cine::conv_mfma_kernel<8, ..., 9, 1> (3x3x3 convs as three 3x3 passes) + <4, ..., 27, 0> (small / narrow levels)", fft_bytes=None)
 
 
 def _cfg5():
     import reconstruction.models as M
-    from oracle import recurrent_ref as R
     return dict(name="BASELINE.json configs[4]: CRNN-VarNet, 5 cascades, sens net 8ch/3 pools, 16 hidden channels, "
                      "15 coils x 15 frames x 200x200, R=8", metric="cine slices/sec, CRNN-VarNet R=8 15-coil 200x200x15t",
                 accel=8, noise=0.0, wseed=9, keep=("lambda",), hip=lambda: M.VarNet_RNN(5, 8, 3, 16),
-                ref=lambda: R.VarNet_RNN(5, 8, 3, 16), needs_sens=False, conv_flop=155.0e9,
+                ref=lambda: oracle_model(5), needs_sens=False, conv_flop=155.0e9,
                 conv_kernel="cine::conv_mfma_kernel<8, ..., 9> (CRNN cells: summed-input 3x3 convs with bias/addend/ReLU epilogue)",
                 fft_bytes=None)
 
@@ -136,7 +152,10 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl), the device barrier and the all-gather of the volume assembly even at --gpus 1 "
                          "(start under `python -m torch.distributed.run --nproc-per-node=1`, or alone: rank 0 of a world of 1)")
-    ap.add_argument("--headline-only", action="store_true", help="skip the other_configs / train_step extras of the default 1-GPU line")
+    ap.add_argument("--no-conv-plane", action="store_true", help="A/B: route the plane-wide 3x3 convs through the general kernel (cine_set_conv_plane(0))")
+    ap.add_argument("--pin-numa", action="store_true", help="pin this process to its GPU's NUMA node at --gpus 1 too (always done for N > 1)")
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the extra sustained region (0 = skip)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the latency / sustained regions and the other_configs / train_step extras of the default 1-GPU line")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the launcher, sharding, timed region and all-gather on "
                          "gloo/CPU with a stand-in for the forward; the line is marked invalid and measures nothing")
@@ -158,6 +177,72 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------ CPU affinity of a rank
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(local_rank, sysfs="/sys"):
+    """CPUs of the NUMA node the `local_rank`-th GPU hangs off, read from sysfs alone (no HIP call: the affinity must be set
+    before the runtime starts its threads and pins its host buffers).  KFD lists the GPUs in the order HIP enumerates them
+    (topology nodes with simd_count > 0); `location_id` (bus << 8 | devfn) + `domain` name the PCI function whose `numa_node`
+    and `local_cpulist` the kernel exports.  Returns (node, cpus) or (None, None) when anything is missing."""
+    try:
+        base = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+        gpus = []
+        for name in sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30):
+            props = {}
+            with open(os.path.join(base, name, "properties")) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(props)
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis and all(x.strip().isdigit() for x in vis.split(",")):
+            gpus = [gpus[int(x)] for x in vis.split(",") if int(x) < len(gpus)]
+        pr = gpus[local_rank]
+        loc, dom = int(pr["location_id"]), int(pr.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"
+        dev = os.path.join(sysfs, "bus/pci/devices", bdf)
+        with open(os.path.join(dev, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, None
+        with open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return node, (cpus or None)
+    except (OSError, KeyError, IndexError, ValueError):
+        return None, None
+
+
+def pin_rank_to_gpu_numa(local_rank, world, sysfs="/sys"):
+    """os.sched_setaffinity to the GPU's NUMA node, intersected with what this process may use (cgroup / taskset).  Never a
+    re-exec.  With N ranks on one node that would otherwise all inherit every CPU, the host side of a rank (graph launches,
+    pinned buffers, the phantom generator) stays next to its GPU."""
+    info = {"numa_node": None, "cpus": None, "applied": False}
+    node, cpus = gpu_numa_cpus(local_rank, sysfs)
+    if node is None:
+        return info
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = cpus & allowed
+        info["numa_node"] = node
+        if want and want != allowed:
+            os.sched_setaffinity(0, want)
+            info["applied"] = True
+        info["cpus"] = len(want or allowed)
+    except (OSError, AttributeError):
+        pass
+    return info
 
 
 # ------------------------------------------------------------------ measurement helpers
@@ -248,11 +333,14 @@ def timed_steps(run, nsteps, batch, outs, world, sync, barrier, device):
         barrier()
     sync()
     dt = time.perf_counter() - t0
+    per_rank = [dt]
     if coll:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    return dt, volume
+        mine = torch.tensor([dt], device=device, dtype=torch.float64)
+        allr = torch.empty(dist.get_world_size(), device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)               # every rank's own clock over the same region: a straggler shows
+        per_rank = [float(v) for v in allr.cpu()]
+        dt = max(per_rank)                                     # the contract's time: MAX over ranks
+    return dt, volume, per_rank
 
 
 def selftest_cpu(args, world, rank):
@@ -272,12 +360,13 @@ def selftest_cpu(args, world, rank):
             outs[k] = standin(rank + k * world)                       # rank r owns slices r, r + N, ...
 
     run(args.warmup)
-    dt, volume = timed_steps(run, K, 1, outs, world, lambda: None, dist.barrier, torch.device("cpu"))
+    dt, volume, per_rank = timed_steps(run, K, 1, outs, world, lambda: None, dist.barrier, torch.device("cpu"))
     ok = bool(torch.equal(volume, torch.stack([standin(i) for i in range(world * K)])))
     if rank == 0:
         print(json.dumps({"metric": "selftest (no measurement)", "value": None, "valid": False, "n_gpus": world, "rccl_ranks": world,
                           "steps": K, "warmup": args.warmup, "volume_ok": ok, "volume_slices": int(volume.shape[0]),
-                          "data": "cpu stand-in for the forward (test only)", "timed_region_s": dt}))
+                          "data": "cpu stand-in for the forward (test only)", "timed_region_s": dt,
+                          "per_rank_timed_region_s": per_rank, "cpu_affinity": AFFINITY}))
     if world > 1:
         dist.destroy_process_group()
     if not ok:
@@ -370,8 +459,57 @@ class Workload:
             torch.cuda.current_stream().wait_stream(st)
 
     def timed(self, nsteps, h2d=False):
-        return timed_steps(lambda n: self.run(n, True, h2d), nsteps, self.B, self.outs, self.world, torch.cuda.synchronize,
-                           lambda: dist.barrier(device_ids=[self.local]), self.dev)[0]
+        dt, _, self.per_rank_s = timed_steps(lambda n: self.run(n, True, h2d), nsteps, self.B, self.outs, self.world, torch.cuda.synchronize,
+                                             lambda: dist.barrier(device_ids=[self.local]), self.dev)
+        return dt
+
+    def latency_one_slice(self, reps=15):
+        """One slice, one stream, nothing else on the GPU: what the reference's inference loop times per slice
+        (traintest_scripts/run_inference.py:53-61: model(masked_kspace, mask) between two clocks, batch 1).  Median of `reps`."""
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            with torch.cuda.stream(self.streams[0]):
+                if self.use_graph:
+                    self.graphs[0].replay()
+                else:
+                    self.forward(0)
+            self.streams[0].synchronize()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
+
+    def sustained(self, seconds, est_step_s):
+        """One long region of the timed mode (no volume assembly, no host sync inside): an event per finished slice, then the
+        slices finished in every 1-s window.  Shows what clocks / power settle at, which a 0.13 s region cannot."""
+        S, B = self.S, self.B
+        n = max(S, int(seconds / est_step_s / S + 1) * S)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        torch.cuda.synchronize()
+        for st in self.streams:
+            st.wait_stream(torch.cuda.current_stream())
+        ev0.record(self.streams[0])
+        t0 = time.perf_counter()
+        for k in range(n):
+            i = k % S
+            with torch.cuda.stream(self.streams[i]):
+                if self.use_graph:
+                    self.graphs[i].replay()
+                else:
+                    self.forward(i)
+                evs[k].record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        done = sorted(ev0.elapsed_time(e) * 1e-3 for e in evs)              # completion times, seconds after the start
+        total = done[-1]
+        nwin = int(total)                                                    # whole 1-s windows
+        per = [sum(1 for d in done if w <= d < w + 1) * B for w in range(nwin)]
+        return {"value": n * B / total, "unit": "cine slices/sec", "steps": n, "seconds": total, "host_wall_s": wall,
+                "window_s": 1.0, "window_min": min(per) if per else None, "window_max": max(per) if per else None,
+                "windows": per,
+                "note": "same graphs / streams as the timed region, one event per finished slice on its stream; no volume assembly inside"}
 
     def replayed_output(self):
         """Output of stream 0's slice through the timed mode (a graph replay when graphs are in use)."""
@@ -392,7 +530,7 @@ def pmc_families(cfg_id):
     """HBM-side bytes / MFMA busy fractions per kernel family from the committed rocprofv3 --pmc passes of this same command
     (tools/collect_profiles.sh -> tools/pmc_traffic.py / pmc_mfma.py; PMC collection cannot run inside the bench itself)."""
     sfx = "" if cfg_id == 2 else f"_cfg{cfg_id}"
-    for rnd_ in ("r03", "r02", "r01"):
+    for rnd_ in ("r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd_}_pmc_traffic{sfx}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -402,19 +540,23 @@ def pmc_families(cfg_id):
 
 
 def conv_roofline(wl, fam, dt, slices):
+    """`achieved` / `frac` describe the TIMED mode (the family's algorithmic FLOPs of the timed slices over the timed region's
+    wall time: kernels of several slices overlap there, so no per-launch duration exists -- this is the whole-chip fp32-MFMA
+    utilisation, a lower bound on the family's own rate); the *_isolated keys are the per-launch view (one slice in flight,
+    hipEvent pairs around every launch of the family)."""
     cfg = wl.cfg
     conv_ms, conv_n = fam["conv3x3_mfma"]
-    roofline = {"bound": "mfma", "kernel": cfg["conv_kernel"], "mode": "isolated: eager launches, one slice in flight, hipEvent pairs per launch",
-                "achieved": cfg["conv_flop"] / (conv_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "traffic": None, "launches_per_slice": conv_n, "ms_per_slice": conv_ms, "avg_launch_us": conv_ms * 1e3 / max(conv_n, 1),
-                "flop_per_slice": cfg["conv_flop"]}
-    roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    # the same FLOPs over the driver-timed wall time of the in-flight graph replay: whole-chip fp32-MFMA utilisation of the
-    # timed mode, a lower bound on the conv family's own rate there (its kernels overlap other families' on other streams)
-    roofline["in_flight"] = {"tflops_lower_bound": cfg["conv_flop"] * slices / wl.world / dt / 1e12,
-                             "frac_lower_bound": cfg["conv_flop"] * slices / wl.world / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                             "mode": ("hipGraph replay" if wl.use_graph else "eager") + f", {wl.S} slices in flight (the timed region)"}
-    return roofline
+    timed_tf = cfg["conv_flop"] * slices / wl.world / dt / 1e12
+    iso_tf = cfg["conv_flop"] / (conv_ms * 1e-3) / 1e12
+    mode_t = ("hipGraph replay" if wl.use_graph else "eager") + f", {wl.S} slices in flight (the timed region)"
+    return {"bound": "mfma", "kernel": cfg["conv_kernel"],
+            "achieved": timed_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": timed_tf / MFMA_F32_PEAK_TFLOPS,
+            "mode": "timed mode: " + mode_t + "; FLOPs of the 3x3 family / wall time of the timed region",
+            "frac_timed_mode": timed_tf / MFMA_F32_PEAK_TFLOPS, "achieved_timed_mode": timed_tf,
+            "frac_isolated": iso_tf / MFMA_F32_PEAK_TFLOPS, "achieved_isolated": iso_tf,
+            "mode_isolated": "eager launches, one slice in flight, hipEvent pairs per launch",
+            "traffic": None, "launches_per_slice": conv_n, "ms_per_slice_isolated": conv_ms,
+            "avg_launch_us_isolated": conv_ms * 1e3 / max(conv_n, 1), "flop_per_slice": cfg["conv_flop"]}
 
 
 def measure_other_config(cfg_id, args, dev, threads):
@@ -433,8 +575,8 @@ def measure_other_config(cfg_id, args, dev, threads):
         roof["traffic_unit"] = f"HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE, {tr_src}"
     res = {"workload": wl.cfg["name"], "metric": wl.cfg["metric"], "value": steps * wl.B / dt, "unit": "cine slices/sec", "steps": steps,
            "ms_per_step": dt / steps * 1e3, "slices_in_flight": wl.S, "launch": "hipGraph replay" if wl.use_graph else "eager",
-           "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_slice", "launches_per_slice")},
-           "mfma_frac_in_flight_lower_bound": roof["in_flight"]["frac_lower_bound"],
+           "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_timed_mode", "frac_isolated", "traffic",
+                                             "ms_per_slice_isolated", "launches_per_slice")},
            "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items() if v[1]}}
     chk = wl.replayed_output().cpu()
     ex0 = wl.exs[0][0]
@@ -486,6 +628,7 @@ def measure_training_step(args, dev, threads, cfg_id=2, cpu=True):
 
     with torch.enable_grad():
         step = make(cfg["hip"](), dev)
+        torch.cuda.reset_peak_memory_stats()                    # the peak of THIS training step, not of the workloads run before it
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -522,6 +665,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs")
+    if world > 1 or args.pin_numa:
+        # before the first GPU call: the runtime's threads and pinned buffers inherit the rank's CPU set
+        AFFINITY.update(pin_rank_to_gpu_numa(local, world, os.environ.get("CINE_SYSFS_ROOT", "/sys")))
     if args.selftest_cpu:
         return selftest_cpu(args, world, rank)
     use_dist = world > 1 or args.force_dist
@@ -541,6 +687,9 @@ def main():
 
     from cine_hip import shard
     shard.FORCE_COLLECTIVE = bool(args.force_dist)
+    if args.no_conv_plane:
+        from cine_hip._lib import lib
+        lib().cine_set_conv_plane(0)
     wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
     cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
     wl.run(args.warmup, False)
@@ -551,9 +700,12 @@ def main():
         shard.assemble_volume(wl.outs, world * args.steps * B)
         torch.cuda.synchronize()
     dt = wl.timed(args.steps)                                         # THE timed region: exactly K steps
+    contract_per_rank_s = list(wl.per_rank_s)
     extra = sorted(wl.timed(args.steps) for _ in range(max(0, args.repeats)))
     dt_h2d = wl.timed(args.steps, h2d=True)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
+    lat_med, lat_min = (None, None) if args.headline_only else wl.latency_one_slice()
+    sustained = wl.sustained(args.sustained_seconds, dt / args.steps) if args.sustained_seconds > 0 and not args.headline_only else None
 
     if rank != 0:
         if use_dist:
@@ -581,7 +733,11 @@ def main():
                              f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}",
                    "parallelism": f"slice-sharded x{world}, one all-gather for volume assembly"},
         "rccl_ranks": rccl_ranks, "rccl_initialised": bool(dist.is_initialized()),
-        "timed_region_s": dt,
+        "timed_region_s": dt, "per_rank_timed_region_s": contract_per_rank_s, "cpu_affinity": AFFINITY,
+        "latency_ms_one_slice": lat_med, "latency_ms_one_slice_min": lat_min,
+        "latency_note": "one hipGraph replay on one stream, nothing else in flight, host clock around launch + stream sync: what "
+                        "run_inference.py:53-61 times per slice (median / min of 15)",
+        "sustained_value": sustained["value"] if sustained else None, "sustained": sustained,
         "repeat_values": [slices / d for d in extra], "repeat_median_value": (slices / extra[len(extra) // 2]) if extra else None,
         "value_with_h2d": slices / dt_h2d,
         "value_with_h2d_note": "same K steps with each slice's 72 MB k-space copied pinned-host -> HBM on its stream ahead of the "
@@ -592,18 +748,21 @@ def main():
     if cfg["fft_bytes"]:
         roof_fft = {"bound": "hbm", "kernel": "cine::imgdc200_kernel + imgdc_sum_kernel (x6: sens_expand + FFT2 + DC + IFFT2 + sens_reduce on the "
                                               "coil-combined image), col200_kernel + row200_reduce_kernel (first reduce, zero-filled term, sens prologue)",
-                    "mode": roofline["mode"], "achieved": cfg["fft_bytes"] / (fft_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "mode": roofline["mode_isolated"], "achieved": cfg["fft_bytes"] / (fft_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "algorithmic_bytes": cfg["fft_bytes"], "traffic": None, "ms_per_slice": fft_ms,
                     "note": "achieved = SURVEY 8(d) bytes at the reference's module boundaries / kernel time; the image-space chain "
                             "moves far fewer bytes than that (traffic), so this is the step's speed in the survey's units, not a bandwidth: "
                             "achieved_traffic_gbs is the bandwidth (PMC bytes / kernel time)"}
         roof_fft["frac"] = roof_fft["achieved"] / roof_fft["peak"]
+        roof_fft["frac_survey_units"] = roof_fft["frac"]            # SURVEY 8(d) bytes / kernel time: the step's speed, not a bandwidth
+        roof_fft["frac_real_bandwidth"] = None                      # PMC bytes / kernel time: the bandwidth the kernels really run at
         if tr and "fft_col_pass" in tr:
             roof_fft["traffic"] = (tr.get("fft_col_pass", {}).get("hbm_MB_per_slice", 0.0) + tr.get("fft_row_pass", {}).get("hbm_MB_per_slice", 0.0)) * 1e6 or None
             roof_fft["traffic_unit"] = f"HBM bytes per slice over all FFT / DC passes, PMC, {tr_src}"
             if roof_fft["traffic"]:
                 roof_fft["achieved_traffic_gbs"] = roof_fft["traffic"] / (fft_ms * 1e-3) / 1e9
                 roof_fft["frac_traffic"] = roof_fft["achieved_traffic_gbs"] / HBM_PEAK_GBS
+                roof_fft["frac_real_bandwidth"] = roof_fft["frac_traffic"]
         line["roofline_fft_dc"] = roof_fft
     # ---- parity of a GRAPH-REPLAYED output (stream 0's slice) and the CPU baseline
     chk = wl.replayed_output()

@@ -31,6 +31,23 @@ from ._lib import CineHipError, check, lib
 _p = ops._p
 _stream = ops._stream
 
+_SIDE_STREAMS = {}
+
+
+def _use_side_stream(device: torch.device) -> None:
+    """Hand this thread's second stream (one torch stream per device, created here: the library creates none) to the backward
+    entry points that run weight gradients beside the input-gradient chain (cine_set_side_stream).  CINE_SIDE_STREAM=0 in the
+    environment of THIS binding keeps the whole backward pass on the caller's stream."""
+    import os
+    if os.environ.get("CINE_SIDE_STREAM", "1") == "0":
+        check(lib().cine_set_side_stream(None), "cine_set_side_stream")
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(idx)
+    if st is None:
+        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    check(lib().cine_set_side_stream(st.cuda_stream), "cine_set_side_stream")
+
 
 def _c(x: torch.Tensor) -> torch.Tensor:
     return x if x.is_contiguous() else x.contiguous()
@@ -48,6 +65,7 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
     """cine_unet2d_forward_train: returns (y, workspace with every raw layer output)."""
     x = ops._dev(x, "unet input")
     n, cin, h, w = _unet_call_shapes(x, weights)
+    key = weights.training_key()                     # raises for Dropout in training mode
     need = lib().cine_unet2d_train_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)
     if need == 0:
         raise CineHipError("cine_unet2d_train_ws_bytes rejected the shape")
@@ -56,6 +74,7 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
     check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(), len(weights.unets), n, h, w, cin,
                                           weights.out_ch, weights.chans, weights.pools, ws.data_ptr(), ws.numel(), _stream()),
           "cine_unet2d_forward_train")
+    ws.cine_training_key = key                       # checked by unet2d_backward
     return y, ws
 
 
@@ -83,6 +102,8 @@ def unet2d_backward(x: torch.Tensor, gy: torch.Tensor, weights: "ops.UnetWeights
     grads = _zero_grads(plists, x.device)
     gptr = (ctypes.c_void_p * (nsets * len(plists[0])))(*[g.data_ptr() for gl in grads for g in gl])
     gx = torch.empty_like(x) if need_gx else None
+    weights.check_training_key(getattr(fwd_ws, "cine_training_key", None), "cine_unet2d_backward")
+    _use_side_stream(x.device)
     check(lib().cine_unet2d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, nsets, n, h, w, cin,
                                      weights.out_ch, weights.chans, weights.pools, fwd_ws.data_ptr(), fwd_ws.numel(),
                                      ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_unet2d_backward")
@@ -248,6 +269,7 @@ class MwcnnFn(Function):
                                          n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters,
                                          int(net.res), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
         ctx.cfg = (w, w2 if two else None, int(split) if two else n)
+        ctx.keys = tuple(tuple((p.data_ptr(), p._version) for p in wt.param_list()) for wt in ((w, w2) if two else (w,)))
         ctx.ws, ctx.params = ws, params
         ctx.save_for_backward(x)
         return y
@@ -257,6 +279,10 @@ class MwcnnFn(Function):
         (x,) = ctx.saved_tensors
         w, w2, split = ctx.cfg
         net = w.net
+        for wt, key in zip((w, w2) if w2 is not None else (w,), ctx.keys):
+            if key != tuple((p.data_ptr(), p._version) for p in wt.param_list()):
+                raise RuntimeError("cine_mwcnn_backward: an MWCNN parameter was modified between the forward and the backward pass; "
+                                   "the saved activations belong to the old weights")
         gy = ops._dev(_c(gy), "mwcnn output gradient")
         n, cin, h, wd = x.shape
         L = lib()
@@ -270,6 +296,7 @@ class MwcnnFn(Function):
         p1, g1, gp1 = grads_of(w)
         p2, g2, gp2 = grads_of(w2) if w2 is not None else (None, None, None)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _use_side_stream(x.device)
         check(L.cine_mwcnn_backward(x.data_ptr(), gy.data_ptr(), w.dgrad_pointers(), w2.dgrad_pointers() if w2 is not None else None, gp1, gp2,
                                     split, n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters,
                                     ctx.ws.data_ptr(), ctx.ws.numel(), ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_mwcnn_backward")
@@ -479,6 +506,8 @@ class Unet3dFn(Function):
         n, cin, d, h, w = x.shape
         if len(weights.unets) != 1 or cin != weights.in_ch:
             raise ValueError("unet3d: one weight set, input channels as built")
+        ctx.training_key = weights.training_key()    # raises for Dropout in training mode
+        ctx.weights_obj = weights
         weights.pointers()
         packs, plist = weights._keep, weights.param_lists()[0]
         P = weights.pools
@@ -537,6 +566,7 @@ class Unet3dFn(Function):
     @staticmethod
     def backward(ctx, gy):
         x, A, B, Tc, Cc, Ec, chs, dims, plist = ctx.state
+        ctx.weights_obj.check_training_key(ctx.training_key, "unet3d backward")
         gy = ops._dev(_c(gy), "unet3d output gradient")
         n, cin = x.shape[:2]
         P = len(chs) - 1

@@ -658,6 +658,23 @@ class UnetWeights:
         self._old = []
 
     # ---- training (cine_unet2d_backward)
+    def training_key(self):
+        """Called where a training ``autograd.Function`` is entered.  Refuses what the backward kernels do not model -- Dropout
+        (reference unet.py:22,40,159-168 applies Dropout2d / Dropout3d after every LeakyReLU when the module is in training
+        mode) -- and returns the parameters' (address, version) key: the backward pass re-packs the input-gradient weights from
+        the parameters' CURRENT values and compares this key first (torch would raise 'modified by an inplace operation')."""
+        for u in self.unets:
+            if u.training and getattr(u, "drop_prob", 0.0) > 0:
+                raise NotImplementedError("training with Dropout (drop_prob > 0) is not on the HIP path: the backward kernels "
+                                          "have no dropout mask; build the U-Nets with drop_prob=0.0 (the reference scripts' value) "
+                                          "or call .eval()")
+        return tuple((p.data_ptr(), p._version) for seq in self._params() for _, p in seq)
+
+    def check_training_key(self, key, what: str) -> None:
+        if key is not None and key != tuple((p.data_ptr(), p._version) for seq in self._params() for _, p in seq):
+            raise RuntimeError(f"{what}: a U-Net parameter was modified between the forward and the backward pass "
+                               "(optimizer.step() or an in-place update before loss.backward()); the saved activations belong to the old weights")
+
     def param_lists(self):
         """Per weight set, the parameters in the order of the pointer lists (bias last)."""
         return [[p for _, p in seq] for seq in self._params()]

@@ -46,23 +46,50 @@ class GradientAllReduce:
     shape for xGMI's per-link rings: one latency, no per-layer hooks to overlap.  Aliased parameters (the cascades share their networks)
     appear once.  Usage:  sync = GradientAllReduce(model);  loss.backward();  sync();  optimiser.step()."""
 
-    def __init__(self, module: torch.nn.Module, group=None):
+    def __init__(self, module: torch.nn.Module, group=None, broadcast: bool = True):
         seen, self.params = set(), []
         for p in module.parameters():
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p)); self.params.append(p)
         self.group = group
+        # Replicas must start from identical weights (torch DDP does the same in its constructor): ONE flat broadcast from the
+        # group's first rank, so differently seeded ranks cannot diverge silently.  broadcast=False only checks (a checksum
+        # all-reduce) and raises on a mismatch.
+        if self._active() and self.params:
+            flat = torch.cat([p.detach().reshape(-1) for p in self.params])
+            if broadcast:
+                dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                with torch.no_grad():
+                    torch._foreach_copy_([p.data for p in self.params],
+                                         [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in self.params]), self.params)])
+            else:
+                ck = torch.stack([flat.double().sum(), flat.double().abs().sum()])
+                lo, hi = ck.clone(), ck.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+                if not torch.equal(lo, hi):
+                    raise RuntimeError("GradientAllReduce: the ranks hold different parameter values (seed them identically or pass broadcast=True)")
+
+    def _active(self) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 or FORCE_COLLECTIVE
 
     def __call__(self) -> None:
-        if not (dist.is_available() and dist.is_initialized()):
+        if not self._active():
             return
         world = dist.get_world_size(self.group)
-        if world == 1 and not FORCE_COLLECTIVE:
-            return
-        params = [p for p in self.params if p.grad is not None]
-        if len(params) != len(self.params):
-            raise RuntimeError("GradientAllReduce: a parameter has no gradient on this rank (every rank must run the same graph)")
-        flat = torch.cat([p.grad.reshape(-1) for p in params])                   # one gather kernel, one collective, one scatter
+        # A parameter without a gradient (a sub-network this step did not use, e.g. the sensitivity network when sens_maps are
+        # passed in) contributes zeros and keeps grad None afterwards -- every rank runs the same graph, so the slots line up.
+        # Ranks that disagree about WHICH parameters are unused would still exchange equally sized buffers; they get the average
+        # over all ranks with zeros for the missing ones (what DDP's find_unused_parameters does).
+        have = [p.grad is not None for p in self.params]
+        flat = torch.cat([p.grad.reshape(-1) if h else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
+                          for p, h in zip(self.params, have)])          # one gather kernel, one collective, one scatter
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.mul_(1.0 / world)
-        torch._foreach_copy_([p.grad for p in params], [c.view_as(p.grad) for c, p in zip(flat.split([p.numel() for p in params]), params)])
+        pieces = flat.split([p.numel() for p in self.params])
+        dst = [p.grad for p, h in zip(self.params, have) if h]
+        src = [c.view_as(p.grad) for c, p, h in zip(pieces, self.params, have) if h]
+        if dst:
+            torch._foreach_copy_(dst, src)

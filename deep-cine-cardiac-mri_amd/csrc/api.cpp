@@ -58,7 +58,7 @@ int cine_profile_end(double* ms, long* launches, int nfam) {
 int cine_profile_families(void) { return cine::F_COUNT; }
 const char* cine_profile_family_name(int i) {
     static const char* names[] = {"fft_col_pass", "fft_row_pass", "conv3x3_mfma", "instnorm_stats", "tconv2x2",
-                                  "conv1x1_bias", "pack_unpack", "misc", "unet_plane"};
+                                  "conv1x1_bias", "pack_unpack", "misc"};
     return (i >= 0 && i < cine::F_COUNT) ? names[i] : "";
 }
 int cine_version(void) { return 1; }

@@ -65,22 +65,12 @@ template <typename T> inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 // Optional per-kernel-family timing (cine_profile_begin / cine_profile_end): when enabled every
 // launch is bracketed by a hipEvent pair on ITS stream.  Disabled (the default, and always during
 // graph capture) it costs one relaxed load.
-enum Family { F_FFT_COL = 0, F_FFT_ROW, F_CONV3, F_STATS, F_TCONV, F_CONV1, F_PACK, F_MISC, F_UNET_PLANE, F_COUNT };
+enum Family { F_FFT_COL = 0, F_FFT_ROW, F_CONV3, F_STATS, F_TCONV, F_CONV1, F_PACK, F_MISC, F_COUNT };
 struct ProfScope {
     int fam; hipStream_t st; hipEvent_t e0, e1; bool on;
     ProfScope(int family, hipStream_t stream);
     ~ProfScope();
 };
 
-// Launch recorder of conv_kernels.hip: between plane_record_begin() and plane_record_end() the conv / transpose-conv / 1x1
-// entry points called on THIS thread keep their prepared launches; plane_record_end() issues them as one plane-persistent
-// kernel when the sequence allows it, else one by one.  For sequences in which every step reads only data of its own sample.
-struct PlaneRecorder;
-PlaneRecorder* plane_record_begin();
-int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev);   // prog_dev: plane_program_bytes() of device memory, or NULL
-size_t plane_program_bytes();
-bool plane_kernel_enabled();   // CINE_PLANE_KERNEL=1 in the environment
-void plane_record_abort(PlaneRecorder* r);
-int plane_record_end_pair(PlaneRecorder* r, hipStream_t st);          // two steps (3x3 conv, transpose conv on its output): fused when one workgroup owns the plane in both
 
 }  // namespace cine

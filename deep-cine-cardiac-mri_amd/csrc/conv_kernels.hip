@@ -28,95 +28,13 @@
 #include <vector>
 #include "common.h"
 #include "conv_src.h"
+#include "conv_cfg.h"
 
 namespace cine {
 
-// Diagnostic variant builds only (tools/build_variant.sh NAME conv_kernels.hip -DCINE_ABL=bits, run by tools/variant_run.sh):
-// leave out a phase of conv_tile to see what the rest costs -- 1 the MFMA sweep, 2 the global loads + staging.  Results are
-// wrong by design; the product build has CINE_ABL 0 and the compiler drops the tests.
-#ifndef CINE_ABL
-#define CINE_ABL 0
-#endif
-#ifndef CINE_PRIO
-#define CINE_PRIO 2          // s_setprio level of the non-MFMA phases of conv_tile (the sweeps run at 0)
-#endif
-struct ConvArgs {
-    Src s0, s1;
-    const float* wp0; const float* wp1; int set_split;   // samples >= set_split use wp1
-    const float* bias; const float* bias1;   // bias1: samples >= set_split (two weight sets in one launch)
-    const float* addend; int relu;       // epilogue: y = [relu](conv + bias + addend), addend shaped like y
-    float* accum;                        // optional second output, shaped like y: accum += y (BCRNN: output_f + output_b, recurrent_varnet.py:254)
-    float* y; float* ypart;
-    int n, cin, rows, rowsp, H, W;       // GEMM rows (cout, or 4*cout / 8*cout for tconv), padded to 16
-    int D, tiles_hw;                     // output depth (1 in 2-D); tiles per depth slice
-    int vol;                             // 1: 3-D entry point (a depth-1 volume is still a volume: 8-way transpose conv)
-    int tconv_cout;                      // > 0: transpose-conv store mapping with this many channels
-    int add_src1;                        // 1: source 1 is ADDED to source 0 channel-wise (MWCNN skips, mwcnn.py:164,172)
-                                         //    instead of concatenated
-    float slope, eps;
-    int tiles_w, tiles, nchunks, fast;
-    int vfast;                           // volumes (TAPS 27): row-wise 16-byte staging of plain / normalised / 2x2x2-pooled sources
-    int wav;                             // fast staging of a Haar DWT / IWT source (modes 3 / 4), optionally + an added plain / normalised skip
-    int tvec;                            // transpose conv: paired 16-byte stores (W multiple of the lane's pixel run, aligned y)
-    int ncc;                             // V3 kernels: channel chunks per depth offset (nchunks = 3 * ncc, chunk = (dz + 1) * ncc + cc)
-    int accum_store;                     // 1: the second output is written (accum = y), not added to
-    // pair launches (conv_mfma_pair_kernel, the two directions of a BCRNN time sweep in one grid): samples >= pair_n take
-    // these pointers instead (and count from 0 again)
-    int pair_n, accum_store_b;
-    const float* x_b; const float* addend_b; float* y_b; float* accum_b;
-};
-
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
-struct ConvCfg {
-    static constexpr int NT = 64 * WM * WN;
-    static constexpr int HALO = TAPS == 1 ? 0 : 1;
-    static constexpr int ZP = TAPS == 27 ? 3 : 1;  // input depth slices held in LDS
-    static constexpr int RPF = 16 / TW;            // rows per fragment
-    static constexpr int NF = WN * MT;             // fragments per workgroup
-    static constexpr int TH = NF * RPF;            // tile rows
-    static constexpr int ROWS = TH + 2 * HALO;
-    // LDS row: [0, TW) interior, then (3x3 only) right halo at TW and left halo at COLS-1, i.e. image
-    // column x lives at (x + COLS) % COLS.  COLS is a multiple of the staging piece so interior
-    // pieces are 16-byte aligned (ds_write_b128).
-    static constexpr int COLS = HALO ? (TW >= 4 ? TW + 4 : TW + 2) : TW;
-    static constexpr int ZS = ROWS * COLS;         // stride between the depth slices of one channel
-    static constexpr int PS = ((ZP * ROWS * COLS + 31) / 32) * 32 + 16;   // channel stride == 16 (mod 32)
-    static constexpr int COT = 16 * CT * WM;
-    static constexpr int COTP = (COT % 32 == 0) ? COT + 16 : COT;
-    static constexpr int PW = TW >= 4 ? 4 : TW;    // floats per staging piece
-    static constexpr int PR = TW / PW;             // pieces per row
-    static constexpr int NPIECE = CK * ROWS * PR;
-    static constexpr int NPT = (NPIECE + NT - 1) / NT;
-    // staging map of the vectorised path: a thread owns one (row, piece) slot of the tile -- KR of them when
-    // there are more slots than threads -- in channels g, g + G, ...: slot arithmetic happens once, the
-    // pieces of a thread differ by compile-time strides
-    static constexpr int RP = ROWS * PR;
-    static constexpr int KR = (RP + NT - 1) / NT;
-    static constexpr int gsel() { int g = 1; while (2 * g <= CK && 2 * g * RP <= NT) g *= 2; return g; }
-    static constexpr int G = gsel();
-    static constexpr int NCI = CK / G, NPF = KR * NCI;
-    static constexpr int IN_FLOATS = CK * PS;
-    static constexpr int W_FLOATS = TAPS * CK * COTP;
-    static constexpr int RED_FLOATS = 3 * WN * COT;
-#ifndef CINE_REG_OVH
-#define CINE_REG_OVH 48
-#endif
-    // waves per SIMD to ask the register allocator for (= workgroups per CU for 256-thread groups), from an
-    // estimate of the live registers: accumulators + two operand groups + the chunk prefetched during the sweep
-    static constexpr int NWT = (TAPS * CK * (COT / 4) + NT - 1) / NT;   // weight float4 per thread and chunk
-    static constexpr int REGS = 4 * CT * MT + 2 * (CT + MT) + PW * NPF + 4 * NWT + CINE_REG_OVH;
-    static constexpr int MINW = REGS <= 128 ? 4 : (REGS <= 168 ? 3 : 2);
-    static_assert(RED_FLOATS <= IN_FLOATS, "reduction scratch must fit in the input tile");
-    static size_t lds_bytes(int src_chans) { return (size_t)(IN_FLOATS + W_FLOATS + 2 * src_chans) * sizeof(float); }
-};
-
-
-template <int PW> struct Piece;
-template <> struct Piece<4> { typedef float4 T; };
-template <> struct Piece<2> { typedef float2 T; };
-
+constexpr int kPrio = 2;     // s_setprio level of the non-MFMA phases of conv_tile (the sweeps run at 0)
 // One workgroup's share of one layer: tile `tile` (depth slice, tile row, tile column) of sample n, output-row block
-// `coblk`.  Called once per workgroup by conv_mfma_kernel and once per (layer, tile) by the plane-persistent U-Net kernel.
+// `coblk`.  Called once per workgroup by conv_mfma_kernel.
 // V3 = 1 (with TAPS = 9): a 3x3x3 convolution over (depth, h, w) volumes as three 3x3 passes -- chunk = (depth offset dz, 8 input
 // channels), staged from slice z + dz exactly like a 2-D plane (same LDS footprint, prefetch and vectorised transforms as the 2-D
 // kernel), accumulated into the same MFMA accumulators; chunks whose slice lies outside the volume are skipped.
@@ -147,7 +65,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     // B operand (k x rows): lane = output row q of the 16-row tile, channel kk
     const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
 
-    __builtin_amdgcn_s_setprio(CINE_PRIO);
+    __builtin_amdgcn_s_setprio(kPrio);
     CINE_STAMP_RT(9);
     CINE_STAMP(0);
     // ---- chunk pipeline.  issue(c) puts the global loads of chunk c (weight slab + raw input pieces) in
@@ -170,7 +88,6 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         return first ? a.s0 : a.s1;
     };
     auto issue = [&](int chunk) {
-        if (CINE_ABL & 2) return;
         if (V3 == 1 && !chunk_live(chunk)) return;
         const float* wsrc = wp + (long)chunk * TAPS * CK * a.rowsp;
 #pragma unroll
@@ -240,7 +157,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     if (early) {
         if (tid < nch) {
             float2 mr = make_float2(0.f, 1.f);
-            if (pneed && !(CINE_ABL & 16)) {
+            if (pneed) {
                 if (npm <= 4) { float r4[12];
 #pragma unroll
                     for (int i = 0; i < 12; ++i) r4[i] = prec[i];
@@ -259,7 +176,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         st_lds[2 * ci] = mr.y; st_lds[2 * ci + 1] = -mr.x * mr.y;      // {scale, shift} of act()
     }
     CINE_STAMP(13);
-    if (HALO && !(CINE_ABL & 16)) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
+    if (HALO) {   // halo columns stay zero for the whole kernel when the image is no wider than the tile
         for (int e = tid; e < CK * C::ZP * C::ROWS * 2; e += C::NT) {
             const int ck = e / (C::ZP * C::ROWS * 2), rem = e % (C::ZP * C::ROWS * 2);
             in_lds[ck * C::PS + (rem >> 1) * C::COLS + ((rem & 1) ? C::COLS - 1 : TW)] = 0.f;
@@ -282,7 +199,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         if (chunk == 0) CINE_STAMP(2);
         // ---- commit: weight slab [tap][ck][COT] (packed layout [chunk][tap][ck][rowsp])
 #pragma unroll
-        for (int i = 0; i < ((CINE_ABL & 2) ? 0 : NWT); ++i) {
+        for (int i = 0; i < NWT; ++i) {
             const int e = tid + i * C::NT;
             if (e >= TAPS * CK * (C::COT / 4)) break;
             const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
@@ -293,8 +210,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         const int zs = chunk_zs(chunk);                 // V3: the volume slice this chunk stages (0 otherwise)
         int cl0;
         const Src& s = chunk_src(chunk, cl0);
-        if (CINE_ABL & 2) {
-        } else if (a.fast) {
+        if (a.fast) {
             // ---- vectorised staging: every piece = PW consecutive floats of one (channel, row)
             if (a.wav) {
                 // Haar wavelets on load (mwcnn.py:216-263).  DWT: a piece of PW outputs of band b, channel c comes from the
@@ -619,8 +535,8 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         // on the same SIMD.  Sweeps run at the lowest priority, everything else above it: the short phases finish at their own
         // pace and the workgroup is back in a sweep sooner (the sweeping wave loses 4 cycles per such instruction either way).
         __builtin_amdgcn_s_setprio(0);
-        if (!(CINE_ABL & 1)) sweep(std::integral_constant<int, CK / 4>{});
-        __builtin_amdgcn_s_setprio(CINE_PRIO);
+        sweep(std::integral_constant<int, CK / 4>{});
+        __builtin_amdgcn_s_setprio(kPrio);
         if (chunk == 0) CINE_STAMP(5);
     }
 
@@ -754,7 +670,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
         }
     }
     CINE_STAMP(7);
-    if (a.ypart && !(CINE_ABL & 8)) {
+    if (a.ypart) {
         // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass
         // per WAVE in registers (sum -> wave mean -> squared deviations), the WN wave records are merged
         // with Chan's formula by one thread per row.
@@ -832,20 +748,6 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     conv_tile<CK, CT, WM, WN, MT, TW, TAPS, V3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
 }
 
-// Experiment (-DCINE_PERSIST=<workgroups>): a fixed grid of workgroups that walk the tiles in launch order (x fastest), one after the other.
-#ifdef CINE_PERSIST
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3 = 0>
-__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_persist_kernel(ConvArgs a, int gx, int gy, int gz) {
-    extern __shared__ __align__(16) float smem_f[];
-    const long total = (long)gx * gy * gz;
-    for (long t = blockIdx.x; t < total; t += gridDim.x) {
-        const int bx = (int)(t % gx), by = (int)((t / gx) % gy), bz = (int)(t / ((long)gx * gy));
-        conv_tile<CK, CT, WM, WN, MT, TW, TAPS, V3>(a, bx, by, bz, smem_f);
-        __syncthreads();
-    }
-}
-#endif
-
 // Two independent sample sets in one grid: samples [0, pair_n) use the ordinary pointers, samples [pair_n, n) the *_b set.
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
 __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_pair_kernel(ConvArgs a) {
@@ -915,86 +817,6 @@ template <int COUT>
 __global__ __launch_bounds__(256) void conv1x1_stream_kernel(Conv1Args a) {
     extern __shared__ __align__(16) float smem_c1[];
     conv1x1_tile<COUT>(a, blockIdx.y, (long)blockIdx.x * 256 + threadIdx.x, a.hw, smem_c1);
-}
-
-// ---------------------------------------------------------------- plane-persistent U-Net
-// InstanceNorm is per (sample, channel) plane and nothing else in a U-Net pass couples samples, so ONE workgroup can carry
-// its sample through every layer with no grid-wide dependency: a workgroup barrier between layers is all the ordering the
-// data needs (stores and later loads of one workgroup share the CU's L1).  The caller gives every layer output its own
-// memory (sample n at n * dense size): samples are at different layers at the same time, so no buffer may change shape.  Workgroups drift apart, so the load / statistics /
-// store phases of one overlap the MFMA sweeps of its neighbour on the CU without extra streams, and the per-sample working
-// set stays in the Infinity Cache between layers.  The program is recorded from the ordinary per-layer entry points.
-constexpr int kMaxPlaneSteps = 24;
-struct PlaneStep { int cfg, ntiles, ncoblk, pad; ConvArgs a; };
-struct PlaneProgram { int nsteps, has_c1; Conv1Args c1; PlaneStep s[kMaxPlaneSteps]; };
-
-// the layer configurations a 16-channel U-Net on <= 16-wide planes uses (levels 0..3 and the three transpose convs)
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
-constexpr int plane_cfg_id() {
-    if (CK == 8 && TAPS == 9) {
-        if (CT == 1 && WM == 1 && WN == 4 && MT == 13 && TW == 16) return 0;
-        if (CT == 1 && WM == 2 && WN == 2 && MT == 13 && TW == 8) return 1;
-        if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 2;
-        if (CT == 2 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 3;
-    }
-    if (CK == 16 && TAPS == 1) {
-        if (CT == 4 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 7;        // all 4 x cout rows of the 128 -> 64 transpose conv in one workgroup
-        if (CT == 2 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 8;       // ... of the 64 -> 32 one
-        if (CT == 2 && WM == 4 && WN == 1 && MT == 4 && TW == 2) return 4;
-        if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 4) return 5;
-        if (CT == 1 && WM == 4 && WN == 1 && MT == 13 && TW == 8) return 6;
-    }
-    return -1;
-}
-
-// The program lives in device memory (written by plane_program_write_kernel from its kernarg copy): indexing a by-value
-// kernel argument with the loop variable would make the compiler keep a private copy of all of it.
-__global__ void plane_program_write_kernel(PlaneProgram src, PlaneProgram* dst) {
-    const int* s = reinterpret_cast<const int*>(&src);
-    int* d = reinterpret_cast<int*>(dst);
-    for (int i = threadIdx.x; i < (int)(sizeof(PlaneProgram) / sizeof(int)); i += blockDim.x) d[i] = s[i];
-}
-
-// Every layer configuration is a real function call here (its own register allocation): inlining all seven bodies into
-// one kernel made the allocator spill hundreds of registers.  Arguments travel in VGPRs, so the uniform ones are made
-// scalar again on entry.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-template <typename T> __device__ __forceinline__ T* uni_ptr(T* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>
-__device__ __attribute__((noinline)) void conv_tile_call(const ConvArgs* a, int tile, int coblk, int n, float* smem_f) {
-    conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(*uni_ptr(a), uni(tile), uni(coblk), uni(n), smem_f);
-}
-
-__global__ __launch_bounds__(256, 2) void unet_plane_kernel(const PlaneProgram* __restrict__ prog) {
-    extern __shared__ __align__(16) float smem_f[];
-    const int n = blockIdx.x;
-    const int nsteps = prog->nsteps;
-    for (int i = 0; i < nsteps; ++i) {
-        const ConvArgs* a = &prog->s[i].a;
-        const int cfg = prog->s[i].cfg, nt = prog->s[i].ntiles, ncb = prog->s[i].ncoblk;
-        for (int cb = 0; cb < ncb; ++cb)
-            for (int t = 0; t < nt; ++t) {
-                switch (cfg) {
-#ifndef CINE_FAST_BUILD
-                    case 0: conv_tile_call<8, 1, 1, 4, 13, 16, 9>(a, t, cb, n, smem_f); break;
-                    case 1: conv_tile_call<8, 1, 2, 2, 13, 8, 9>(a, t, cb, n, smem_f); break;
-                    case 2: conv_tile_call<8, 1, 4, 1, 13, 4, 9>(a, t, cb, n, smem_f); break;
-                    case 3: conv_tile_call<8, 2, 4, 1, 4, 2, 9>(a, t, cb, n, smem_f); break;
-                    case 4: conv_tile_call<16, 2, 4, 1, 4, 2, 1>(a, t, cb, n, smem_f); break;
-                    case 5: conv_tile_call<16, 1, 4, 1, 13, 4, 1>(a, t, cb, n, smem_f); break;
-                    default: conv_tile_call<16, 1, 4, 1, 13, 8, 1>(a, t, cb, n, smem_f); break;
-#else
-                    default: break;
-#endif
-                }
-                __syncthreads();      // the tile's stores and statistics are ordered before whatever reads them next; LDS is free again
-            }
-    }
-    if (prog->has_c1) conv1x1_tile<2>(prog->c1, n, threadIdx.x, 256, smem_f);
 }
 
 // ---------------------------------------------------------------- weight packing
@@ -1124,126 +946,12 @@ static int allow_big_lds(K kern, std::once_flag (&once)[64], const char* what) {
 }
 
 
-// ---------------------------------------------------------------- launch recorder (plane-persistent U-Net)
-struct RecStep {
-    int cfg; ConvArgs a; dim3 grid; size_t lds; int fam;
-    int (*launch)(const RecStep&, hipStream_t);
-    bool is_c1; Conv1Args c1; int c1_cout;
-};
-struct PlaneRecorder { std::vector<RecStep> steps; };
-static thread_local PlaneRecorder* g_rec = nullptr;
-
-PlaneRecorder* plane_record_begin() { g_rec = new PlaneRecorder(); return g_rec; }
-void plane_record_abort(PlaneRecorder* r) { if (g_rec == r) g_rec = nullptr; delete r; }
-
-// Issue what was recorded: as ONE plane-persistent kernel when every step is one of its configurations and there are
-// enough samples to fill the chip, else layer by layer exactly as if nothing had been recorded.
-size_t plane_program_bytes() { return sizeof(PlaneProgram); }
-
-// Opt-in (CINE_PLANE_KERNEL=1): on cfg 2 the plane-persistent kernel matches the per-layer launches for ONE slice in flight
-// (12.5 vs 13.0 ms) but loses with three in flight (102 vs 134 slices/s): two workgroups per CU cannot hide a 17-layer
-// latency chain.  It is kept as the base for a version with more parallelism per sample.
-bool plane_kernel_enabled() {
-    const char* e = getenv("CINE_PLANE_KERNEL");
-    return e != nullptr && atoi(e) != 0;
-}
-
-int plane_record_end(PlaneRecorder* r, hipStream_t st, void* prog_dev) {
-    g_rec = nullptr;
-    std::unique_ptr<PlaneRecorder> own(r);
-    bool ok = plane_kernel_enabled() && prog_dev && !r->steps.empty() && r->steps.size() <= (size_t)kMaxPlaneSteps + 1;
-    int n = -1;
-    size_t lds = 0;
-    for (size_t i = 0; ok && i < r->steps.size(); ++i) {
-        const RecStep& q = r->steps[i];
-        if (q.is_c1) { ok = i + 1 == r->steps.size() && q.c1_cout == 2 && (int)q.grid.y == n; lds = std::max(lds, q.lds); continue; }
-        ok = q.cfg >= 0 && !q.a.vol && (n < 0 || (int)q.grid.z == n) && i < (size_t)kMaxPlaneSteps;
-        n = (int)q.grid.z; lds = std::max(lds, q.lds);
-    }
-    ok = ok && n >= 128;
-    if (!ok) {
-        for (const RecStep& q : r->steps) if (int e = q.launch(q, st)) return e;
-        return CINE_OK;
-    }
-    PlaneProgram pp{};
-    for (const RecStep& q : r->steps) {
-        if (q.is_c1) { pp.has_c1 = 1; pp.c1 = q.c1; continue; }
-        PlaneStep& s = pp.s[pp.nsteps++];
-        s.cfg = q.cfg; s.ntiles = (int)q.grid.x; s.ncoblk = (int)q.grid.y; s.a = q.a;
-    }
-    static std::once_flag once[64];
-    if (int e = allow_big_lds(unet_plane_kernel, once, "unet_plane_kernel")) return e;
-    ProfScope prof(F_UNET_PLANE, st);
-    PlaneProgram* dprog = reinterpret_cast<PlaneProgram*>(prog_dev);
-    hipLaunchKernelGGL(plane_program_write_kernel, dim3(1), dim3(256), 0, st, pp, dprog);
-    hipLaunchKernelGGL(unet_plane_kernel, dim3(n), dim3(256), lds, st, dprog);
-    return check_launch("unet_plane_kernel");
-}
-
-// ---------------------------------------------------------------- conv + transpose conv of a plane-owning level in one kernel
-// At the two lowest levels of the cfg-2 U-Net one workgroup owns a whole plane in BOTH the second conv of the level and the
-// transpose conv that follows (unet.py:99-104, 212-218): the statistics of the conv's output are workgroup-local (one record per
-// channel), so the transpose conv can run right behind it in the same workgroup -- a barrier orders the plane's stores before its
-// re-load (same CU: L1 / L2 hits) -- without a launch boundary or a grid-wide drain in between.
-template <int CKA, int CTA, int WMA, int WNA, int MTA, int TWA, int CKB, int CTB, int WMB, int WNB, int MTB, int TWB>
-__global__ __launch_bounds__(256, 2) void conv_tconv_fused_kernel(ConvArgs a, ConvArgs b) {
-    extern __shared__ __align__(16) float smem_f[];
-    static_assert(64 * WMA * WNA == 256 && 64 * WMB * WNB == 256, "both steps use 256 threads");
-    const int n = blockIdx.x;
-    conv_tile<CKA, CTA, WMA, WNA, MTA, TWA, 9>(a, 0, 0, n, smem_f);
-    __syncthreads();                         // the plane's raw output and its statistics records are visible to the whole workgroup
-    conv_tile<CKB, CTB, WMB, WNB, MTB, TWB, 1>(b, 0, 0, n, smem_f);
-}
-
-// Issue two recorded steps (a 3x3 conv and the transpose conv reading its output) as one fused kernel when both are
-// one-workgroup-per-plane launches of a known configuration pair; else one after the other.
-int plane_record_end_pair(PlaneRecorder* r, hipStream_t st) {
-    g_rec = nullptr;
-    std::unique_ptr<PlaneRecorder> own(r);
-    bool ok = r->steps.size() == 2 && !r->steps[0].is_c1 && !r->steps[1].is_c1;
-    if (ok) {
-        const RecStep &s0 = r->steps[0], &s1 = r->steps[1];
-        ok = s0.grid.x == 1 && s0.grid.y == 1 && s1.grid.x == 1 && s1.grid.y == 1 && s0.grid.z == s1.grid.z && !s0.a.vol && !s1.a.vol &&
-             s1.a.s0.x == s0.a.y && s1.a.s0.part == s0.a.ypart && s1.a.tconv_cout > 0;
-        if (ok) {
-            const size_t lds = std::max(s0.lds, s1.lds);
-            const dim3 grid(s0.grid.z);
-            auto launch = [&](auto kern, const char* what) -> int {
-                static std::once_flag once[64];
-                if (lds > 64 * 1024) if (int e = allow_big_lds(kern, once, what)) return e;
-                ProfScope prof(F_CONV3, st);
-                hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, s0.a, s1.a);
-                return check_launch(what);
-            };
-#ifndef CINE_FAST_BUILD
-            if (s0.cfg == 3 && s1.cfg == 7) return launch(conv_tconv_fused_kernel<8, 2, 4, 1, 4, 2, 16, 4, 4, 1, 4, 2>, "conv_tconv_fused_kernel");
-            if (s0.cfg == 2 && s1.cfg == 8) return launch(conv_tconv_fused_kernel<8, 1, 4, 1, 13, 4, 16, 2, 4, 1, 13, 4>, "conv_tconv_fused_kernel");
-#endif
-        }
-    }
-    for (const RecStep& q : r->steps) if (int e = q.launch(q, st)) return e;
-    return CINE_OK;
-}
-
 // ---------------------------------------------------------------- host dispatch
-#ifndef CINE_MT16
-#define CINE_MT16 13         // pixel fragments per wave of the <= 16-row configurations (variant builds: 7 fits four waves per SIMD)
-#endif
-#ifndef CINE_WN16
-#define CINE_WN16 4
-#endif
-#ifndef CINE_WN32
-#define CINE_WN32 4
-#endif
-#ifndef CINE_SMALL_MT
-#define CINE_SMALL_MT 4      // 16-fragment tiles: 2 is ~5 % faster with ONE slice in flight, 4 is ~8 % faster with 12 (cfg 5: 286 -> 309 slices/s)
-#endif
-constexpr int kWN16 = CINE_WN16, kWN32 = CINE_WN32;   // waves (each 13 pixel fragments) per workgroup for <= 16 / <= 32 output rows
+constexpr int kSmallMT = 4;  // 16-fragment tiles: 2 is ~5 % faster with ONE slice in flight, 4 is ~8 % faster with 12 (cfg 5: 286 -> 309 slices/s)
+constexpr int kMT16 = 13;   // pixel fragments per wave of the <= 16-row configurations
+constexpr int kWN16 = 4;   // waves (each 13 pixel fragments) per workgroup for <= 16 / <= 32 output rows
 constexpr int kCK3 = 8;     // conv3x3: input channels per chunk
-#ifndef CINE_CK1
-#define CINE_CK1 16
-#endif
-constexpr int kCK1 = CINE_CK1;    // 1x1 / tconv: input channels per chunk
+constexpr int kCK1 = 16;    // 1x1 / tconv: input channels per chunk
 constexpr int kCK27 = 4;    // conv3x3x3: three input depth slices per channel live in LDS
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, bool PAIR = false, int V3 = 0>
@@ -1286,27 +994,12 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     a.tvec = a.tconv_cout > 0 && a.W % 2 == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
-    if (g_rec && !PAIR && !V3) {          // plane_record_begin() is active: keep the prepared launch instead of issuing it
-        RecStep r{};
-        r.cfg = plane_cfg_id<CK, CT, WM, WN, MT, TW, TAPS>(); r.a = a; r.grid = grid; r.lds = lds; r.fam = fam;
-        r.launch = [](const RecStep& q, hipStream_t s2) {
-            ProfScope prof(q.fam, s2);
-            hipLaunchKernelGGL((conv_mfma_kernel<CK, CT, WM, WN, MT, TW, TAPS>), q.grid, dim3(C::NT), q.lds, s2, q.a);
-            return check_launch("conv_mfma_kernel");
-        };
-        g_rec->steps.push_back(r);
-        return CINE_OK;
+    if constexpr (TAPS == 9 && !PAIR && V3 == 0) {       // plane-wide tiles of the U-Nets: the lean kernel (conv_plane.hip), bit-identical
+        bool handled = false;
+        const int e = launch_conv_plane(a, CK, CT, WM, WN, MT, TW, st, &handled);
+        if (e || handled) return e;
     }
     ProfScope prof(fam, st);
-#ifdef CINE_PERSIST
-    if constexpr (!PAIR) {
-        const long total = (long)grid.x * grid.y * grid.z;
-        if (total > CINE_PERSIST && lds <= 64 * 1024) {
-            hipLaunchKernelGGL((conv_mfma_persist_kernel<CK, CT, WM, WN, MT, TW, TAPS, V3>), dim3(CINE_PERSIST), dim3(C::NT), lds, st, a, (int)grid.x, (int)grid.y, (int)grid.z);
-            return check_launch("conv_mfma_persist_kernel");
-        }
-    }
-#endif
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, a);
     return check_launch("conv_mfma_kernel");
 }
@@ -1317,21 +1010,19 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
 static int regular_nf(int rowsp, long frags, bool plane3x3 = false) {
     if (plane3x3 && rowsp > 16 && rowsp <= 32 && frags <= 14) return 14;
     if (plane3x3 && rowsp > 32 && rowsp <= 64 && frags <= 4) return 4;
-    if (rowsp <= 16) return CINE_MT16 * CINE_WN16;
+    if (rowsp <= 16) return kMT16 * kWN16;
     if (rowsp <= 32) return 26;
     if (rowsp <= 64 || frags > 8) return 13;
     return 4;
 }
 // volumes whose regular tiling gives fewer than 128 workgroups per sample (the rule depends on the layer shape only, so the
 // statistics-record count of cine_conv_stat_partials3d stays a function of the shape)
-#ifndef CINE_VOL_SMALL
-#define CINE_VOL_SMALL 128      // regular tiling with fewer workgroups than this -> 4-fragment tiles
-#endif
+constexpr int kVolSmall = 128;      // regular tiling with fewer workgroups than this -> 4-fragment tiles
 static bool vol_small_tiles(int rowsp, int h, int w, int d) {
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
     const int TH = regular_nf(rowsp, frags) * 16 / TW;
-    return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < CINE_VOL_SMALL;
+    return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < kVolSmall;
 }
 
 template <int TW, int TAPS, int CK>
@@ -1340,8 +1031,8 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     // few samples, no statistics record (the CRNN cells' single-plane convolutions, recurrent_varnet.py:241-252): 52-fragment
     // tiles would give 52 workgroups for a 200 x 200 plane; 16-fragment tiles give 169
     if (a.rowsp <= 16 && !a.ypart && TAPS == 9 && !a.vol && (long)a.n * ceil_div(frags, 52L) < 200) {
-        if (a.pair_n > 0) return launch_cfg<CK, 1, 1, 4, CINE_SMALL_MT, TW, 9, true>(a, st);
-        return launch_cfg<CK, 1, 1, 4, CINE_SMALL_MT, TW, TAPS>(a, st);
+        if (a.pair_n > 0) return launch_cfg<CK, 1, 1, 4, kSmallMT, TW, 9, true>(a, st);
+        return launch_cfg<CK, 1, 1, 4, kSmallMT, TW, TAPS>(a, st);
     }
     CINE_REQUIRE(a.pair_n == 0, CINE_EUNSUPPORTED, "conv: pair launches exist for the single-plane CRNN configuration only");
     if (TAPS == 27 && vol_small_tiles(a.rowsp, a.H, a.W, a.D)) {
@@ -1360,9 +1051,9 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     if constexpr (TAPS == 9 && CK == 8) {
         // the first layer of every U-Net (2 -> chans, unet.py:51): a 4-channel chunk and one k-step per tap instead of an 8-channel
         // chunk that is three quarters zeros (half the MFMAs and half the staging of that layer)
-        if (a.rowsp <= 16 && !a.vol && a.cin <= 4 && a.s1.c == 0 && a.nchunks == 1) return launch_cfg<4, 1, 1, kWN16, CINE_MT16, TW, 9>(a, st);
+        if (a.rowsp <= 16 && !a.vol && a.cin <= 4 && a.s1.c == 0 && a.nchunks == 1) return launch_cfg<4, 1, 1, kWN16, kMT16, TW, 9>(a, st);
     }
-    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, CINE_MT16, TW, TAPS>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, kMT16, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
     // workgroups per CU): a touch slower than one 4-wave workgroup per plane in isolation, but it packs better with the
     // kernels of the other slices in flight (134.8 -> 138.0 slices/s on cfg 2)
@@ -1392,7 +1083,7 @@ static bool conv3d_v3_ok(const ConvArgs& a) {
 static int dispatch_v3(const ConvArgs& a, hipStream_t st) {
     if (vol_small_tiles(a.rowsp, a.H, a.W, a.D)) return launch_cfg<kCK3, 1, 4, 1, 4, 16, 9, false, 1>(a, st);    // 64 rows per workgroup
     const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
-    if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, CINE_MT16, 16, 9, false, 1>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, kMT16, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 32) return launch_cfg<kCK3, 1, 2, 2, 13, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK3, 1, 4, 1, 13, 16, 9, false, 1>(a, st);
     return launch_cfg<kCK3, 2, 4, 1, 4, 16, 9, false, 1>(a, st);
@@ -1405,7 +1096,7 @@ static bool vol1x1_fast_ok(const ConvArgs& a) {
 }
 static int dispatch_vol1x1(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
-    if (a.rowsp <= 16) return launch_cfg<kCK1, 1, 1, kWN16, CINE_MT16, 16, 1, false, 2>(a, st);
+    if (a.rowsp <= 16) return launch_cfg<kCK1, 1, 1, kWN16, kMT16, 16, 1, false, 2>(a, st);
     if (a.rowsp <= 32) return launch_cfg<kCK1, 1, 2, 2, 13, 16, 1, false, 2>(a, st);
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<kCK1, 1, 4, 1, 13, 16, 1, false, 2>(a, st);
     return launch_cfg<kCK1, 2, 4, 1, 4, 16, 1, false, 2>(a, st);
@@ -1666,22 +1357,6 @@ extern "C" int cine_conv1x1_bias(const float* x, const float* part_x, int np_x, 
         const dim3 grid((unsigned)ceil_div(hw / 4, 256L), n);
         const size_t lds = (size_t)(2 + cout) * cin * sizeof(float);
         hipStream_t st = as_stream(stream);
-        if (g_rec) {
-            RecStep r{};
-            r.is_c1 = true; r.c1 = c; r.c1_cout = cout; r.grid = grid; r.lds = lds; r.fam = F_CONV1; r.cfg = -1;
-            r.launch = [](const RecStep& q, hipStream_t s2) {
-                ProfScope prof(F_CONV1, s2);
-                switch (q.c1_cout) {
-                    case 1: hipLaunchKernelGGL(conv1x1_stream_kernel<1>, q.grid, dim3(256), q.lds, s2, q.c1); break;
-                    case 2: hipLaunchKernelGGL(conv1x1_stream_kernel<2>, q.grid, dim3(256), q.lds, s2, q.c1); break;
-                    case 3: hipLaunchKernelGGL(conv1x1_stream_kernel<3>, q.grid, dim3(256), q.lds, s2, q.c1); break;
-                    default: hipLaunchKernelGGL(conv1x1_stream_kernel<4>, q.grid, dim3(256), q.lds, s2, q.c1); break;
-                }
-                return check_launch("conv1x1_stream_kernel");
-            };
-            g_rec->steps.push_back(r);
-            return CINE_OK;
-        }
         ProfScope prof(F_CONV1, st);
         switch (cout) {
             case 1: hipLaunchKernelGGL(conv1x1_stream_kernel<1>, grid, dim3(256), lds, st, c); break;

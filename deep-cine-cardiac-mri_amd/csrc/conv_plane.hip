@@ -1,0 +1,449 @@
+// conv_plane.hip -- the lean 3x3 convolution of the cascade U-Nets (reference denoisers/unet.py:159-168 on x-f / y-f planes).
+//
+// conv_kernels.hip's conv_tile serves every shape, source mode and epilogue of the repository from one body: 13 k instructions
+// (100 KB of code per instantiation), run-time widths in every address, wavelet / volume / ragged-edge branches the U-Nets never
+// take.  Its profile on the cfg-2 layers is 2.1 - 3.0 vector instructions per fp32 MFMA -- and the fp32 MFMA shares the SIMD's
+// vector issue, so those instructions are paid in matrix time.  This kernel is the same algorithm for the one shape class that
+// carries 95 % of cfg 2's FLOPs, with everything that can be a compile-time constant made one:
+//   * the tile spans the plane's width (W == TW in {16, 8, 4, 2}): no halo columns to fetch, a tile's rows are ONE contiguous
+//     run of memory per channel, every store offset of the epilogue is an instruction immediate;
+//   * sources: one plain tensor (first layer, <= 4 channels), one or two InstanceNorm + LeakyReLU-on-load tensors of the plane's
+//     own extent (conv 2 of a block, the up path's concat), or one 2x2-average-pooled tensor (first conv below a pool);
+//   * rows outside the image and the halo columns are zeroed ONCE (the thread -> slot map is the same for every chunk), so the
+//     staging phase has no per-element selects;
+//   * wave-level sums of the statistics epilogue use gfx950's v_permlane16/32_swap instead of ds_bpermute round trips.
+// Same tile geometry (ConvCfg), weight packing, accumulation order and statistics arithmetic as conv_tile: the outputs and the
+// {count, mean, M2} records are BIT-IDENTICAL to the general kernel's (tests/test_hip_parity.py::test_conv_plane_bit_identical),
+// so producers and consumers of either kind mix freely.
+#include <atomic>
+#include <mutex>
+#include <type_traits>
+#include "common.h"
+#include "conv_cfg.h"
+
+namespace cine {
+namespace {
+
+std::atomic<int> g_plane_on{1};
+
+struct PlaneArgs {
+    const float* x0; const float* part0; int c0, np0;
+    const float* x1; const float* part1; int c1, np1;
+    long cs0;                            // MODE 2: floats between the channels of the pooled source
+    int sh0;                             // MODE 2: source height (2H or 2H + 1); its row pitch is 2 TW
+    const float* wp0; const float* wp1; int set_split;
+    float* y; float* ypart;
+    int cin, rows, rowsp, H, nchunks, tiles;
+    float slope, eps;
+};
+
+// x + (x of lane ^ 16) and x + (x of lane ^ 32): the swaps hand every lane both halves, the add is commutative -> the same
+// bits as x + __shfl_xor(x, 16 / 32)
+__device__ __forceinline__ float add_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);          // {own, partner} or {partner, own}: IEEE addition commutes
+}
+__device__ __forceinline__ float add_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// MODE 0: plain source (no statistics); 1: InstanceNorm + LeakyReLU on load, one source or the concat of two; 2: the same + 2x2 average pool
+template <int CK, int CT, int WM, int WN, int MT, int TW, int MODE>
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::MINW)) void conv_plane_kernel(PlaneArgs a) {
+    using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
+    constexpr int PW = C::PW, NT = C::NT, PR = C::PR, RP = C::RP, G = C::G, NCI = C::NCI, NWT = C::NWT;
+    static_assert(C::KR == 1, "one (row, piece) slot per thread");
+    typedef typename Piece<PW>::T piece_t;
+    extern __shared__ __align__(16) float smem_f[];
+    float* in_lds = smem_f;
+    float* w_lds = smem_f + C::IN_FLOATS;
+    float* st_lds = w_lds + C::W_FLOATS;            // {scale, shift} per input channel
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = blockIdx.x, n = blockIdx.z;
+    const int r0 = tile * C::TH, co0 = blockIdx.y * C::COT;
+    const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
+    const int q = lane & 15, kk = lane >> 4;
+    const int qr = q / TW, qc = q % TW;
+    int base_in[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+        base_in[dx] = kk * C::PS + (wn * MT * C::RPF + qr) * C::COLS + (qc + dx - 1 + C::COLS) % C::COLS;
+    const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
+
+    __builtin_amdgcn_s_setprio(2);
+    // ---- my slot of the staging map: (row, piece) srp of channel group sg; fixed for the whole kernel
+    const int sg = tid / RP, srp = tid - sg * RP;
+    const bool slot = sg < G;
+    const int sgc = G == 1 ? 0 : min(sg, G - 1);
+    const int srow = srp / PR, sj = srp % PR;
+    const int gy = r0 - 1 + srow;                                   // image row of my slot
+    const bool rowok = gy >= 0 && gy < a.H;
+    // modes 0 / 1: both sources have the plane's extent, so one channel stride; my byte offset inside a chunk's first channel
+    const unsigned cstride = (unsigned)(a.H * TW) * 4u;
+    const unsigned voff = (unsigned)(min(max(gy, 0), a.H - 1) * TW + PW * sj) * 4u + (unsigned)sgc * cstride;
+    float* const lrow = in_lds + sgc * C::PS + srow * C::COLS + PW * sj;
+
+    float4 wraw[NWT];
+    piece_t xraw[MODE == 2 ? 1 : NCI];
+    auto issue = [&](int chunk) {
+        const float* wsrc = wp + (long)chunk * 9 * CK * a.rowsp;
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int e = tid + i * NT;
+            int row = e / (C::COT / 4);
+            const int c4 = (e % (C::COT / 4)) * 4;
+            const bool v = e < 9 * CK * (C::COT / 4) && co0 + c4 < a.rowsp;
+            if (CK == 4) row = (row / CK) * 8 + row % CK;           // 4-channel chunk over the 8-channel packing
+            wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wp);
+        }
+        if constexpr (MODE != 2) {
+            const int ci0 = chunk * CK;
+            const bool first = ci0 < a.c0;
+            const int cl0 = first ? ci0 : ci0 - a.c0;
+            const int sc = first ? a.c0 : a.c1;
+            const char* sb = reinterpret_cast<const char*>(first ? a.x0 : a.x1) + ((size_t)n * sc + cl0) * cstride;   // uniform
+            const int cmax = sc - 1 - cl0;
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) {
+                const int cku = G == 1 ? min(i, cmax) : i * G;       // uniform part of the channel (G > 1: whole chunks only, host check)
+                xraw[i] = *reinterpret_cast<const piece_t*>(sb + (size_t)cku * cstride + voff);
+            }
+        }
+    };
+
+    // ---- statistics records of the input channels first (their latency is not paid behind the first chunk's 16-byte loads)
+    const int nch = a.c0 + a.c1;
+    constexpr int NPQ = 16;
+    float prec[MODE == 0 ? 1 : 3 * NPQ];
+    const bool pfirst = tid < a.c0;
+    const int pnp = pfirst ? a.np0 : a.np1;
+    const int npm = max(a.np0, a.c1 > 0 ? a.np1 : 0);
+    if constexpr (MODE != 0) {
+        if (tid < nch) {
+            const float* pp = (pfirst ? a.part0 + ((long)n * a.c0 + tid) * pnp * 3 : a.part1 + ((long)n * a.c1 + (tid - a.c0)) * pnp * 3);
+            if (npm <= 4) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) prec[i] = pp[min(i, 3 * pnp - 1)];
+            } else load_partials<NPQ>(pp, pnp, prec);
+        }
+    }
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MODE != 0) {
+        if (tid < nch) {
+            float2 mr;
+            if (npm <= 4) { float r4[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) r4[i] = prec[i];
+                mr = merge_loaded<4>(r4, pnp, a.eps);
+            } else mr = merge_loaded<NPQ>(prec, pnp, a.eps);
+            st_lds[2 * tid] = mr.y; st_lds[2 * tid + 1] = -mr.x * mr.y;
+        }
+    }
+    // ---- what no chunk ever writes is zeroed once: the halo columns, the rows outside the image, and (a chunk wider than the
+    // layer's input, i.e. the 2-channel first layer) the channels that do not exist
+    if (a.cin % CK != 0) {
+        for (int e = tid; e < C::IN_FLOATS; e += NT) in_lds[e] = 0.f;
+    } else {
+        for (int e = tid; e < CK * C::ROWS * 2; e += NT) {
+            const int ck = e / (C::ROWS * 2), rem = e % (C::ROWS * 2);
+            in_lds[ck * C::PS + (rem >> 1) * C::COLS + ((rem & 1) ? C::COLS - 1 : TW)] = 0.f;
+        }
+        if (slot && !rowok) {
+            piece_t z;
+            float* zf = reinterpret_cast<float*>(&z);
+#pragma unroll
+            for (int u = 0; u < PW; ++u) zf[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = z;
+        }
+    }
+
+    f32x4 acc[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        __syncthreads();                              // stats table + zero fill ready / previous sweep done with LDS
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int e = tid + i * NT;
+            if (e >= 9 * CK * (C::COT / 4)) break;
+            const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
+            *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = co0 + c4 < a.rowsp ? wraw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int ci0 = chunk * CK;
+        if constexpr (MODE != 2) {
+            if (slot && rowok) {
+                const float* stp = st_lds + 2 * (ci0 + sgc);
+#pragma unroll
+                for (int i = 0; i < NCI; ++i) {
+                    if (G == 1 && ci0 + i >= a.cin) break;          // uniform; only the narrow first layer
+                    piece_t o = xraw[i];
+                    if constexpr (MODE == 1) {
+                        const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                        act_piece<PW>(reinterpret_cast<float*>(&o), ss.x, ss.y, a.slope);
+                    }
+                    *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                }
+            }
+        } else {
+            // pooled source (extent sh0 x 2 TW): 2 PW floats from each of two rows per piece
+            if (slot && rowok && 2 * gy + 1 < a.sh0) {
+                const float* sb = a.x0 + ((long)n * a.c0 + ci0 + sgc) * a.cs0 + (long)(2 * gy) * (2 * TW) + 2 * PW * sj;
+                const float* stp = st_lds + 2 * (ci0 + sgc);
+#pragma unroll 2
+                for (int i = 0; i < NCI; ++i) {
+                    const float* src = sb + (long)i * G * a.cs0;
+                    const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                    float t0[2 * PW], t1[2 * PW];
+                    if constexpr (PW == 4) {
+#pragma unroll
+                        for (int u = 0; u < 8; u += 4) {
+                            *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(src + u);
+                            *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(src + 2 * TW + u);
+                        }
+                    } else {
+                        *reinterpret_cast<float4*>(t0) = *reinterpret_cast<const float4*>(src);
+                        *reinterpret_cast<float4*>(t1) = *reinterpret_cast<const float4*>(src + 2 * TW);
+                    }
+                    piece_t o;
+                    float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+                    for (int u = 0; u < PW; ++u)
+                        ov[u] = 0.25f * (act(t0[2 * u], ss.x, ss.y, a.slope) + act(t0[2 * u + 1], ss.x, ss.y, a.slope) +
+                                         act(t1[2 * u], ss.x, ss.y, a.slope) + act(t1[2 * u + 1], ss.x, ss.y, a.slope));
+                    *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                }
+            }
+        }
+        __syncthreads();
+        if (chunk + 1 < a.nchunks) issue(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA sweep: 9 taps x CK/4 operand groups, software-pipelined one group ahead (as conv_tile: same accumulation order)
+        {
+            constexpr int KS = CK / 4, NG = 9 * KS;
+            float af[2][CT], bf[2][MT];
+            auto load_group = [&](int g, float (&wa)[CT], float (&xa)[MT]) {
+                const int tap = g / KS, ks = g % KS;
+                const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) wa[ct] = w_lds[base_w + (tap * CK + 4 * ks) * C::COTP + 16 * ct];
+#pragma unroll
+                for (int f = 0; f < MT; ++f) xa[f] = in_lds[base_in[dx] + (4 * ks) * C::PS + (f * C::RPF + dy) * C::COLS];
+            };
+            __builtin_amdgcn_s_setprio(0);
+            load_group(0, af[0], bf[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int f = 0; f < MT; ++f)
+                        acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g & 1][f], af[g & 1][ct], acc[ct][f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(2);
+        }
+    }
+
+    // ---- epilogue.  Lane holds output row m = co0 + 16 (wm CT + ct) + q at pixels 4 kk .. 4 kk + 3 of fragment f; a fragment is
+    // 16 consecutive floats of the plane (RPF rows of TW), so fragment f sits 64 f bytes behind fragment 0: instruction immediates
+    constexpr int PPR = TW >= 4 ? 4 : TW;
+    const int pr0 = (4 * kk) / TW, pc0 = (4 * kk) % TW;
+    const int fr0 = r0 + wn * MT * C::RPF;                          // first image row of my fragments
+    const bool full = r0 + C::TH <= a.H;
+    unsigned long long vmask = ~0ull;
+    if (!full) {
+        vmask = 0;
+#pragma unroll
+        for (int f = 0; f < MT; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (fr0 + f * C::RPF + (4 * kk + j) / TW < a.H) vmask |= 1ull << (4 * f + j);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = co0 + 16 * (wm * CT + ct) + q;
+        if (m >= a.rows) continue;
+        float* yb = a.y + ((long)n * a.rows + m) * a.H * TW + (fr0 + pr0) * TW + pc0;
+        if (full) {
+#pragma unroll
+            for (int f = 0; f < MT; ++f) {
+                if constexpr (PPR == 4) {
+                    *reinterpret_cast<float4*>(yb + 16 * f) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+                } else {
+                    *reinterpret_cast<float2*>(yb + 16 * f) = make_float2(acc[ct][f][0], acc[ct][f][1]);
+                    *reinterpret_cast<float2*>(yb + 16 * f + TW) = make_float2(acc[ct][f][2], acc[ct][f][3]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < MT; ++f) {
+                if constexpr (PPR == 4) {
+                    if ((vmask >> (4 * f)) & 1ull)
+                        *reinterpret_cast<float4*>(yb + 16 * f) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+                } else {
+                    if ((vmask >> (4 * f)) & 1ull) *reinterpret_cast<float2*>(yb + 16 * f) = make_float2(acc[ct][f][0], acc[ct][f][1]);
+                    if ((vmask >> (4 * f + 2)) & 1ull) *reinterpret_cast<float2*>(yb + 16 * f + TW) = make_float2(acc[ct][f][2], acc[ct][f][3]);
+                }
+            }
+        }
+    }
+    if (a.ypart) {
+        // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass per WAVE in registers,
+        // the WN wave records merged with Chan's formula by one thread per row (conv_tile's arithmetic, operation for operation)
+        const int rows_w = min(max(a.H - fr0, 0), MT * C::RPF);
+        const float cnt_w = (float)(rows_w * TW);
+        float mean_w[CT], m2_w[CT];
+        auto wave_stats = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc += (FULL || ((vmask >> (4 * f + j)) & 1ull)) ? acc[ct][f][j] : 0.f;
+                sacc = add_xor16(sacc);
+                sacc = add_xor32(sacc);
+                mean_w[ct] = cnt_w > 0.f ? sacc / cnt_w : 0.f;
+                float qacc = 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = acc[ct][f][j] - mean_w[ct];
+                        qacc += (FULL || ((vmask >> (4 * f + j)) & 1ull)) ? d * d : 0.f;
+                    }
+                qacc = add_xor16(qacc);
+                qacc = add_xor32(qacc);
+                m2_w[ct] = qacc;
+            }
+        };
+        if (full) wave_stats(std::true_type{}); else wave_stats(std::false_type{});
+        __syncthreads();                            // everyone is done reading in_lds
+        float* red = in_lds;                        // [WN][COT][3]
+        if (kk == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float* o = red + (wn * C::COT + 16 * (wm * CT + ct) + q) * 3;
+                o[0] = cnt_w; o[1] = mean_w[ct]; o[2] = m2_w[ct];
+            }
+        }
+        __syncthreads();
+        if (tid < C::COT && co0 + tid < a.rows) {
+            float cnt = 0.f, mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { const float* r = red + (w * C::COT + tid) * 3; cnt += r[0]; mean += r[0] * r[1]; }
+            mean /= cnt;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                const float* r = red + (w * C::COT + tid) * 3;
+                const float d = r[1] - mean;
+                m2 += r[2] + r[0] * d * d;
+            }
+            float* o = a.ypart + (((long)n * a.rows + co0 + tid) * a.tiles + tile) * 3;
+            o[0] = cnt; o[1] = mean; o[2] = m2;
+        }
+    }
+}
+
+template <int CK, int CT, int WM, int WN, int MT, int TW, int MODE>
+int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
+    using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
+    auto kern = conv_plane_kernel<CK, CT, WM, WN, MT, TW, MODE>;
+    const size_t lds = C::lds_bytes(p.c0 + p.c1);
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "conv_plane_kernel: device index %d", dev);
+        std::call_once(once[dev], [&] {
+            status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "conv_plane_kernel: hipFuncSetAttribute: %s", hipGetErrorString(status[dev]));
+    }
+    CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv_plane_kernel: %d input channels need %zu bytes of LDS", p.cin, lds);
+    const dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
+    ProfScope prof(F_CONV3, st);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, p);
+    return check_launch("conv_plane_kernel");
+}
+
+}  // namespace
+
+// The general dispatcher (conv_kernels.hip: launch_cfg) has chosen the tile configuration (ck, ct, wm, wn, mt, tw); take the
+// launch when the layer is one of this kernel's shapes.
+int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled) {
+    *handled = false;
+    if (!g_plane_on.load(std::memory_order_relaxed)) return CINE_OK;
+    if (a.vol || a.D != 1 || a.add_src1 || a.bias || a.addend || a.relu || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
+    if (a.W != tw || a.n <= 0 || a.n > 65535) return CINE_OK;
+    const Src& s0 = a.s0; const Src& s1 = a.s1;
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || !al16(a.wp0) || !al16(a.wp1)) return CINE_OK;
+    int mode;
+    if (s0.mode == 0 && s1.c == 0) mode = 0;                            // the 2-channel first layer (4-channel chunk); the input-gradient convs of training
+    else if (s0.mode == 1 && (s1.c == 0 || s1.mode == 1) && ck == 8) mode = 1;
+    else if (s0.mode == 2 && s1.c == 0 && ck == 8) mode = 2;
+    else return CINE_OK;
+    if (mode != 2) {
+        if (s0.w != a.W || s0.h != a.H || (s1.c > 0 && (s1.w != a.W || s1.h != a.H))) return CINE_OK;
+        if (s1.c > 0 && s0.c % ck != 0) return CINE_OK;
+    } else {
+        if (s0.w != 2 * a.W || (s0.h != 2 * a.H && s0.h != 2 * a.H + 1)) return CINE_OK;
+    }
+    if (mode != 0) {
+        if (s0.np < 1 || s0.np > 16 || !s0.part || (s1.c > 0 && (s1.np < 1 || s1.np > 16 || !s1.part))) return CINE_OK;
+        if (s0.c + s1.c > 256) return CINE_OK;
+    }
+    const bool whole = a.cin % ck == 0;             // a narrower last chunk: only as the layer's ONE chunk, on the G == 1 shapes
+    const bool one = a.nchunks == 1;
+    PlaneArgs p{};
+    p.x0 = s0.x; p.part0 = s0.part; p.c0 = s0.c; p.np0 = s0.np;
+    p.x1 = s1.c > 0 ? s1.x : nullptr; p.part1 = s1.c > 0 ? s1.part : nullptr; p.c1 = s1.c; p.np1 = s1.c > 0 ? s1.np : 0;
+    p.cs0 = (long)s0.h * s0.w; p.sh0 = s0.h;
+    p.wp0 = a.wp0; p.wp1 = a.wp1; p.set_split = a.set_split;
+    p.y = a.y; p.ypart = a.ypart; p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.H = a.H; p.nchunks = a.nchunks; p.tiles = a.tiles;
+    p.slope = a.slope; p.eps = a.eps;
+    // G > 1 configurations (planes narrower than 16) stage whole chunks only
+#define CINE_PLANE_CASE(CK_, CT_, WM_, WN_, MT_, TW_, MODE_, NEEDWHOLE)                                                   \
+    if (ck == CK_ && ct == CT_ && wm == WM_ && wn == WN_ && mt == MT_ && tw == TW_ && mode == MODE_ && (whole || (!(NEEDWHOLE) && one))) { \
+        *handled = true;                                                                                                  \
+        return launch_plane<CK_, CT_, WM_, WN_, MT_, TW_, MODE_>(p, a.n, st);                                              \
+    }
+    CINE_PLANE_CASE(4, 1, 1, 4, 13, 16, 0, false)
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 16, 1, false)
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 16, 0, false)
+    CINE_PLANE_CASE(8, 1, 2, 2, 13, 16, 0, true)
+    CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 0, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 13, 8, 0, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 0, true)
+    CINE_PLANE_CASE(8, 2, 4, 1, 4, 2, 0, true)
+    CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 1, true)
+    CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 2, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 1, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 2, true)
+    CINE_PLANE_CASE(8, 2, 4, 1, 4, 2, 1, true)
+    CINE_PLANE_CASE(8, 2, 4, 1, 4, 2, 2, true)
+#undef CINE_PLANE_CASE
+    return CINE_OK;
+}
+
+}  // namespace cine
+
+// Diagnostics: route the plane-wide 3x3 convolutions through the general kernel (0) or the lean one (1, the default).  The two are
+// bit-identical; the switch exists for that test and for A/B timing.  Process-wide.
+extern "C" int cine_set_conv_plane(int on) {
+    cine::g_plane_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return CINE_OK;
+}

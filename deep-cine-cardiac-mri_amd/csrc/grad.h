@@ -51,10 +51,11 @@ int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, fl
 
 // Weight gradients beside the input-gradient chain.  Per conv layer the backward pass is in_lrelu_bwd (writes g) -> {wgrad(g), dgrad(g)}:
 // the two consumers are independent, and a backward pass on ONE stream pays every launch's half-empty last round.  SideLane
-// puts the weight gradients on a second, per-device stream: fork() after the producer of g has been enqueued, launched() after the wgrad;
+// puts the weight gradients on a second stream supplied by the caller (cine_set_side_stream; none: everything on the caller's stream): fork() after the producer of g has been enqueued, launched() after the wgrad;
 // g alternates between two buffers and before_write(slot) makes the main stream wait for the wgrad that still reads that slot; join()
 // before the call returns.  The weight gradients stay serial among themselves (they share the partial-sum workspace), and nothing about
-// the results depends on timing.  CINE_WGRAD_OVERLAP=0 keeps everything on the caller's stream.
+// the results depends on timing.
+void set_side_stream(hipStream_t s);      // thread-local
 class SideLane {
 public:
     explicit SideLane(hipStream_t main);

@@ -839,21 +839,12 @@ extern "C" int cine_in_lrelu_bwd(const float* r, const float* part, int np, cons
 namespace cine {
 // ---- SideLane -------------------------------------------------------------------------------------------------------------------------
 namespace {
-std::mutex g_side_mu;
-hipStream_t g_side[64] = {};
-hipStream_t side_stream_of_device() {
-    const char* env = getenv("CINE_WGRAD_OVERLAP");
-    if (env && env[0] == '0') return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(g_side_mu);
-    if (!g_side[dev] && hipStreamCreateWithFlags(&g_side[dev], hipStreamNonBlocking) != hipSuccess) g_side[dev] = nullptr;
-    return g_side[dev];
-}
+thread_local hipStream_t g_side_tls = nullptr;      // the caller's second stream (cine_set_side_stream); never created by the library
 }  // namespace
+void set_side_stream(hipStream_t s) { g_side_tls = s; }
 
 SideLane::SideLane(hipStream_t main) : main_(main) {
-    side_ = side_stream_of_device();
+    side_ = g_side_tls == main ? nullptr : g_side_tls;
     if (!side_) return;
     bool ok = hipEventCreateWithFlags(&ready_, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&done_[i], hipEventDisableTiming) == hipSuccess;
@@ -884,3 +875,10 @@ void SideLane::join() {
 }
 
 }  // namespace cine
+
+// The backward entry points that overlap weight gradients with the input-gradient chain (cine_unet2d_backward, cine_mwcnn_backward)
+// put the weight-gradient launches on this stream of the CALLING THREAD; NULL (the default) keeps everything on `stream`.
+extern "C" int cine_set_side_stream(void* side_stream) {
+    cine::set_side_stream(reinterpret_cast<hipStream_t>(side_stream));
+    return CINE_OK;
+}

@@ -14,20 +14,6 @@ using namespace cine;
 
 extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 
-namespace cine {
-// unet_bottom.hip: levels P-1 and P of the U as one kernel per plane
-struct BottomArgs {
-    const float* x1; const float* px1; int np1;
-    const float* w[7][2];
-    int set_split;
-    float* skip2;
-    float* y; float* py;
-    float eps, slope;
-};
-bool unet_bottom_applies(int chans2, int h2, int w2);
-int launch_unet_bottom(const BottomArgs& a, int n, hipStream_t st);
-}  // namespace cine
-
 namespace {
 
 constexpr float kEps = 1e-5f;     // nn.InstanceNorm2d default (unet.py:161)
@@ -53,13 +39,11 @@ struct Plan {
     float *up[8], *pup[8];             // transpose-conv output at level d
     float *ca[8], *pca[8];             // up-path ConvBlock at level d: first conv ...
     float *cb[8], *pcb[8];             // ... and second conv
-    float* prog;                       // device copy of the plane-persistent kernel's program (private layout only)
 };
 
 // private == false: three rotating scratch buffers sized for the largest layer (layers are separated by kernel boundaries, so
 // a buffer may hold different shapes over time).  private == true: every layer output owns its memory, sample n of every
-// tensor sits at n * (its dense size) -- what the plane-persistent kernel needs, where the samples are at different layers
-// at the same time.
+// tensor sits at n * (its dense size) -- what the training path needs (the backward pass reads all of them).
 void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools, bool priv) {
     p.P = pools;
     for (int d = 0; d <= pools; ++d) {
@@ -76,9 +60,7 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools, bool pri
         p.skip[d] = b.take(elems(d));
         p.pskip[d] = b.take(pelems(d, false));
     }
-    p.prog = nullptr;
     if (priv) {
-        p.prog = b.take((plane_program_bytes() + 3) / 4);
         for (int d = 0; d <= pools; ++d) { p.mid[d] = b.take(elems(d)); p.pmid[d] = b.take(pelems(d, false)); }
         p.bott = b.take(elems(pools)); p.pbott = b.take(pelems(pools, false));
         for (int d = 0; d < pools; ++d) {
@@ -108,16 +90,13 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools, bool pri
     }
 }
 
-// samples from which the plane-persistent kernel is worth trying (conv_kernels.hip applies the same threshold)
-constexpr int kPlaneMinSamples = 128;
-
 }  // namespace
 
 extern "C" size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools) {
     if (n <= 0 || h <= 0 || w <= 0 || chans <= 0 || pools <= 0 || pools > 6) return 0;
     (void)in_ch; (void)out_ch;
     Plan p; Bump b{nullptr, 0};
-    build(p, b, n, h, w, chans, pools, plane_kernel_enabled() && n >= kPlaneMinSamples);
+    build(p, b, n, h, w, chans, pools, false);
     return b.off;
 }
 
@@ -163,15 +142,8 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
         CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", i);
 
     Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
-    build(p, b, n, h, w, chans, pools, train || (plane_kernel_enabled() && n >= kPlaneMinSamples));
+    build(p, b, n, h, w, chans, pools, train);
     const int split = n / nsets;
-    // every step below reads only its own sample's data, so the launches are recorded and issued together: as one
-    // plane-persistent kernel when the layer shapes are the ones it is built for, else layer by layer (conv_kernels.hip)
-    // (recording only for the opt-in plane-persistent kernel; otherwise every launch is issued where it stands)
-    struct Guard {
-        PlaneRecorder* r;
-        ~Guard() { if (r) plane_record_abort(r); }
-    } guard{plane_kernel_enabled() && !train ? plane_record_begin() : nullptr};
     int wi = 0;
     const float *w0, *w1;
     auto next = [&]() {
@@ -180,23 +152,8 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
         ++wi;
     };
     int e;
-    // levels P-1 / P (second-lowest ConvBlock, pool, bottleneck, transpose conv, first up-path ConvBlock): one fused kernel per
-    // plane when the planes are cfg 2's 52 x 4 with 64 channels (unet_bottom.hip); its output carries ONE statistics record
-    const bool fuse = pools >= 2 && !train && !plane_kernel_enabled() && unet_bottom_applies(p.ch[pools - 1], p.hs[pools - 1], p.wsz[pools - 1]) &&
-                      p.ch[pools - 2] * 2 == p.ch[pools - 1] && p.hs[pools - 2] == 2 * p.hs[pools - 1] && p.wsz[pools - 2] == 2 * p.wsz[pools - 1];
-    // Opt-in (CINE_PAIR_FUSE=1): the second conv of a level and the transpose conv that reads its output issued as ONE kernel where one
-    // workgroup owns the plane in both (plane_record_end_pair: the two lowest levels of the cfg-2 U-Net).  Measured on cfg 2: 14 fewer
-    // launches per slice, transpose-conv family 0.84 -> 0.36 ms per slice, 3x3 family 7.96 -> 8.36 ms, 154.5 / 154.7 vs 154.7 / 155.1
-    // slices/s in flight -- the time moves, it does not shrink (the launch boundary was never the cost), so it stays off by default.
-    struct PairGuard {
-        PlaneRecorder* r = nullptr;
-        ~PairGuard() { if (r) plane_record_abort(r); }
-    } pair;
-    static const bool pair_env = [] { const char* v = getenv("CINE_PAIR_FUSE"); return v && atoi(v) != 0; }();
-    const bool pair_ok = pair_env && !train && !plane_kernel_enabled() && !fuse;
     // ---- down path (unet.py:94-97) + bottleneck (:99)
     for (int d = 0; d <= pools; ++d) {
-        if (fuse && d >= pools - 1) { wi += 2; continue; }
         const bool last = d == pools;
         float* mid = p.mid[d]; float* pmid = p.pmid[d];
         float* out = last ? p.bott : p.skip[d];
@@ -211,7 +168,6 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
                                 mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
         next();
-        if (last && pair_ok) pair.r = plane_record_begin();          // bottleneck output -> first transpose conv
         e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                             w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
@@ -221,37 +177,16 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
     int np_cur = p.np_conv[pools];
     for (int u = 0; u < pools; ++u) {
         const int d = pools - 1 - u;
-        if (fuse && u == 0) {
-            // weights in module order: [2(P-1)], [2(P-1)+1] level P-1 block; [2P], [2P+1] bottleneck; then tconv, conv, conv
-            BottomArgs ba{};
-            ba.x1 = p.skip[d - 1]; ba.px1 = p.pskip[d - 1]; ba.np1 = p.np_conv[d - 1];
-            const int base = 2 * d;
-            for (int l = 0; l < 7; ++l) {
-                ba.w[l][0] = reinterpret_cast<const float*>(weights[base + l]);
-                ba.w[l][1] = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + base + l]) : ba.w[l][0];
-            }
-            ba.set_split = split; ba.skip2 = p.skip[d]; ba.y = p.cb[d]; ba.py = p.pcb[d]; ba.eps = kEps; ba.slope = kSlope;
-            if ((e = launch_unet_bottom(ba, n, as_stream(stream)))) return e;
-            wi = base + 7;
-            cur = p.cb[d]; pcur = p.pcb[d]; np_cur = 1;
-            continue;
-        }
         next();   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
         e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
                              p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
         if (e) return e;
-        if (pair.r) {                                                 // issue the recorded (conv, transpose conv) pair
-            PlaneRecorder* r = pair.r;
-            pair.r = nullptr;
-            if ((e = plane_record_end_pair(r, as_stream(stream)))) return e;
-        }
         next();   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
         e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
                             p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
                             p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
         next();
-        if (d >= 1 && pair_ok) pair.r = plane_record_begin();        // this level's output -> the next transpose conv
         e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                             w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
         if (e) return e;
@@ -264,10 +199,7 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
     const float* bf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi + 1]) : nullptr;
     e = cine_conv1x1_bias(cur, pcur, np_cur, 1, wf0, bf0, wf1, bf1, split, y, n, chans, out_ch, h, w,
                           kEps, kSlope, stream);
-    if (e) return e;
-    PlaneRecorder* rec = guard.r;
-    guard.r = nullptr;
-    return rec ? plane_record_end(rec, as_stream(stream), p.prog) : CINE_OK;
+    return e;
 }
 
 // ---------------------------------------------------------------- backward pass (training)

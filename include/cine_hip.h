@@ -18,7 +18,9 @@
  *   - scratch comes from the caller: `ws`/`ws_bytes` with a matching *_ws_bytes() query.
  *   - re-entrant: per-call state only.  Process-wide state is limited to the thread-local error string, the optional launch
  *     profiler (cine_profile_begin/end: a mutex-guarded event list, off by default), per-(kernel, device) once-flags for the
- *     > 64 KB LDS opt-in, and two environment switches read at call time (CINE_PLANE_KERNEL, CINE_UNET_BOTTOM).
+ *     > 64 KB LDS opt-in, and the calling thread's optional side stream (cine_set_side_stream).  No environment switches.
+ *   - the library creates no streams.  The two backward entry points that overlap weight gradients with the input-gradient
+ *     chain (cine_unet2d_backward, cine_mwcnn_backward) create and destroy hipEvents (no timing) to order the two streams.
  */
 #ifndef CINE_HIP_H
 #define CINE_HIP_H
@@ -467,6 +469,18 @@ size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, in
 int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                               void* ws, size_t ws_bytes, void* stream);
+/* Diagnostics.  3x3 convolutions whose tile spans the plane's width (the x-f / y-f planes of the cascade U-Nets, reference
+ * denoisers/unet.py:159-168) run on a lean kernel (csrc/conv_plane.hip) that is BIT-IDENTICAL to the general one; `on` = 0
+ * routes them through the general kernel (the bit-identity test, A/B timing).  Process-wide, default 1. */
+int cine_set_conv_plane(int on);
+
+/* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_mwcnn_backward (they
+ * depend only on a layer's output gradient, not on the input-gradient chain behind it): the calls fork onto it with events
+ * and join before returning, so on return everything is ordered on `stream` again and the results do not depend on timing.
+ * NULL (the default) or the same stream as `stream`: every launch stays on `stream`.  Replaces nothing in the reference
+ * (torch.autograd runs its backward nodes on one stream); it is how `loss.backward()` (pl_modules/varnet_module.py:97-113) fills
+ * the chip. */
+int cine_set_side_stream(void* side_stream);
 /* Backward pass of the U-Net (the autograd graph of unet.py:73-125): from gy = d loss / d y, the forward's input x and its
  * filled workspace `fwd_ws`.  `wdgrad`: HOST array of device pointers ordered like `weights` of the forward, holding the
  * input-gradient packings (the bias slot is ignored).  `grads`: HOST array in the same order of device pointers to the weight

@@ -58,22 +58,40 @@ def _train_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.manual_seed(7)                                       # the same weights on every rank
+    torch.manual_seed(7 + rank)                                # DIFFERENT weights per rank: the constructor broadcasts rank 0's
     shared = torch.nn.Conv2d(2, 3, 3, padding=1)
-    net = torch.nn.ModuleList([shared, shared, torch.nn.Conv2d(3, 1, 1)])     # an aliased module, like the cascades' networks
+    unused = torch.nn.Conv2d(1, 1, 1)                          # a sub-network this step does not use (VarNet with explicit sens_maps)
+    net = torch.nn.ModuleList([shared, shared, torch.nn.Conv2d(3, 1, 1), unused])     # an aliased module, like the cascades' networks
     sync = shard.GradientAllReduce(net)
-    assert len(sync.params) == 4
+    assert len(sync.params) == 6
+    w0 = [torch.empty_like(p) for p in sync.params]
+    for w, p in zip(w0, sync.params):
+        w.copy_(p.detach())
+        dist.broadcast(w, src=0)
+    same_start = all(torch.equal(w, p.detach()) for w, p in zip(w0, sync.params))   # rank 0's values everywhere
 
     def loss_of(r):
         g = torch.Generator().manual_seed(50 + r)
         x = torch.randn(1, 2, 6, 5, generator=g)
         return net[2](net[1](x) + net[0](x)).square().mean()
     loss_of(rank).backward()
-    sync()
-    got = [p.grad.clone() for p in sync.params]
+    sync()                                                                      # the unused parameters have grad None: no error
+    used = [p for p in sync.params if p.grad is not None]
+    got = [p.grad.clone() for p in used]
     net.zero_grad()
     (sum(loss_of(r) for r in range(world)) / world).backward()                 # the same average on one rank
-    ok = all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, sync.params))
+    ok = same_start and len(used) == 4 and all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, used))
+    try:                                                                        # broadcast=False only checks: equal now ...
+        shard.GradientAllReduce(net, broadcast=False)
+        with torch.no_grad():
+            net[2].bias.add_(float(rank))                                       # ... and different after this
+        try:
+            shard.GradientAllReduce(net, broadcast=False)
+            ok = False
+        except RuntimeError:
+            pass
+    except RuntimeError:
+        ok = False
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -131,3 +149,56 @@ def test_bench_without_a_gpu_fails_loudly():
         return
     r, line = _bench("--steps", "1", "--warmup", "0", "--no-cpu-baseline")
     assert r.returncode != 0 and line is None and "no CPU fallback" in (r.stderr + r.stdout)
+
+
+def test_bench_selftest_eight_ranks_gloo():
+    """The driver's N = 8 launch shape on CPU: eight ranks under torch.distributed.run, slice sharding + all-gather assembly of all
+    8 K slices, every rank's own timed-region seconds on rank 0's line (a straggler is visible in SCALE_rNN.json)."""
+    r, line = _bench("--gpus", "8", "--steps", "3", "--warmup", "1", "--selftest-cpu", env_extra={"OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["volume_ok"] and line["volume_slices"] == 24
+    assert len(line["per_rank_timed_region_s"]) == 8 and line["timed_region_s"] == max(line["per_rank_timed_region_s"])
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: list of (bus, numa_node); node 0 of the KFD topology is the CPU (simd_count 0), as on a real box."""
+    import pathlib
+    root = pathlib.Path(root)
+    nodes = root / "class/kfd/kfd/topology/nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, (bus, numa) in enumerate(gpus):
+        (nodes / str(i + 1)).mkdir()
+        (nodes / str(i + 1) / "properties").write_text(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        dev = root / "bus/pci/devices" / f"0000:{bus:02x}:00.0"
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text(f"{numa}\n")
+    for n, cl in ((0, "0-3,64-67"), (1, "4-7")):
+        d = root / f"devices/system/node/node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cl + "\n")
+
+
+def test_rank_numa_affinity_from_sysfs(tmp_path):
+    """bench.py pins a rank to its GPU's NUMA node from sysfs alone (no GPU call): KFD order -> PCI function -> numa_node -> cpulist."""
+    sys.path.insert(0, ROOT)
+    import bench
+    _fake_sysfs(tmp_path, [(0x05, 0), (0x85, 1), (0xc5, -1)])
+    assert bench.gpu_numa_cpus(0, str(tmp_path)) == (0, {0, 1, 2, 3, 64, 65, 66, 67})
+    assert bench.gpu_numa_cpus(1, str(tmp_path)) == (1, {4, 5, 6, 7})
+    assert bench.gpu_numa_cpus(2, str(tmp_path)) == (None, None)          # numa_node -1: no pinning
+    assert bench.gpu_numa_cpus(7, str(tmp_path)) == (None, None)          # no such GPU
+    assert bench.gpu_numa_cpus(0, str(tmp_path / "missing")) == (None, None)
+    # applied in a child process (the affinity of the test runner itself stays untouched)
+    import subprocess
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; before = os.sched_getaffinity(0); "
+            "info = bench.pin_rank_to_gpu_numa(1, 2, %r); print(json.dumps([sorted(before), sorted(os.sched_getaffinity(0)), info]))" % (ROOT, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    import json
+    before, after, info = json.loads(out.stdout.strip().splitlines()[-1])
+    want = sorted(set(before) & {4, 5, 6, 7})
+    if want and want != before:
+        assert after == want and info["applied"] and info["numa_node"] == 1
+    else:
+        assert after == before and not info["applied"]

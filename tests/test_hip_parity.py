@@ -326,20 +326,50 @@ def test_conv3x3_random_shapes_vs_torch(dev):
         assert (st[..., 0] - ref.mean(dim=(2, 3))).abs().max() < 1e-4 * max(1.0, float(ref.abs().max())), (case, kind)
 
 
-def test_plane_persistent_unet_matches_per_layer_launches(dev, tmp_path):
-    """CINE_PLANE_KERNEL=1 (one workgroup carries a sample through all layers) must reproduce the per-layer launches bit for
-    bit: same kernels' code, same order of operations.  The switch is read once per process, hence the subprocesses."""
-    import subprocess, sys, os
-    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "plane_debug.py")
-    env = dict(os.environ)
-    env.pop("CINE_PLANE_KERNEL", None)
-    env.pop("CINE_UNET_BOTTOM", None)             # per-layer launches at every level
-    env["TMPDIR"] = str(tmp_path)
-    a = subprocess.run([sys.executable, script, "256", "3", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
-    assert a.returncode == 0 and "saved reference" in a.stdout, a.stdout + a.stderr
-    env["CINE_PLANE_KERNEL"] = "1"
-    b = subprocess.run([sys.executable, script, "256", "3", str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
-    assert b.returncode == 0 and "max abs diff 0.0 " in b.stdout, b.stdout + b.stderr
+def test_conv_plane_bit_identical_to_general_kernel(dev):
+    """csrc/conv_plane.hip (the lean kernel of plane-wide tiles) against conv_tile on every cfg-2 U-Net layer kind: raw output AND
+    statistics records bit for bit -- same geometry, accumulation order and statistics arithmetic (incl. the v_permlane swaps
+    standing in for __shfl_xor).  Two weight sets, 7 samples (full and boundary tiles in every launch)."""
+    from cine_hip import ops
+    from cine_hip._lib import lib
+    n = 7
+    cases = []            # (kind, c0, cout, h, w)
+    for d, (c, h, w) in enumerate(((16, 208, 16), (32, 104, 8), (64, 52, 4), (128, 26, 2))):
+        cases += [("norm", c, c, h, w), ("plain", c, c, h, w)]
+        if d == 0:
+            cases += [("plain", 2, c, h, w)]
+        else:
+            cases += [("pool", c // 2, c, h, w)]
+        if d < 3:
+            cases += [("concat", c, c, h, w), ("plain", c, 2 * c, h, w)]          # up path; input gradient of the concat conv
+    cases += [("norm", 16, 16, 200, 16), ("pool", 16, 32, 100, 8), ("norm", 128, 128, 25, 2), ("norm", 24, 16, 52, 16)]     # ragged last tiles, 3 chunks
+    try:
+        for kind, c0, cout, h, w in cases:
+            g = torch.Generator().manual_seed(c0 * 131 + cout + h)
+            cin = 2 * c0 if kind == "concat" else c0
+            wa = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
+            wb = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
+            if kind == "pool":
+                x = torch.randn(n, c0, 2 * h, 2 * w, generator=g).to(dev)
+                srcs = [(x, ops.instnorm_partials(x), 2)]
+            elif kind == "concat":
+                x = torch.randn(n, c0, h, w, generator=g).to(dev); x2 = torch.randn(n, c0, h, w, generator=g).to(dev)
+                # `up` comes out of a transpose conv: several statistics records per plane
+                p_up = ops.tconv2x2_in(torch.randn(n, 8, h // 2, w // 2, generator=g).to(dev), None, 0,
+                                       ops.pack_tconv2x2((torch.randn(8, c0, 2, 2, generator=g) / 3).to(dev)), c0)
+                srcs = [(p_up[0], p_up[1], 1), (x2, ops.instnorm_partials(x2), 1)]
+            else:
+                x = torch.randn(n, c0, h, w, generator=g).to(dev)
+                srcs = [(x, ops.instnorm_partials(x) if kind == "norm" else None, 1 if kind == "norm" else 0)]
+            outs = []
+            for on in (1, 0):
+                assert lib().cine_set_conv_plane(on) == 0
+                outs.append(ops.conv3x3_in(srcs, ops.pack_conv3x3(wa), cout, h, w, wpacked2=ops.pack_conv3x3(wb), set_split=4))
+            (y1, p1), (y0, p0) = outs
+            assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
+            assert torch.equal(p1, p0), (kind, c0, cout, h, w)
+    finally:
+        lib().cine_set_conv_plane(1)
 
 
 # ------------------------------------------------------------------ blocks and models
@@ -1051,12 +1081,11 @@ def test_apply_mask_zero_filled_and_fft_norms_vs_reference_golden(golden, dev):
     assert zf.shape == (1, 15, 200, 200) and rel_err(zf.cpu(), want) < OP_TOL
 
 
-# ------------------------------------------------------------------ fused bottom of the U (unet_bottom.hip)
+# ------------------------------------------------------------------ the cfg-2 U-Net on its own plane shape
 @pytest.mark.parametrize("n,sets", [(6, 2), (3, 1), (1, 1)])
-def test_unet_cfg2_planes_fused_bottom_vs_oracle(dev, n, sets, monkeypatch):
-    """U-Net(16 ch, 3 pools) on cfg 2's 208 x 16 planes with the opt-in fused bottom-of-U kernel (CINE_UNET_BOTTOM=1: levels
-    2 / 3 = 52 x 4 x 64 / 26 x 2 x 128 channels in one workgroup per plane) and with the default per-layer launches, one and
-    two weight sets (x-f / y-f nets in the same launches), against the CPU oracle's Unet."""
+def test_unet_cfg2_planes_vs_oracle(dev, n, sets):
+    """U-Net(16 ch, 3 pools) on cfg 2's 208 x 16 planes (levels 2 / 3 = 52 x 4 x 64 / 26 x 2 x 128 channels: one workgroup owns
+    a plane there), one and two weight sets (x-f / y-f nets in the same launches), against the CPU oracle's Unet."""
     from cine_hip import ops, synth
     from oracle import regularisers as R
     from reconstruction.models.denoisers.unet import Unet
@@ -1069,13 +1098,8 @@ def test_unet_cfg2_planes_fused_bottom_vs_oracle(dev, n, sets, monkeypatch):
     with torch.no_grad():
         per = n // sets
         want = torch.cat([nets_r[k](x[k * per:(k + 1) * per]) for k in range(sets)])
-    outs = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("CINE_UNET_BOTTOM", flag)
-        outs[flag] = ops.unet2d_forward(x.to(dev), ops.UnetWeights(nets_h)).cpu()
-        assert rel_err(outs[flag], want) < BLOCK_TOL, flag
-    assert not torch.equal(outs["0"], outs["1"]) or n == 0            # two different code paths were really taken
-    assert rel_err(outs["1"], outs["0"]) < 1e-5
+    got = ops.unet2d_forward(x.to(dev), ops.UnetWeights(nets_h)).cpu()
+    assert rel_err(got, want) < BLOCK_TOL
 
 
 # ------------------------------------------------------------------ direct tests of the small helpers

@@ -3,6 +3,10 @@
 # rocprofv3 gets the python program directly after "--" (no env / bash -c hops); PMC passes are separate from the trace passes.
 set -u
 export TMPDIR=/tmp
+# a plain shell export: under rocprofv3 the profiler's library initialises the GPU before Python starts, so bench.py's own
+# os.environ.setdefault comes too late and the runs would see the runtime's default of 4 hardware queues
+export GPU_MAX_HW_QUEUES=16
+echo "GPU_MAX_HW_QUEUES=$GPU_MAX_HW_QUEUES"
 R=$PWD; O=$R/gpurun_out/prof; mkdir -p $O
 COMMIT=${1:-unknown}
 PART=${2:-all}          # "main" = the cfg-2 evidence, "others" = cfg 3/4/5, "train" = the training step, "all" = main + others (separate gpurun calls fit the 20-minute limit)
