@@ -74,6 +74,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
     const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
 
     __builtin_amdgcn_s_setprio(2);
+    CINE_STAMP_RT(9);
+    CINE_STAMP(0);
     // ---- my slot of the staging map: (row, piece) srp of channel group sg; fixed for the whole kernel
     const int sg = tid / RP, srp = tid - sg * RP;
     const bool slot = sg < G;
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
 
     float4 wraw[NWT];
     piece_t xraw[MODE == 2 ? 1 : NCI];
+    // pooled source: the first NPRE pieces of a chunk are prefetched like the plain ones (2 PW floats of two source rows each)
+    constexpr int NPRE = MODE == 2 ? (NCI < 2 ? NCI : 2) : 0;
+    float4 praw[NPRE > 0 ? NPRE : 1][PW == 4 ? 4 : 2];
+    const float* const pbase = MODE == 2 ? a.x0 + ((long)n * a.c0 + sgc) * a.cs0 + (long)(2 * min(max(gy, 0), a.H - 1)) * (2 * TW) + 2 * PW * sj : nullptr;
     auto issue = [&](int chunk) {
         const float* wsrc = wp + (long)chunk * 9 * CK * a.rowsp;
 #pragma unroll
@@ -110,6 +116,17 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             for (int i = 0; i < NCI; ++i) {
                 const int cku = G == 1 ? min(i, cmax) : i * G;       // uniform part of the channel (G > 1: whole chunks only, host check)
                 xraw[i] = *reinterpret_cast<const piece_t*>(sb + (size_t)cku * cstride + voff);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const float* src = pbase + (long)(chunk * CK + i * G) * a.cs0;
+                if constexpr (PW == 4) {
+                    praw[i][0] = *reinterpret_cast<const float4*>(src); praw[i][1] = *reinterpret_cast<const float4*>(src + 4);
+                    praw[i][2] = *reinterpret_cast<const float4*>(src + 2 * TW); praw[i][3] = *reinterpret_cast<const float4*>(src + 2 * TW + 4);
+                } else {
+                    praw[i][0] = *reinterpret_cast<const float4*>(src); praw[i][1] = *reinterpret_cast<const float4*>(src + 2 * TW);
+                }
             }
         }
     };
@@ -168,8 +185,10 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
 #pragma unroll
         for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    CINE_STAMP(1);
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
         __syncthreads();                              // stats table + zero fill ready / previous sweep done with LDS
+        if (chunk == 0) CINE_STAMP(2);
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int e = tid + i * NT;
@@ -193,14 +212,34 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
                 }
             }
         } else {
-            // pooled source (extent sh0 x 2 TW): 2 PW floats from each of two rows per piece
+            // pooled source (extent sh0 x 2 TW): 2 PW floats from each of two rows per piece; pieces >= NPRE are loaded here
             if (slot && rowok && 2 * gy + 1 < a.sh0) {
-                const float* sb = a.x0 + ((long)n * a.c0 + ci0 + sgc) * a.cs0 + (long)(2 * gy) * (2 * TW) + 2 * PW * sj;
+                const float* sb = pbase + (long)ci0 * a.cs0;
                 const float* stp = st_lds + 2 * (ci0 + sgc);
-#pragma unroll 2
-                for (int i = 0; i < NCI; ++i) {
-                    const float* src = sb + (long)i * G * a.cs0;
+                auto pooled = [&](const float* t0, const float* t1, int i) {
                     const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                    piece_t o;
+                    float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+                    for (int u = 0; u < PW; ++u)
+                        ov[u] = 0.25f * (act(t0[2 * u], ss.x, ss.y, a.slope) + act(t0[2 * u + 1], ss.x, ss.y, a.slope) +
+                                         act(t1[2 * u], ss.x, ss.y, a.slope) + act(t1[2 * u + 1], ss.x, ss.y, a.slope));
+                    *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                };
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    float t0[2 * PW], t1[2 * PW];
+                    if constexpr (PW == 4) {
+                        *reinterpret_cast<float4*>(t0) = praw[i][0]; *reinterpret_cast<float4*>(t0 + 4) = praw[i][1];
+                        *reinterpret_cast<float4*>(t1) = praw[i][2]; *reinterpret_cast<float4*>(t1 + 4) = praw[i][3];
+                    } else {
+                        *reinterpret_cast<float4*>(t0) = praw[i][0]; *reinterpret_cast<float4*>(t1) = praw[i][1];
+                    }
+                    pooled(t0, t1, i);
+                }
+#pragma unroll 2
+                for (int i = NPRE; i < NCI; ++i) {
+                    const float* src = sb + (long)i * G * a.cs0;
                     float t0[2 * PW], t1[2 * PW];
                     if constexpr (PW == 4) {
 #pragma unroll
@@ -212,17 +251,13 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
                         *reinterpret_cast<float4*>(t0) = *reinterpret_cast<const float4*>(src);
                         *reinterpret_cast<float4*>(t1) = *reinterpret_cast<const float4*>(src + 2 * TW);
                     }
-                    piece_t o;
-                    float* ov = reinterpret_cast<float*>(&o);
-#pragma unroll
-                    for (int u = 0; u < PW; ++u)
-                        ov[u] = 0.25f * (act(t0[2 * u], ss.x, ss.y, a.slope) + act(t0[2 * u + 1], ss.x, ss.y, a.slope) +
-                                         act(t1[2 * u], ss.x, ss.y, a.slope) + act(t1[2 * u + 1], ss.x, ss.y, a.slope));
-                    *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                    pooled(t0, t1, i);
                 }
             }
         }
+        if (chunk == 0) CINE_STAMP(3);
         __syncthreads();
+        if (chunk == 0) CINE_STAMP(4);
         if (chunk + 1 < a.nchunks) issue(chunk + 1);
         __builtin_amdgcn_sched_barrier(0);
         // ---- MFMA sweep: 9 taps x CK/4 operand groups, software-pipelined one group ahead (as conv_tile: same accumulation order)
@@ -251,7 +286,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             }
             __builtin_amdgcn_s_setprio(2);
         }
+        if (chunk == 0) CINE_STAMP(5);
     }
+    CINE_STAMP(6);
 
     // ---- epilogue.  Lane holds output row m = co0 + 16 (wm CT + ct) + q at pixels 4 kk .. 4 kk + 3 of fragment f; a fragment is
     // 16 consecutive floats of the plane (RPF rows of TW), so fragment f sits 64 f bytes behind fragment 0: instruction immediates
@@ -296,6 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             }
         }
     }
+    CINE_STAMP(7);
     if (a.ypart) {
         // InstanceNorm partial {count, mean, M2} of this workgroup's pixels per output row: exact two-pass per WAVE in registers,
         // the WN wave records merged with Chan's formula by one thread per row (conv_tile's arithmetic, operation for operation)
@@ -328,39 +366,57 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             }
         };
         if (full) wave_stats(std::true_type{}); else wave_stats(std::false_type{});
-        __syncthreads();                            // everyone is done reading in_lds
-        float* red = in_lds;                        // [WN][COT][3]
-        if (kk == 0) {
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                float* o = red + (wn * C::COT + 16 * (wm * CT + ct) + q) * 3;
-                o[0] = cnt_w; o[1] = mean_w[ct]; o[2] = m2_w[ct];
-            }
-        }
-        __syncthreads();
-        if (tid < C::COT && co0 + tid < a.rows) {
+        // the WN wave records of a row are merged with Chan's formula (conv_tile's expressions verbatim: same bits)
+        auto merge_store = [&](const float (&rc)[WN], const float (&rm)[WN], const float (&rq)[WN], int row) {
             float cnt = 0.f, mean = 0.f;
 #pragma unroll
-            for (int w = 0; w < WN; ++w) { const float* r = red + (w * C::COT + tid) * 3; cnt += r[0]; mean += r[0] * r[1]; }
+            for (int w = 0; w < WN; ++w) { cnt += rc[w]; mean += rc[w] * rm[w]; }
             mean /= cnt;
             float m2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WN; ++w) {
-                const float* r = red + (w * C::COT + tid) * 3;
-                const float d = r[1] - mean;
-                m2 += r[2] + r[0] * d * d;
+                const float d = rm[w] - mean;
+                m2 += rq[w] + rc[w] * d * d;
             }
-            float* o = a.ypart + (((long)n * a.rows + co0 + tid) * a.tiles + tile) * 3;
+            float* o = a.ypart + (((long)n * a.rows + co0 + row) * a.tiles + tile) * 3;
             o[0] = cnt; o[1] = mean; o[2] = m2;
+        };
+        if constexpr (WN == 1) {
+            // one wave holds all pixels of its rows: no exchange, no barrier
+            if (kk == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int row = 16 * (wm * CT + ct) + q;
+                    if (co0 + row < a.rows) { const float rc[1] = {cnt_w}, rm[1] = {mean_w[ct]}, rq[1] = {m2_w[ct]}; merge_store(rc, rm, rq, row); }
+                }
+            }
+        } else {
+            float* red = st_lds + 2 * nch;              // [WN][COT][3], a region of its own: no barrier against the last sweep's LDS reads
+            if (kk == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float* o = red + (wn * C::COT + 16 * (wm * CT + ct) + q) * 3;
+                    o[0] = cnt_w; o[1] = mean_w[ct]; o[2] = m2_w[ct];
+                }
+            }
+            __syncthreads();
+            if (tid < C::COT && co0 + tid < a.rows) {
+                float rc[WN], rm[WN], rq[WN];
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { const float* r = red + (w * C::COT + tid) * 3; rc[w] = r[0]; rm[w] = r[1]; rq[w] = r[2]; }
+                merge_store(rc, rm, rq, tid);
+            }
         }
     }
+    CINE_STAMP(8);
+    CINE_STAMP_RT(10);
 }
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int MODE>
 int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
     auto kern = conv_plane_kernel<CK, CT, WM, WN, MT, TW, MODE>;
-    const size_t lds = C::lds_bytes(p.c0 + p.c1);
+    const size_t lds = C::lds_bytes(p.c0 + p.c1) + (WN > 1 ? C::RED_FLOATS * sizeof(float) : 0);      // + the statistics exchange of the epilogue
     static std::once_flag once[64];
     static hipError_t status[64];
     if (lds > 64 * 1024) {
