@@ -152,7 +152,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl), the device barrier and the all-gather of the volume assembly even at --gpus 1 "
                          "(start under `python -m torch.distributed.run --nproc-per-node=1`, or alone: rank 0 of a world of 1)")
-    ap.add_argument("--no-conv-plane", action="store_true", help="A/B: route the plane-wide 3x3 convs through the general kernel (cine_set_conv_plane(0))")
+    ap.add_argument("--no-conv-plane", action="store_true", help="A/B: route the plane-wide 3x3 / transpose convs through the general kernel (cine_set_conv_plane(0))")
+    ap.add_argument("--conv-plane-mask", type=int, default=-1, help="A/B: cine_set_conv_plane(mask): bit 0 the 3x3 convs, bit 1 the transpose convs")
     ap.add_argument("--pin-numa", action="store_true", help="pin this process to its GPU's NUMA node at --gpus 1 too (always done for N > 1)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the extra sustained region (0 = skip)")
     ap.add_argument("--headline-only", action="store_true", help="skip the latency / sustained regions and the other_configs / train_step extras of the default 1-GPU line")
@@ -687,9 +688,9 @@ def main():
 
     from cine_hip import shard
     shard.FORCE_COLLECTIVE = bool(args.force_dist)
-    if args.no_conv_plane:
+    if args.no_conv_plane or args.conv_plane_mask >= 0:
         from cine_hip._lib import lib
-        lib().cine_set_conv_plane(0)
+        lib().cine_set_conv_plane(0 if args.no_conv_plane else args.conv_plane_mask)
     wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
     cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
     wl.run(args.warmup, False)

@@ -83,4 +83,7 @@ template <> struct Piece<2> { typedef float2 T; };
 // there, *handled = false (and CINE_OK) when it is not one of that kernel's shapes.
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled);
 
+// the k2 s2 transpose conv of plane-wide tiles (pixel tile = mt fragments of 16 pixels, plane width tw)
+int launch_tconv_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled);
+
 }  // namespace cine

@@ -24,7 +24,7 @@
 namespace cine {
 namespace {
 
-std::atomic<int> g_plane_on{1};
+std::atomic<int> g_plane_on{3};          // bit 0: 3x3 convs, bit 1: transpose convs
 
 struct PlaneArgs {
     const float* x0; const float* part0; int c0, np0;
@@ -441,7 +441,7 @@ int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
 // launch when the layer is one of this kernel's shapes.
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
-    if (!g_plane_on.load(std::memory_order_relaxed)) return CINE_OK;
+    if (!(g_plane_on.load(std::memory_order_relaxed) & 1)) return CINE_OK;
     if (a.vol || a.D != 1 || a.add_src1 || a.bias || a.addend || a.relu || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
@@ -500,6 +500,267 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
 // Diagnostics: route the plane-wide 3x3 convolutions through the general kernel (0) or the lean one (1, the default).  The two are
 // bit-identical; the switch exists for that test and for A/B timing.  Process-wide.
 extern "C" int cine_set_conv_plane(int on) {
-    cine::g_plane_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    cine::g_plane_on.store(on, std::memory_order_relaxed);       // bit 0 the 3x3 convs, bit 1 the transpose convs (3 = both, the default)
     return CINE_OK;
 }
+
+// ================================================================ transpose conv k2 s2 of plane-wide tiles
+// unet.py:212-218 as a GEMM with 4 cout rows over the input pixels (row m = 2 (s cout + co) + b -> output (2y + s, 2x + b)), for the
+// cascade U-Nets' shapes: ALL input channels of the tile are staged at once (InstanceNorm + LeakyReLU on load; one barrier in the
+// whole kernel instead of a barrier pair per 16-channel chunk), the weights never touch LDS -- every lane streams its own B operand
+// W[k][row] from L2 two k-steps ahead of the MFMAs that use it.  Same pixel tiles, accumulation order (k ascending), paired 16-byte
+// stores and statistics records as conv_tile's TAPS = 1 path: bit-identical outputs.
+namespace cine {
+namespace {
+
+struct TconvPlaneArgs {
+    const float* x; const float* part; int np, mode;
+    const float* wp0; const float* wp1; int set_split;
+    float* y; float* ypart;
+    int cout, rows, rowsp, H, tiles;
+    float slope, eps;
+};
+
+template <int CIN, int CT, int WM, int MT, int TW>
+struct TconvCfg {
+    static constexpr int NT = 64 * WM;
+    static constexpr int TPX = 16 * MT;                    // pixels of a tile: TH rows of TW, contiguous in the plane
+    static constexpr int TH = TPX / TW;
+    static constexpr int PS = ((TPX + 31) / 32) * 32 + 16; // channel stride == 16 (mod 32)
+    static constexpr int NV = TPX / 4;                     // 16-byte pieces per channel
+    static constexpr int G = NT / NV;                      // channel groups staged in parallel
+    static constexpr int NCI = (CIN + G - 1) / G;          // pieces per thread
+    static constexpr int COT = 16 * CT * WM;
+    static constexpr int KSN = CIN / 4;
+    static_assert(TPX % 4 == 0 && G >= 1 && CIN % 4 == 0, "tile shape");
+    static size_t lds_bytes() { return (size_t)(CIN * PS + 2 * CIN) * sizeof(float); }
+};
+
+template <int CIN, int CT, int WM, int MT, int TW>
+__global__ __launch_bounds__(64 * WM, (WM > 4 ? 4 : 2)) void tconv_plane_kernel(TconvPlaneArgs a) {
+    using C = TconvCfg<CIN, CT, WM, MT, TW>;
+    constexpr int G = C::G, NCI = C::NCI, NV = C::NV, KSN = C::KSN;
+    extern __shared__ __align__(16) float smem_f[];
+    float* in_lds = smem_f;
+    float* st_lds = smem_f + CIN * C::PS;
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int tile = blockIdx.x, n = blockIdx.z;
+    const int co0 = blockIdx.y * C::COT;
+    const int q = lane & 15, kk = lane >> 4;
+    const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
+    __builtin_amdgcn_s_setprio(2);
+    // ---- staging map: piece sv of channel group sg; rows beyond the image (a last tile that overhangs) read as zero
+    const int sg = tid / NV, sv = tid - sg * NV;
+    const bool slot = sg < G;
+    const int sgc = min(sg, G - 1);
+    const int hw = a.H * TW;                                // plane size in pixels
+    const int p0 = tile * C::TPX + 4 * sv;                  // my first pixel in the plane
+    const bool pok = p0 < hw;                               // (TW divides 4 or 4 divides TW, hw % 4 == 0: a piece is inside or outside as a whole)
+    const float* xb = a.x + (long)n * CIN * hw + (long)sgc * hw + min(p0, hw - 4);
+    // statistics records first, then all the input pieces, then the first weights
+    float2 mr = make_float2(0.f, 1.f);
+    constexpr int NPQ = 16;
+    float prec[3 * NPQ];
+    const bool need = a.mode == 1 && tid < CIN;
+    if (need) {
+        const float* pp = a.part + ((long)n * CIN + tid) * a.np * 3;
+        if (a.np <= 4) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) prec[i] = pp[min(i, 3 * a.np - 1)];
+        } else load_partials<NPQ>(pp, a.np, prec);
+    }
+    float4 xraw[NCI];
+#pragma unroll
+    for (int i = 0; i < NCI; ++i) xraw[i] = *reinterpret_cast<const float4*>(xb + (long)min(i * G, CIN - 1 - sgc) * hw);
+    // B operand (k x rows): lane = output row q of a 16-row block, channel kk of the k-step
+    const float* wl = wp + (long)kk * a.rowsp + co0 + 16 * (wm * CT) + q;
+    constexpr int PD = 2;                                   // k-steps of weights in flight
+    float wreg[PD][CT];
+    auto wload = [&](int ks, float (&w)[CT]) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = co0 + 16 * (wm * CT + ct) < a.rowsp ? wl[(long)(4 * ks) * a.rowsp + 16 * ct] : 0.f;
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) wload(min(d, KSN - 1), wreg[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tid < CIN) {
+        if (need) {
+            if (a.np <= 4) { float r4[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) r4[i] = prec[i];
+                mr = merge_loaded<4>(r4, a.np, a.eps);
+            } else mr = merge_loaded<NPQ>(prec, a.np, a.eps);
+        }
+        st_lds[2 * tid] = mr.y; st_lds[2 * tid + 1] = -mr.x * mr.y;
+    }
+    __syncthreads();
+    if (slot) {
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) {
+            const int c = sgc + i * G;
+            if (c >= CIN) break;
+            float4 o = xraw[i];
+            if (a.mode == 1) {
+                const float2 ss = *reinterpret_cast<const float2*>(st_lds + 2 * c);
+                act_piece<4>(reinterpret_cast<float*>(&o), ss.x, ss.y, a.slope);
+            }
+            if (!pok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(in_lds + c * C::PS + 4 * sv) = o;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* ain = in_lds + kk * C::PS + q;             // A operand (pixels x k): lane = pixel q of the fragment, channel kk
+    __builtin_amdgcn_s_setprio(0);
+#pragma unroll 2
+    for (int ks = 0; ks < KSN; ++ks) {
+        float wcur[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) wcur[ct] = wreg[ks % PD][ct];
+        if (ks + PD < KSN) wload(ks + PD, wreg[ks % PD]);
+        float xa[MT];
+#pragma unroll
+        for (int f = 0; f < MT; ++f) xa[f] = ain[(4 * ks) * C::PS + 16 * f];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
+                acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[f], wcur[ct], acc[ct][f], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(2);
+
+    // ---- epilogue: lanes q, q ^ 1 hold the two x-parities of the same 4 pixels; swapping halves gives each lane 4 consecutive output floats
+    const int r0 = tile * C::TH;
+    const bool full = r0 + C::TH <= a.H;
+    unsigned long long vmask = ~0ull;
+    if (!full) {
+        vmask = 0;
+#pragma unroll
+        for (int f = 0; f < MT; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (r0 + (16 * f + 4 * kk + j) / TW < a.H) vmask |= 1ull << (4 * f + j);
+    }
+    const bool odd = q & 1;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = co0 + 16 * (wm * CT + ct) + q;
+        if (m >= a.rows) continue;
+        const int me = m >> 1, co = me % a.cout, ay = me / a.cout;
+        float* yb = a.y + ((long)n * a.cout + co) * (2 * a.H) * (2 * TW);
+#pragma unroll
+        for (int f = 0; f < MT; ++f) {
+            const float s0 = odd ? acc[ct][f][0] : acc[ct][f][2], s1 = odd ? acc[ct][f][1] : acc[ct][f][3];
+            const float t0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+            const float t1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xf, 0xf, true));
+            const float4 o = odd ? make_float4(t0, acc[ct][f][2], t1, acc[ct][f][3]) : make_float4(acc[ct][f][0], t0, acc[ct][f][1], t1);
+            const int p = 16 * f + 4 * kk + (odd ? 2 : 0);
+            const int gy = r0 + p / TW, gx = p % TW;
+            if (gy < a.H) *reinterpret_cast<float4*>(yb + (long)(2 * gy + ay) * (2 * TW) + 2 * gx) = o;
+        }
+    }
+    if (a.ypart) {
+        const int rows_w = min(max(a.H - r0, 0), C::TH);
+        const float cnt_w = (float)(rows_w * TW);
+        float mean_w[CT], m2_w[CT];
+        auto wave_stats = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc += (FULL || ((vmask >> (4 * f + j)) & 1ull)) ? acc[ct][f][j] : 0.f;
+                sacc = add_xor16(sacc);
+                sacc = add_xor32(sacc);
+                mean_w[ct] = cnt_w > 0.f ? sacc / cnt_w : 0.f;
+                float qacc = 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = acc[ct][f][j] - mean_w[ct];
+                        qacc += (FULL || ((vmask >> (4 * f + j)) & 1ull)) ? d * d : 0.f;
+                    }
+                qacc = add_xor16(qacc);
+                qacc = add_xor32(qacc);
+                m2_w[ct] = qacc;
+            }
+        };
+        if (full) wave_stats(std::true_type{}); else wave_stats(std::false_type{});
+        if (kk == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int m = co0 + 16 * (wm * CT + ct) + q;
+                if (m >= a.rows) continue;
+                // one wave holds all pixels of its rows; conv_tile's single-record merge, expression for expression
+                float cnt = 0.f, mean = 0.f;
+                cnt += cnt_w; mean += cnt_w * mean_w[ct];
+                mean /= cnt;
+                float m2 = 0.f;
+                const float d = mean_w[ct] - mean;
+                m2 += m2_w[ct] + cnt_w * d * d;
+                const int co = (m >> 1) % a.cout, ab = 2 * ((m >> 1) / a.cout) + (m & 1);
+                float* o = a.ypart + (((long)n * a.cout + co) * (a.tiles * 4) + tile * 4 + ab) * 3;
+                o[0] = cnt; o[1] = mean; o[2] = m2;
+            }
+        }
+    }
+}
+
+template <int CIN, int CT, int WM, int MT, int TW>
+int launch_tconv(const TconvPlaneArgs& p, int n, hipStream_t st) {
+    using C = TconvCfg<CIN, CT, WM, MT, TW>;
+    auto kern = tconv_plane_kernel<CIN, CT, WM, MT, TW>;
+    const size_t lds = C::lds_bytes();
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "tconv_plane_kernel: device index %d", dev);
+        std::call_once(once[dev], [&] {
+            status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "tconv_plane_kernel: hipFuncSetAttribute: %s", hipGetErrorString(status[dev]));
+    }
+    const dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
+    ProfScope prof(F_TCONV, st);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, p);
+    return check_launch("tconv_plane_kernel");
+}
+
+}  // namespace
+
+// Called by the general dispatcher for a 2-D transpose conv with the pixel-tile shape (mt fragments, tw) it chose.
+int launch_tconv_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled) {
+    *handled = false;
+    if (!(g_plane_on.load(std::memory_order_relaxed) & 2)) return CINE_OK;
+    if (a.vol || a.D != 1 || a.tconv_cout <= 0 || !a.tvec || a.bias || a.addend || a.relu || a.accum || a.s1.c > 0 || a.add_src1) return CINE_OK;
+    if (a.W != tw || a.n <= 0 || a.n > 65535 || a.s0.mode > 1 || a.s0.w != a.W || a.s0.h != a.H || (a.H * a.W) % 4 != 0) return CINE_OK;
+    if (a.s0.mode == 1 && (!a.s0.part || a.s0.np < 1 || a.s0.np > 16)) return CINE_OK;
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (!al16(a.y) || !al16(a.s0.x)) return CINE_OK;
+    TconvPlaneArgs p{};
+    p.x = a.s0.x; p.part = a.s0.part; p.np = a.s0.np; p.mode = a.s0.mode;
+    p.wp0 = a.wp0; p.wp1 = a.wp1; p.set_split = a.set_split; p.y = a.y; p.ypart = a.ypart;
+    p.cout = a.tconv_cout; p.rows = a.rows; p.rowsp = a.rowsp; p.H = a.H; p.tiles = a.tiles; p.slope = a.slope; p.eps = a.eps;
+#define CINE_TCONV_CASE(CIN_, CT_, WM_, MT_, TW_)                                   \
+    if (a.cin == CIN_ && mt == MT_ && tw == TW_) {                                   \
+        *handled = true;                                                            \
+        return launch_tconv<CIN_, CT_, WM_, MT_, TW_>(p, a.n, st);                   \
+    }
+    CINE_TCONV_CASE(32, 1, 4, 13, 8)
+    CINE_TCONV_CASE(64, 1, 8, 13, 4)         // eight waves: all 128 rows of a plane in one workgroup, the 64-channel input staged once
+    CINE_TCONV_CASE(128, 2, 8, 4, 2)
+#undef CINE_TCONV_CASE
+    return CINE_OK;
+}
+
+}  // namespace cine

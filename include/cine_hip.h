@@ -470,8 +470,9 @@ int cine_unet2d_forward_train(const float* x, float* y, const void* const* weigh
                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                               void* ws, size_t ws_bytes, void* stream);
 /* Diagnostics.  3x3 convolutions whose tile spans the plane's width (the x-f / y-f planes of the cascade U-Nets, reference
- * denoisers/unet.py:159-168) run on a lean kernel (csrc/conv_plane.hip) that is BIT-IDENTICAL to the general one; `on` = 0
- * routes them through the general kernel (the bit-identity test, A/B timing).  Process-wide, default 1. */
+ * denoisers/unet.py:159-168) and the k2 s2 transpose convs between them (unet.py:212-218) run on lean kernels (csrc/conv_plane.hip)
+ * that are BIT-IDENTICAL to the general one; `on` is a mask -- bit 0 the 3x3 convolutions, bit 1 the transpose convolutions; a
+ * cleared bit routes that kind through the general kernel (the bit-identity tests, A/B timing).  Process-wide, default 3. */
 int cine_set_conv_plane(int on);
 
 /* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_mwcnn_backward (they

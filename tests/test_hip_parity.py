@@ -362,14 +362,43 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
                 x = torch.randn(n, c0, h, w, generator=g).to(dev)
                 srcs = [(x, ops.instnorm_partials(x) if kind == "norm" else None, 1 if kind == "norm" else 0)]
             outs = []
-            for on in (1, 0):
+            for on in (3, 0):
                 assert lib().cine_set_conv_plane(on) == 0
                 outs.append(ops.conv3x3_in(srcs, ops.pack_conv3x3(wa), cout, h, w, wpacked2=ops.pack_conv3x3(wb), set_split=4))
             (y1, p1), (y0, p0) = outs
             assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
             assert torch.equal(p1, p0), (kind, c0, cout, h, w)
     finally:
-        lib().cine_set_conv_plane(1)
+        lib().cine_set_conv_plane(3)
+
+
+def test_tconv_plane_bit_identical_to_general_kernel(dev):
+    """The lean transpose conv of csrc/conv_plane.hip (all input channels staged at once, weights streamed from L2) against
+    conv_tile's TAPS = 1 path on the cfg-2 U-Net's three transpose convs, plus overhanging last tiles and a plain source."""
+    from cine_hip import ops
+    from cine_hip._lib import lib
+    n = 5
+    try:
+        for cin, cout, h, w, mode in ((32, 16, 104, 8, 1), (64, 32, 52, 4, 1), (128, 64, 26, 2, 1), (32, 16, 100, 8, 1), (128, 64, 25, 2, 1),
+                                      (64, 32, 50, 4, 0)):
+            g = torch.Generator().manual_seed(cin + h)
+            x = torch.randn(n, cin, h, w, generator=g).to(dev)
+            wt = ops.pack_tconv2x2((torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5).to(dev))
+            if mode:      # several statistics records per plane, as a conv output has them
+                px = ops.conv3x3_in([(x, None, 0)], ops.pack_conv3x3(torch.eye(cin, device=dev).view(cin, cin, 1, 1) * torch.tensor([[0., 0, 0], [0, 1, 0], [0, 0, 0]], device=dev)), cin, h, w)
+                assert torch.equal(px[0], x)
+                part = px[1]
+            else:
+                part = None
+            outs = []
+            for on in (3, 0):
+                assert lib().cine_set_conv_plane(on) == 0
+                outs.append(ops.tconv2x2_in(x, part, mode, wt, cout))
+            (y1, p1), (y0, p0) = outs
+            assert torch.equal(y1, y0), (cin, cout, h, w, float((y1 - y0).abs().max()))
+            assert torch.equal(p1, p0), (cin, cout, h, w)
+    finally:
+        lib().cine_set_conv_plane(3)
 
 
 # ------------------------------------------------------------------ blocks and models
