@@ -1001,6 +1001,11 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
             if (e || handled) return e;
         }
     }
+    if constexpr (TAPS == 9 && !PAIR && V3 <= 1 && CK == 8 && TW == 16) {      // wider planes / volumes in 16-wide column tiles: conv_plane.hip, bit-identical
+        bool handled = false;
+        const int e = launch_conv_wide(a, CT, WM, WN, MT, V3, st, &handled);
+        if (e || handled) return e;
+    }
     if constexpr (TAPS == 9 && !PAIR && V3 == 0) {       // plane-wide tiles of the U-Nets: the lean kernel (conv_plane.hip), bit-identical
         bool handled = false;
         const int e = launch_conv_plane(a, CK, CT, WM, WN, MT, TW, st, &handled);

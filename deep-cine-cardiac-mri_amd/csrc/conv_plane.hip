@@ -24,7 +24,7 @@
 namespace cine {
 namespace {
 
-std::atomic<int> g_plane_on{3};          // bit 0: 3x3 convs, bit 1: transpose convs
+std::atomic<int> g_plane_on{7};          // bit 0: plane-wide 3x3 convs, bit 1: transpose convs, bit 2: wide planes / volumes
 
 struct PlaneArgs {
     const float* x0; const float* part0; int c0, np0;
@@ -500,7 +500,7 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
 // Diagnostics: route the plane-wide 3x3 convolutions through the general kernel (0) or the lean one (1, the default).  The two are
 // bit-identical; the switch exists for that test and for A/B timing.  Process-wide.
 extern "C" int cine_set_conv_plane(int on) {
-    cine::g_plane_on.store(on, std::memory_order_relaxed);       // bit 0 the 3x3 convs, bit 1 the transpose convs (3 = both, the default)
+    cine::g_plane_on.store(on, std::memory_order_relaxed);       // bit 0 plane-wide 3x3 convs, bit 1 transpose convs, bit 2 wide planes / volumes (7 = all, the default)
     return CINE_OK;
 }
 
@@ -760,6 +760,412 @@ int launch_tconv_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* 
     CINE_TCONV_CASE(64, 1, 8, 13, 4)         // eight waves: all 128 rows of a plane in one workgroup, the 64-channel input staged once
     CINE_TCONV_CASE(128, 2, 8, 4, 2)
 #undef CINE_TCONV_CASE
+    return CINE_OK;
+}
+
+}  // namespace cine
+
+// ================================================================ 3x3 (x3) convolutions of planes / volumes wider than one tile
+// The sensitivity network's 208 x 208 planes, the CRNN hybrids' all-frame convolutions on 200 x 200 planes and the 3-D U-Net's
+// 15 x 200 x 200 / 7 x 100 x 100 volumes (3x3x3 as three 3x3 passes per depth offset, the V3 form of conv_tile).  Same idea as
+// conv_plane_kernel; what the column tiling adds: the two halo columns of a tile row ride in the SAME prefetch as the row's
+// 16-byte pieces (one extra 4-byte load per channel in the threads that own a row's first / last piece) instead of conv_tile's
+// synchronous element-wise fetch after every chunk's staging, and columns / rows / slices that lie outside the source are
+// zeroed once or by a wave-uniform branch.  Optional bias / addend / ReLU epilogue (the CRNN cells, recurrent_varnet.py:122-134).
+// Bit-identical to conv_tile (same chunk order, accumulation order, epilogue and statistics arithmetic).
+namespace cine {
+namespace {
+
+struct WideArgs {
+    const float* x0; const float* part0; int c0, np0, d0;
+    const float* x1; const float* part1; int c1, np1, d1;
+    const float* wp0; const float* wp1; int set_split;
+    const float* bias; const float* bias1; const float* addend; int relu;
+    float* y; float* ypart;
+    int cin, rows, rowsp, D, H, W, nchunks, ncc, tiles, tiles_w, tiles_hw;
+    float slope, eps;
+};
+
+// MODE 0: plain sources; 1: InstanceNorm + LeakyReLU on load.  V3: volumes, chunk = (depth offset, 8 channels).
+template <int CT, int WM, int WN, int MT, int MODE, int V3>
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::MINW)) void conv_wide_kernel(WideArgs a) {
+    constexpr int CK = 8, TW = 16;
+    using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
+    constexpr int NT = C::NT, PR = C::PR, RP = C::RP, G = C::G, NCI = C::NCI, NWT = C::NWT;
+    static_assert(C::KR == 1 && C::PW == 4, "one (row, 16-byte piece) slot per thread");
+    extern __shared__ __align__(16) float smem_f[];
+    float* in_lds = smem_f;
+    float* w_lds = smem_f + C::IN_FLOATS;
+    float* st_lds = w_lds + C::W_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = blockIdx.x, n = blockIdx.z;
+    const int z0 = tile / a.tiles_hw, t2 = tile - z0 * a.tiles_hw;
+    const int ty = t2 / a.tiles_w, tx = t2 - ty * a.tiles_w;
+    const int r0 = ty * C::TH, c0 = tx * TW, co0 = blockIdx.y * C::COT;
+    const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
+    const int q = lane & 15, kk = lane >> 4;
+    int base_in[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) base_in[dx] = kk * C::PS + (wn * MT) * C::COLS + (q + dx - 1 + C::COLS) % C::COLS;
+    const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
+    __builtin_amdgcn_s_setprio(2);
+    // ---- my slot: row srow, piece sj of channel group sg; the first / last piece of a row also carries the row's left / right halo column
+    const int sg = tid / RP, srp = tid - sg * RP;
+    const bool slot = sg < G;
+    const int sgc = G == 1 ? 0 : min(sg, G - 1);
+    const int srow = srp / PR, sj = srp % PR;
+    const int gy = r0 - 1 + srow, gx = c0 + 4 * sj;
+    const bool rowok = gy >= 0 && gy < a.H;
+    const bool pok = rowok && gx < a.W;                              // my piece lies inside the plane (W % 4 == 0: as a whole)
+    const int hx = sj == 0 ? c0 - 1 : c0 + TW;                       // my halo column (sj 0 / PR - 1 only)
+    const bool hslot = slot && (sj == 0 || sj == PR - 1);
+    const bool hok = rowok && hx >= 0 && hx < a.W;
+    const long hwl = (long)a.H * a.W;
+    const unsigned voff = (unsigned)(min(max(gy, 0), a.H - 1) * a.W + min(gx, a.W - 4)) * 4u;
+    const unsigned hoff = (unsigned)(min(max(gy, 0), a.H - 1) * a.W + min(max(hx, 0), a.W - 1)) * 4u;
+    float* const lrow = in_lds + sgc * C::PS + srow * C::COLS + 4 * sj;
+    float* const lhalo = in_lds + sgc * C::PS + srow * C::COLS + (sj == 0 ? C::COLS - 1 : TW);
+
+    auto chunk_cc = [&](int chunk) { return V3 ? chunk % a.ncc : chunk; };
+    auto chunk_zs = [&](int chunk) { return V3 ? z0 + chunk / a.ncc - 1 : 0; };
+    auto chunk_live = [&](int chunk) { return !V3 || (chunk_zs(chunk) >= 0 && chunk_zs(chunk) < a.D); };
+    float4 wraw[NWT];
+    float4 xraw[NCI];
+    float hraw[NCI];
+    auto issue = [&](int chunk) {
+        if (V3 && !chunk_live(chunk)) return;
+        const float* wsrc = wp + (long)chunk * 9 * CK * a.rowsp;
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int e = tid + i * NT;
+            const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
+            const bool v = e < 9 * CK * (C::COT / 4) && co0 + c4 < a.rowsp;
+            wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wp);
+        }
+        const int ci0 = chunk_cc(chunk) * CK;
+        const bool first = ci0 < a.c0;
+        const int cl0 = first ? ci0 : ci0 - a.c0;
+        const int sc = first ? a.c0 : a.c1, sd = first ? a.d0 : a.d1;
+        const int zsc = V3 ? min(chunk_zs(chunk), sd - 1) : 0;
+        const size_t cstride = (size_t)sd * hwl * 4u;
+        const char* sb = reinterpret_cast<const char*>(first ? a.x0 : a.x1) + (((size_t)n * sc + cl0) * sd + zsc) * hwl * 4u + (size_t)sgc * cstride;
+        const int cmax = sc - 1 - cl0;
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) {
+            const int cku = G == 1 ? min(i, cmax) : i * G;
+            xraw[i] = *reinterpret_cast<const float4*>(sb + (size_t)cku * cstride + voff);
+            if (hslot) hraw[i] = *reinterpret_cast<const float*>(sb + (size_t)cku * cstride + hoff);
+        }
+    };
+    const int nch = a.c0 + a.c1;
+    float prec[MODE == 0 ? 1 : 12];
+    const bool pfirst = tid < a.c0;
+    const int pnp = pfirst ? a.np0 : a.np1;
+    const int npm = max(a.np0, a.c1 > 0 ? a.np1 : 0);
+    const float* const pp = MODE == 0 || tid >= nch ? nullptr
+                            : (pfirst ? a.part0 + ((long)n * a.c0 + tid) * pnp * 3 : a.part1 + ((long)n * a.c1 + (tid - a.c0)) * pnp * 3);
+    if constexpr (MODE != 0) {
+        if (tid < nch && npm <= 4) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) prec[i] = pp[min(i, 3 * pnp - 1)];
+        }
+    }
+    int first_live = 0;
+    if (V3) while (first_live < a.nchunks && !chunk_live(first_live)) ++first_live;
+    issue(first_live);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (MODE != 0) {
+        if (tid < nch) {
+            float2 mr;
+            if (npm <= 4) { float r4[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) r4[i] = prec[i];
+                mr = merge_loaded<4>(r4, pnp, a.eps);
+            } else mr = merge_partials(pp, pnp, a.eps);          // one record per tile of a wide plane (52 for 208 x 208): the loop form
+            st_lds[2 * tid] = mr.y; st_lds[2 * tid + 1] = -mr.x * mr.y;
+        }
+    }
+    // ---- zeroed once: everything when the layer's only chunk is narrower than 8 channels; else my slots that lie outside the plane
+    const bool narrow = a.cin % CK != 0;
+    if (narrow) {
+        for (int e = tid; e < C::IN_FLOATS; e += NT) in_lds[e] = 0.f;
+    } else if (slot) {
+        if (!pok) {
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) *reinterpret_cast<float4*>(lrow + i * G * C::PS) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (hslot && !hok) {
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) lhalo[i * G * C::PS] = 0.f;
+        }
+    }
+
+    f32x4 acc[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = first_live; chunk < a.nchunks; ++chunk) {
+        if (V3 && !chunk_live(chunk)) break;           // the live chunks of a tile are one run: the dead ones behind it are skipped
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int e = tid + i * NT;
+            if (e >= 9 * CK * (C::COT / 4)) break;
+            const int row = e / (C::COT / 4), c4 = (e % (C::COT / 4)) * 4;
+            *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = co0 + c4 < a.rowsp ? wraw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int ci0 = chunk_cc(chunk) * CK;
+        const bool first = ci0 < a.c0;
+        const bool srcok = !V3 || chunk_zs(chunk) < (first ? a.d0 : a.d1);       // a shorter `up` volume reads as zero behind its end (unet.py:106-120)
+        if (slot) {
+            const float* stp = st_lds + 2 * (ci0 + sgc);
+            if (pok) {
+#pragma unroll
+                for (int i = 0; i < NCI; ++i) {
+                    if (G == 1 && ci0 + i >= a.cin) break;
+                    float4 o = xraw[i];
+                    if constexpr (MODE == 1) {
+                        const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                        act_piece<4>(reinterpret_cast<float*>(&o), ss.x, ss.y, a.slope);
+                    }
+                    if (!srcok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(lrow + i * G * C::PS) = o;
+                }
+            }
+            if (hslot && hok) {
+#pragma unroll
+                for (int i = 0; i < NCI; ++i) {
+                    if (G == 1 && ci0 + i >= a.cin) break;
+                    float v = hraw[i];
+                    if constexpr (MODE == 1) {
+                        const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+                        v = act(v, ss.x, ss.y, a.slope);
+                    }
+                    lhalo[i * G * C::PS] = srcok ? v : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (chunk + 1 < a.nchunks) issue(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            constexpr int KS = CK / 4, NG = 9 * KS;
+            float af[2][CT], bf[2][MT];
+            auto load_group = [&](int g, float (&wa)[CT], float (&xa)[MT]) {
+                const int tap = g / KS, ks = g % KS;
+                const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) wa[ct] = w_lds[base_w + (tap * CK + 4 * ks) * C::COTP + 16 * ct];
+#pragma unroll
+                for (int f = 0; f < MT; ++f) xa[f] = in_lds[base_in[dx] + (4 * ks) * C::PS + (f + dy) * C::COLS];
+            };
+            __builtin_amdgcn_s_setprio(0);
+            load_group(0, af[0], bf[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int f = 0; f < MT; ++f)
+                        acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[g & 1][f], af[g & 1][ct], acc[ct][f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(2);
+        }
+    }
+
+    // ---- epilogue: fragment f = image row fr0 + f, my 4 pixels at columns gx0 .. gx0 + 3 (inside or outside the plane as a whole)
+    const int fr0 = r0 + wn * MT, gx0 = c0 + 4 * kk;
+    const bool colok = gx0 < a.W;
+    if (a.bias) {
+        const float* bsel = n >= a.set_split ? a.bias1 : a.bias;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int m = co0 + 16 * (wm * CT + ct) + q;
+            const float bv = m < a.rows ? bsel[m] : 0.f;
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ct][f][j] += bv;
+        }
+    }
+    const bool full = r0 + C::TH <= a.H && c0 + TW <= a.W;
+    if (a.addend || a.relu) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int m = co0 + 16 * (wm * CT + ct) + q;
+            if (m >= a.rows) continue;
+            const float* ab = a.addend ? a.addend + (((long)n * a.rows + m) * a.D + z0) * hwl : nullptr;
+#pragma unroll
+            for (int f = 0; f < MT; ++f) {
+                if (fr0 + f >= a.H || !colok) continue;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ab) t = *reinterpret_cast<const float4*>(ab + (long)(fr0 + f) * a.W + gx0);
+                const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[ct][f][j];
+                    if (ab) v += tv[j];
+                    acc[ct][f][j] = a.relu ? fmaxf(v, 0.f) : v;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = co0 + 16 * (wm * CT + ct) + q;
+        if (m >= a.rows || !colok) continue;
+        float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * hwl + (long)fr0 * a.W + gx0;
+#pragma unroll
+        for (int f = 0; f < MT; ++f)
+            if (full || fr0 + f < a.H)
+                *reinterpret_cast<float4*>(yb + (long)f * a.W) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+    }
+    if (a.ypart) {
+        const int rows_w = min(max(a.H - fr0, 0), MT);
+        const float cnt_w = (float)(rows_w * min(TW, a.W - c0));
+        float mean_w[CT], m2_w[CT];
+        auto wave_stats = [&](auto fullc) {
+            constexpr bool FULL = decltype(fullc)::value;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc += (FULL || (colok && fr0 + f < a.H)) ? acc[ct][f][j] : 0.f;
+                sacc = add_xor16(sacc);
+                sacc = add_xor32(sacc);
+                mean_w[ct] = cnt_w > 0.f ? sacc / cnt_w : 0.f;
+                float qacc = 0.f;
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = acc[ct][f][j] - mean_w[ct];
+                        qacc += (FULL || (colok && fr0 + f < a.H)) ? d * d : 0.f;
+                    }
+                qacc = add_xor16(qacc);
+                qacc = add_xor32(qacc);
+                m2_w[ct] = qacc;
+            }
+        };
+        if (full) wave_stats(std::true_type{}); else wave_stats(std::false_type{});
+        auto merge_store = [&](const float (&rc)[WN], const float (&rm)[WN], const float (&rq)[WN], int row) {
+            float cnt = 0.f, mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { cnt += rc[w]; mean += rc[w] * rm[w]; }
+            mean /= cnt;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) {
+                const float d = rm[w] - mean;
+                m2 += rq[w] + rc[w] * d * d;
+            }
+            float* o = a.ypart + (((long)n * a.rows + co0 + row) * a.tiles + tile) * 3;
+            o[0] = cnt; o[1] = mean; o[2] = m2;
+        };
+        if constexpr (WN == 1) {
+            if (kk == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int row = 16 * (wm * CT + ct) + q;
+                    if (co0 + row < a.rows) { const float rc[1] = {cnt_w}, rm[1] = {mean_w[ct]}, rq[1] = {m2_w[ct]}; merge_store(rc, rm, rq, row); }
+                }
+            }
+        } else {
+            float* red = st_lds + 2 * nch;
+            if (kk == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float* o = red + (wn * C::COT + 16 * (wm * CT + ct) + q) * 3;
+                    o[0] = cnt_w; o[1] = mean_w[ct]; o[2] = m2_w[ct];
+                }
+            }
+            __syncthreads();
+            if (tid < C::COT && co0 + tid < a.rows) {
+                float rc[WN], rm[WN], rq[WN];
+#pragma unroll
+                for (int w = 0; w < WN; ++w) { const float* r = red + (w * C::COT + tid) * 3; rc[w] = r[0]; rm[w] = r[1]; rq[w] = r[2]; }
+                merge_store(rc, rm, rq, tid);
+            }
+        }
+    }
+}
+
+template <int CT, int WM, int WN, int MT, int MODE, int V3>
+int launch_wide(const WideArgs& p, int n, hipStream_t st) {
+    using C = ConvCfg<8, CT, WM, WN, MT, 16, 9>;
+    auto kern = conv_wide_kernel<CT, WM, WN, MT, MODE, V3>;
+    const size_t lds = C::lds_bytes(p.c0 + p.c1) + (WN > 1 ? C::RED_FLOATS * sizeof(float) : 0);
+    static std::once_flag once[64];
+    static hipError_t status[64];
+    if (lds > 64 * 1024) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "conv_wide_kernel: device index %d", dev);
+        std::call_once(once[dev], [&] {
+            status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "conv_wide_kernel: hipFuncSetAttribute: %s", hipGetErrorString(status[dev]));
+    }
+    CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv_wide_kernel: %d input channels need %zu bytes of LDS", p.cin, lds);
+    const dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
+    ProfScope prof(F_CONV3, st);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, p);
+    return check_launch("conv_wide_kernel");
+}
+
+}  // namespace
+
+// general dispatcher -> wide kernel: 16-wide column tiles of 2-D planes (v3 = 0) or of volumes in the three-pass form (v3 = 1)
+int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, hipStream_t st, bool* handled) {
+    *handled = false;
+    if (!(g_plane_on.load(std::memory_order_relaxed) & 4)) return CINE_OK;
+    if (a.add_src1 || a.accum || a.pair_n > 0 || a.tconv_cout > 0 || a.n <= 0 || a.n > 65535) return CINE_OK;
+    if ((v3 != 0) != (a.vol != 0) || (!v3 && a.D != 1)) return CINE_OK;
+    if (a.W <= 16 || a.W % 4 != 0) return CINE_OK;
+    const Src& s0 = a.s0; const Src& s1 = a.s1;
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || (a.addend && !al16(a.addend))) return CINE_OK;
+    int mode;
+    if (s0.mode == 0 && (s1.c == 0 || s1.mode == 0)) mode = 0;
+    else if (s0.mode == 1 && (s1.c == 0 || s1.mode == 1)) mode = 1;
+    else return CINE_OK;
+    if (s0.w != a.W || s0.h != a.H || (s1.c > 0 && (s1.w != a.W || s1.h != a.H))) return CINE_OK;
+    const int d0 = v3 ? s0.d : 1, d1 = v3 && s1.c > 0 ? s1.d : 1;
+    if (v3 && (d0 < 1 || d0 > a.D || d1 < 1 || d1 > a.D)) return CINE_OK;
+    if (mode == 1) {
+        if (!s0.part || s0.np < 1 || (s1.c > 0 && (!s1.part || s1.np < 1))) return CINE_OK;
+        if (s0.c + s1.c > 256) return CINE_OK;
+    }
+    const int ncc = v3 ? a.ncc : a.nchunks;
+    // whole 8-channel chunks (two sources: the first one too); a narrower layer only as ONE chunk on the one-channel-group shape
+    const bool whole = a.cin % 8 == 0 && (s1.c == 0 || s0.c % 8 == 0);
+    const bool narrow_ok = ncc == 1 && s1.c == 0 && ct == 1 && wm == 1 && wn == 4;
+    if (!whole && !narrow_ok) return CINE_OK;
+    WideArgs p{};
+    p.x0 = s0.x; p.part0 = s0.part; p.c0 = s0.c; p.np0 = s0.np; p.d0 = d0;
+    p.x1 = s1.c > 0 ? s1.x : nullptr; p.part1 = s1.c > 0 ? s1.part : nullptr; p.c1 = s1.c; p.np1 = s1.c > 0 ? s1.np : 0; p.d1 = d1;
+    p.wp0 = a.wp0; p.wp1 = a.wp1; p.set_split = a.set_split;
+    p.bias = a.bias; p.bias1 = a.bias1; p.addend = a.addend; p.relu = a.relu;
+    p.y = a.y; p.ypart = a.ypart; p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.D = a.D; p.H = a.H; p.W = a.W;
+    p.nchunks = a.nchunks; p.ncc = ncc; p.tiles = a.tiles; p.tiles_w = a.tiles_w; p.tiles_hw = a.tiles_hw;
+    p.slope = a.slope; p.eps = a.eps;
+#define CINE_WIDE_CASE(CT_, WM_, WN_, MT_)                                                                     \
+    if (ct == CT_ && wm == WM_ && wn == WN_ && mt == MT_) {                                                     \
+        *handled = true;                                                                                        \
+        if (v3) return mode ? launch_wide<CT_, WM_, WN_, MT_, 1, 1>(p, a.n, st) : launch_wide<CT_, WM_, WN_, MT_, 0, 1>(p, a.n, st); \
+        return mode ? launch_wide<CT_, WM_, WN_, MT_, 1, 0>(p, a.n, st) : launch_wide<CT_, WM_, WN_, MT_, 0, 0>(p, a.n, st);         \
+    }
+    CINE_WIDE_CASE(1, 1, 4, 13)
+    CINE_WIDE_CASE(1, 2, 2, 13)
+    CINE_WIDE_CASE(1, 4, 1, 13)
+#undef CINE_WIDE_CASE
     return CINE_OK;
 }
 

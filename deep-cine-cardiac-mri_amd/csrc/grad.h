@@ -24,6 +24,7 @@ struct InBwdArgs {
     float eps, slope;
 };
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st);
+int launch_in_lrelu_bwd_fast(const InBwdArgs& a, hipStream_t st, bool* handled);      // inbwd_fast.hip: the U-Nets' plane shapes, one pass over HBM
 
 // Weight gradient of a convolution y = conv(X) whose input X is described like the forward's sources (modes 0 / 1 / 2 vectorised; the
 // Haar modes 3 / 4 and added sources element by element; channel concat or sum of two sources):  dW[row][ci][tap] += sum_{n, pixels} G[n][row][p] * X[n][ci][p + tap offset].

@@ -127,6 +127,12 @@ int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st) {
     }
     const long planes = (long)a.n * a.c;
     const bool haar = a.a.type >= 3 || a.b.type >= 3;
+    if (!haar) {
+        ProfScope prof(F_STATS, st);
+        bool handled = false;
+        const int e = launch_in_lrelu_bwd_fast(a, st, &handled);
+        if (e || handled) return e;
+    }
     CINE_REQUIRE(haar || ((long)a.a.gh * a.a.gw < (1L << 31) && (long)a.b.gh * a.b.gw < (1L << 31)), CINE_EUNSUPPORTED, "in_lrelu_bwd: plane too large");
     ProfScope prof(F_STATS, st);
     if ((long)a.h * a.w <= 1024) {

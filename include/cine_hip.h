@@ -471,8 +471,10 @@ int cine_unet2d_forward_train(const float* x, float* y, const void* const* weigh
                               void* ws, size_t ws_bytes, void* stream);
 /* Diagnostics.  3x3 convolutions whose tile spans the plane's width (the x-f / y-f planes of the cascade U-Nets, reference
  * denoisers/unet.py:159-168) and the k2 s2 transpose convs between them (unet.py:212-218) run on lean kernels (csrc/conv_plane.hip)
- * that are BIT-IDENTICAL to the general one; `on` is a mask -- bit 0 the 3x3 convolutions, bit 1 the transpose convolutions; a
- * cleared bit routes that kind through the general kernel (the bit-identity tests, A/B timing).  Process-wide, default 3. */
+ * that are BIT-IDENTICAL to the general one, and so do the 3x3 (x3) convolutions of wider planes and volumes in 16-wide column
+ * tiles (sensitivity network, CRNN cells, 3-D U-Net); `on` is a mask -- bit 0 the plane-wide 3x3 convolutions, bit 1 the
+ * transpose convolutions, bit 2 the wide planes / volumes; a cleared bit routes that kind through the general kernel (the
+ * bit-identity tests, A/B timing).  Process-wide, default 7. */
 int cine_set_conv_plane(int on);
 
 /* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_mwcnn_backward (they

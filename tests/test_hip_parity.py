@@ -362,14 +362,14 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
                 x = torch.randn(n, c0, h, w, generator=g).to(dev)
                 srcs = [(x, ops.instnorm_partials(x) if kind == "norm" else None, 1 if kind == "norm" else 0)]
             outs = []
-            for on in (3, 0):
+            for on in (7, 0):
                 assert lib().cine_set_conv_plane(on) == 0
                 outs.append(ops.conv3x3_in(srcs, ops.pack_conv3x3(wa), cout, h, w, wpacked2=ops.pack_conv3x3(wb), set_split=4))
             (y1, p1), (y0, p0) = outs
             assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
             assert torch.equal(p1, p0), (kind, c0, cout, h, w)
     finally:
-        lib().cine_set_conv_plane(3)
+        lib().cine_set_conv_plane(7)
 
 
 def test_tconv_plane_bit_identical_to_general_kernel(dev):
@@ -391,14 +391,67 @@ def test_tconv_plane_bit_identical_to_general_kernel(dev):
             else:
                 part = None
             outs = []
-            for on in (3, 0):
+            for on in (7, 0):
                 assert lib().cine_set_conv_plane(on) == 0
                 outs.append(ops.tconv2x2_in(x, part, mode, wt, cout))
             (y1, p1), (y0, p0) = outs
             assert torch.equal(y1, y0), (cin, cout, h, w, float((y1 - y0).abs().max()))
             assert torch.equal(p1, p0), (cin, cout, h, w)
     finally:
-        lib().cine_set_conv_plane(3)
+        lib().cine_set_conv_plane(7)
+
+
+def test_conv_wide_bit_identical_to_general_kernel(dev):
+    """csrc/conv_plane.hip's kernel for 16-wide column tiles of wider planes and volumes (sensitivity network, CRNN cells, 3-D
+    U-Net) against conv_tile: 2-D layers of every source kind it takes (ragged last column tile, 52 statistics records per plane,
+    bias + addend + ReLU epilogue), then a whole 3-D U-Net and the CRNN hybrids' conv3d on odd depths (three-pass form, `up`
+    volumes shorter than the skip, narrow first layer)."""
+    from cine_hip import ops, synth
+    from cine_hip._lib import lib
+    from reconstruction.models.denoisers.unet import Unet
+    import torch.nn.functional as F
+    n = 4                # (>= 4 planes of 200 x 200: the regular 52-row tiles, not the few-sample small-tile configuration)
+    try:
+        for kind, c0, cout, h, w in (("norm", 8, 8, 208, 208), ("norm", 16, 16, 104, 104), ("norm", 32, 32, 52, 52), ("norm", 64, 64, 26, 28),
+                                     ("plain", 2, 8, 208, 208), ("concat", 8, 8, 120, 200), ("sum", 16, 16, 200, 200), ("sum1", 16, 2, 200, 200)):
+            g = torch.Generator().manual_seed(c0 * 7 + cout + h)
+            cin = 2 * c0 if kind in ("concat", "sum") else c0
+            wp = ops.pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev))
+            x = torch.randn(n, c0, h, w, generator=g).to(dev); x2 = torch.randn(n, c0, h, w, generator=g).to(dev)
+            bias = torch.randn(cout, generator=g).to(dev); add = torch.randn(n, cout, h, w, generator=g).to(dev)
+            outs = []
+            for on in (7, 3):
+                assert lib().cine_set_conv_plane(on) == 0
+                if kind in ("sum", "sum1"):
+                    outs.append((ops.conv3x3_sum([x, x2] if kind == "sum" else [x], wp, bias, cout, addend=add, relu=kind == "sum"), None))
+                elif kind == "concat":
+                    outs.append(ops.conv3x3_in([(x, ops.instnorm_partials(x), 1), (x2, ops.instnorm_partials(x2), 1)], wp, cout, h, w))
+                else:
+                    part = None
+                    if kind == "norm":           # one record per tile of the producing layer, as inside the network
+                        ident = torch.zeros(c0, c0, 3, 3, device=dev); ident[range(c0), range(c0), 1, 1] = 1.0
+                        part = ops.conv3x3_in([(x, None, 0)], ops.pack_conv3x3(ident), c0, h, w)[1]
+                    outs.append(ops.conv3x3_in([(x, part, 1 if kind == "norm" else 0)], wp, cout, h, w))
+            (y1, p1), (y0, p0) = outs
+            assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
+            assert p1 is None or torch.equal(p1, p0), (kind, c0, cout, h, w)
+        # volumes (enough tiles for the regular three-pass configurations): a 3-D U-Net (unet.py dims = 3: `up` volumes of depth 14
+        # under a skip of depth 15, narrow first layer) and the hybrids' conv3d + bias + ReLU with 32 and 64 output channels
+        net = Unet(in_chans=2, out_chans=2, chans=8, num_pool_layers=2, dims=3).eval(); synth.fill_parameters_(net, 5, keep=())
+        net = net.to(dev)
+        vol = torch.randn(1, 2, 15, 104, 104, generator=torch.Generator().manual_seed(3)).to(dev)
+        v16 = torch.randn(1, 16, 7, 104, 104, generator=torch.Generator().manual_seed(6)).to(dev)
+        ws_ = [(torch.randn(co, 16, 3, 3, 3, generator=torch.Generator().manual_seed(4 + co)) / 20).to(dev) for co in (32, 64)]
+        bs_ = [torch.randn(co, generator=torch.Generator().manual_seed(5)).to(dev) for co in (32, 64)]
+        outs = []
+        for on in (7, 3):
+            assert lib().cine_set_conv_plane(on) == 0
+            outs.append([ops.unet3d_forward(vol, ops.UnetWeights([net]))] + [ops.conv3d_bias_relu(v16, w_, b_, True) for w_, b_ in zip(ws_, bs_)])
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_)
+        assert rel_err(outs[0][1].cpu(), F.relu(F.conv3d(v16.cpu(), ws_[0].cpu(), bs_[0].cpu(), padding=1))) < OP_TOL
+    finally:
+        lib().cine_set_conv_plane(7)
 
 
 # ------------------------------------------------------------------ blocks and models
