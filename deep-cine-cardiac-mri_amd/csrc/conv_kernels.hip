@@ -1001,7 +1001,7 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
             if (e || handled) return e;
         }
     }
-    if constexpr (TAPS == 9 && !PAIR && V3 <= 1 && CK == 8 && TW == 16) {      // wider planes / volumes in 16-wide column tiles: conv_plane.hip, bit-identical
+    if constexpr (TAPS == 9 && V3 <= 1 && CK == 8 && TW == 16) {      // wider planes / volumes in 16-wide column tiles (pair launches too): conv_plane.hip, bit-identical
         bool handled = false;
         const int e = launch_conv_wide(a, CT, WM, WN, MT, V3, st, &handled);
         if (e || handled) return e;

@@ -784,11 +784,14 @@ struct WideArgs {
     float* y; float* ypart;
     int cin, rows, rowsp, D, H, W, nchunks, ncc, tiles, tiles_w, tiles_hw;
     float slope, eps;
+    // CRNN time-sweep steps: optional second output (accum += y, or = y), and the second sample set of a pair launch
+    float* accum; int accum_store;
+    int pair_n, accum_store_b; const float* x_b; const float* addend_b; float* y_b; float* accum_b;
 };
 
 // MODE 0: plain sources; 1: InstanceNorm + LeakyReLU on load.  V3: volumes, chunk = (depth offset, 8 channels).
 template <int CT, int WM, int WN, int MT, int MODE, int V3>
-__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::MINW)) void conv_wide_kernel(WideArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::MINW)) void conv_wide_kernel(WideArgs a) {       // (by value: a pair launch swaps pointers)
     constexpr int CK = 8, TW = 16;
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
     constexpr int NT = C::NT, PR = C::PR, RP = C::RP, G = C::G, NCI = C::NCI, NWT = C::NWT;
@@ -799,8 +802,15 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
     float* st_lds = w_lds + C::W_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x, n = blockIdx.z;
+    // (measured and rejected: a grid of D x (tiles per slice rounded up to 8) blocks, so that the three depth offsets of an (x, y)
+    // tile land on one XCD and share its L2 -- cfg 4 150.6 vs 153.2 slices/s, the dummy blocks and the changed dispatch order cost more)
+    int n = blockIdx.z;
+    const int tile = blockIdx.x;
     const int z0 = tile / a.tiles_hw, t2 = tile - z0 * a.tiles_hw;
+    if (a.pair_n > 0 && n >= a.pair_n) {               // second sample set of a pair launch (both directions of a BCRNN time sweep in one grid)
+        n -= a.pair_n;
+        a.x0 = a.x_b; a.addend = a.addend_b; a.y = a.y_b; a.accum = a.accum_b; a.accum_store = a.accum_store_b;
+    }
     const int ty = t2 / a.tiles_w, tx = t2 - ty * a.tiles_w;
     const int r0 = ty * C::TH, c0 = tx * TW, co0 = blockIdx.y * C::COT;
     const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
@@ -1019,11 +1029,20 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
     for (int ct = 0; ct < CT; ++ct) {
         const int m = co0 + 16 * (wm * CT + ct) + q;
         if (m >= a.rows || !colok) continue;
-        float* yb = a.y + (((long)n * a.rows + m) * a.D + z0) * hwl + (long)fr0 * a.W + gx0;
+        const long yoff = (((long)n * a.rows + m) * a.D + z0) * hwl + (long)fr0 * a.W + gx0;
+        float* yb = a.y + yoff;
+        float* ab2 = a.accum ? a.accum + yoff : nullptr;
 #pragma unroll
         for (int f = 0; f < MT; ++f)
-            if (full || fr0 + f < a.H)
-                *reinterpret_cast<float4*>(yb + (long)f * a.W) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+            if (full || fr0 + f < a.H) {
+                const float4 o = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+                *reinterpret_cast<float4*>(yb + (long)f * a.W) = o;
+                if (ab2) {
+                    float4 t = o;
+                    if (!a.accum_store) { t = *reinterpret_cast<float4*>(ab2 + (long)f * a.W); t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+                    *reinterpret_cast<float4*>(ab2 + (long)f * a.W) = t;
+                }
+            }
     }
     if (a.ypart) {
         const int rows_w = min(max(a.H - fr0, 0), MT);
@@ -1126,12 +1145,14 @@ int launch_wide(const WideArgs& p, int n, hipStream_t st) {
 int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, hipStream_t st, bool* handled) {
     *handled = false;
     if (!(g_plane_on.load(std::memory_order_relaxed) & 4)) return CINE_OK;
-    if (a.add_src1 || a.accum || a.pair_n > 0 || a.tconv_cout > 0 || a.n <= 0 || a.n > 65535) return CINE_OK;
+    if (a.add_src1 || a.tconv_cout > 0 || a.n <= 0 || a.n > 65535) return CINE_OK;
+    if ((a.accum || a.pair_n > 0) && (v3 || a.s1.c > 0 || a.s0.mode != 0)) return CINE_OK;
     if ((v3 != 0) != (a.vol != 0) || (!v3 && a.D != 1)) return CINE_OK;
     if (a.W <= 16 || a.W % 4 != 0) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || (a.addend && !al16(a.addend))) return CINE_OK;
+    if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || (a.addend && !al16(a.addend)) || (a.accum && !al16(a.accum))) return CINE_OK;
+    if (a.pair_n > 0 && (!al16(a.x_b) || !al16(a.y_b) || (a.addend_b && !al16(a.addend_b)) || (a.accum_b && !al16(a.accum_b)) || !a.addend == !!a.addend_b)) return CINE_OK;
     int mode;
     if (s0.mode == 0 && (s1.c == 0 || s1.mode == 0)) mode = 0;
     else if (s0.mode == 1 && (s1.c == 0 || s1.mode == 1)) mode = 1;
@@ -1156,6 +1177,8 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     p.y = a.y; p.ypart = a.ypart; p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.D = a.D; p.H = a.H; p.W = a.W;
     p.nchunks = a.nchunks; p.ncc = ncc; p.tiles = a.tiles; p.tiles_w = a.tiles_w; p.tiles_hw = a.tiles_hw;
     p.slope = a.slope; p.eps = a.eps;
+    p.accum = a.accum; p.accum_store = a.accum_store; p.pair_n = a.pair_n; p.accum_store_b = a.accum_store_b;
+    p.x_b = a.x_b; p.addend_b = a.addend_b; p.y_b = a.y_b; p.accum_b = a.accum_b;
 #define CINE_WIDE_CASE(CT_, WM_, WN_, MT_)                                                                     \
     if (ct == CT_ && wm == WM_ && wn == WN_ && mt == MT_) {                                                     \
         *handled = true;                                                                                        \
@@ -1165,6 +1188,7 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     CINE_WIDE_CASE(1, 1, 4, 13)
     CINE_WIDE_CASE(1, 2, 2, 13)
     CINE_WIDE_CASE(1, 4, 1, 13)
+    CINE_WIDE_CASE(1, 1, 4, 4)                      // 16-row tiles of few planes: the CRNN cells' single-plane steps
 #undef CINE_WIDE_CASE
     return CINE_OK;
 }

@@ -435,6 +435,23 @@ def test_conv_wide_bit_identical_to_general_kernel(dev):
             (y1, p1), (y0, p0) = outs
             assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
             assert p1 is None or torch.equal(p1, p0), (kind, c0, cout, h, w)
+        # one step of both directions of a BCRNN time sweep (recurrent_varnet.py:241-254: pair launch, addend + ReLU, second output
+        # stored by one direction and added to by the other) and a single direction
+        gg = torch.Generator().manual_seed(11)
+        hx = [torch.randn(1, 16, 200, 200, generator=gg).to(dev) for _ in range(4)]
+        w_hh = ops.pack_conv3x3((torch.randn(16, 16, 3, 3, generator=gg) / 12).to(dev))
+        res = []
+        for on in (7, 3):
+            assert lib().cine_set_conv_plane(on) == 0
+            yf, yb, acc_f, acc_b = (torch.zeros_like(hx[0]) for _ in range(4))
+            acc_b.fill_(0.5)
+            ops.crnn_step2(w_hh, (hx[0], hx[1], yf, acc_f, True), (hx[2], hx[3], yb, acc_b, False))
+            y1 = torch.zeros_like(hx[0])
+            ops.crnn_step2(w_hh, (hx[2], hx[1], y1, acc_f, False))
+            res.append((yf, yb, acc_f, acc_b, y1))
+        for a_, b_ in zip(*res):
+            assert torch.equal(a_, b_)
+        assert torch.equal(res[0][3], 0.5 + res[0][1]) and torch.equal(res[0][2], res[0][0] + res[0][4])      # accum = y (store), then += y
         # volumes (enough tiles for the regular three-pass configurations): a 3-D U-Net (unet.py dims = 3: `up` volumes of depth 14
         # under a skip of depth 15, narrow first layer) and the hybrids' conv3d + bias + ReLU with 32 and 64 output channels
         net = Unet(in_chans=2, out_chans=2, chans=8, num_pool_layers=2, dims=3).eval(); synth.fill_parameters_(net, 5, keep=())
