@@ -126,6 +126,7 @@ _SIGS = {
     "cine_unet2d_forward_train": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_set_side_stream": (c_int, [P]),
     "cine_set_conv_plane": (c_int, [c_int]),
+    "cine_set_lrelu_slope": (c_int, [ctypes.c_float]),
     "cine_unet2d_backward_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_size_t, P, P]),
     "cine_mwcnn_train_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),

@@ -17,7 +17,7 @@ extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 namespace {
 
 constexpr float kEps = 1e-5f;     // nn.InstanceNorm2d default (unet.py:161)
-constexpr float kSlope = 0.2f;    // nn.LeakyReLU(0.2)        (unet.py:162)
+#define kSlope (::cine::unet_slope())      // nn.LeakyReLU(0.2) (unet.py:162); a function so that the linear-activation test fixtures can change it
 
 struct Bump {
     char* base; size_t off;

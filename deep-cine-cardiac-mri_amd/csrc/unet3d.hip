@@ -20,7 +20,8 @@ extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x
 extern "C" int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream);
 
 namespace {
-constexpr float kEps = 1e-5f, kSlope = 0.2f;
+constexpr float kEps = 1e-5f;
+#define kSlope (::cine::unet_slope())      // nn.LeakyReLU(0.2) (unet.py:162); see cine_set_lrelu_slope
 struct Bump {
     char* base; size_t off;
     float* take(size_t floats) {

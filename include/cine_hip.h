@@ -469,6 +469,12 @@ size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, in
 int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                               void* ws, size_t ws_bytes, void* stream);
+/* Test hook.  LeakyReLU slope used INSIDE the fused U-Net sequences (cine_unet2d_forward / _forward_train / _backward,
+ * cine_unet3d_forward; reference unet.py:162 hard-wires 0.2, and so does this library by default).  slope = 1 makes the
+ * activation the identity: tests/test_hip_grad.py compares full-size gradients with reference fixtures generated the same way
+ * (no LeakyReLU kinks -> the comparison is sharp).  The per-layer entry points take their slope as an argument.  Process-wide. */
+int cine_set_lrelu_slope(float slope);
+
 /* Diagnostics.  3x3 convolutions whose tile spans the plane's width (the x-f / y-f planes of the cascade U-Nets, reference
  * denoisers/unet.py:159-168) and the k2 s2 transpose convs between them (unet.py:212-218) run on lean kernels (csrc/conv_plane.hip)
  * that are BIT-IDENTICAL to the general one, and so do the 3x3 (x3) convolutions of wider planes and volumes in 16-wide column

@@ -769,7 +769,68 @@ def g_rnn_grad_cfg5():
     _grad_fingerprint("rnn_grad_cfg5", net, ex, nper=2)
 
 
-GENERATORS = dict(xpdnet_grad_cfg3=g_xpdnet_grad_cfg3, cinenet_grad_cfg4=g_cinenet_grad_cfg4, rnn_grad_cfg5=g_rnn_grad_cfg5, rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+def _linear_activation():
+    """Context: LeakyReLU -> identity inside the reference (nn.LeakyReLU.forward calls F.leaky_relu): the networks keep their InstanceNorms
+    but lose their kinks, so float32 gradients are smooth functions of the input and a full-size comparison is sharp."""
+    import contextlib
+    import torch.nn.functional as F
+
+    @contextlib.contextmanager
+    def cm():
+        orig = F.leaky_relu
+        F.leaky_relu = lambda x, *a, **k: x
+        try:
+            yield
+        finally:
+            F.leaky_relu = orig
+    return cm()
+
+
+def _grad_fingerprint_linear(name, make, ex, extra=()):
+    """Full-size gradient fingerprints with the LeakyReLUs replaced by the identity (the HIP path: cine_set_lrelu_slope(1) + slope 1 at the
+    per-layer calls): the reference's float32 gradients, its float64 gradients, and their distance (the float32 floor) per parameter."""
+    target = ex["target"].contiguous()
+    mk = ex["masked_kspace"]
+    with _linear_activation():
+        loss, grads, new, out = _training_step(make(), mk, ex["mask"], target, extra=extra)
+        loss64, grads64, _, _ = _training_step(make(), mk, ex["mask"], target, dtype=torch.float64, extra=extra)
+    a = dict(loss=loss, loss64=loss64, out_strided=out[:, :, ::4, ::4].contiguous())
+    for k, g in grads.items():
+        g64 = grads64[k]
+        st = max(1, g.numel() // 256)
+        a[f"grad::{k}"] = g.reshape(-1)[::st].contiguous()
+        a[f"grad64::{k}"] = g64.reshape(-1)[::st].contiguous()
+        a[f"gmax::{k}"] = g64.abs().max()
+        a[f"gnorm::{k}"] = g64.norm()
+        a[f"floormax::{k}"] = float((g.double() - g64).abs().max() / g64.abs().max().clamp_min(1e-300))
+        a[f"floornorm::{k}"] = float((g.double() - g64).norm() / g64.norm().clamp_min(1e-300))
+    save(name, **a)
+
+
+def g_varnet_grad_cfg2_linear():
+    """cfg 2 with identity activations: see _grad_fingerprint_linear."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+
+    def make():
+        net = RM.VarNet(6, 8, 3, 16, 3, "XF")
+        synth.fill_parameters_(net, 1)
+        return net
+    _grad_fingerprint_linear("varnet_grad_cfg2_linear", make, ex)
+
+
+def g_cinenet_grad_cfg4_linear():
+    """cfg 4 (3-D U-Net: LeakyReLU only) with identity activations."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=6, seed=0)
+
+    def make():
+        net = RM.CineNet(6, 6, 16, 3, "3D")
+        synth.fill_parameters_(net, 7)
+        return net
+    _grad_fingerprint_linear("cinenet_grad_cfg4_linear", make, ex, extra=(ex["sens_maps"],))
+
+
+
+GENERATORS = dict(varnet_grad_cfg2_linear=g_varnet_grad_cfg2_linear, cinenet_grad_cfg4_linear=g_cinenet_grad_cfg4_linear, xpdnet_grad_cfg3=g_xpdnet_grad_cfg3, cinenet_grad_cfg4=g_cinenet_grad_cfg4, rnn_grad_cfg5=g_rnn_grad_cfg5, rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)

@@ -479,6 +479,54 @@ def test_other_configs_training_step_vs_reference_fingerprint(dev, golden, name)
     assert not bad, bad
 
 
+_LINEAR = {
+    "varnet_grad_cfg2_linear": (lambda M: M.VarNet(6, 8, 3, 16, 3, "XF"), 1, 4, False),
+    "cinenet_grad_cfg4_linear": (lambda M: M.CineNet(6, 6, 16, 3, "3D"), 7, 6, True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_LINEAR))
+def test_full_size_gradients_with_identity_activations_vs_reference(dev, golden, name, monkeypatch):
+    """The sharp full-size pin of the backward pass.  With the LeakyReLUs replaced by the identity on BOTH sides (the reference run of
+    make_golden.py patches F.leaky_relu; here cine_set_lrelu_slope(1) + slope 1 at the per-layer calls) the networks have no kinks: the
+    reference's float32 gradients are a smooth function of the input and their distance from its own float64 gradients (stored per
+    parameter) is pure rounding.  An indexing or staging error in a full-size code path (200-wide planes, 15 x 200 x 200 volumes) moves a
+    gradient by O(1) of its size; the bar is 1e-4 of each tensor's largest entry, or twice the reference's own float32 floor where that
+    is larger -- against the kinked fixtures the same tensors are only held to 5e-3."""
+    import reconstruction.models as M
+    from cine_hip import ops, synth
+    from cine_hip._lib import lib
+    make, wseed, accel, needs_sens = _LINEAR[name]
+    g = golden(name)
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=accel, seed=0)
+    net = make(M)
+    synth.fill_parameters_(net, wseed)
+    net = net.to(dev).train()
+    monkeypatch.setattr(ops, "LRELU_SLOPE", 1.0)
+    assert lib().cine_set_lrelu_slope(1.0) == 0
+    try:
+        with torch.enable_grad():
+            loss, grads, out = _training_step(net, ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev),
+                                              extra=(ex["sens_maps"].to(dev),) if needs_sens else ())
+    finally:
+        lib().cine_set_lrelu_slope(0.2)
+    assert rel_err(out[:, :, ::4, ::4].cpu(), g["out_strided"]) < TOL
+    assert abs(float(loss) - float(g["loss64"])) < 1e-4
+    bad, worst = {}, 0.0
+    for k in (k[8:] for k in g if k.startswith("grad64::")):
+        flat = grads[k].reshape(-1)
+        got = flat[::max(1, flat.numel() // 256)].cpu().double()
+        want = torch.from_numpy(g[f"grad64::{k}"]).double()
+        gmax = max(float(g[f"gmax::{k}"]), 1e-300)
+        e = float((got - want).abs().max() / gmax)
+        en = abs(float(grads[k].double().norm()) - float(g[f"gnorm::{k}"])) / max(float(g[f"gnorm::{k}"]), 1e-300)
+        bar = max(1e-4, 2 * float(g[f"floormax::{k}"])); barn = max(1e-4, 2 * float(g[f"floornorm::{k}"]))
+        worst = max(worst, e / bar)
+        if e > bar or en > barn:
+            bad[k] = (e, en, float(g[f"floormax::{k}"]), float(g[f"floornorm::{k}"]))
+    assert not bad, bad
+
+
 def _odd_mask(t, h):
     m = torch.zeros(1, t, 1, h, 1, 1, dtype=torch.uint8)
     c0 = h // 2 - 2
