@@ -86,6 +86,8 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
 // the k2 s2 transpose conv of plane-wide tiles (pixel tile = mt fragments of 16 pixels, plane width tw)
 int launch_tconv_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled);
 
+// input gradient of the k2 s2 transpose conv (1x1 GEMM over the space-to-depth view of the output gradient, source mode 5)
+int launch_tconv_dgrad_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled);
 // 3x3 convolutions over 16-wide column tiles of wider planes (v3 = 0) / volumes in the three-pass form (v3 = 1)
 int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, hipStream_t st, bool* handled);
 

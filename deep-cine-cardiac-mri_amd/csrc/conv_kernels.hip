@@ -994,10 +994,14 @@ static int launch_cfg(ConvArgs a, hipStream_t st) {
     a.tvec = a.tconv_cout > 0 && a.W % 2 == 0 && a.H % 2 == 0 && reinterpret_cast<uintptr_t>(a.y) % 16 == 0;
     dim3 grid(a.tiles, ceil_div(a.rowsp, C::COT), a.n);
     const int fam = TAPS != 1 ? F_CONV3 : (a.tconv_cout > 0 ? F_TCONV : F_CONV1);
-    if constexpr (TAPS == 1 && !PAIR && V3 == 0 && WN == 1) {      // 2-D transpose conv of plane-wide tiles: conv_plane.hip, bit-identical
+    if constexpr (TAPS == 1 && !PAIR && V3 == 0) {      // 2-D transpose conv of plane-wide tiles and its input gradient: conv_plane.hip, bit-identical
         if (a.tconv_cout > 0) {
             bool handled = false;
             const int e = launch_tconv_plane(a, MT, TW, st, &handled);
+            if (e || handled) return e;
+        } else if (a.s0.mode == 5) {
+            bool handled = false;
+            const int e = launch_tconv_dgrad_plane(a, MT, TW, st, &handled);
             if (e || handled) return e;
         }
     }

@@ -1194,3 +1194,162 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
 }
 
 }  // namespace cine
+
+// ================================================================ input gradient of the k2 s2 transpose conv (training)
+// gx[ci][y][x] = sum_{co, a, b} W[ci][co][a][b] gy[co][2y + a][2x + b] (what autograd derives for unet.py:212-215): a 1x1 GEMM whose K
+// dimension is the space-to-depth view of the output gradient (source mode 5 of conv_tile, which stages it element by element:
+// 126 - 178 us per launch at cfg 2 for 1.4 GFLOP).  Here a K-chunk of 64 s2d channels is staged with two 16-byte loads per
+// (channel, row parity) -- the even floats are the b = 0 piece, the odd ones the b = 1 piece -- prefetched one chunk ahead, and the
+// weights stream from L2 as in tconv_plane_kernel.  Same K order as conv_tile: bit-identical.
+namespace cine {
+namespace {
+
+struct S2dArgs {
+    const float* g; const float* wp0; const float* wp1; int set_split;
+    float* y;
+    int cout, rows, rowsp, H, nk;            // cout: channels of g (K = 4 cout); rows: channels of y; H: rows of the LOW-resolution plane; nk: K chunks
+};
+
+template <int CT, int WM, int MT, int TW, int KC>       // KC: s2d channels per chunk = KC / 2 (channel, row parity) pairs
+__global__ __launch_bounds__(64 * WM, 2) void s2d_gemm_plane_kernel(S2dArgs a) {
+    constexpr int NT = 64 * WM;
+    constexpr int TPX = 16 * MT, PS = ((TPX + 31) / 32) * 32 + 16, NV = TPX / 4, G = NT / NV;
+    constexpr int NPAIR = KC / 2, NCI = (NPAIR + G - 1) / G;
+    static_assert(G >= 1 && TPX % 4 == 0, "tile shape");
+    extern __shared__ __align__(16) float smem_f[];
+    float* in_lds = smem_f;                                // [KC][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+    const int tile = blockIdx.x, n = blockIdx.z;
+    const int co0 = blockIdx.y * (16 * CT * WM);
+    const int q = lane & 15, kk = lane >> 4;
+    const float* wp = n >= a.set_split ? a.wp1 : a.wp0;
+    __builtin_amdgcn_s_setprio(2);
+    const int sg = tid / NV, sv = tid - sg * NV;
+    const bool slot = sg < G;
+    const int sgc = min(sg, G - 1);
+    const int hw = a.H * TW;
+    const int p0 = tile * TPX + 4 * sv;
+    const bool pok = p0 < hw;
+    const int pc = min(p0, hw - 4);
+    // source offsets of my 4 low-resolution pixels inside one (channel, row parity 0) plane of g (2H x 2TW): TW >= 4: one row, 8 floats;
+    // TW = 2: two rows of 4 floats
+    const int y0 = pc / TW, x0 = pc % TW;
+    const long o0 = (long)(2 * y0) * (2 * TW) + 2 * x0;
+    const long o1 = TW >= 4 ? o0 + 4 : o0 + 2 * (2 * TW);
+    const long gplane = (long)(2 * a.H) * (2 * TW);
+    const float* gb = a.g + (long)n * a.cout * gplane;
+    float4 xraw[NCI][2];
+    auto issue = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NCI; ++i) {
+            const int pr = min(kc * NPAIR + sgc + i * G, 2 * a.cout - 1);        // (channel c, row parity s): pr = 2 c + s
+            const float* src = gb + (long)(pr >> 1) * gplane + (long)(pr & 1) * (2 * TW);
+            xraw[i][0] = *reinterpret_cast<const float4*>(src + o0);
+            xraw[i][1] = *reinterpret_cast<const float4*>(src + o1);
+        }
+    };
+    issue(0);
+    const float* wl = wp + (long)kk * a.rowsp + co0 + 16 * (wm * CT) + q;
+    constexpr int PD = 2;
+    float wreg[PD][CT];
+    const int ksn = 4 * a.cout / 4;                          // k-steps in all
+    auto wload = [&](int ks, float (&w)[CT]) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) w[ct] = co0 + 16 * (wm * CT + ct) < a.rowsp ? wl[(long)(4 * ks) * a.rowsp + 16 * ct] : 0.f;
+    };
+#pragma unroll
+    for (int d = 0; d < PD; ++d) wload(min(d, ksn - 1), wreg[d]);
+    f32x4 acc[CT][MT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* ain = in_lds + kk * PS + q;
+    for (int kc = 0; kc < a.nk; ++kc) {
+        if (kc) __syncthreads();                            // the previous chunk's sweep is done with the tile
+        if (slot) {
+#pragma unroll
+            for (int i = 0; i < NCI; ++i) {
+                const int prl = sgc + i * G;                 // pair inside the chunk
+                if (prl >= NPAIR) break;
+                const bool ok = pok && kc * NPAIR + prl < 2 * a.cout;
+                const float4 u = xraw[i][0], v = xraw[i][1];
+                const float4 e = ok ? make_float4(u.x, u.z, v.x, v.z) : make_float4(0.f, 0.f, 0.f, 0.f);     // b = 0: even source columns
+                const float4 o = ok ? make_float4(u.y, u.w, v.y, v.w) : make_float4(0.f, 0.f, 0.f, 0.f);     // b = 1
+                *reinterpret_cast<float4*>(in_lds + (2 * prl) * PS + 4 * sv) = e;
+                *reinterpret_cast<float4*>(in_lds + (2 * prl + 1) * PS + 4 * sv) = o;
+            }
+        }
+        __syncthreads();
+        if (kc + 1 < a.nk) issue(kc + 1);
+        __builtin_amdgcn_s_setprio(0);
+        const int ks0 = kc * (KC / 4), ks1 = min(ks0 + KC / 4, ksn);        // (both even: K = 4 cout, cout a multiple of 16)
+        auto kstep = [&](int ks, float (&w)[CT]) {
+            float wcur[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) wcur[ct] = w[ct];
+            if (ks + PD < ksn) wload(ks + PD, w);
+            float xa[MT];
+#pragma unroll
+            for (int f = 0; f < MT; ++f) xa[f] = ain[(4 * (ks - ks0)) * PS + 16 * f];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int f = 0; f < MT; ++f)
+                    acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[f], wcur[ct], acc[ct][f], 0, 0, 0);
+        };
+        for (int ks = ks0; ks < ks1; ks += 2) { kstep(ks, wreg[0]); kstep(ks + 1, wreg[1]); }
+        __builtin_amdgcn_s_setprio(2);
+    }
+    // lane: output channel m, 4 consecutive pixels of fragment f
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = co0 + 16 * (wm * CT + ct) + q;
+        if (m >= a.rows) continue;
+        float* yb = a.y + ((long)n * a.rows + m) * hw + (long)tile * TPX + 4 * kk;
+#pragma unroll
+        for (int f = 0; f < MT; ++f)
+            if (tile * TPX + 16 * f + 4 * kk < hw)
+                *reinterpret_cast<float4*>(yb + 16 * f) = make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
+    }
+}
+
+template <int CT, int WM, int MT, int TW, int KC>
+int launch_s2d(const S2dArgs& p, int n, int tiles, hipStream_t st) {
+    constexpr int PS = ((16 * MT + 31) / 32) * 32 + 16;
+    auto kern = s2d_gemm_plane_kernel<CT, WM, MT, TW, KC>;
+    const size_t lds = (size_t)KC * PS * sizeof(float);
+    const dim3 grid(tiles, ceil_div(p.rowsp, 16 * CT * WM), n);
+    ProfScope prof(F_TCONV, st);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM), lds, st, p);
+    return check_launch("s2d_gemm_plane_kernel");
+}
+
+}  // namespace
+
+// general dispatcher -> input gradient of a 2-D transpose conv (TAPS = 1, source mode 5) with the pixel tile (mt, tw) it chose
+int launch_tconv_dgrad_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled) {
+    *handled = false;
+    if (!(g_plane_on.load(std::memory_order_relaxed) & 2)) return CINE_OK;
+    if (a.vol || a.D != 1 || a.tconv_cout > 0 || a.bias || a.addend || a.relu || a.accum || a.ypart || a.s1.c > 0 || a.add_src1 || a.s0.mode != 5) return CINE_OK;
+    if (a.W != tw || a.n <= 0 || a.n > 65535 || a.s0.w != 2 * a.W || a.s0.h != 2 * a.H || (a.H * a.W) % 4 != 0 || a.s0.c % 16 != 0) return CINE_OK;
+    auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (!al16(a.y) || !al16(a.s0.x)) return CINE_OK;
+    S2dArgs p{};
+    p.g = a.s0.x; p.wp0 = a.wp0; p.wp1 = a.wp1; p.set_split = a.set_split; p.y = a.y;
+    p.cout = a.s0.c; p.rows = a.rows; p.rowsp = a.rowsp; p.H = a.H;
+    (void)mt;                                   // no statistics records: the pixel tiling is this kernel's own
+#define CINE_S2D_CASE(ROWSP_, CT_, WM_, MT_, TW_, KC_)                                                      \
+    if (a.rowsp == ROWSP_ && tw == TW_) {                                                                   \
+        *handled = true;                                                                                   \
+        p.nk = ceil_div(4 * a.s0.c, KC_);                                                                  \
+        return launch_s2d<CT_, WM_, MT_, TW_, KC_>(p, a.n, ceil_div(a.H * a.W, 16 * MT_), st);              \
+    }
+    CINE_S2D_CASE(32, 1, 2, 13, 8, 32)         // level 1 <- level 0: 32 output channels = two waves of 16 rows, 4 tiles of 208 pixels
+    CINE_S2D_CASE(64, 1, 4, 13, 4, 64)         // 64 channels, one tile per plane
+    CINE_S2D_CASE(128, 2, 4, 4, 2, 64)         // 128
+#undef CINE_S2D_CASE
+    return CINE_OK;
+}
+
+}  // namespace cine

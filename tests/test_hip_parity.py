@@ -471,6 +471,36 @@ def test_conv_wide_bit_identical_to_general_kernel(dev):
         lib().cine_set_conv_plane(7)
 
 
+def test_tconv_dgrad_plane_bit_identical_and_vs_torch(dev):
+    """Input gradient of the k2 s2 transpose conv (cine_tconv2x2_dgrad: a 1x1 GEMM over the space-to-depth view of the output
+    gradient) on the lean kernel of csrc/conv_plane.hip against conv_tile's element-wise mode-5 staging (bit for bit) and against
+    torch's autograd of conv_transpose2d, on the cfg-2 U-Net's three shapes and an overhanging last tile."""
+    from cine_hip import ops
+    from cine_hip._lib import lib, check
+    import torch.nn.functional as F
+    n = 5
+    try:
+        for cin, cout, h, w in ((32, 16, 104, 8), (64, 32, 52, 4), (128, 64, 26, 2), (32, 16, 98, 8), (128, 64, 25, 2)):
+            g = torch.Generator().manual_seed(cin + h)
+            wt = (torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5)
+            gy = torch.randn(n, cout, 2 * h, 2 * w, generator=g)
+            wp, wp2 = ops._pack("tcd", wt.to(dev)), ops._pack("tcd", (2 * wt).to(dev))
+            outs = []
+            for on in (7, 5):
+                assert lib().cine_set_conv_plane(on) == 0
+                gx = torch.empty(n, cin, h, w, device=dev)
+                check(lib().cine_tconv2x2_dgrad(gy.to(dev).data_ptr(), wp.data_ptr(), wp2.data_ptr(), 3, gx.data_ptr(), n, cin, cout, h, w, None), "cine_tconv2x2_dgrad")
+                outs.append(gx)
+            assert torch.equal(outs[0], outs[1]), (cin, cout, h, w, float((outs[0] - outs[1]).abs().max()))
+            x = torch.zeros(n, cin, h, w, requires_grad=True)
+            with torch.enable_grad():
+                (F.conv_transpose2d(x, wt, stride=2) * gy).sum().backward()
+            want = x.grad.clone(); want[3:] *= 2                                   # samples >= set_split use the second weight set
+            assert rel_err(outs[0].cpu(), want) < OP_TOL, (cin, cout, h, w)
+    finally:
+        lib().cine_set_conv_plane(7)
+
+
 # ------------------------------------------------------------------ blocks and models
 @pytest.mark.parametrize("dyn", ["XF", "XT", "2D", "3D"])
 def test_varnet_block_vs_reference_golden(golden, dev, dyn):

@@ -42,12 +42,12 @@ if [ "$PART" != main ]; then
 for c in 3 4 5; do
   python3 bench.py --config $c --steps 12 --warmup 3 --cpu-forwards 1 --cpu-threads 16 > $O/bench_cfg$c.json 2> $O/bench_cfg$c.err
   cd /tmp
-  rocprofv3 --kernel-trace --stats -d $O/trace_cfg$c -o t --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --repeats 0 --inflight 1 > $O/trace_cfg$c.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/trace_cfg$c -o t --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 2 --no-cpu-baseline --repeats 0 --inflight 1 --headline-only > $O/trace_cfg$c.log 2>&1
   for k in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $k -d $O/pmc_${k}_cfg$c -o p --output-format csv -- python3 $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph > $O/pmc_${k}_cfg$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $k -d $O/pmc_${k}_cfg$c -o p --output-format csv -- python3 $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph --headline-only > $O/pmc_${k}_cfg$c.log 2>&1
   done
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE \
-    -d $O/pmc_mfma_cfg$c -o p --output-format csv -- python3 $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph > $O/pmc_mfma_cfg$c.log 2>&1
+    -d $O/pmc_mfma_cfg$c -o p --output-format csv -- python3 $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph --headline-only > $O/pmc_mfma_cfg$c.log 2>&1
   cd $R
   python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE_cfg$c/p_counter_collection.csv $O/pmc_WRITE_SIZE_cfg$c/p_counter_collection.csv 7 $O/pmc_traffic_cfg$c.json $COMMIT > $O/pmc_traffic_cfg$c.txt
   python3 tools/pmc_mfma.py $O/pmc_mfma_cfg$c/p_counter_collection.csv 7 $O/pmc_mfma_cfg$c.json $COMMIT > $O/pmc_mfma_cfg$c.txt

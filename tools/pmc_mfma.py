@@ -11,7 +11,7 @@ per = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(set)
 dur = collections.defaultdict(float)
 for r in rows:
-    k = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+    k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "")).replace("void ", "")
     per[k][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Dispatch_Id"] not in cnt[k]:
         dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
