@@ -32,6 +32,7 @@ struct PlaneArgs {
     long cs0;                            // MODE 2: floats between the channels of the pooled source
     int sh0;                             // MODE 2: source height (2H or 2H + 1); its row pitch is 2 TW
     const float* wp0; const float* wp1; int set_split;
+    const float* bias; const float* bias1; int relu;      // optional epilogue y = [ReLU](conv + bias) (the MWCNN's conv blocks, mwcnn.py:60-75)
     float* y; float* ypart;
     int cin, rows, rowsp, H, nchunks, tiles;
     float slope, eps;
@@ -295,6 +296,26 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
     constexpr int PPR = TW >= 4 ? 4 : TW;
     const int pr0 = (4 * kk) / TW, pc0 = (4 * kk) % TW;
     const int fr0 = r0 + wn * MT * C::RPF;                          // first image row of my fragments
+    if (a.bias) {
+        const float* bsel = n >= a.set_split ? a.bias1 : a.bias;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int m = co0 + 16 * (wm * CT + ct) + q;
+            const float bv = m < a.rows ? bsel[m] : 0.f;
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ct][f][j] += bv;
+        }
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int f = 0; f < MT; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ct][f][j] = fmaxf(acc[ct][f][j], 0.f);
+    }
     const bool full = r0 + C::TH <= a.H;
     unsigned long long vmask = ~0ull;
     if (!full) {
@@ -442,7 +463,7 @@ int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
     if (!(g_plane_on.load(std::memory_order_relaxed) & 1)) return CINE_OK;
-    if (a.vol || a.D != 1 || a.add_src1 || a.bias || a.addend || a.relu || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
+    if (a.vol || a.D != 1 || a.add_src1 || a.addend || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
@@ -468,7 +489,7 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     p.x0 = s0.x; p.part0 = s0.part; p.c0 = s0.c; p.np0 = s0.np;
     p.x1 = s1.c > 0 ? s1.x : nullptr; p.part1 = s1.c > 0 ? s1.part : nullptr; p.c1 = s1.c; p.np1 = s1.c > 0 ? s1.np : 0;
     p.cs0 = (long)s0.h * s0.w; p.sh0 = s0.h;
-    p.wp0 = a.wp0; p.wp1 = a.wp1; p.set_split = a.set_split;
+    p.wp0 = a.wp0; p.wp1 = a.wp1; p.set_split = a.set_split; p.bias = a.bias; p.bias1 = a.bias1; p.relu = a.relu;
     p.y = a.y; p.ypart = a.ypart; p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.H = a.H; p.nchunks = a.nchunks; p.tiles = a.tiles;
     p.slope = a.slope; p.eps = a.eps;
     // G > 1 configurations (planes narrower than 16) stage whole chunks only
@@ -485,6 +506,9 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 8, 0, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 0, true)
     CINE_PLANE_CASE(8, 2, 4, 1, 4, 2, 0, true)
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 0, true)           // the MWCNN's plane shapes (XT / XF planes at its coarser scales)
+    CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 0, true)
+    CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 0, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 2, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 1, true)

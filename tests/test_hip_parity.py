@@ -343,6 +343,7 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
         if d < 3:
             cases += [("concat", c, c, h, w), ("plain", c, 2 * c, h, w)]          # up path; input gradient of the concat conv
     cases += [("norm", 16, 16, 200, 16), ("pool", 16, 32, 100, 8), ("norm", 128, 128, 25, 2), ("norm", 24, 16, 52, 16)]     # ragged last tiles, 3 chunks
+    cases += [("relu", 16, 16, 208, 8), ("relu", 32, 32, 100, 4), ("relu", 64, 64, 50, 2), ("relu", 16, 16, 200, 16)]       # the MWCNN's conv + bias + ReLU blocks
     try:
         for kind, c0, cout, h, w in cases:
             g = torch.Generator().manual_seed(c0 * 131 + cout + h)
@@ -364,10 +365,14 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
             outs = []
             for on in (7, 0):
                 assert lib().cine_set_conv_plane(on) == 0
-                outs.append(ops.conv3x3_in(srcs, ops.pack_conv3x3(wa), cout, h, w, wpacked2=ops.pack_conv3x3(wb), set_split=4))
+                if kind == "relu":
+                    bias = torch.randn(cout, generator=torch.Generator().manual_seed(cout)).to(dev)
+                    outs.append((ops.conv3x3_sum([x], ops.pack_conv3x3(wa), bias, cout, relu=True), None))
+                else:
+                    outs.append(ops.conv3x3_in(srcs, ops.pack_conv3x3(wa), cout, h, w, wpacked2=ops.pack_conv3x3(wb), set_split=4))
             (y1, p1), (y0, p0) = outs
             assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
-            assert torch.equal(p1, p0), (kind, c0, cout, h, w)
+            assert p1 is None or torch.equal(p1, p0), (kind, c0, cout, h, w)
     finally:
         lib().cine_set_conv_plane(7)
 
