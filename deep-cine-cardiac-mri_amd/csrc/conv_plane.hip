@@ -50,11 +50,8 @@ __device__ __forceinline__ float add_xor32(float x) {
 }
 
 // MODE 0: plain source (no statistics); 1: InstanceNorm + LeakyReLU on load, one source or the concat of two; 2: the same + 2x2 average pool
-#ifndef PLANE_MINW4_TW
-#define PLANE_MINW4_TW 0          // experiment: bit mask of tile widths whose kernels are built for four waves per SIMD
-#endif
 template <int CK, int CT, int WM, int WN, int MT, int TW, int MODE>
-__global__ __launch_bounds__(64 * WM * WN, ((PLANE_MINW4_TW & TW) ? 4 : ConvCfg<CK, CT, WM, WN, MT, TW, 9>::MINW)) void conv_plane_kernel(PlaneArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::MINW)) void conv_plane_kernel(PlaneArgs a) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
     constexpr int PW = C::PW, NT = C::NT, PR = C::PR, RP = C::RP, G = C::G, NCI = C::NCI, NWT = C::NWT;
     static_assert(C::KR == 1, "one (row, piece) slot per thread");
