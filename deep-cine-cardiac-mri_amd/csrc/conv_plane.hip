@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "common.h"
 #include "conv_cfg.h"
+#include "grad.h"
 
 namespace cine {
 namespace {
@@ -524,7 +525,8 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
 // Diagnostics: route the plane-wide 3x3 convolutions through the general kernel (0) or the lean one (1, the default).  The two are
 // bit-identical; the switch exists for that test and for A/B timing.  Process-wide.
 extern "C" int cine_set_conv_plane(int on) {
-    cine::g_plane_on.store(on, std::memory_order_relaxed);       // bit 0 plane-wide 3x3 convs, bit 1 transpose convs, bit 2 wide planes / volumes (7 = all, the default)
+    cine::set_wgrad_plane((on & 16) ? 0 : 1);       // bit 4 SET: the plane-wide weight gradients (training) on the general kernel
+    cine::g_plane_on.store(on & 7, std::memory_order_relaxed);       // bit 0 plane-wide 3x3 convs, bit 1 transpose convs, bit 2 wide planes / volumes (7 = all, the default)
     return CINE_OK;
 }
 

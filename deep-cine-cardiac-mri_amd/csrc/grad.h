@@ -24,6 +24,7 @@ struct InBwdArgs {
     float eps, slope;
 };
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st);
+void set_wgrad_plane(int on);        // diagnostics: 0 routes the plane-wide weight gradients through the general kernel (cine_set_conv_plane bit 4)
 int launch_in_lrelu_bwd_fast(const InBwdArgs& a, hipStream_t st, bool* handled);      // inbwd_fast.hip: the U-Nets' plane shapes, one pass over HBM
 
 // Weight gradient of a convolution y = conv(X) whose input X is described like the forward's sources (modes 0 / 1 / 2 vectorised; the

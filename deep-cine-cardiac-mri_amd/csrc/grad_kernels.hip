@@ -13,6 +13,7 @@
 // Reference: reconstruction/models/denoisers/unet.py:73-125 (what autograd differentiates there).
 #include <algorithm>
 #include "grad.h"
+#include <atomic>
 #include <mutex>
 #include <cstdlib>
 
@@ -529,6 +530,187 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgLaunch L) {
     }
 }
 
+// ---------------------------------------------------------------- weight gradient of the U-Nets' plane-wide 3x3 convs (lean)
+// wgrad_mfma_kernel serves every source mode, width and tap count from one body (230 - 250 VGPRs: one or two workgroups per CU) and
+// re-derives every staging slot of every tile with integer divisions; a third of its instructions per tile go into a halo-column loop
+// that writes zeros whenever the tile spans the plane's width.  Same algorithm for exactly that case (W == TW, plain or
+// InstanceNorm + LeakyReLU sources, at most a concat of two whose first ends on a 16-channel boundary, plain output gradient):
+// the slot tables are built once per thread, the halo columns are zeroed once, the statistics table holds this workgroup's
+// 16 channels instead of all of them.  Same tile order, K split and reduction order: the partial sums are BIT-IDENTICAL.
+template <int TW, int CT, int WM, int NPIX>
+__global__ __launch_bounds__(256, 2) void wgrad_plane_kernel(WgLaunch L) {
+    using C = WgCfg<9, TW, CT, WM, NPIX>;
+    constexpr int PW = C::PW, PR = C::PR, NIP = C::NIP, NGP = C::NGP;
+    typedef typename WgPiece<PW>::T piece_t;
+    extern __shared__ __align__(16) float smem_g[];
+    float* in_lds = smem_g;
+    float* g_lds = smem_g + C::IN_FLOATS;
+    float* st_lds = smem_g + C::LDS_FLOATS;           // two tables (sample parity) of {scale, shift} of this workgroup's 16 input channels
+    const WgArgs& a = L.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 15, kk = lane >> 4;
+    const int wm = wave % WM, wk = wave / WM;
+    const int ci0 = blockIdx.x * 16, co0 = blockIdx.y * C::COB;
+    const int set = blockIdx.z / L.nchunks, ch = blockIdx.z - set * L.nchunks;
+
+    f32x4 acc[9][CT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntile = (a.H + C::TH - 1) / C::TH;
+    const int sbase = set ? a.set_split : 0;
+    const int items = ((set ? a.n : a.set_split) - sbase) * ntile;
+    const int ibeg = min(ch * L.chunk, items), iend = min(ibeg + L.chunk, items);
+    const int total = iend - ibeg;
+    const int hw = a.H * TW;
+    // the source that holds my 16-channel chunk (uniform: the first source ends on a chunk boundary)
+    const bool f0 = ci0 < a.s0.c;
+    const float* const sx = f0 ? a.s0.x : a.s1.x;
+    const float* const spart = f0 ? a.s0.part : a.s1.part;
+    const int sc_ = f0 ? a.s0.c : a.s1.c, snp = f0 ? a.s0.np : a.s1.np, smode = f0 ? a.s0.mode : a.s1.mode;
+    const int cl0 = f0 ? ci0 : ci0 - a.s0.c;
+    const int nci = min(16, a.cin - ci0);             // channels of the chunk that exist
+    // ---- slot tables (fixed for the kernel)
+    int xko[NIP], xrm[NIP], xl[NIP];                  // channel + column offset in the source, row - 1 in the tile, LDS offset (-1: no slot / no channel)
+#pragma unroll
+    for (int i = 0; i < NIP; ++i) {
+        const int e = tid + i * 256;
+        const int ec = min(e, C::NIU - 1);
+        const int k = ec / (C::ROWS * PR), rem = ec - k * (C::ROWS * PR);
+        const int row = rem / PR, j = rem - row * PR;
+        xko[i] = min(k, nci - 1) * hw + PW * j; xrm[i] = row - 1;
+        xl[i] = (e < C::NIU) ? ((k * C::PSI + row * C::COLS + PW * j) << 1) | (k < nci ? 1 : 0) : -1;      // bit 0: the channel exists
+    }
+    int gko[NGP], grw[NGP], gl[NGP];
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) {
+        const int e = tid + i * 256;
+        const int ec = min(e, C::NGU - 1);
+        const int co = ec / (NPIX / PW), pp = (ec - co * (NPIX / PW)) * PW;
+        gko[i] = min(co0 + co, a.rows - 1) * hw + pp % TW; grw[i] = pp / TW;
+        gl[i] = (e < C::NGU) ? ((co * C::PSG + pp) << 1) | (co0 + co < a.rows ? 1 : 0) : -1;
+    }
+    auto table = [&](int n, float* st) {
+        if (tid < 16) {
+            float2 mr = make_float2(0.f, 1.f);
+            if (smode == 1 && tid < nci) mr = merge_partials(spart + ((long)n * sc_ + cl0 + tid) * snp * 3, snp, a.eps);
+            st[2 * tid] = mr.y; st[2 * tid + 1] = -mr.x * mr.y;
+        }
+    };
+    piece_t xin[NIP], gin[NGP];
+    auto issue = [&](int it) {
+        const int n = sbase + (ibeg + it) / ntile, r0 = ((ibeg + it) % ntile) * C::TH;
+        const float* xb = sx + ((long)n * sc_ + cl0) * hw;
+        const float* gb = a.g + (long)n * a.rows * hw;
+#pragma unroll
+        for (int i = 0; i < NIP; ++i) xin[i] = *reinterpret_cast<const piece_t*>(xb + xko[i] + min(max(r0 + xrm[i], 0), a.H - 1) * TW);
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) gin[i] = *reinterpret_cast<const piece_t*>(gb + gko[i] + min(r0 + grw[i], a.H - 1) * TW);
+    };
+    auto commit = [&](int it) {
+        const int r0 = ((ibeg + it) % ntile) * C::TH;
+        const float* st = st_lds + 32 * (((ibeg + it) / ntile) & 1);
+#pragma unroll
+        for (int i = 0; i < NIP; ++i) {
+            if (xl[i] < 0) continue;
+            const int gy = r0 + xrm[i];
+            const bool ok = (xl[i] & 1) && gy >= 0 && gy < a.H;
+            piece_t o = xin[i];
+            float* ov = reinterpret_cast<float*>(&o);
+            const int k2 = 2 * min((xl[i] >> 1) / C::PSI, 15);
+            const float sc = st[k2], sh = st[k2 + 1];
+#pragma unroll
+            for (int u = 0; u < PW; ++u) ov[u] = ok ? (smode == 0 ? ov[u] : act(ov[u], sc, sh, a.slope)) : 0.f;
+            float* dst = in_lds + (xl[i] >> 1);
+#pragma unroll
+            for (int u = 0; u < PW; u += 2) *reinterpret_cast<float2*>(dst + u) = make_float2(ov[u], ov[u + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < NGP; ++i) {
+            if (gl[i] < 0) continue;
+            const bool ok = (gl[i] & 1) && r0 + grw[i] < a.H;
+            const piece_t o = gin[i];
+            const float* ov = reinterpret_cast<const float*>(&o);
+            float* dst = g_lds + (gl[i] >> 1);
+#pragma unroll
+            for (int u = 0; u < PW; u += 2) *reinterpret_cast<float2*>(dst + u) = ok ? make_float2(ov[u], ov[u + 1]) : make_float2(0.f, 0.f);
+        }
+    };
+    // the halo columns of a plane-wide tile are zero for every item
+    for (int e = tid; e < 16 * C::ROWS * 2; e += 256) {
+        const int k = e / (C::ROWS * 2), rem = e - k * (C::ROWS * 2);
+        in_lds[k * C::PSI + (rem >> 1) * C::COLS + ((rem & 1) ? TW : C::COLS - 1)] = 0.f;
+    }
+    if (total > 0) { table(sbase + ibeg / ntile, st_lds + 32 * ((ibeg / ntile) & 1)); issue(0); }
+    for (int it = 0; it < total; ++it) {
+        __syncthreads();
+        if ((ibeg + it + 1) % ntile == 0 && it + 1 < total)
+            table(sbase + (ibeg + it + 1) / ntile, st_lds + 32 * (((ibeg + it + 1) / ntile) & 1));
+        commit(it);
+        __syncthreads();
+        if (it + 1 < total) issue(it + 1);
+        constexpr int NSTEP = NPIX / 4 / C::WK;
+        float gv[2][CT], xv[2][9];
+        auto load_step = [&](int i, float (&gq)[CT], float (&xq)[9]) {
+            const int p = 4 * (wk + i * C::WK) + kk;
+            const int prow = p / TW, pcol = p % TW;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) gq[ct] = g_lds[(16 * (wm * CT + ct) + q) * C::PSG + p];
+            const float* ib = in_lds + q * C::PSI + prow * C::COLS;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                int xc = pcol + (t % 3) - 1; xc = xc < 0 ? C::COLS - 1 : xc;
+                xq[t] = ib[(t / 3) * C::COLS + xc];
+            }
+        };
+        load_step(0, gv[0], xv[0]);
+#pragma unroll
+        for (int i = 0; i < NSTEP; ++i) {
+            if (i + 1 < NSTEP) load_step(i + 1, gv[(i + 1) & 1], xv[(i + 1) & 1]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[i & 1][t], gv[i & 1][ct], acc[t][ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* part = L.part + (((long)blockIdx.z * L.rowsp + co0) * L.cinp + ci0) * 9;
+    if (C::WK == 1) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    part[((long)(16 * (wm * CT + ct) + q) * L.cinp + 4 * kk + j) * 9 + t] = acc[t][ct][j];
+        return;
+    }
+    __syncthreads();
+    float* red = smem_g;
+    for (int turn = 0; turn < C::WK; ++turn) {
+        if (wk == turn) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* o = red + ((t * (CT * WM) + wm * CT + ct) * 16 + 4 * kk + j) * 16 + q;
+                        *o = turn == 0 ? acc[t][ct][j] : *o + acc[t][ct][j];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 9 * C::COB * 16; e += 256) {
+        const int t = e % 9, r2 = e / 9;
+        const int ci = r2 % 16, co = r2 / 16;
+        part[((long)co * L.cinp + ci) * 9 + t] = red[((t * (CT * WM) + co / 16) * 16 + ci) * 16 + (co % 16)];
+    }
+}
+
 // grad += sum over the partial sums of one weight set.  A workgroup owns 64 consecutive weights (coalesced 256-byte reads of
 // every partial) and splits the chunks over its 16 waves; the 16 wave sums are added in a fixed order (deterministic).
 // One plane (sample n, conv-input channel cg) of the transformed conv input -- concat or sum of the two sources, any on-load mode -- written
@@ -611,13 +793,24 @@ size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
     return (size_t)std::max(wgrad_runs(rows, cin, 1), 2 * wgrad_runs(rows, cin, 2)) * rowsb * cinp * taps;
 }
 
+static std::atomic<int> g_wgrad_plane{1};
+bool wgrad_plane_enabled() { return g_wgrad_plane.load(std::memory_order_relaxed) != 0; }
+void set_wgrad_plane(int on) { g_wgrad_plane.store(on, std::memory_order_relaxed); }
+
 template <int TAPS, int TW, int CT, int WM, int NPIX>
 static int launch_wg_cfg(const WgLaunch& L, dim3 grid, hipStream_t st) {
     using C = WgCfg<TAPS, TW, CT, WM, NPIX>;
-    const size_t lds = (size_t)(C::LDS_FLOATS + 4 * (L.a.s0.c + L.a.s1.c)) * sizeof(float);
+    const size_t lds = (size_t)(C::LDS_FLOATS + std::max(4 * (L.a.s0.c + L.a.s1.c), 64)) * sizeof(float);     // (wgrad_plane_kernel: two tables of 16 channels)
     static_assert(C::LDS_FLOATS * sizeof(float) <= 60 * 1024, "wgrad tile exceeds the default LDS limit");
     CINE_REQUIRE(lds <= 64 * 1024, CINE_EUNSUPPORTED, "wgrad: %d source channels need %zu bytes of LDS", L.a.s0.c + L.a.s1.c, lds);
     if constexpr (TAPS == 9) {
+        const WgArgs& a = L.a;
+        auto same = [&](const Src& s) { return s.c == 0 || (s.mode <= 1 && s.h == a.H && s.w == a.W); };
+        if (wgrad_plane_enabled() && L.fast_in && L.fast_g == 1 && a.W == TW && !a.add_src1 && same(a.s0) && same(a.s1) && (a.s1.c == 0 || a.s0.c % 16 == 0) &&
+            (a.s0.mode == 0 || (a.s0.part && a.s0.np > 0)) && (a.s1.c == 0 || a.s1.mode == 0 || (a.s1.part && a.s1.np > 0))) {
+            hipLaunchKernelGGL((wgrad_plane_kernel<TW, CT, WM, NPIX>), grid, dim3(256), lds, st, L);
+            return check_launch("wgrad_plane_kernel");
+        }
         if (L.a.add_src1) {
             hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX, true>), grid, dim3(256), lds, st, L);
             return check_launch("wgrad_mfma_kernel");

@@ -480,7 +480,8 @@ int cine_set_lrelu_slope(float slope);
  * that are BIT-IDENTICAL to the general one, and so do the 3x3 (x3) convolutions of wider planes and volumes in 16-wide column
  * tiles (sensitivity network, CRNN cells, 3-D U-Net); `on` is a mask -- bit 0 the plane-wide 3x3 convolutions, bit 1 the
  * transpose convolutions, bit 2 the wide planes / volumes; a cleared bit routes that kind through the general kernel (the
- * bit-identity tests, A/B timing).  Process-wide, default 7. */
+ * bit-identity tests, A/B timing).  Bit 4 SET routes the plane-wide weight gradients of training (grad_kernels.hip:
+ * wgrad_plane_kernel, also bit-identical) through the general weight-gradient kernel.  Process-wide, default 7. */
 int cine_set_conv_plane(int on);
 
 /* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_mwcnn_backward (they

@@ -479,6 +479,29 @@ def test_other_configs_training_step_vs_reference_fingerprint(dev, golden, name)
     assert not bad, bad
 
 
+def test_plane_wgrad_kernel_bit_identical_to_general_kernel(dev):
+    """The lean weight-gradient kernel of the U-Nets' plane-wide 3x3 convs (grad_kernels.hip: wgrad_plane_kernel) against
+    wgrad_mfma_kernel on a whole XF-VarNet training step at cfg 2's plane shapes (2 cascades): every parameter gradient bit for bit
+    -- same tile order, K split and reduction order.  cine_set_conv_plane bit 4 routes the weight gradients through the general kernel."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    from cine_hip._lib import lib
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+    res = []
+    try:
+        for mask in (7, 7 | 16):
+            assert lib().cine_set_conv_plane(mask) == 0
+            net = M.VarNet(2, 8, 3, 16, 3, "XF"); synth.fill_parameters_(net, 1); net = net.to(dev).train()
+            with torch.enable_grad():
+                out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev))
+                (out - ex["target"].to(dev)).pow(2).sum().backward()
+            res.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    finally:
+        lib().cine_set_conv_plane(7)
+    bad = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    assert not bad, bad
+
+
 _LINEAR = {
     "varnet_grad_cfg2_linear": (lambda M: M.VarNet(6, 8, 3, 16, 3, "XF"), 1, 4, False),
     "cinenet_grad_cfg4_linear": (lambda M: M.CineNet(6, 6, 16, 3, "3D"), 7, 6, True),
