@@ -1410,4 +1410,12 @@ def test_training_gradient_all_reduce_runs_on_rccl(dev):
     assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
     m = re.search(r"training step: ([0-9.]+) ms\s+loss ([0-9.]+).*\[1 rank\(s\), RCCL gradient all-reduce of ([0-9.]+) MiB", r.stdout)
     assert m, r.stdout[-2000:] + "\n" + r.stderr[-2000:]
-    assert float(m.group(1)) < 60.0 and 0.0 < float(m.group(2)) < 1.0 and 3.5 < float(m.group(3)) < 5.0
+    assert 0.0 < float(m.group(2)) < 1.0 and 3.5 < float(m.group(3)) < 5.0
+    # the same step in the same situation (a child of this test process, right now) without a process group: the bar is relative --
+    # an absolute one depends on what the box and the parent process are doing (60.7 ms measured once at the end of a whole -m gpu run,
+    # 36.0 ms alone); four hardware queues instead of sixteen cost 13 % (40.4 -> 45.7 ms)
+    env.pop("CINE_FORCE_COLLECTIVE")
+    r0 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "4", "2"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r0.returncode == 0, r0.stdout[-2000:] + "\n" + r0.stderr[-4000:]
+    m0 = re.search(r"training step: ([0-9.]+) ms", r0.stdout)
+    assert m0 and float(m.group(1)) < 1.25 * float(m0.group(1)) + 3.0, (m.group(1), m0 and m0.group(1))
