@@ -124,6 +124,12 @@ _SIGS = {
     "cine_conv1x1_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_unet2d_train_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_forward_train": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_complex_mul": (c_int, [P, P, P, c_int, P, P, P, P]),
+    "cine_complex_conj": (c_int, [P, P, c_long, P]),
+    "cine_complex_abs_sq": (c_int, [P, P, c_long, P]),
+    "cine_rss": (c_int, [P, P, c_long, c_int, c_long, c_int, P]),
+    "cine_roll": (c_int, [P, P, c_long, c_int, c_long, c_int, P]),
+    "cine_pad2d": (c_int, [P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_set_side_stream": (c_int, [P]),
     "cine_set_conv_plane": (c_int, [c_int]),
     "cine_set_lrelu_slope": (c_int, [ctypes.c_float]),

@@ -267,6 +267,89 @@ def complex_abs(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ------------------------------------------------------------------ the reference's small helpers (utils/math.py, coil_combine.py, fftc.roll, padding.py)
+def complex_mul(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """reference utils/math.py:20-33 with broadcasting: the operands are read through their own strides (0 on broadcast dimensions)."""
+    x = _dev(x, "complex_mul x"); y = _dev(y, "complex_mul y")
+    shape = torch.broadcast_shapes(x.shape[:-1], y.shape[:-1])
+    if len(shape) > 6:
+        raise ValueError("complex_mul: at most 6 dimensions besides the complex pair")
+    xe, ye = x.expand(*shape, 2), y.expand(*shape, 2)
+    out = torch.empty((*shape, 2), device=x.device, dtype=x.dtype)
+    if out.numel() == 0:
+        return out
+    nd = len(shape)
+    sh = (ctypes.c_int * max(nd, 1))(*shape)
+    xs = (ctypes.c_long * max(nd, 1))(*[s // 2 for s in xe.stride()[:-1]])       # (contiguous pairs: every stride is even)
+    ys = (ctypes.c_long * max(nd, 1))(*[s // 2 for s in ye.stride()[:-1]])
+    check(lib().cine_complex_mul(x.data_ptr(), y.data_ptr(), out.data_ptr(), nd, sh, xs, ys, _stream()), "cine_complex_mul")
+    return out
+
+
+def complex_conj(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "complex_conj input")
+    out = torch.empty_like(x)
+    if x.numel():
+        check(lib().cine_complex_conj(x.data_ptr(), out.data_ptr(), x.numel() // 2, _stream()), "cine_complex_conj")
+    return out
+
+
+def complex_abs_sq(x: torch.Tensor) -> torch.Tensor:
+    x = _dev(x, "complex_abs_sq input")
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=x.dtype)
+    if out.numel():
+        check(lib().cine_complex_abs_sq(x.data_ptr(), out.data_ptr(), out.numel(), _stream()), "cine_complex_abs_sq")
+    return out
+
+
+def rss(x: torch.Tensor, dim: int, is_complex: bool) -> torch.Tensor:
+    """reference utils/coil_combine.py: sqrt(sum over `dim` of x^2), or of |x|^2 for (..., 2) data (dim counts the tensor's own dims)."""
+    x = _dev(x, "rss input")
+    nd = x.dim()
+    dim = dim % nd
+    if is_complex and dim == nd - 1:
+        raise ValueError("rss_complex: dim is the complex pair")
+    lead = x.shape[:dim]; k = x.shape[dim]; tail = x.shape[dim + 1:nd - 1] if is_complex else x.shape[dim + 1:]
+    outer = 1
+    for d in lead: outer *= d
+    inner = 1
+    for d in tail: inner *= d
+    out = torch.empty(tuple(lead) + tuple(tail), device=x.device, dtype=x.dtype)
+    if out.numel():
+        check(lib().cine_rss(x.data_ptr(), out.data_ptr(), outer, k, inner, int(is_complex), _stream()), "cine_rss")
+    return out
+
+
+def roll(x: torch.Tensor, shifts, dims) -> torch.Tensor:
+    """reference utils/fftc.py:141-163: one kernel launch per rolled dimension."""
+    x = _dev(x, "roll input")
+    cur = x
+    for s, d in zip(shifts, dims):
+        d = d % cur.dim()
+        n = cur.shape[d]
+        outer = 1
+        for v in cur.shape[:d]: outer *= v
+        inner = 1
+        for v in cur.shape[d + 1:]: inner *= v
+        out = torch.empty_like(cur)
+        if cur.numel():
+            check(lib().cine_roll(cur.data_ptr(), out.data_ptr(), outer, n, inner, int(s) % n if n else 0, _stream()), "cine_roll")
+        cur = out
+    return cur if cur is not x else x.clone()
+
+
+def pad2d(x: torch.Tensor, left: int, right: int, top: int, bottom: int) -> torch.Tensor:
+    """Zero padding of the last two dimensions (reference utils/padding.py:46 F.pad(x, [left, right, top, bottom]))."""
+    x = _dev(x, "pad input")
+    h, w = x.shape[-2], x.shape[-1]
+    hp, wp = h + top + bottom, w + left + right
+    out = torch.empty(x.shape[:-2] + (hp, wp), device=x.device, dtype=x.dtype)
+    planes = x.numel() // (h * w) if h * w else 0
+    if out.numel():
+        check(lib().cine_pad2d(x.data_ptr(), out.data_ptr(), planes, h, w, top, left, hp, wp, _stream()), "cine_pad2d")
+    return out
+
+
 # ------------------------------------------------------------------ the steps either side of the path (SURVEY 8(f))
 def apply_mask(kspace: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """kspace * mask + 0.0 (reference data/transforms.py:66-92) for a row mask; kspace (..., c, h, w, 2) with the mask's

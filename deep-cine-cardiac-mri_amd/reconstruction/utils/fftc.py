@@ -2,7 +2,8 @@
 
 Interface of the reference's utils/fftc.py (fft1c :5, ifft1c :32, fft2c :59,
 ifft2c :86, roll :141, fftshift :166, ifftshift :191).  The transforms need GPU
-tensors; the shift helpers are pure index permutations and work anywhere.
+tensors; the shift helpers are index permutations: a HIP kernel on float32 GPU tensors (inside the
+path they are folded into the FFT kernels' loads and stores), torch.roll on host tensors.
 """
 from typing import List, Optional
 
@@ -60,6 +61,8 @@ def ifft2c(data: torch.Tensor, norm: Optional[str] = "ortho") -> torch.Tensor:
 def roll(x: torch.Tensor, shift: List[int], dim: List[int]) -> torch.Tensor:
     if len(shift) != len(dim):
         raise ValueError("len(shift) must match len(dim)")
+    if x.is_cuda and x.dtype == torch.float32:                 # csrc/ew_kernels.hip: cine_roll, one launch per rolled dimension
+        return ops.roll(x, [int(s) for s in shift], [int(d) for d in dim])
     return torch.roll(x, shifts=tuple(int(s) for s in shift), dims=tuple(int(d) for d in dim))
 
 

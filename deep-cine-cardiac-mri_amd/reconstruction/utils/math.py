@@ -2,8 +2,9 @@
 
 The fused kernels never call these -- sens-multiply, conjugate and magnitude live
 inside the FFT passes -- they exist so user code written against the reference
-keeps working.  ``complex_abs`` runs the HIP kernel on GPU tensors; the others
-are a handful of tensor-view operations with no heavy arithmetic.
+keeps working.  On float32 GPU tensors every one of them is a HIP kernel (csrc/ew_kernels.hip:
+``cine_complex_mul`` with broadcasting, ``cine_complex_conj``, ``cine_complex_abs[_sq]``); host tensors -- the
+reference's numpy-side dataset code -- take the tensor expressions of the reference.
 """
 import numpy as np
 import torch
@@ -20,12 +21,16 @@ def _check(*xs):
 def complex_mul(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     if not x.shape[-1] == y.shape[-1] == 2:
         raise ValueError("Tensors do not have separate complex dim.")
+    if x.is_cuda and y.is_cuda and x.dtype == y.dtype == torch.float32:
+        return ops.complex_mul(x, y)
     z = torch.view_as_complex(x.contiguous()) * torch.view_as_complex(y.contiguous())
     return torch.view_as_real(z)
 
 
 def complex_conj(x: torch.Tensor) -> torch.Tensor:
     _check(x)
+    if x.is_cuda and x.dtype == torch.float32:
+        return ops.complex_conj(x)
     return x * x.new_tensor([1.0, -1.0])
 
 
@@ -38,6 +43,8 @@ def complex_abs(data: torch.Tensor) -> torch.Tensor:
 
 def complex_abs_sq(data: torch.Tensor) -> torch.Tensor:
     _check(data)
+    if data.is_cuda and data.dtype == torch.float32:
+        return ops.complex_abs_sq(data)
     return (data * data).sum(dim=-1)
 
 

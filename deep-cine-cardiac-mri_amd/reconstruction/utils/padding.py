@@ -2,12 +2,15 @@
 
 ``pad_for_mwcnn`` pads the last two dims to a multiple of 2^n_scales, the extra element of an odd
 size going on the LEFT (reference padding.py:26-47); paddings are returned as plain ints (the
-reference returns 0-d tensors, which force a host sync when used as slice bounds).
+reference returns 0-d tensors, which force a host sync when used as slice bounds).  Float32 GPU tensors are
+padded by ``cine_pad2d``; the path's own pads are fused into ``cine_mwcnn_pad`` / ``cine_xpd_pack``.
 """
 from typing import List, Tuple
 
 import torch
 import torch.nn.functional as F
+
+from cine_hip import ops
 
 
 def pad_for_mwcnn(x: torch.Tensor, n_scales: int) -> Tuple[torch.Tensor, List[int]]:
@@ -19,6 +22,8 @@ def pad_for_mwcnn(x: torch.Tensor, n_scales: int) -> Tuple[torch.Tensor, List[in
         n_pad = 0 if d % m == 0 else (d // m + 1) * m - d
         left = n_pad // 2 if (d % 2 == 0 or n_pad == 0) else 1 + n_pad // 2
         paddings += [left, n_pad // 2]
+    if x.is_cuda and x.dtype == torch.float32:             # csrc/ew_kernels.hip: cine_pad2d
+        return ops.pad2d(x, *paddings), paddings
     return F.pad(x, paddings), paddings
 
 

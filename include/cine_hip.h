@@ -469,6 +469,20 @@ size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, in
 int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
                               void* ws, size_t ws_bytes, void* stream);
+/* The reference's small tensor helpers as device kernels, for user code written against its utils (the fused path never calls
+ * them).  utils/math.py:20-44: complex_mul with broadcasting -- `shape` = the broadcast result's dimensions WITHOUT the trailing
+ * complex pair (at most 6), `xstride` / `ystride` the operands' strides in complex elements, 0 on broadcast dimensions; out is dense.
+ * complex_conj, complex_abs_sq: n complex elements.  utils/coil_combine.py: out (outer, inner) = sqrt(sum_k v(x[outer][k][inner])),
+ * v = x^2 or, with is_complex, re^2 + im^2 of (outer, k, inner, 2).  utils/fftc.py:141-213 roll along one dimension:
+ * out[o][(j + shift) mod n][i] = x[o][j][i] (out of place; fftshift = shift n / 2, ifftshift = (n + 1) / 2).
+ * utils/padding.py:22-47: zero padding of `planes` (h, w) planes to (hp, wp) with the data at (top, left). */
+int cine_complex_mul(const float* x, const float* y, float* out, int ndim, const int* shape, const long* xstride, const long* ystride, void* stream);
+int cine_complex_conj(const float* x, float* out, long n, void* stream);
+int cine_complex_abs_sq(const float* x, float* out, long n, void* stream);
+int cine_rss(const float* x, float* out, long outer, int k, long inner, int is_complex, void* stream);
+int cine_roll(const float* x, float* out, long outer, int n, long inner, int shift, void* stream);
+int cine_pad2d(const float* x, float* out, long planes, int h, int w, int top, int left, int hp, int wp, void* stream);
+
 /* Test hook.  LeakyReLU slope used INSIDE the fused U-Net sequences (cine_unet2d_forward / _forward_train / _backward,
  * cine_unet3d_forward; reference unet.py:162 hard-wires 0.2, and so does this library by default).  slope = 1 makes the
  * activation the identity: tests/test_hip_grad.py compares full-size gradients with reference fixtures generated the same way

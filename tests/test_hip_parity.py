@@ -1032,6 +1032,35 @@ def test_complex_math_helpers_vs_reference_golden(golden, dev):
         U.complex_abs(x[..., :1])
     with pytest.raises(ValueError):
         U.complex_mul(x[..., :1], y)
+    # the helpers are HIP kernels on GPU tensors (csrc/ew_kernels.hip): bit-exact against the reference's unfused tensor expressions
+    # evaluated on the host, with broadcasting (a (b, t, 1, h, w, 2) image times (b, 1, c, h, w, 2) maps), a non-contiguous operand, every
+    # rolled / reduced dimension, and pads with the odd element on the left
+    gen = torch.Generator().manual_seed(5)
+    img, maps = torch.randn(2, 3, 1, 9, 7, 2, generator=gen), torch.randn(2, 1, 4, 9, 7, 2, generator=gen)
+    ref_mul = torch.stack([img[..., 0] * maps[..., 0] - img[..., 1] * maps[..., 1], img[..., 0] * maps[..., 1] + img[..., 1] * maps[..., 0]], -1)
+    assert torch.equal(U.complex_mul(img.to(dev), maps.to(dev)).cpu(), ref_mul)
+    nc = torch.randn(7, 9, 2, 2, generator=gen).permute(2, 1, 0, 3)                  # non-contiguous (2, 9, 7, 2)
+    assert torch.equal(U.complex_conj(nc.to(dev)).cpu(), nc * torch.tensor([1.0, -1.0]))
+    assert torch.equal(U.complex_abs_sq(maps.to(dev)).cpu(), maps[..., 0] * maps[..., 0] + maps[..., 1] * maps[..., 1])
+    for d in range(5):
+        want = torch.zeros_like(maps.select(d, 0)[..., 0])
+        for k in range(maps.shape[d]):
+            v = maps.select(d, k)
+            want = want + (v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1])
+        assert rel_err(U.rss_complex(maps.to(dev), dim=d).cpu(), want.sqrt()) < 2e-7, d        # (the device square root is within 1 ulp)
+    for d in (0, 3, -1):
+        want = torch.zeros_like(maps.select(d, 0))
+        for k in range(maps.shape[d]):
+            want = want + maps.select(d, k) * maps.select(d, k)
+        assert rel_err(U.rss(maps.to(dev), dim=d).cpu(), want.sqrt()) < 2e-7, d
+    for shift, dims in (([1], [0]), ([4, 3], [-3, -2]), ([-2, 5, 1], [1, 3, 4]), ([9], [3])):
+        assert torch.equal(U.roll(maps.to(dev), shift, dims).cpu(), torch.roll(maps, shift, dims))
+    from reconstruction.utils.padding import pad_for_mwcnn, unpad_from_mwcnn
+    for shape, ns in (((3, 2, 9, 7), 2), ((2, 16, 8), 3), ((5, 13, 15), 3)):
+        t_ = torch.randn(*shape, generator=gen)
+        got, pads = pad_for_mwcnn(t_.to(dev), ns)
+        want, pads_h = pad_for_mwcnn(t_, ns)
+        assert pads == pads_h and torch.equal(got.cpu(), want) and torch.equal(unpad_from_mwcnn(got, pads).cpu(), t_)
 
 
 # ------------------------------------------------------------------ image-space data consistency (cine_image_dc)
