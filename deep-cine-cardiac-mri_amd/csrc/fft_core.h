@@ -47,6 +47,13 @@ template <int DIR> CINE_HD cf mul_mi(cf a) { return DIR > 0 ? mk(a.y, -a.x) : mk
 // ---- radix-2/4/5 butterflies, in place on register arrays, natural order ----
 template <int DIR> CINE_HD void dft2(cf& a, cf& b) { cf t = csub(a, b); a = cadd(a, b); b = t; }
 
+template <int DIR> CINE_HD void dft3(cf& a0, cf& a1, cf& a2) {
+    const float s3 = 0.86602540378443865f;    // sin(2pi/3)
+    cf t = cadd(a1, a2), d = mul_mi<DIR>(cscale(csub(a1, a2), s3));
+    cf m = mk(a0.x - 0.5f * t.x, a0.y - 0.5f * t.y);
+    a0 = cadd(a0, t); a1 = cadd(m, d); a2 = csub(m, d);
+}
+
 template <int DIR> CINE_HD void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
     cf s02 = cadd(a0, a2), d02 = csub(a0, a2);
     cf s13 = cadd(a1, a3), d13 = mul_mi<DIR>(csub(a1, a3));
@@ -186,6 +193,61 @@ struct DirectDft {
             idx += k; if (idx >= n) idx -= n;
         }
         dst[k * LP + line] = mk(ax, ay);
+    }
+};
+
+// ------------------------------------------------------------------ N = 2^a 3^b 5^c: Stockham autosort, radices 4 / 2 / 3 / 5
+// tw[j] = exp(-2 pi i j / n), j in [0, n), UNSCALED; the ortho scale 1 / sqrt(n) is applied by the last stage.  Stage s with radix R
+// and Ns = product of the radices before it: butterfly j in [0, n / R) reads src[j + m n / R], m < R, multiplies by
+// w_n^(m (j mod Ns) n / (Ns R)), transforms, and writes dst[(j / Ns) Ns R + (j mod Ns) + m Ns] -- natural order in, natural order out
+// after the last stage, the two tiles ping-pong.  Lengths with another prime factor keep the direct engine.
+struct MixedRadix {
+    static constexpr int kMaxStages = 10;
+    CINE_HD static bool smooth(int n) {
+        if (n < 2) return false;
+        while (n % 2 == 0) n /= 2;
+        while (n % 3 == 0) n /= 3;
+        while (n % 5 == 0) n /= 5;
+        return n == 1;
+    }
+    // radix of stage s (4s first, then one 2, then 3s, then 5s); returns the stage count
+    CINE_HD static int plan(int n, int (&radix)[kMaxStages]) {
+        int ns = 0;
+        while (n % 4 == 0) { radix[ns++] = 4; n /= 4; }
+        if (n % 2 == 0) { radix[ns++] = 2; n /= 2; }
+        while (n % 3 == 0) { radix[ns++] = 3; n /= 3; }
+        while (n % 5 == 0) { radix[ns++] = 5; n /= 5; }
+        return ns;
+    }
+    CINE_HD static int items(int lines, int n, int R) { return lines * (n / R); }
+    template <int DIR, int R>
+    CINE_HD static void stage_r(const cf* src, cf* dst, int LP, int item, int lines, int n, int Ns, const cf* tw, float scale) {
+        const int line = item % lines, j = item / lines;
+        const int m = n / R, k = j % Ns;
+        const int step = k * (n / (Ns * R));                // twiddle index of input 1; input q uses q * step (< n)
+        cf v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            cf x = src[(j + q * m) * LP + line];
+            if (q > 0 && step > 0) { const cf w = tw[q * step]; x = DIR > 0 ? cmul(x, w) : cmulc(x, w); }
+            v[q] = x;
+        }
+        if constexpr (R == 4) dft4<DIR>(v[0], v[1], v[2], v[3]);
+        else if constexpr (R == 2) dft2<DIR>(v[0], v[1]);
+        else if constexpr (R == 3) dft3<DIR>(v[0], v[1], v[2]);
+        else dft5<DIR>(v[0], v[1], v[2], v[3], v[4]);
+        const int o = (j / Ns) * Ns * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) dst[(o + q * Ns) * LP + line] = cscale(v[q], scale);
+    }
+    template <int DIR>
+    CINE_HD static void stage(const cf* src, cf* dst, int LP, int item, int lines, int n, int R, int Ns, const cf* tw, float scale) {
+        switch (R) {
+            case 4: stage_r<DIR, 4>(src, dst, LP, item, lines, n, Ns, tw, scale); break;
+            case 2: stage_r<DIR, 2>(src, dst, LP, item, lines, n, Ns, tw, scale); break;
+            case 3: stage_r<DIR, 3>(src, dst, LP, item, lines, n, Ns, tw, scale); break;
+            default: stage_r<DIR, 5>(src, dst, LP, item, lines, n, Ns, tw, scale); break;
+        }
     }
 };
 

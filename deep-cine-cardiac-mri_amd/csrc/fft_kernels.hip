@@ -9,8 +9,10 @@
 //   row pass load  : S * img                (sens_expand, varnet.py:181-185)
 //   col pass store : soft / hard DC blend   (varnet.py:281-282, cinenet.py:129)
 //   row pass store : conj(S) * x, coil sum, optional magnitude (varnet.py:187-194, 150-151)
-// N == 200 uses the 10 x 20 Cooley-Tukey engine; any other N <= 400 a direct DFT.
+// N == 200 uses the 10 x 20 Cooley-Tukey engine; any other N = 2^a 3^b 5^c <= 512 the mixed-radix Stockham engine
+// (radices 4 / 2 / 3 / 5, two tiles ping-pong); lengths with another prime factor, <= 400, a direct DFT.
 #include <algorithm>
+#include <mutex>
 #include "common.h"
 #include "fft_core.h"
 
@@ -22,7 +24,8 @@ __device__ const float2 TW200[200] = {
 
 constexpr int kLines200 = 32, kThreads200 = 320;   // 640 r10 items = 2 rounds, 320 r20 items = 1 round
 constexpr int kLinesGen = 8, kThreadsGen = 256;
-constexpr int kMaxGenericN = 400;
+constexpr int kMaxGenericN = 400;                  // direct DFT, O(n^2): any length
+constexpr int kMaxSmoothN = 512;                   // mixed radix: 2^a 3^b 5^c (two 512 x 9 tiles + twiddles = 78 KB of LDS, opted in per kernel)
 constexpr int kMaxOut = 4;                          // reduce outputs per thread
 
 enum { POST_NONE = 0, POST_DC = 1, POST_HARD = 2, POST_RESID = 3 };   // RESID: mask ? k - kref : 0 (xpdnet.py:128-131,295-298)
@@ -33,7 +36,8 @@ template <bool F200> __device__ __forceinline__ void load_twiddles(cf* tw, int n
     if (F200) {
         for (int j = threadIdx.x; j < 200; j += blockDim.x) tw[j] = TW200[j];
     } else {
-        const double s = 1.0 / sqrt((double)n);
+        // the mixed-radix engine scales in its last stage (unit twiddles keep the butterflies exact rotations); the direct one here
+        const double s = MixedRadix::smooth(n) ? 1.0 : 1.0 / sqrt((double)n);
         for (int j = threadIdx.x; j < n; j += blockDim.x) {
             double sn, cs;
             sincospi(2.0 * (double)j / (double)n, &sn, &cs);
@@ -43,7 +47,8 @@ template <bool F200> __device__ __forceinline__ void load_twiddles(cf* tw, int n
 }
 
 // Transform every line of the tile along p; returns the tile that holds the result
-// (natural order for the direct engine, Fft200::pos_of order for the 200 engine).
+// (natural order for the direct and mixed-radix engines -- t0 or t1 by the parity of the stage count --, Fft200::pos_of order for
+// the 200 engine).  The other tile is free afterwards.
 template <bool F200, int DIR, int LINES>
 __device__ __forceinline__ cf* run_lines(cf* t0, cf* t1, int n, const cf* tw) {
     constexpr int LP = LINES + 1;
@@ -55,6 +60,21 @@ __device__ __forceinline__ cf* run_lines(cf* t0, cf* t1, int n, const cf* tw) {
         for (int i = tid; i < Fft200::items_r20(LINES); i += nt) Fft200::stage_r20<DIR>(t0, LP, i, LINES);
         __syncthreads();
         return t0;
+    } else if (MixedRadix::smooth(n)) {           // uniform over the workgroup
+        int radix[MixedRadix::kMaxStages];
+        const int ns = MixedRadix::plan(n, radix);
+        const float scale = 1.0f / sqrtf((float)n);
+        cf* src = t0; cf* dst = t1;
+        int Ns = 1;
+        for (int s = 0; s < ns; ++s) {
+            const int R = radix[s];
+            const float sc = s == ns - 1 ? scale : 1.f;
+            for (int i = tid; i < MixedRadix::items(LINES, n, R); i += nt) MixedRadix::stage<DIR>(src, dst, LP, i, LINES, n, R, Ns, tw, sc);
+            __syncthreads();
+            Ns *= R;
+            cf* x = src; src = dst; dst = x;
+        }
+        return src;
     } else {
         for (int i = tid; i < DirectDft::items(LINES, n); i += nt)
             DirectDft::stage<DIR>(t0, t1, LP, i, LINES, n, tw);
@@ -740,8 +760,8 @@ __global__ __launch_bounds__(256) void imgdc_sum_kernel(ImgDcArgs a, int nz, lon
     }
 }
 
-// Any H <= kMaxGenericN: direct DFT in LDS, kLinesGen columns per workgroup, one coil at a time.
-constexpr int kDcAcc = (kMaxGenericN * kLinesGen + kThreadsGen - 1) / kThreadsGen;
+// Any other supported H: mixed-radix or direct DFT in LDS, kLinesGen columns per workgroup, one coil at a time.
+constexpr int kDcAcc = (kMaxSmoothN * kLinesGen + kThreadsGen - 1) / kThreadsGen;
 __global__ __launch_bounds__(kThreadsGen) void imgdc_generic_kernel(ImgDcArgs a) {
     constexpr int LINES = kLinesGen, LP = LINES + 1;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -773,17 +793,16 @@ __global__ __launch_bounds__(kThreadsGen) void imgdc_generic_kernel(ImgDcArgs a)
             t0[n * LP + l] = v;
         }
         __syncthreads();
-        for (int i = tid; i < DirectDft::items(LINES, H); i += nt) DirectDft::stage<1>(t0, t1, LP, i, LINES, H, tw);
-        __syncthreads();
+        cf* res = run_lines<false, 1, LINES>(t0, t1, H, tw);
+        cf* other = res == t0 ? t1 : t0;
         for (int e = tid; e < H * LINES; e += nt) {
             const int i = e / LINES, l = e - i * LINES;
             int k = i - s_out; if (k < 0) k += H;
             int n = i + s_in; if (n >= H) n -= H;
-            t0[n * LP + l] = cscale(t1[k * LP + l], mrow[i] ? w1 : w0);
+            other[n * LP + l] = cscale(res[k * LP + l], mrow[i] ? w1 : w0);
         }
         __syncthreads();
-        for (int i = tid; i < DirectDft::items(LINES, H); i += nt) DirectDft::stage<-1>(t0, t1, LP, i, LINES, H, tw);
-        __syncthreads();
+        const cf* res2 = run_lines<false, -1, LINES>(other, res, H, tw);
 #pragma unroll
         for (int m = 0; m < kDcAcc; ++m) {
             const int e = tid + m * nt;
@@ -791,7 +810,7 @@ __global__ __launch_bounds__(kThreadsGen) void imgdc_generic_kernel(ImgDcArgs a)
             const int i = e / LINES, l = e - i * LINES, col = w0c + l;
             if (col >= a.W) continue;
             int k = i - s_out; if (k < 0) k += H;
-            const cf mm = cmulc(t1[k * LP + l], sp[(long)i * a.W + col]);
+            const cf mm = cmulc(res2[k * LP + l], sp[(long)i * a.W + col]);
             acc[m].x += mm.x; acc[m].y += mm.y;
         }
     }
@@ -891,8 +910,26 @@ static size_t lds_bytes(bool f200, int n, int lines) {
 
 static int check_n(int n, const char* what) {
     CINE_REQUIRE(n >= 1, CINE_EINVAL, "%s: length %d < 1", what, n);
-    CINE_REQUIRE(n == 200 || n <= kMaxGenericN, CINE_EUNSUPPORTED,
-                 "%s: FFT length %d unsupported (200, or <= %d via the direct engine)", what, n, kMaxGenericN);
+    CINE_REQUIRE(n <= kMaxGenericN || (n <= kMaxSmoothN && MixedRadix::smooth(n)), CINE_EUNSUPPORTED,
+                 "%s: FFT length %d unsupported (2^a 3^b 5^c up to %d via the mixed-radix engine, any length up to %d via the direct one)",
+                 what, n, kMaxSmoothN, kMaxGenericN);
+    return CINE_OK;
+}
+
+// lengths above 400 need more than the 64 KB of dynamic LDS a kernel gets by default: raise the limit once per (kernel, device)
+// and keep the result, so that a refused request fails every later launch with its own message
+template <typename K>
+static int allow_lds(K kern, size_t lds, const char* what) {
+    if (lds <= 64 * 1024) return CINE_OK;
+    static std::once_flag once[64];               // per template instance = per kernel
+    static hipError_t status[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "%s: device index %d", what, dev);
+    std::call_once(once[dev], [&] {
+        status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(status[dev]));
     return CINE_OK;
 }
 
@@ -911,8 +948,13 @@ static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st)
     } else {
         static_assert(!INV_AFTER || true, "");
         const size_t lds = lds_bytes(false, a.H, lines);
-        if (inverse) hipLaunchKernelGGL((col_pass_kernel<false, -1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
-        else hipLaunchKernelGGL((col_pass_kernel<false, 1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        if (inverse) {
+            if (int e = allow_lds(col_pass_kernel<false, -1, POST, kLinesGen>, lds, "col_pass_kernel")) return e;
+            hipLaunchKernelGGL((col_pass_kernel<false, -1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        } else {
+            if (int e = allow_lds(col_pass_kernel<false, 1, POST, kLinesGen>, lds, "col_pass_kernel")) return e;
+            hipLaunchKernelGGL((col_pass_kernel<false, 1, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        }
     }
     return check_launch("col_pass_kernel");
 }
@@ -932,8 +974,13 @@ static int launch_row(RowArgs a, dim3 grid, bool inverse, hipStream_t st) {
         if (inverse) hipLaunchKernelGGL((row_pass_kernel<true, -1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
         else hipLaunchKernelGGL((row_pass_kernel<true, 1, PRE, POST, kLines200>), grid, dim3(kThreads200), lds, st, a);
     } else {
-        if (inverse) hipLaunchKernelGGL((row_pass_kernel<false, -1, PRE, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
-        else hipLaunchKernelGGL((row_pass_kernel<false, 1, PRE, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        if (inverse) {
+            if (int e = allow_lds(row_pass_kernel<false, -1, PRE, POST, kLinesGen>, lds, "row_pass_kernel")) return e;
+            hipLaunchKernelGGL((row_pass_kernel<false, -1, PRE, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        } else {
+            if (int e = allow_lds(row_pass_kernel<false, 1, PRE, POST, kLinesGen>, lds, "row_pass_kernel")) return e;
+            hipLaunchKernelGGL((row_pass_kernel<false, 1, PRE, POST, kLinesGen>), grid, dim3(kThreadsGen), lds, st, a);
+        }
     }
     return check_launch("row_pass_kernel");
 }
@@ -1097,8 +1144,9 @@ static int image_dc_impl(const float* img, const float* sens, const float* zf, c
             hipLaunchKernelGGL(imgdc_sum_kernel, dim3(pd_part ? 256u : (unsigned)std::min<long>(ceil_div(n, 256L), 2048)), dim3(256), 0, st, a, nz, n);
         }
     } else {
-        hipLaunchKernelGGL(imgdc_generic_kernel, dim3(ceil_div(w, kLinesGen), b * t), dim3(kThreadsGen),
-                           lds_bytes(false, h, kLinesGen), st, a);
+        const size_t lds = lds_bytes(false, h, kLinesGen);
+        if (int e = allow_lds(imgdc_generic_kernel, lds, "imgdc_generic_kernel")) return e;
+        hipLaunchKernelGGL(imgdc_generic_kernel, dim3(ceil_div(w, kLinesGen), b * t), dim3(kThreadsGen), lds, st, a);
     }
     return check_launch("imgdc_kernel");
 }
@@ -1231,6 +1279,9 @@ extern "C" int cine_image_dc_sens_grad(const float* img, const float* gout, cons
     const dim3 grid(ceil_div(w, kLinesGen), c, b * t);
     const size_t lds = (size_t)(2 * h * (kLinesGen + 1) + h) * sizeof(cf);
     if (h == 200) hipLaunchKernelGGL(imgdc_sgrad_kernel<true>, grid, dim3(kThreadsGen), lds, st, a);
-    else hipLaunchKernelGGL(imgdc_sgrad_kernel<false>, grid, dim3(kThreadsGen), lds, st, a);
+    else {
+        if (int e = allow_lds(imgdc_sgrad_kernel<false>, lds, "imgdc_sgrad_kernel")) return e;
+        hipLaunchKernelGGL(imgdc_sgrad_kernel<false>, grid, dim3(kThreadsGen), lds, st, a);
+    }
     return check_launch("imgdc_sgrad_kernel");
 }

@@ -830,10 +830,33 @@ def g_cinenet_grad_cfg4_linear():
 
 
 
+def g_fft_smooth():
+    """fftc.py:13-117 on the lengths the mixed-radix line engine serves (2^a 3^b 5^c, not 200): inputs regenerated from the seed,
+    outputs stored whole for the small planes and on a strided lattice for the large ones (every sample of a transform depends on
+    every input sample, so a lattice pins the whole transform)."""
+    a = {}
+    shapes = dict(a96x120=(2, 96, 120), a192x160=(1, 192, 160), a256x320=(1, 256, 320), a384x512=(1, 384, 512), a45x250=(2, 45, 250),
+                  a400x405=(1, 400, 405))
+    for i, (tag, (n, h, w)) in enumerate(shapes.items()):
+        x = rnd(900 + i, n, h, w, 2)
+        sh, sw = (1, 1) if h * w <= 192 * 160 else (5, 7)
+        a[f"{tag}_seed"] = 900 + i
+        a[f"{tag}_shape"] = np.array([n, h, w])
+        a[f"{tag}_stride"] = np.array([sh, sw])
+        a[f"{tag}_fft2c"] = RU.fft2c(x)[:, ::sh, ::sw].contiguous()
+        a[f"{tag}_ifft2c"] = RU.ifft2c(x)[:, ::sh, ::sw].contiguous()
+    for i, n in enumerate((30, 128, 360, 512)):      # fft1c along the second-to-last axis (the XF transform's axis)
+        x = rnd(950 + i, 3, n, 2)
+        a[f"l{n}_seed"] = 950 + i
+        a[f"l{n}_fft1c"] = RU.fft1c(x)
+        a[f"l{n}_ifft1c"] = RU.ifft1c(x)
+    save("fft_smooth", **a)
+
+
 GENERATORS = dict(varnet_grad_cfg2_linear=g_varnet_grad_cfg2_linear, cinenet_grad_cfg4_linear=g_cinenet_grad_cfg4_linear, xpdnet_grad_cfg3=g_xpdnet_grad_cfg3, cinenet_grad_cfg4=g_cinenet_grad_cfg4, rnn_grad_cfg5=g_rnn_grad_cfg5, rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
-                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend)
+                  cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend, fft_smooth=g_fft_smooth)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -84,6 +84,41 @@ int main() {
             for (int n = 0; n < N; ++n) { ref[l * N + n] = cd(x[n * LP + l].x, x[n * LP + l].y); got[l * N + n] = t[n * LP + l]; }
         worst = std::max(worst, check(ref, got, "NP fwd -> PN inv round trip"));
     }
+    // mixed-radix engine (N = 2^a 3^b 5^c) against the double-precision DFT, both directions, every supported kind of length
+    for (int n : {2, 4, 6, 8, 12, 15, 16, 30, 45, 96, 120, 192, 240, 256, 320, 360, 384, 400, 450, 512}) {
+        if (!MixedRadix::smooth(n)) { std::printf("n = %d not smooth?\n", n); return 1; }
+        std::vector<cf> twn(n);
+        for (int j = 0; j < n; ++j) { double a = -2.0 * M_PI * j / n; twn[j] = mk((float)std::cos(a), (float)std::sin(a)); }
+        std::vector<cf> a(n * LP), b(n * LP);
+        for (auto& v : a) v = mk(rand() / (float)RAND_MAX - .5f, rand() / (float)RAND_MAX - .5f);
+        const std::vector<cf> x0 = a;
+        for (int dir = 1; dir >= -1; dir -= 2) {
+            a = x0;
+            int radix[MixedRadix::kMaxStages];
+            const int ns = MixedRadix::plan(n, radix);
+            cf* src = a.data(); cf* dst = b.data();
+            int Ns = 1;
+            for (int s2 = 0; s2 < ns; ++s2) {
+                const float sc = s2 == ns - 1 ? (float)(1.0 / std::sqrt((double)n)) : 1.f;
+                for (int i = 0; i < MixedRadix::items(LINES, n, radix[s2]); ++i)
+                    dir > 0 ? MixedRadix::stage<1>(src, dst, LP, i, LINES, n, radix[s2], Ns, twn.data(), sc)
+                            : MixedRadix::stage<-1>(src, dst, LP, i, LINES, n, radix[s2], Ns, twn.data(), sc);
+                Ns *= radix[s2];
+                std::swap(src, dst);
+            }
+            std::vector<cd> ref(n * LINES); std::vector<cf> got(n * LINES);
+            for (int l = 0; l < LINES; ++l)
+                for (int k = 0; k < n; ++k) {
+                    cd acc = 0;
+                    for (int q = 0; q < n; ++q)
+                        acc += cd(x0[q * LP + l].x, x0[q * LP + l].y) * std::polar(1.0, -dir * 2.0 * M_PI * (((long)q * k) % n) / n);
+                    ref[l * n + k] = acc / std::sqrt((double)n);
+                    got[l * n + k] = src[k * LP + l];
+                }
+            char what[64]; std::snprintf(what, sizeof what, "mixed radix n=%d %s", n, dir > 0 ? "fwd" : "inv");
+            worst = std::max(worst, check(ref, got, what));
+        }
+    }
     std::printf("%s\n", worst < 2e-6 ? "OK" : "FAIL");
     return worst < 2e-6 ? 0 : 1;
 }

@@ -134,10 +134,11 @@ def test_xfyf_backward_vs_oracle(dev, dyn, share):
         assert rel_err(ih.grad.cpu(), ir.grad) < TOL
 
 
-@pytest.mark.parametrize("t,c,h,w", [(3, 4, 24, 20), (2, 3, 200, 12), (4, 7, 17, 9)])
+@pytest.mark.parametrize("t,c,h,w", [(3, 4, 24, 20), (2, 3, 200, 12), (4, 7, 17, 9), (2, 2, 96, 10), (1, 2, 512, 9)])
 def test_image_dc_backward_vs_oracle(dev, t, c, h, w):
     """cine_image_dc under autograd against the literal k-space formula of varnet.py:181-194, 281-282 differentiated by torch:
-    gradients for the image, the maps, the zero-filled term and lambda_reg (h = 200 takes the 10 x 20 FFT engine)."""
+    gradients for the image, the maps, the zero-filled term and lambda_reg (h = 200 takes the 10 x 20 FFT engine, 24 / 96 / 512 the
+    mixed-radix one, 17 the direct DFT)."""
     from cine_hip import autograd as ag
     from oracle import centered_fft as cf, complex_ops as co
     m, sens, kref = rnd(9, 1, t, 1, h, w, 2), rnd(10, 1, 1, c, h, w, 2), rnd(11, 1, t, c, h, w, 2)

@@ -74,11 +74,50 @@ def test_fft2c_full_batch_properties(dev):
     assert torch.equal(z, X)
 
 
+@pytest.mark.parametrize("tag", ["a96x120", "a192x160", "a256x320", "a384x512", "a45x250", "a400x405"])
+def test_fft2c_mixed_radix_vs_reference_golden(golden, dev, tag):
+    """2^a 3^b 5^c lengths other than 200 run the mixed-radix Stockham engine (fft_core.h MixedRadix; 512 needs the > 64 KB LDS
+    opt-in); the reference's outputs are pinned whole or on a strided lattice (make_golden.py g_fft_smooth)."""
+    import reconstruction.utils as U
+    g = golden("fft_smooth")
+    n, h, w = (int(v) for v in g[f"{tag}_shape"])
+    sh, sw = (int(v) for v in g[f"{tag}_stride"])
+    x = rnd(int(g[f"{tag}_seed"]), n, h, w, 2).to(dev)
+    X = U.fft2c(x)
+    assert rel_err(X.cpu()[:, ::sh, ::sw], g[f"{tag}_fft2c"]) < OP_TOL
+    assert rel_err(U.ifft2c(x).cpu()[:, ::sh, ::sw], g[f"{tag}_ifft2c"]) < OP_TOL
+    assert rel_err(U.ifft2c(X).cpu(), x.cpu()) < OP_TOL
+    assert abs(float((X.double() ** 2).sum() / (x.double() ** 2).sum()) - 1) < 1e-5
+
+
+@pytest.mark.parametrize("n", [30, 128, 360, 512])
+def test_fft1c_mixed_radix_vs_reference_golden(golden, dev, n):
+    import reconstruction.utils as U
+    g = golden("fft_smooth")
+    x = rnd(int(g[f"l{n}_seed"]), 3, n, 2).to(dev)
+    assert rel_err(U.fft1c(x).cpu(), g[f"l{n}_fft1c"]) < OP_TOL
+    assert rel_err(U.ifft1c(x).cpu(), g[f"l{n}_ifft1c"]) < OP_TOL
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 6, 8, 9, 10, 12, 18, 20, 25, 27, 32, 48, 50, 64, 75, 100, 125, 243, 250, 300, 320, 375, 480, 486, 500])
+def test_fft1c_every_radix_pattern_vs_oracle(dev, n):
+    """Each stage pattern of the planner (4s, one 2, 3s, 5s; one stage only; even and odd stage counts -> result in either tile)."""
+    from cine_hip import ops
+    from oracle import centered_fft as cf
+    x = rnd(n, 11, n, 2)
+    for inv in (False, True):
+        ref = (cf.ifft1c if inv else cf.fft1c)(x)
+        assert rel_err(ops.fft1c(x.to(dev), inverse=inv).cpu(), ref) < OP_TOL, (n, inv)
+
+
 def test_unsupported_length_fails_loudly(dev):
+    """Lengths with a prime factor above 5 stop at 400 (direct DFT), smooth ones at 512."""
     from cine_hip._lib import CineHipError
     import reconstruction.utils as U
     with pytest.raises(CineHipError):
         U.fft2c(torch.zeros(1, 401, 8, 2, device=dev))
+    with pytest.raises(CineHipError):
+        U.fft2c(torch.zeros(1, 8, 540, 2, device=dev))
 
 
 # ------------------------------------------------------------------ coil operators
@@ -1071,7 +1110,9 @@ def _row_mask(t, h, seed, keep=0.35):
     return m
 
 
-@pytest.mark.parametrize("t,c,h,w", [(5, 3, 24, 20), (2, 1, 7, 5), (3, 4, 15, 33), (1, 2, 400, 9),      # direct-DFT engine
+@pytest.mark.parametrize("t,c,h,w", [(5, 3, 24, 20), (2, 1, 7, 5), (3, 4, 15, 33), (1, 2, 400, 9),      # mixed-radix engine (odd / even stage counts)
+                                     (2, 3, 96, 120), (1, 2, 512, 12), (1, 3, 18, 512), (1, 2, 256, 320),
+                                     (2, 2, 7, 11), (1, 2, 77, 26), (1, 2, 398, 14),                         # direct-DFT engine (other prime factors)
                                      (2, 15, 200, 200), (1, 1, 200, 37), (3, 16, 200, 8), (2, 17, 200, 203), (1, 5, 200, 1)])
 def test_image_dc_vs_oracle(dev, t, c, h, w):
     """cine_image_dc == sens_reduce(DC(sens_expand(x))) of reference varnet.py:181-194, 281-282 for row masks: soft DC

@@ -33,6 +33,29 @@ def test_fft2c_200(golden):
     assert rel_err(cf.ifft2c(cf.fft2c(x)), x) < OP_TOL
 
 
+SMOOTH_PLANES = ["a96x120", "a192x160", "a256x320", "a384x512", "a45x250", "a400x405"]
+SMOOTH_LINES = [30, 128, 360, 512]
+
+
+@pytest.mark.parametrize("tag", SMOOTH_PLANES)
+def test_fft2c_smooth_lengths(golden, tag):
+    """The lengths the HIP mixed-radix engine serves (2^a 3^b 5^c); large planes are pinned on a strided lattice."""
+    g = golden("fft_smooth")
+    n, h, w = (int(v) for v in g[f"{tag}_shape"])
+    sh, sw = (int(v) for v in g[f"{tag}_stride"])
+    x = rnd(int(g[f"{tag}_seed"]), n, h, w, 2)
+    assert rel_err(cf.fft2c(x)[:, ::sh, ::sw], g[f"{tag}_fft2c"]) < OP_TOL
+    assert rel_err(cf.ifft2c(x)[:, ::sh, ::sw], g[f"{tag}_ifft2c"]) < OP_TOL
+
+
+@pytest.mark.parametrize("n", SMOOTH_LINES)
+def test_fft1c_smooth_lengths(golden, n):
+    g = golden("fft_smooth")
+    x = rnd(int(g[f"l{n}_seed"]), 3, n, 2)
+    assert rel_err(cf.fft1c(x), g[f"l{n}_fft1c"]) < OP_TOL
+    assert rel_err(cf.ifft1c(x), g[f"l{n}_ifft1c"]) < OP_TOL
+
+
 def test_fft_rejects_non_pair():
     with pytest.raises(ValueError):
         cf.fft2c(torch.zeros(4, 4, 3))
