@@ -1049,7 +1049,8 @@ class ConjGradFn(Function):
     """CineNetBlock.ConjGrad (cinenet.py:136-171): K iterations of conjugate gradients on H x = b, H = A^H M A + softplus(lambda) I,
     from the start value x0.  The reference takes alpha and beta out of the graph (``.item()``, :159-169), so the iteration it
     differentiates is LINEAR in (x0, b) with the recorded step sizes; H is self-adjoint, so the adjoint recurrence is K + 1 more
-    applications of the same image-space kernel (cine_normal_op), run backwards:
+    applications of the same operator (ops.h_operator: the image-space kernel cine_normal_op for row masks, the literal
+    expand -> mask -> reduce chain for masks that vary along w), run backwards:
         gp_k = beta_k gp_{k+1} + alpha_k gx - alpha_k H(gr_{k+1} + gp_{k+1}),   gr_k = gr_{k+1} + gp_{k+1}
         gb = gr_0 + gp_0,  gx0 = gx - H(gb),  d/d v = -sum_k alpha_k <gr_{k+1} + gp_{k+1}, p_k> - <gb, x0>."""
 
@@ -1057,13 +1058,13 @@ class ConjGradFn(Function):
     def forward(ctx, x0, b, lam, mask, sens, iters):
         x0 = ops._dev(x0, "CG start value"); b = ops._dev(b, "CG right-hand side")
         one = torch.ones(1, device=x0.device, dtype=torch.float32)
-        r = ops.axpby_dev(b, ops.normal_op(x0, sens, mask, lam), num=one, sign=-1.0)
+        r = ops.axpby_dev(b, ops.h_operator(x0, sens, mask, lam), num=one, sign=-1.0)
         p = r.clone()
         x = x0.clone()
         rr = ops.dot(r, r)
         ps, scal = [], []
         for _ in range(iters):
-            d = ops.normal_op(p, sens, mask, lam)
+            d = ops.h_operator(p, sens, mask, lam)
             pd = ops.dot(p, d)
             ps.append(p)
             x = ops.axpby_dev(x, p, num=rr, den=pd)                   # x + alpha p
@@ -1087,7 +1088,7 @@ class ConjGradFn(Function):
         for k in reversed(range(len(ps))):
             rr, pd, rr_new = ctx.scal[k]
             grp = gr + gp                                             # gradient reaching r_{k+1} (through p_{k+1} = r_{k+1} + beta p_k too)
-            hg = ops.normal_op(grp, sens, mask, lam)
+            hg = ops.h_operator(grp, sens, mask, lam)
             gv = gv - ops.dot(grp, ps[k]) * (rr / pd)
             gp_new = ops.axpby_dev(ops.axpby_dev(torch.zeros_like(gx), gp, num=rr_new, den=rr), gx, num=rr, den=pd)     # beta gp + alpha gx
             gp = ops.axpby_dev(gp_new, hg, num=rr, den=pd, sign=-1.0)                                                   # - alpha H(grp)
@@ -1097,7 +1098,7 @@ class ConjGradFn(Function):
         gx0 = None
         if need[0]:
             one = torch.ones(1, device=gx.device, dtype=torch.float32)
-            gx0 = ops.axpby_dev(gx, ops.normal_op(gb, sens, mask, lam), num=one, sign=-1.0)
+            gx0 = ops.axpby_dev(gx, ops.h_operator(gb, sens, mask, lam), num=one, sign=-1.0)
         glam = _lam_grad(gv - ops.dot(gb, x0), lam) if need[2] else None
         return gx0, (gb if need[1] else None), glam, None, None, None
 

@@ -137,19 +137,46 @@ def kspace_to_hybrid(k: torch.Tensor, out: Optional[torch.Tensor] = None, mask: 
     return out
 
 
-def as_mask_u8(mask: torch.Tensor) -> torch.Tensor:
-    """The kernels read uint8 masks; the reference's models accept any numeric 0 / 1 mask (``apply_mask`` returns a float
-    one, data/transforms.py:66-92).  Converted once, outside any kernel (not during hipGraph capture)."""
-    if mask.dtype == torch.uint8:
+def as_mask_u8(mask: torch.Tensor, kspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The kernels read uint8 masks; the reference's models accept any numeric 0 / 1 mask that broadcasts against the k-space
+    (``apply_mask`` returns a float one, data/transforms.py:66-92; varnet.py:281-282 multiplies).  Converted once, outside any kernel
+    (not during hipGraph capture).  With ``kspace`` (b, t, c, h, w, 2) the mask is also brought into one of the two layouts the
+    models dispatch on: a mask that is constant along w -- (b|1, t|1, 1, h, 1, 1) -- becomes the (b, t, 1, h, 1, 1) ROW mask of
+    the fused kernels; one that varies along w becomes a GENERAL mask (b, t, 1, h, w, 1), served by the literal k-space chain."""
+    if mask.dtype != torch.uint8:
+        _no_capture("a uint8 copy of the sampling mask")
+        mask = (mask != 0).to(torch.uint8)
+    if kspace is None or kspace.dim() != 6:
         return mask
-    _no_capture("a uint8 copy of the sampling mask")
-    return (mask != 0).to(torch.uint8)
+    b, t, _, h, w, _ = kspace.shape
+    if mask.dim() != 6 or mask.shape[2] != 1 or mask.shape[5] != 1 or mask.shape[3] != h or mask.shape[0] not in (1, b) or \
+            mask.shape[1] not in (1, t) or mask.shape[4] not in (1, w):
+        raise ValueError(f"mask {tuple(mask.shape)} does not broadcast against k-space {tuple(kspace.shape)} as (b|1, t|1, 1, h, w|1, 1)")
+    want = (b, t, 1, h, mask.shape[4], 1)
+    if tuple(mask.shape) != want:
+        _no_capture("an expanded copy of the sampling mask")
+        mask = mask.expand(want).contiguous()
+    return mask
 
 
 def is_row_mask(mask: torch.Tensor, kspace: torch.Tensor) -> bool:
     """True for the reference's mask layout (b, t, 1, h, 1, 1) (data/transforms.py:341-343)."""
     b, t, _, h, _, _ = kspace.shape
     return mask.dim() == 6 and tuple(mask.shape) == (b, t, 1, h, 1, 1)
+
+
+def is_general_mask(mask: torch.Tensor, kspace: torch.Tensor) -> bool:
+    """True for a mask that varies along w: (b, t, 1, h, w, 1) (what ``as_mask_u8(mask, kspace)`` returns for one)."""
+    b, t, _, h, w, _ = kspace.shape
+    return mask.dim() == 6 and w > 1 and tuple(mask.shape) == (b, t, 1, h, w, 1)
+
+
+def soft_dc_blend(model_term: torch.Tensor, ref_kspace: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor) -> torch.Tensor:
+    """The data-consistency line of reference varnet.py:281-282 for a GENERAL mask, term by term on the coil-wise k-space
+    (torch elementwise kernels: the fused DC kernels read row masks).  Differentiable in model_term and lambda_reg."""
+    m = mask.to(model_term.dtype)
+    v = torch.nn.functional.softplus(lambda_reg)
+    return (1 - m) * model_term + m * (model_term + v * ref_kspace) / (1 + v)
 
 
 def image_dc(img: torch.Tensor, sens: torch.Tensor, zf: Optional[torch.Tensor], mask: torch.Tensor,
@@ -194,6 +221,21 @@ def normal_op(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_
     check(lib().cine_normal_op(img.data_ptr(), sens.data_ptr(), mask.data_ptr(), lam.data_ptr(), out.data_ptr(), b, t, c, h, w,
                                _p(ws), nbytes, _stream()), "cine_normal_op")
     return out
+
+
+def h_operator(x: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor,
+               _hyb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """CineNet's H = A^H M A + softplus(lambda) I (reference cinenet.py:121-133) for either mask layout: the one-kernel image-space
+    operator for a (b, t, 1, h, 1, 1) row mask, the literal expand -> mask -> reduce chain for a mask that varies along w."""
+    full = sens.expand(-1, x.shape[1], -1, -1, -1, -1)
+    if is_row_mask(mask, full):
+        return normal_op(x, sens, mask, lambda_reg)
+    if is_general_mask(mask, full):
+        k = sens_expand_dc(x, sens)
+        k = k * mask.to(k.dtype) + 0.0                       # cinenet.py:129
+        return axpby_dev(sens_reduce(k, sens, destroy_input=True), x, lambda_reg=lambda_reg)
+    hyb = expand_mask_hybrid(x, sens, mask, out=_hyb)         # b * t * h mask entries in another shape
+    return axpby_dev(hybrid_reduce(hyb, sens), x, lambda_reg=lambda_reg)
 
 
 def hybrid_reduce(hyb: torch.Tensor, sens: torch.Tensor, magnitude: bool = False) -> torch.Tensor:

@@ -39,10 +39,7 @@ class CineNetBlock(nn.Module):
     def HOperator(self, x, mask, sens_maps, _hyb=None):
         """A^H M A x + softplus(lambda) x  (reference cinenet.py:121-133).  With the reference's row mask the normal
         operator is one image-space kernel (cine_image_dc with weights (1, 0, 0)): the mask commutes with the row FFT."""
-        if ops.is_row_mask(mask, sens_maps.expand(-1, x.shape[1], -1, -1, -1, -1)):
-            return ops.normal_op(x, sens_maps, mask, self.lambda_reg)
-        hyb = ops.expand_mask_hybrid(x, sens_maps, mask, out=_hyb)
-        return ops.axpby_dev(ops.hybrid_reduce(hyb, sens_maps), x, lambda_reg=self.lambda_reg)
+        return ops.h_operator(x, sens_maps, mask, self.lambda_reg, _hyb)
 
     def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int):
         """Hx = b with exactly CG_iters iterations (reference cinenet.py:136-171)."""
@@ -107,8 +104,6 @@ class CineNetBlock(nn.Module):
 
     def forward(self, image_pred, image_ref, mask, sens_maps):
         if ag.grad_mode(self):
-            if not ops.is_row_mask(mask, sens_maps.expand(-1, image_pred.shape[1], -1, -1, -1, -1)):
-                raise NotImplementedError("training through the HIP path needs the reference's (b, t, 1, h, 1, 1) row mask")
             model_out = self.regularise(image_pred)
             rhs = ag.AxpbyLamFn.apply(image_ref, model_out, self.lambda_reg)
             return ag.ConjGradFn.apply(model_out, rhs, self.lambda_reg, mask, sens_maps, self.CG_iters)
@@ -142,7 +137,7 @@ class CineNet(nn.Module):
             [CineNetBlock(self.model, CG_iters, dynamic_type, weight_sharing) for _ in range(num_cascades)])
 
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
-        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        mask = ops.as_mask_u8(mask, masked_kspace)          # any numeric 0 / 1 mask that broadcasts, like the reference
         if ag.grad_mode(self):               # k-space and maps are data: the graph starts at the first regulariser
             with torch.no_grad():
                 image_pred = ops.sens_reduce(masked_kspace, sens_maps)

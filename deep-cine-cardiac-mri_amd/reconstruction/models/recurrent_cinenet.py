@@ -23,7 +23,7 @@ class CineNet_RNN(CRNNBody):
     ConjGrad = CineNetBlock.ConjGrad
 
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
-        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        mask = ops.as_mask_u8(mask, ref_kspace)          # any numeric 0 / 1 mask; broadcast along batch / time like the reference
         if ag.grad_mode(self):
             return self._forward_train(ref_kspace, mask, sens_maps)
         with torch.no_grad():

@@ -20,7 +20,7 @@ class VarNet_RNN(CRNNBody):
         self.lambda_reg = nn.Parameter(torch.full((1,), math.log(math.e - 1.0)))
 
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
-        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        mask = ops.as_mask_u8(mask, ref_kspace)          # any numeric 0 / 1 mask; broadcast along batch / time like the reference
         if ag.grad_mode(self):
             return self._forward_train(ref_kspace, mask, acs)
         with torch.no_grad():

@@ -31,7 +31,7 @@ class XPDNet_RNN(CRNNBody):
         return concat_kspace[..., [0, 2]] - concat_kspace[..., [1, 3]]
 
     def forward(self, ref_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
-        mask = ops.as_mask_u8(mask)          # any numeric 0 / 1 mask, like the reference
+        mask = ops.as_mask_u8(mask, ref_kspace)          # any numeric 0 / 1 mask; broadcast along batch / time like the reference
         if ag.grad_mode(self):
             return self._forward_train(ref_kspace, mask, acs)
         with torch.no_grad():

@@ -41,6 +41,9 @@ class SensitivityModel(nn.Module):
     def acs_window(mask: torch.Tensor):
         """Rows [pad, pad + n_low) to keep (reference varnet.py:64-68: frame 0's mask only).
         Data dependent, so it reads the 1-D mask back to the host."""
+        if mask.shape[-2] != 1:
+            raise ValueError("the ACS window is read from a row mask (reference varnet.py:64-68 indexes the mask's h axis); with a mask that "
+                             "varies along w pass acs=(pad, n_low) or sens_maps")
         rows = mask[:, 0].reshape(-1).cpu()
         cent = mask.shape[-3] // 2
         left = int(torch.nonzero(rows[:cent] == 0)[-1])
@@ -114,6 +117,8 @@ class VarNetBlock(nn.Module):
         image = ops.sens_reduce(current_kspace, sens_maps, destroy_input=_destroy_current)
         model_out = self.regularise(image)
         out = current_kspace if _destroy_current else None
+        if ops.is_general_mask(mask, ref_kspace):          # varies along w: the DC line of reference varnet.py:281-282 term by term
+            return ops.soft_dc_blend(ops.sens_expand_dc(model_out, sens_maps, out=out), ref_kspace, mask, self.lambda_reg.detach())
         return ops.sens_expand_dc(model_out, sens_maps, ref_kspace, mask, self.lambda_reg, out=out)
 
 
@@ -138,7 +143,7 @@ class VarNet(nn.Module):
         (b,1,c,h,w,2)) bypasses the sens-map network; ``acs`` = (pad, n_low) skips the host
         read-back of the mask (needed inside hipGraph capture).  Masks of another dtype (the reference's
         apply_mask returns a float mask) are converted once."""
-        mask = ops.as_mask_u8(mask)
+        mask = ops.as_mask_u8(mask, masked_kspace)         # row mask (b,t,1,h,1,1), or general mask (b,t,1,h,w,1) when it varies along w
         if ag.grad_mode(self):
             return self._forward_train(masked_kspace, mask, sens_maps, acs)
         with torch.no_grad():
@@ -146,10 +151,17 @@ class VarNet(nn.Module):
 
     def _forward_train(self, masked_kspace, mask, sens_maps, acs):
         """The image-space cascade chain of ``_forward_infer`` as an autograd graph (reference varnet.py:143-151)."""
-        if not ops.is_row_mask(mask, masked_kspace):
-            raise NotImplementedError("training through the HIP path needs the reference's (b, t, 1, h, 1, 1) row mask")
         if sens_maps is None:
             sens_maps = self.sens_net(masked_kspace, mask, acs)
+        if not ops.is_row_mask(mask, masked_kspace):
+            # a mask that varies along w: the literal k-space chain of reference varnet.py:145-151 as an autograd graph -- coil
+            # operators through their HIP kernels and adjoints (SensReduceFn / SensExpandFn), the DC line in torch elementwise ops
+            kspace = masked_kspace
+            for cascade in self.cascades:
+                image = ag.SensReduceFn.apply(kspace, sens_maps, None)
+                model_term = ag.SensExpandFn.apply(cascade.regularise(image), sens_maps, None)
+                kspace = ops.soft_dc_blend(model_term, masked_kspace, mask, cascade.lambda_reg)
+            return ag.AbsFn.apply(ag.SensReduceFn.apply(kspace, sens_maps, None).squeeze(2))
         image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)          # first cascade's sens_reduce(masked_kspace)
         if len(self.cascades) == 0:
             return ag.AbsFn.apply(image.squeeze(2))

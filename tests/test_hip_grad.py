@@ -614,6 +614,81 @@ def test_training_gradients_on_odd_shapes_vs_oracle_float64(dev, family):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("family", ["varnet_XF", "cinenet_XF", "cinenet_3D"])
+def test_masks_that_vary_along_w_inference_and_training_vs_oracle_float64(dev, family):
+    """A sampling mask that varies along w (b|1, t, 1, h, w, 1) -- varnet.py:281-282 and cinenet.py:129 multiply by any mask that
+    broadcasts -- is served by the literal k-space chain (coil operators through their kernels and adjoints, the DC line term by
+    term): forward and training gradients against the oracle's float64 autograd.  VarNet gets its maps from the caller here: the
+    reference's sens-net reads the ACS window off a 1-D mask (varnet.py:64-68) and has no meaning for a 2-D one."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    from oracle import varnet_ref as V, cinenet_ref as C
+    t, c, h, w = 5, 3, 20, 18
+    make = {"varnet_XF": (lambda m: m.VarNet(2, 4, 2, 4, 2, "XF"), V), "cinenet_XF": (lambda m: m.CineNet(2, 3, 4, 2, "XF"), C),
+            "cinenet_3D": (lambda m: m.CineNet(2, 2, 4, 2, "3D"), C)}[family]
+    net = make[0](M)
+    synth.fill_parameters_(net, 13, keep=("lambda",))
+    ref = make[0](make[1]).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()}, strict=True)
+    net = net.to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(1, t, 1, h, w, 1, generator=g) < 0.4).to(torch.uint8)
+    mask[:, :, :, h // 2 - 2:h // 2 + 2, w // 2 - 3:w // 2 + 3] = 1
+    sens = rnd(32, 1, 1, c, h, w, 2)
+    sens = sens / sens.pow(2).sum(dim=(2, 5), keepdim=True).sqrt()
+    target = rnd(33, 1, t, h, w).abs() + 0.1
+
+    def run(model, mk, device, dtype):
+        mk, sm, m = mk.to(device, dtype), sens.to(device, dtype), mask.to(device)
+        out = model(mk, m, sm)            # (the oracle's VarNet takes the caller's maps the same way: varnet.py:145-151 after :144)
+        return out, ((out - target.to(device, dtype)) ** 2).mean()
+    best, worst = {}, {}
+    for seed in (31, 41, 51):
+        mk = rnd(seed, 1, t, c, h, w, 2) * mask
+        ref.zero_grad(); net.zero_grad()
+        with torch.enable_grad():
+            o64, l64 = run(ref, mk, torch.device("cpu"), torch.float64); l64.backward()
+            o32, l32 = run(net, mk, dev, torch.float32); l32.backward()
+        assert rel_err(o32.detach().cpu(), o64.detach().float()) < 2e-5, seed
+        with torch.no_grad():
+            oi, _ = run(net, mk, dev, torch.float32)                      # the inference path on the same mask
+        assert rel_err(oi.cpu(), o64.detach().float()) < 2e-5, seed
+        want = {k: p for k, p in ref.named_parameters() if p.grad is not None}
+        assert len(want) >= 10
+        for k, p in net.named_parameters():
+            if k not in want:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            e = rel_err(p.grad.cpu(), want[k].grad.float())
+            best[k] = min(best.get(k, 1e9), e); worst[k] = max(worst.get(k, 0.0), e)
+    bad = {k: (best[k], worst[k]) for k in best if best[k] > 1e-3 or worst[k] > 5e-2}
+    assert not bad, bad
+
+
+def test_masks_that_broadcast_along_batch_and_time_take_the_row_mask_kernels(dev, golden):
+    """(1, 1, 1, h, 1, 1) (one pattern for every frame) and float masks are what the reference's ``*`` accepts: they are expanded to the
+    (b, t, 1, h, 1, 1) row layout once and give the row-mask path's bits."""
+    import reconstruction.models as M
+    from cine_hip import ops
+    g = golden("varnet_grad")
+    net = M.VarNet(2, 4, 2, 4, 2, "XF")
+    net.load_state_dict(state_dict_from(g, "XF::sd::"), strict=True)
+    net = net.to(dev)
+    mk, mask = torch.from_numpy(g["masked_kspace"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    b, t, c, h, w, _ = mk.shape
+    shared = mask[:, :1].contiguous()                                            # frame 0's pattern for every frame
+    full = shared.expand(b, t, 1, h, 1, 1).contiguous()
+    mk = mk * full
+    want = net(mk, full)
+    assert torch.equal(net(mk, shared), want) and torch.equal(net(mk, shared.float()), want)
+    assert ops.is_row_mask(ops.as_mask_u8(shared, mk), mk)
+    with pytest.raises(ValueError):
+        net(mk, mask[:, :, :, : h - 1])                                          # does not broadcast
+    cn = M.CineNet(2, 2, 4, 2, "XF").to(dev)
+    sens = torch.randn(b, 1, c, h, w, 2, device=dev)
+    assert torch.equal(cn(mk, shared, sens), cn(mk, full, sens))
+
+
 def test_inference_path_untouched_by_grad_mode(dev, golden):
     """With autograd off the drop-in model takes the inference path (bit-identical to a no_grad call), and a grad-mode forward
     returns the same values to rounding."""
