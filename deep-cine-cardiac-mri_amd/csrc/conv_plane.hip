@@ -510,6 +510,9 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 0, true)           // the MWCNN's plane shapes (XT / XF planes at its coarser scales)
     CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 0, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 0, true)
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 1, true)           // ... and their InstanceNorm + LeakyReLU inner convs (mwcnn.py:143-168)
+    CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 1, true)
+    CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 2, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 1, true)
