@@ -24,6 +24,10 @@ struct InBwdArgs {
     float eps, slope;
 };
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st);
+// few, large planes (volumes; the sens-net's 200 x 200 coil planes): two passes over chunks of a plane with `ws` holding the chunk sums;
+// falls back to launch_in_lrelu_bwd for every other shape or without a workspace
+size_t in_lrelu_bwd_ws_floats(int n, int c, int h, int w);
+int launch_in_lrelu_bwd_split(const InBwdArgs& a, float* ws, size_t ws_floats, hipStream_t st);
 void set_wgrad_plane(int on);        // diagnostics: 0 routes the plane-wide weight gradients through the general kernel (cine_set_conv_plane bit 4)
 int launch_in_lrelu_bwd_fast(const InBwdArgs& a, hipStream_t st, bool* handled);      // inbwd_fast.hip: the U-Nets' plane shapes, one pass over HBM
 

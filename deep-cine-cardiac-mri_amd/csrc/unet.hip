@@ -208,8 +208,8 @@ static int unet2d_forward_impl(const float* x, float* y, const void* const* weig
 // gradient, and the partial sums of the weight-gradient kernel.
 namespace {
 struct BwdPlan {
-    float *A, *B[2], *cat[8], *pool, *wg, *mat;
-    size_t wg_floats, mat_floats;
+    float *A, *B[2], *cat[8], *pool, *wg, *mat, *inb;
+    size_t wg_floats, mat_floats, inb_floats;
 };
 void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch) {
     const int P = p.P;
@@ -239,6 +239,10 @@ void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch)
     for (int d = 1; d <= P; ++d) mat = std::max(mat, (size_t)n * p.ch[d - 1] * p.hs[d] * p.wsz[d]);
     q.mat_floats = mat;
     q.mat = b.take(mat);
+    size_t inb = 16;                                          // chunk sums of the InstanceNorm backward on few, large planes (the sens-net's 200 x 200 ones)
+    for (int d = 0; d <= P; ++d) inb = std::max(inb, in_lrelu_bwd_ws_floats(n, p.ch[d], p.hs[d], p.wsz[d]));
+    q.inb_floats = inb;
+    q.inb = b.take(inb);
 }
 }  // namespace
 
@@ -301,7 +305,7 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
     auto inbwd = [&](const float* r, const float* part, int np, int c, int hh, int ww, const float* ga, int ca_total, int ca_off,
                      int ha, int wa, const float* gb, int hb, int wb, float* out) {
         InBwdArgs a{r, part, np, GradPiece{ga, 1, ca_total, ca_off, ha, wa}, GradPiece{gb, gb ? 2 : 0, c, 0, hb, wb}, out, n, c, hh, ww, kEps, kSlope};
-        return launch_in_lrelu_bwd(a, st);
+        return launch_in_lrelu_bwd_split(a, q.inb, q.inb_floats, st);      // one workgroup per plane unless the planes are few and large
     };
 
     // ---- final 1x1 conv + bias (unet.py:69): y = W act(cb_0) + b
