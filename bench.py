@@ -98,7 +98,7 @@ def _cfg2():
                      "Cartesian mask, sens net 8ch/3 pools, U-Net 16ch/3 pools",
                 metric="cine slices/sec, XF-VarNet R=4 15-coil 200x200x15t", accel=4, noise=0.0, wseed=1, keep=("lambda",),
                 hip=lambda: M.VarNet(6, 8, 3, 16, 3, "XF"), ref=lambda: oracle_model(2), needs_sens=False,
-                conv_flop=flop, conv_kernel="cine::conv_mfma_kernel<8, CT, WM, WN, MT, TW, 9, 0> (the 3x3 instantiations)",
+                conv_flop=flop, conv_kernel="the 3x3 family: cine::conv_plane_kernel<8, CT, WM, WN, MT, TW, MODE> (U-Net planes, 84 of 98 launches), conv_wide_kernel / conv_mfma_kernel<..., 9, 0> (sens-net)",
                 fft_bytes=fft_bytes)
 
 
@@ -108,7 +108,7 @@ def _cfg3():
     return dict(name="BASELINE.json configs[2]: XT-XPDNet, MWCNN regulariser (script defaults), 10 cascades, n_primal 5, "
                      "15 coils x 15 frames x 200x200, R=8", metric="cine slices/sec, XT-XPDNet R=8 15-coil 200x200x15t",
                 accel=8, noise=0.01, wseed=6, keep=(), hip=lambda: M.XPDNet(**kw), ref=lambda: oracle_model(3), needs_sens=False,
-                conv_flop=416.2e9, conv_kernel="cine::conv_mfma_kernel<8, ..., 9> (MWCNN 3x3 convs with Haar DWT / IWT on load)",
+                conv_flop=416.2e9, conv_kernel="cine::conv_mfma_kernel<8, ..., 9, 0> (MWCNN 3x3 convs with Haar DWT / IWT on load) + conv_plane_kernel (its InstanceNorm inner convs)",
                 fft_bytes=None)
 
 
@@ -117,7 +117,7 @@ def _cfg4():
     return dict(name="BASELINE.json configs[3]: 3D CineNet, 6 cascades, CG 6, U-Net3D 16ch/3 pools, 15 coils x 15 frames x 200x200, R=6",
                 metric="cine slices/sec, 3D CineNet R=6 15-coil 200x200x15t", accel=6, noise=0.0, wseed=7, keep=("lambda",),
                 hip=lambda: M.CineNet(6, 6, 16, 3, "3D"), ref=lambda: oracle_model(4), needs_sens=True,
-                conv_flop=365.2e9, conv_kernel="cine::conv_mfma_kernel<8, ..., 9, 1> (3x3x3 convs as three 3x3 passes) + <4, ..., 27, 0> (small / narrow levels)", fft_bytes=None)
+                conv_flop=365.2e9, conv_kernel="cine::conv_wide_kernel<..., V3 = 1> (3x3x3 convs as three 3x3 passes, levels 0 / 1) + conv_mfma_kernel<8, ..., 9, 1> (coarse levels)", fft_bytes=None)
 
 
 def _cfg5():
@@ -126,7 +126,7 @@ def _cfg5():
                      "15 coils x 15 frames x 200x200, R=8", metric="cine slices/sec, CRNN-VarNet R=8 15-coil 200x200x15t",
                 accel=8, noise=0.0, wseed=9, keep=("lambda",), hip=lambda: M.VarNet_RNN(5, 8, 3, 16),
                 ref=lambda: oracle_model(5), needs_sens=False, conv_flop=155.0e9,
-                conv_kernel="cine::conv_mfma_kernel<8, ..., 9> (CRNN cells: summed-input 3x3 convs with bias/addend/ReLU epilogue)",
+                conv_kernel="cine::conv_wide_kernel (CRNN cells: summed-input 3x3 convs with bias/addend/ReLU epilogue, paired time-sweep steps) + conv_plane_kernel (sens-net)",
                 fft_bytes=None)
 
 
