@@ -105,6 +105,10 @@ _SIGS = {
     "cine_cg_ws_bytes": (c_size_t, []),
     "cine_cg_step": (c_int, [P, P, P, P, c_long, P, P, P, P]),
     "cine_cg_step_pd": (c_int, [P, P, P, P, c_long, P, P, P, P]),
+    "cine_cg_step_pd2": (c_int, [P, P, P, P, c_long, P, P, P, P, P]),
+    "cine_cg_adjoint_part_floats": (c_size_t, []),
+    "cine_cg_adjoint_step": (c_int, [P, P, P, P, P, c_long, P, P, P, P, P]),
+    "cine_cg_adjoint_finish": (c_int, [P, P, P, c_int, P, P]),
     "cine_normal_op_pd": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "cine_dot": (c_int, [P, P, c_long, P, P, P]),
     "cine_axpby_dev": (c_int, [P, P, P, c_long, P, P, P, c_float, P]),

@@ -1052,54 +1052,68 @@ class ConjGradFn(Function):
     applications of the same operator (ops.h_operator: the image-space kernel cine_normal_op for row masks, the literal
     expand -> mask -> reduce chain for masks that vary along w), run backwards:
         gp_k = beta_k gp_{k+1} + alpha_k gx - alpha_k H(gr_{k+1} + gp_{k+1}),   gr_k = gr_{k+1} + gp_{k+1}
-        gb = gr_0 + gp_0,  gx0 = gx - H(gb),  d/d v = -sum_k alpha_k <gr_{k+1} + gp_{k+1}, p_k> - <gb, x0>."""
+        gb = gr_0 + gp_0,  gx0 = gx - H(gb),  d/d v = -sum_k alpha_k <gr_{k+1} + gp_{k+1}, p_k> - <gb, x0>.
+    Forward: the inference path's fused iteration (cine_normal_op_pd + cine_cg_step_pd2, four launches) with p_k kept and the scalars
+    rr_k, p_k.d_k recorded on the device; backward: one operator application + ONE launch per iteration (cine_cg_adjoint_step)."""
 
     @staticmethod
     def forward(ctx, x0, b, lam, mask, sens, iters):
         x0 = ops._dev(x0, "CG start value"); b = ops._dev(b, "CG right-hand side")
-        one = torch.ones(1, device=x0.device, dtype=torch.float32)
+        dev = x0.device
+        one = torch.ones(1, device=dev, dtype=torch.float32)
         r = ops.axpby_dev(b, ops.h_operator(x0, sens, mask, lam), num=one, sign=-1.0)
         p = r.clone()
         x = x0.clone()
-        rr = ops.dot(r, r)
-        ps, scal = [], []
-        for _ in range(iters):
+        # the step sizes stay on the device: rr[k] = r_k . r_k, pd[k] = p_k . H p_k  (alpha_k = rr[k] / pd[k], beta_k = rr[k + 1] / rr[k])
+        rr = torch.empty(iters + 1, device=dev, dtype=torch.float32)
+        pd = torch.empty(max(iters, 1), device=dev, dtype=torch.float32)
+        ops.dot(r, r, out=rr[0:1])
+        bsz, t = x0.shape[0], x0.shape[1]
+        fused = ops.is_row_mask(mask, sens.expand(-1, t, -1, -1, -1, -1)) and \
+            lib().cine_image_dc_ws_bytes(bsz, t, sens.shape[2], sens.shape[3], sens.shape[4]) > 0
+        ps = []
+        for k in range(iters):
+            ps.append(p.clone() if fused else p)
+            if fused:       # the inference path's four launches per iteration (operator with p.d partial sums, update, direction), p.d recorded
+                ops.normal_op_cg_step(x, r, p, sens, mask, lam, rr[k:k + 1], rr[k + 1:k + 2], pd_out=pd[k:k + 1])
+                continue
             d = ops.h_operator(p, sens, mask, lam)
-            pd = ops.dot(p, d)
-            ps.append(p)
-            x = ops.axpby_dev(x, p, num=rr, den=pd)                   # x + alpha p
-            r = ops.axpby_dev(r, d, num=rr, den=pd, sign=-1.0)        # r - alpha d
-            rr_new = ops.dot(r, r)
-            p = ops.axpby_dev(r, p, num=rr_new, den=rr)               # r + beta p
-            scal.append((rr, pd, rr_new))
-            rr = rr_new
-        ctx.save_for_backward(x0, lam, mask, sens, *ps)
-        ctx.scal = scal
+            ops.dot(p, d, out=pd[k:k + 1])
+            x = ops.axpby_dev(x, p, num=rr[k:k + 1], den=pd[k:k + 1])                   # x + alpha p
+            r = ops.axpby_dev(r, d, num=rr[k:k + 1], den=pd[k:k + 1], sign=-1.0)        # r - alpha d
+            ops.dot(r, r, out=rr[k + 1:k + 2])
+            p = ops.axpby_dev(r, p, num=rr[k + 1:k + 2], den=rr[k:k + 1])               # r + beta p
+        ctx.save_for_backward(x0, lam, mask, sens, rr, pd, *ps)
         return x
 
     @staticmethod
     def backward(ctx, gx):
-        x0, lam, mask, sens = ctx.saved_tensors[:4]
-        ps = ctx.saved_tensors[4:]
+        x0, lam, mask, sens, rr, pd = ctx.saved_tensors[:6]
+        ps = ctx.saved_tensors[6:]
         gx = ops._dev(_c(gx), "CG output gradient")
-        gr = torch.zeros_like(gx)
+        dev = gx.device
+        L = lib()
+        K = len(ps)
+        nf = L.cine_cg_adjoint_part_floats()
+        part = torch.empty(max(K, 1) * nf, device=dev, dtype=torch.float32)
+        q = torch.zeros_like(gx)                                      # q_k = gr_{k+1} + gp_{k+1}: the gradient reaching r_{k+1}
         gp = torch.zeros_like(gx)
-        gv = torch.zeros(1, device=gx.device, dtype=torch.float32)
-        for k in reversed(range(len(ps))):
-            rr, pd, rr_new = ctx.scal[k]
-            grp = gr + gp                                             # gradient reaching r_{k+1} (through p_{k+1} = r_{k+1} + beta p_k too)
-            hg = ops.h_operator(grp, sens, mask, lam)
-            gv = gv - ops.dot(grp, ps[k]) * (rr / pd)
-            gp_new = ops.axpby_dev(ops.axpby_dev(torch.zeros_like(gx), gp, num=rr_new, den=rr), gx, num=rr, den=pd)     # beta gp + alpha gx
-            gp = ops.axpby_dev(gp_new, hg, num=rr, den=pd, sign=-1.0)                                                   # - alpha H(grp)
-            gr = grp
-        gb = gr + gp
+        for k in reversed(range(K)):
+            hg = ops.h_operator(q, sens, mask, lam)
+            check(L.cine_cg_adjoint_step(gp.data_ptr(), q.data_ptr(), gx.data_ptr(), hg.data_ptr(), ps[k].data_ptr(), gx.numel(),
+                                         rr[k:k + 1].data_ptr(), pd[k:k + 1].data_ptr(), rr[k + 1:k + 2].data_ptr(),
+                                         part[k * nf:].data_ptr(), _stream()), "cine_cg_adjoint_step")
+        gb = q                                                        # gr_0 + gp_0
         need = ctx.needs_input_grad
         gx0 = None
         if need[0]:
-            one = torch.ones(1, device=gx.device, dtype=torch.float32)
+            one = torch.ones(1, device=dev, dtype=torch.float32)
             gx0 = ops.axpby_dev(gx, ops.h_operator(gb, sens, mask, lam), num=one, sign=-1.0)
-        glam = _lam_grad(gv - ops.dot(gb, x0), lam) if need[2] else None
+        glam = None
+        if need[2]:
+            gv = torch.empty(1, device=dev, dtype=torch.float32)
+            check(L.cine_cg_adjoint_finish(part.data_ptr(), rr.data_ptr(), pd.data_ptr(), K, gv.data_ptr(), _stream()), "cine_cg_adjoint_finish")
+            glam = _lam_grad(gv - ops.dot(gb, x0), lam)
         return gx0, (gb if need[1] else None), glam, None, None, None
 
 

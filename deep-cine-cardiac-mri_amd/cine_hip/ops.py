@@ -488,7 +488,7 @@ def cg_step(x: torch.Tensor, r: torch.Tensor, p: torch.Tensor, d: torch.Tensor, 
     return rr_new
 
 
-def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new) -> torch.Tensor:
+def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One conjugate-gradient iteration of reference cinenet.py:153-169 for a row mask: d = H p with the partial sums of p.d produced by
     the operator's last kernel (cine_normal_op_pd), then the alpha / x / r / r.r / beta / p updates (cine_cg_step_pd).  Falls back to
     normal_op + cg_step where the operator has no partial-sum kernel."""
@@ -496,6 +496,8 @@ def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new) -> torch.
     t = p.shape[1]
     nbytes = lib().cine_image_dc_ws_bytes(b, t, c, h, w)
     if nbytes == 0:
+        if pd_out is not None:
+            raise CineHipError("normal_op_cg_step: this shape's operator has no partial-sum kernel, p.d cannot be recorded")
         return cg_step(x, r, p, normal_op(p, sens, mask, lambda_reg), rr_old, rr_new)
     key = (x.device, torch.cuda.current_stream().cuda_stream)
     ws = _cg_ws.get(key)
@@ -507,6 +509,10 @@ def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new) -> torch.
     lam = _dev(lambda_reg.detach(), "lambda_reg")
     check(lib().cine_normal_op_pd(p.data_ptr(), sens.data_ptr(), mask.data_ptr(), lam.data_ptr(), d.data_ptr(), ws.data_ptr(), b, t, c, h, w,
                                   dws.data_ptr(), nbytes, _stream()), "cine_normal_op_pd")
+    if pd_out is not None:        # training: p.d recorded for the adjoint recurrence
+        check(lib().cine_cg_step_pd2(x.data_ptr(), r.data_ptr(), p.data_ptr(), d.data_ptr(), x.numel(), rr_old.data_ptr(), rr_new.data_ptr(),
+                                     pd_out.data_ptr(), ws.data_ptr(), _stream()), "cine_cg_step_pd2")
+        return rr_new
     check(lib().cine_cg_step_pd(x.data_ptr(), r.data_ptr(), p.data_ptr(), d.data_ptr(), x.numel(), rr_old.data_ptr(), rr_new.data_ptr(),
                                 ws.data_ptr(), _stream()), "cine_cg_step_pd")
     return rr_new

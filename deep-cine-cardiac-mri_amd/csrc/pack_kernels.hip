@@ -488,9 +488,10 @@ __global__ void axpby_dev_kernel(float* out, const float* a, const float* b, lon
 // alpha = rr_old / (p.d), x += alpha p, r -= alpha d, partial sums of r.r -- then cg_direction_kernel: rr_new from the partials,
 // beta = rr_new / rr_old, p = r + beta p.  Same arithmetic and summation orders as cine_dot / cine_axpby_dev: bit-identical.
 __global__ __launch_bounds__(256) void cg_update_kernel(float* x, float* r, const float* p, const float* d, long n,
-                                                        const float* pd_part, const float* rr_old, float* rr_part) {
+                                                        const float* pd_part, const float* rr_old, float* rr_part, float* pd_out) {
     __shared__ float red[16];
     const float pd = block_sum(pd_part[threadIdx.x], red);
+    if (pd_out && blockIdx.x == 0 && threadIdx.x == 0) *pd_out = pd;          // recorded for the adjoint recurrence (training)
     const float alpha = *rr_old / pd;
     const float nalpha = alpha * -1.0f;
     float s = 0.f;
@@ -526,7 +527,7 @@ extern "C" int cine_cg_step(float* x, float* r, float* p, const float* d, long n
     float* part = reinterpret_cast<float*>(ws);
     ProfScope prof(F_MISC, st);
     hipLaunchKernelGGL(dot_partial_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, d, n, part);
-    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks, static_cast<float*>(nullptr));
     hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, r, n, part + kDotBlocks, rr_old_dev, rr_new_dev);
     return check_launch("cine_cg_step");
 }
@@ -539,9 +540,77 @@ extern "C" int cine_cg_step_pd(float* x, float* r, float* p, const float* d, lon
     hipStream_t st = as_stream(stream);
     float* part = reinterpret_cast<float*>(ws);
     ProfScope prof(F_MISC, st);
-    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks, static_cast<float*>(nullptr));
     hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, r, n, part + kDotBlocks, rr_old_dev, rr_new_dev);
     return check_launch("cine_cg_step_pd");
+}
+
+// cine_cg_step_pd that also records p.d (training: the adjoint recurrence needs alpha_k = rr_k / pd_k)
+extern "C" int cine_cg_step_pd2(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
+                                float* pd_out_dev, void* ws, void* stream) {
+    CINE_REQUIRE(x && r && p && d && rr_old_dev && rr_new_dev && pd_out_dev && ws && n > 0, CINE_EINVAL, "cine_cg_step_pd2: bad arguments");
+    CINE_REQUIRE(rr_old_dev != rr_new_dev, CINE_EINVAL, "cine_cg_step_pd2: rr_old and rr_new must be different scalars");
+    hipStream_t st = as_stream(stream);
+    float* part = reinterpret_cast<float*>(ws);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kDotBlocks), dim3(256), 0, st, x, r, p, d, n, part, rr_old_dev, part + kDotBlocks, pd_out_dev);
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, r, n, part + kDotBlocks, rr_old_dev, rr_new_dev);
+    return check_launch("cine_cg_step_pd2");
+}
+
+// ---------------------------------------------------------------- adjoint of the conjugate-gradient iteration (training, cinenet.py:136-171)
+// The reference takes alpha_k and beta_k out of the graph (.item()), so the K iterations are linear in (x0, b) with recorded step sizes and
+// their adjoint runs the same operator backwards (cine_hip/autograd.py ConjGradFn).  With q_k = gr_{k+1} + gp_{k+1} (the gradient reaching
+// r_{k+1}) and hg = H(q_k), one reverse step is
+//     gp_k = beta_k gp_{k+1} + alpha_k gx - alpha_k hg,    q_{k-1} = q_k + gp_k,    s_k = <q_k, p_k>
+// in ONE launch (the axpby / dot / add sequence it replaces is 9 launches): the same fused-multiply-add chain as three cine_axpby_dev calls
+// and the same partial-sum pattern as cine_dot, so the values are bit-identical to that sequence.
+namespace cine {
+__global__ __launch_bounds__(256) void cg_adjoint_step_kernel(float* gp, float* q, const float* gx, const float* hg, const float* pk, long n,
+                                                              const float* rr, const float* pd, const float* rr_new, float* part) {
+    __shared__ float red[16];
+    const float beta = *rr_new / *rr, alpha = *rr / *pd;
+    const float nalpha = alpha * -1.0f;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float qi = q[i];
+        s += qi * pk[i];
+        const float t1 = 0.f + beta * gp[i];
+        const float t2 = t1 + alpha * gx[i];
+        const float g = t2 + nalpha * hg[i];
+        gp[i] = g;
+        q[i] = qi + g;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// gv = - sum_k alpha_k s_k, accumulated from the last iteration to the first like the host loop it replaces
+__global__ __launch_bounds__(256) void cg_adjoint_finish_kernel(const float* part, const float* rr, const float* pd, int iters, float* gv) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int k = iters - 1; k >= 0; --k) {
+        const float sk = block_sum(part[(long)k * kDotBlocks + threadIdx.x], red);
+        acc = acc - sk * (rr[k] / pd[k]);
+    }
+    if (threadIdx.x == 0) *gv = acc;
+}
+}  // namespace cine
+
+extern "C" int cine_cg_adjoint_step(float* gp, float* q, const float* gx, const float* hg, const float* pk, long n, const float* rr_dev,
+                                    const float* pd_dev, const float* rr_new_dev, float* part, void* stream) {
+    CINE_REQUIRE(gp && q && gx && hg && pk && rr_dev && pd_dev && rr_new_dev && part && n > 0, CINE_EINVAL, "cine_cg_adjoint_step: bad arguments");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_adjoint_step_kernel, dim3(kDotBlocks), dim3(256), 0, st, gp, q, gx, hg, pk, n, rr_dev, pd_dev, rr_new_dev, part);
+    return check_launch("cg_adjoint_step_kernel");
+}
+extern "C" size_t cine_cg_adjoint_part_floats(void) { return kDotBlocks; }
+extern "C" int cine_cg_adjoint_finish(const float* part, const float* rr_dev, const float* pd_dev, int iters, float* gv_dev, void* stream) {
+    CINE_REQUIRE(part && rr_dev && pd_dev && gv_dev && iters >= 0, CINE_EINVAL, "cine_cg_adjoint_finish: bad arguments");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_adjoint_finish_kernel, dim3(1), dim3(256), 0, st, part, rr_dev, pd_dev, iters, gv_dev);
+    return check_launch("cg_adjoint_finish_kernel");
 }
 
 extern "C" int cine_dot(const float* a, const float* b, long n, float* out_dev, void* ws, void* stream) {

@@ -404,6 +404,19 @@ int cine_cg_step(float* x, float* r, float* p, const float* d, long n, const flo
 /* cine_cg_step without its p.d pass: ws[0..256) floats already hold the partial sums (cine_normal_op_pd).  Two launches. */
 int cine_cg_step_pd(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                     void* ws, void* stream);
+/* cine_cg_step_pd that also stores p.d into *pd_out_dev (training: the adjoint recurrence needs alpha_k = rr_k / pd_k). */
+int cine_cg_step_pd2(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
+                     float* pd_out_dev, void* ws, void* stream);
+/* Adjoint of ONE conjugate-gradient iteration with recorded step sizes (the reference detaches alpha / beta, cinenet.py:159-169), run from
+ * the last iteration to the first: with q = gr_{k+1} + gp_{k+1} and hg = H(q) (cine_normal_op),
+ *     gp <- (rr_new / rr) gp + (rr / pd) gx - (rr / pd) hg;   part[0..256) <- partial sums of <q, p_k>;   q <- q + gp
+ * in one launch, bit-identical to the cine_axpby_dev / cine_dot / add sequence.  cine_cg_adjoint_finish: gv = - sum_k (rr[k] / pd[k]) <q_k, p_k>
+ * from `iters` consecutive partial-sum blocks of cine_cg_adjoint_part_floats() floats (d loss / d softplus(lambda) of the solve, without the
+ * - <gb, x0> term). */
+size_t cine_cg_adjoint_part_floats(void);
+int cine_cg_adjoint_step(float* gp, float* q, const float* gx, const float* hg, const float* pk, long n, const float* rr_dev,
+                         const float* pd_dev, const float* rr_new_dev, float* part, void* stream);
+int cine_cg_adjoint_finish(const float* part, const float* rr_dev, const float* pd_dev, int iters, float* gv_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * data front-end + sensitivity calibration (the step BEFORE the path)
