@@ -470,6 +470,7 @@ def dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 
 _cg_ws = {}
+FUSED_CG = True      # A/B switch of the diagnostics (tools/whatif_cfg4.py): False = operator + partial-sum pass + update + direction (4 launches)
 
 
 def cg_step(x: torch.Tensor, r: torch.Tensor, p: torch.Tensor, d: torch.Tensor, rr_old: torch.Tensor, rr_new: torch.Tensor) -> torch.Tensor:
@@ -499,6 +500,23 @@ def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: O
         if pd_out is not None:
             raise CineHipError("normal_op_cg_step: this shape's operator has no partial-sum kernel, p.d cannot be recorded")
         return cg_step(x, r, p, normal_op(p, sens, mask, lambda_reg), rr_old, rr_new)
+    lam = _dev(lambda_reg.detach(), "lambda_reg")
+    fbytes = lib().cine_cg_fused_ws_bytes(b, t, c, h, w) if FUSED_CG else 0
+    if fbytes:                    # three launches: the operator's coil-group sums are consumed by the update kernel, H p is never written
+        for t_, name in ((x, "x"), (r, "r"), (p, "p")):
+            if not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.numel() == b * t * h * w * 2):
+                raise ValueError(f"normal_op_cg_step: {name} must be a contiguous float32 GPU tensor of (b, t, 1, h, w, 2)")
+        key = (x.device, torch.cuda.current_stream().cuda_stream, "fused", fbytes)
+        fws = _cg_ws.get(key)
+        if fws is None:
+            _no_capture("the conjugate-gradient workspace of this stream")
+            fws = _cg_ws[key] = torch.empty(fbytes, device=x.device, dtype=torch.uint8)
+        dws = torch.empty(nbytes, device=p.device, dtype=torch.uint8)
+        check(lib().cine_normal_op_cg_fused(x.data_ptr(), r.data_ptr(), p.data_ptr(), _dev(sens, "sens_maps").data_ptr(),
+                                            _dev(mask, "mask", torch.uint8).data_ptr(), lam.data_ptr(), rr_old.data_ptr(), rr_new.data_ptr(),
+                                            _p(pd_out), b, t, c, h, w, dws.data_ptr(), nbytes, fws.data_ptr(), fbytes, _stream()),
+              "cine_normal_op_cg_fused")
+        return rr_new
     key = (x.device, torch.cuda.current_stream().cuda_stream)
     ws = _cg_ws.get(key)
     if ws is None:
@@ -506,7 +524,6 @@ def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: O
         ws = _cg_ws[key] = torch.empty(lib().cine_cg_ws_bytes(), device=x.device, dtype=torch.uint8)
     d = torch.empty((b, t, 1, h, w, 2), device=p.device, dtype=p.dtype)
     dws = torch.empty(nbytes, device=p.device, dtype=torch.uint8)
-    lam = _dev(lambda_reg.detach(), "lambda_reg")
     check(lib().cine_normal_op_pd(p.data_ptr(), sens.data_ptr(), mask.data_ptr(), lam.data_ptr(), d.data_ptr(), ws.data_ptr(), b, t, c, h, w,
                                   dws.data_ptr(), nbytes, _stream()), "cine_normal_op_pd")
     if pd_out is not None:        # training: p.d recorded for the adjoint recurrence

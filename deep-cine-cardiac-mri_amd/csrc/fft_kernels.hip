@@ -588,6 +588,8 @@ struct ImgDcArgs {
     cf* partial; long part_stride;   // H == 200 with more than one coil group: per-group partial sums (workspace)
     float* pd_part;                  // optional: 256 partial sums of <img, out> (the p.d of a conjugate-gradient step, cinenet.py:155), one per workgroup of imgdc_sum_kernel
     int BT, ntx, nz;                 // H == 200: frames x batch, column tiles, coil groups
+    float* pd_wg;                    // optional (H == 200, nz > 1): one partial sum of <img, sum_z partial_z + beta img> per WORKGROUP of imgdc200_kernel
+                                     // (cine_normal_op_cg_fused: the conjugate-gradient step then needs no imgdc_sum pass)
 };
 
 __device__ __forceinline__ void imgdc_weights(const ImgDcArgs& a, float& w1, float& w0, float& beta) {
@@ -632,7 +634,10 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     // ONE XCD, so every XCD's L2 holds 1/8 of the maps instead of each of them streaming all 4.8 MB (twice).
     const int xcd = blockIdx.x & 7, kq = blockIdx.x >> 3;
     const int pair = (kq / a.BT) * 8 + xcd, bt = kq % a.BT;
-    if (pair >= a.ntx * a.nz) return;                           // padding of the pair count to a multiple of 8
+    if (pair >= a.ntx * a.nz) {                                 // padding of the pair count to a multiple of 8
+        if (a.pd_wg && tid == 0) a.pd_wg[blockIdx.x] = 0.f;
+        return;
+    }
     const int zg = pair / a.ntx;
     const int w0c = (pair - zg * a.ntx) * CW;
     const int b = bt / a.T;
@@ -718,6 +723,7 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     // ---- P4: this thread's outputs, summed over the coil slots
     const bool single = a.nz == 1;
     cf* part = a.partial + (long)zg * a.part_stride;
+    float pdl = 0.f;
 #pragma unroll
     for (int k = 0; k < NOUT; ++k) {
         const int e = tid + k * kDcT;
@@ -730,6 +736,19 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
         const long o = (long)bt * HW + (long)row * a.W + col;
         if (single) imgdc_store(a, o, s, beta);
         else part[o] = s;
+        if (a.pd_wg) {                  // <p, this group's share of H p>; the regulariser term beta <p, p> rides with group 0
+            const cf pv = a.img[o];
+            pdl += pv.x * s.x + pv.y * s.y;
+            if (zg == 0) pdl += beta * (pv.x * pv.x + pv.y * pv.y);
+        }
+    }
+    if (a.pd_wg) {                      // uniform
+        __shared__ float pdred[4];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) pdl += __shfl_xor(pdl, o2, 64);
+        if ((tid & 63) == 0) pdred[tid >> 6] = pdl;
+        __syncthreads();
+        if (tid == 0) a.pd_wg[blockIdx.x] = pdred[0] + pdred[1] + pdred[2] + pdred[3];
     }
     CINE_STAMP(9);
 }
@@ -1085,7 +1104,7 @@ extern "C" size_t cine_image_dc_ws_bytes(int b, int t, int c, int h, int w) {
 static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                          const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
                          float* out, int b, int t, int c, int h, int w, int magnitude,
-                         void* ws, size_t ws_bytes, void* stream, float* pd_part = nullptr);
+                         void* ws, size_t ws_bytes, void* stream, float* pd_part = nullptr, float* pd_wg = nullptr);
 
 extern "C" int cine_image_dc(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                              const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
@@ -1110,11 +1129,43 @@ extern "C" int cine_normal_op_pd(const float* img, const float* sens, const uint
     return image_dc_impl(img, sens, img, mask, lambda_dev, 1, 1.f, 0.f, 0.f, out, b, t, c, h, w, 0, ws, ws_bytes, stream, pd_part);
 }
 
+// One conjugate-gradient iteration of cinenet.py:153-169 for a row mask in THREE launches: imgdc200_kernel leaves the coil groups'
+// partial sums of A^H M A p and one partial sum of <p, H p> per workgroup; cg_update_fused_kernel adds the groups and the regulariser term
+// (the arithmetic of imgdc_sum_kernel: d is bit-identical), alpha, x += alpha p, r -= alpha d, partial sums of r.r; cg_direction_kernel
+// beta and p.  H p itself is never written.  p.d is added up per workgroup here instead of per 256-thread stripe of the vector, so alpha
+// differs from cine_normal_op_pd + cine_cg_step_pd in the last bits (deterministic all the same).
+namespace cine {
+int launch_cg_update_fused(float* x, float* r, float* p, const cf* partial, int nz, long part_stride, const float* lam, long ncf,
+                           const float* pd_wg, int npd, const float* rr_old, float* rr_new, float* rr_part, float* pd_out, hipStream_t st);   // pack_kernels.hip
+}
+static long cg_fused_blocks(int b, int t, int c, int h, int w) {
+    if (b <= 0 || t <= 0 || c <= kDcCS || h != 200 || w <= 0) return 0;
+    return 8L * ceil_div(ceil_div(w, kDcCW) * ceil_div(c, kDcCS), 8) * b * t;
+}
+extern "C" size_t cine_cg_fused_ws_bytes(int b, int t, int c, int h, int w) {
+    const long nb = cg_fused_blocks(b, t, c, h, w);
+    return nb ? (size_t)(nb + 256) * sizeof(float) : 0;           // per-workgroup p.d partials + 256 r.r partials
+}
+extern "C" int cine_normal_op_cg_fused(float* x, float* r, float* p, const float* sens, const uint8_t* mask, const float* lambda_dev,
+                                       const float* rr_old_dev, float* rr_new_dev, float* pd_out_dev, int b, int t, int c, int h, int w,
+                                       void* ws_dc, size_t ws_dc_bytes, void* ws_cg, size_t ws_cg_bytes, void* stream) {
+    CINE_REQUIRE(x && r && p && sens && mask && lambda_dev && rr_old_dev && rr_new_dev && ws_dc && ws_cg, CINE_EINVAL, "cine_normal_op_cg_fused: null pointer");
+    CINE_REQUIRE(rr_old_dev != rr_new_dev, CINE_EINVAL, "cine_normal_op_cg_fused: rr_old and rr_new must be different scalars");
+    const long nb = cg_fused_blocks(b, t, c, h, w);
+    CINE_REQUIRE(nb > 0 && nb <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_normal_op_cg_fused: needs h == 200 and more than %d coils", kDcCS);
+    CINE_REQUIRE(ws_cg_bytes >= cine_cg_fused_ws_bytes(b, t, c, h, w), CINE_EWORKSPACE, "cine_normal_op_cg_fused: workspace too small");
+    float* pd_wg = reinterpret_cast<float*>(ws_cg);
+    if (int e = image_dc_impl(p, sens, p, mask, lambda_dev, 1, 1.f, 0.f, 0.f, nullptr, b, t, c, h, w, 0, ws_dc, ws_dc_bytes, stream, nullptr, pd_wg)) return e;
+    const long ncf = (long)b * t * h * w;
+    return launch_cg_update_fused(x, r, p, reinterpret_cast<const cf*>(ws_dc), ceil_div(c, kDcCS), ncf, lambda_dev, ncf, pd_wg, (int)nb,
+                                  rr_old_dev, rr_new_dev, pd_wg + nb, pd_out_dev, as_stream(stream));
+}
+
 static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                          const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
                          float* out, int b, int t, int c, int h, int w, int magnitude,
-                         void* ws, size_t ws_bytes, void* stream, float* pd_part) {
-    CINE_REQUIRE(img && sens && mask && out, CINE_EINVAL, "cine_image_dc: null pointer");
+                         void* ws, size_t ws_bytes, void* stream, float* pd_part, float* pd_wg) {
+    CINE_REQUIRE(img && sens && mask && (out || pd_wg), CINE_EINVAL, "cine_image_dc: null pointer");
     CINE_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_image_dc: bad sizes");
     CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_image_dc: b*t > 65535");
     CINE_REQUIRE(img != out, CINE_EINVAL, "cine_image_dc: out must not alias img (workgroups read neighbouring columns' rows)");
@@ -1136,9 +1187,11 @@ static int image_dc_impl(const float* img, const float* sens, const float* zf, c
         a.BT = b * t; a.ntx = ceil_div(w, kDcCW); a.nz = nz;
         const long nblk = 8L * ceil_div(a.ntx * nz, 8) * a.BT;
         CINE_REQUIRE(nblk <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_image_dc: grid too large");
+        CINE_REQUIRE(!pd_wg || nz > 1, CINE_EUNSUPPORTED, "cine_image_dc: per-workgroup dot partials need more than one coil group");
+        a.pd_wg = pd_wg;
         hipLaunchKernelGGL(imgdc200_kernel, dim3((unsigned)nblk), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
         if (int e = check_launch("imgdc200_kernel")) return e;
-        if (nz > 1) {
+        if (nz > 1 && !pd_wg) {           // (with pd_wg the caller's next kernel adds the coil groups itself: cine_normal_op_cg_fused)
             const long n = a.part_stride;
             a.pd_part = pd_part;        // 256 workgroups when the p.d partial sums ride along (what cg_update_kernel adds up)
             hipLaunchKernelGGL(imgdc_sum_kernel, dim3(pd_part ? 256u : (unsigned)std::min<long>(ceil_div(n, 256L), 2048)), dim3(256), 0, st, a, nz, n);

@@ -515,6 +515,49 @@ __global__ __launch_bounds__(256) void cg_direction_kernel(float* p, const float
 }
 }  // namespace cine
 
+// cg_update_kernel with the operator's last pass folded in (cine_normal_op_cg_fused, fft_kernels.hip): d = sum_z partial_z + softplus(lambda) p
+// formed on the fly with imgdc_sum_kernel's arithmetic, p.d from the operator kernel's per-workgroup partial sums (each thread adds a strided
+// share in index order, then the block sum: deterministic)
+namespace cine {
+typedef float2 cfp;
+__global__ __launch_bounds__(256) void cg_update_fused_kernel(cfp* x, cfp* r, const cfp* p, const cfp* partial, int nz, long part_stride,
+                                                              const float* lam, long ncf, const float* pd_wg, int npd,
+                                                              const float* rr_old, float* rr_part, float* pd_out) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < npd; i += 256) acc += pd_wg[i];
+    const float pd = block_sum(acc, red);
+    if (pd_out && blockIdx.x == 0 && threadIdx.x == 0) *pd_out = pd;
+    const float alpha = *rr_old / pd;
+    const float nalpha = alpha * -1.0f;
+    const float l = *lam;
+    const float beta = l > 20.f ? l : log1pf(expf(l));                 // softplus, as imgdc_weights reads it
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncf; i += (long)gridDim.x * blockDim.x) {
+        cfp d = partial[i];
+        for (int z = 1; z < nz; ++z) { const cfp u = partial[z * part_stride + i]; d.x += u.x; d.y += u.y; }
+        const cfp pv = p[i];
+        d.x = fmaf(beta, pv.x, d.x); d.y = fmaf(beta, pv.y, d.y);
+        cfp xv = x[i], rv = r[i];
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        rv.x = rv.x + nalpha * d.x; rv.y = rv.y + nalpha * d.y;
+        x[i] = xv; r[i] = rv;
+        s += rv.x * rv.x; s += rv.y * rv.y;
+    }
+    __syncthreads();
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) rr_part[blockIdx.x] = s;
+}
+int launch_cg_update_fused(float* x, float* r, float* p, const float2* partial, int nz, long part_stride, const float* lam, long ncf,
+                           const float* pd_wg, int npd, const float* rr_old, float* rr_new, float* rr_part, float* pd_out, hipStream_t st) {
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_update_fused_kernel, dim3(kDotBlocks), dim3(256), 0, st, reinterpret_cast<cfp*>(x), reinterpret_cast<cfp*>(r),
+                       reinterpret_cast<const cfp*>(p), partial, nz, part_stride, lam, ncf, pd_wg, npd, rr_old, rr_part, pd_out);
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(kDotBlocks), dim3(256), 0, st, p, r, 2 * ncf, rr_part, rr_old, rr_new);
+    return check_launch("cine_normal_op_cg_fused");
+}
+}  // namespace cine
+
 extern "C" size_t cine_dot_ws_bytes(void) { return kDotBlocks * sizeof(float); }
 extern "C" size_t cine_cg_ws_bytes(void) { return 2 * kDotBlocks * sizeof(float); }
 

@@ -404,6 +404,15 @@ int cine_cg_step(float* x, float* r, float* p, const float* d, long n, const flo
 /* cine_cg_step without its p.d pass: ws[0..256) floats already hold the partial sums (cine_normal_op_pd).  Two launches. */
 int cine_cg_step_pd(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                     void* ws, void* stream);
+/* One whole conjugate-gradient iteration of models/cinenet.py:153-169 for a row mask in three launches (h == 200, more than 5 coils;
+ * cine_cg_fused_ws_bytes() == 0 otherwise): the operator kernel leaves its coil groups' partial sums in ws_dc (cine_image_dc_ws_bytes) and
+ * one partial sum of <p, H p> per workgroup in ws_cg; the update kernel adds the groups + softplus(lambda) p on the fly (H p is never
+ * written), alpha, x += alpha p, r -= alpha H p, r.r; the direction kernel beta and p.  x, r, p in place; *pd_out_dev (may be NULL)
+ * receives p.Hp.  Same values as cine_normal_op_pd + cine_cg_step_pd up to the summation order of p.Hp. */
+size_t cine_cg_fused_ws_bytes(int b, int t, int c, int h, int w);
+int cine_normal_op_cg_fused(float* x, float* r, float* p, const float* sens, const uint8_t* mask, const float* lambda_dev,
+                            const float* rr_old_dev, float* rr_new_dev, float* pd_out_dev, int b, int t, int c, int h, int w,
+                            void* ws_dc, size_t ws_dc_bytes, void* ws_cg, size_t ws_cg_bytes, void* stream);
 /* cine_cg_step_pd that also stores p.d into *pd_out_dev (training: the adjoint recurrence needs alpha_k = rr_k / pd_k). */
 int cine_cg_step_pd2(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                      float* pd_out_dev, void* ws, void* stream);

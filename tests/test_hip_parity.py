@@ -1202,6 +1202,56 @@ def test_image_dc_batch_and_identities(dev):
     assert rel_err(f(2 * x - 3 * y).cpu(), (2 * f(x) - 3 * f(y)).cpu()) < OP_TOL
 
 
+@pytest.mark.parametrize("t,c,w", [(15, 15, 200), (3, 7, 36), (2, 6, 7)])
+def test_cg_iteration_three_launch_form_vs_oracle_and_four_launch_form(dev, t, c, w):
+    """cine_normal_op_cg_fused (operator with per-workgroup p.Hp partial sums -> update that adds the coil groups itself -> direction)
+    against the literal iteration of reference cinenet.py:153-169 in float64 and against the four-launch form (cine_normal_op_pd +
+    cine_cg_step_pd): same x, r, p, r.r, p.Hp to rounding; three iterations chained (rr_new feeds the next one)."""
+    from cine_hip import ops
+    from oracle import cinenet_ref as C
+    import torch.nn.functional as F
+    h = 200
+    sens = rnd(2, 1, 1, c, h, w, 2)
+    sens = sens / sens.pow(2).sum(dim=(2, 5), keepdim=True).sqrt()
+    mask = _row_mask(t, h, 5)
+    lam = torch.tensor([0.37])
+    x0, r0 = rnd(3, 1, t, 1, h, w, 2), rnd(4, 1, t, 1, h, w, 2)
+    blk = C.CineNetBlock(torch.nn.Identity(), 1, "XF", True).double()
+    with torch.no_grad():
+        blk.lambda_reg.copy_(lam.double())
+
+    def run(fused):
+        ops.FUSED_CG = fused
+        x, r, p = x0.to(dev), r0.to(dev), r0.to(dev).clone()
+        rr = [ops.dot(r, r), torch.empty(1, device=dev)]
+        pd = torch.empty(3, device=dev)
+        for k in range(3):
+            ops.normal_op_cg_step(x, r, p, sens.to(dev), mask.to(dev), lam.to(dev), rr[k % 2], rr[(k + 1) % 2], pd_out=pd[k:k + 1])
+        return x.cpu(), r.cpu(), p.cpu(), rr[1].cpu(), pd.cpu()
+    try:
+        got3, got4 = run(True), run(False)
+    finally:
+        ops.FUSED_CG = True
+    # float64 reference of the same three iterations
+    x, r = x0.double(), r0.double()
+    p = r.clone()
+    rr = torch.dot(r.flatten(), r.flatten())
+    pds = []
+    with torch.no_grad():
+        for _ in range(3):
+            d = blk.HOperator(p, mask, sens.double())
+            pdv = torch.dot(p.flatten(), d.flatten()); pds.append(pdv)
+            al = rr / pdv
+            x = x + al * p; r = r - al * d
+            rn = torch.dot(r.flatten(), r.flatten())
+            p = r + (rn / rr) * p
+            rr = rn
+    want = (x, r, p, rr.reshape(1), torch.stack(pds))
+    for a3, a4, wv, name in zip(got3, got4, want, ("x", "r", "p", "rr", "pd")):
+        assert rel_err(a3, wv.float()) < 2e-5, name
+        assert rel_err(a3, a4) < 2e-6, name
+
+
 # ------------------------------------------------------------------ the steps either side of the path (SURVEY 8(f1), 8(f2))
 def _metric_pair(seed):
     rs = np.random.RandomState(seed)
