@@ -12,7 +12,9 @@
 // N == 200 uses the 10 x 20 Cooley-Tukey engine; any other N = 2^a 3^b 5^c <= 512 the mixed-radix Stockham engine
 // (radices 4 / 2 / 3 / 5, two tiles ping-pong); lengths with another prime factor, <= 400, a direct DFT.
 #include <algorithm>
+#include <map>
 #include <mutex>
+#include <utility>
 #include "common.h"
 #include "fft_core.h"
 
@@ -936,21 +938,26 @@ static int check_n(int n, const char* what) {
 }
 
 // lengths above 400 need more than the 64 KB of dynamic LDS a kernel gets by default: raise the limit once per (kernel, device)
-// and keep the result, so that a refused request fails every later launch with its own message
-template <typename K>
-static int allow_lds(K kern, size_t lds, const char* what) {
+// and keep the result, so that a refused request fails every later launch with its own message.  Keyed by the kernel's ADDRESS: the
+// instantiations of one kernel template share a function-pointer type.
+static int allow_lds(const void* kern, size_t lds, const char* what) {
     if (lds <= 64 * 1024) return CINE_OK;
-    static std::once_flag once[64];               // per template instance = per kernel
-    static hipError_t status[64];
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, hipError_t> done;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    CINE_REQUIRE(dev >= 0 && dev < 64, CINE_EUNSUPPORTED, "%s: device index %d", what, dev);
-    std::call_once(once[dev], [&] {
-        status[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(status[dev]));
+    hipError_t st;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = done.find({kern, dev});
+        if (it == done.end())
+            it = done.emplace(std::make_pair(kern, dev), hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)).first;
+        st = it->second;
+    }
+    CINE_REQUIRE(st == hipSuccess, CINE_EHIP, "%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize): %s", what, hipGetErrorString(st));
     return CINE_OK;
 }
+template <typename K> static int allow_lds(K kern, size_t lds, const char* what) { return allow_lds(reinterpret_cast<const void*>(kern), lds, what); }
 
 template <int POST, bool INV_AFTER = false, bool PREMASK = false>
 static int launch_col(const ColArgs& a, long nimg, bool inverse, hipStream_t st) {
