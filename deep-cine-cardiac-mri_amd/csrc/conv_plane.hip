@@ -204,9 +204,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
                 const float* stp = st_lds + 2 * (ci0 + sgc);
 #pragma unroll
                 for (int i = 0; i < NCI; ++i) {
-                    if (G == 1 && ci0 + i >= a.cin) break;          // uniform; only the narrow first layer
                     piece_t o = xraw[i];
-                    if constexpr (MODE == 1) {
+                    if (G == 1 && ci0 + i >= a.cin) {               // uniform: a chunk wider than what is left of the layer's input (2-channel first
+                        float* zf = reinterpret_cast<float*>(&o);   // layer; the MWCNN's 10 = 8 + 2 channels) -- zeros over the previous chunk's values
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) zf[u] = 0.f;
+                    } else if constexpr (MODE == 1) {
                         const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
                         act_piece<PW>(reinterpret_cast<float*>(&o), ss.x, ss.y, a.slope);
                     }
@@ -484,8 +487,7 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
         if (s0.np < 1 || s0.np > 16 || !s0.part || (s1.c > 0 && (s1.np < 1 || s1.np > 16 || !s1.part))) return CINE_OK;
         if (s0.c + s1.c > 256) return CINE_OK;
     }
-    const bool whole = a.cin % ck == 0;             // a narrower last chunk: only as the layer's ONE chunk, on the G == 1 shapes
-    const bool one = a.nchunks == 1;
+    const bool whole = a.cin % ck == 0;             // a narrower last chunk (2 of 8 channels, 10 = 8 + 2): on the G == 1 shapes, one source
     PlaneArgs p{};
     p.x0 = s0.x; p.part0 = s0.part; p.c0 = s0.c; p.np0 = s0.np;
     p.x1 = s1.c > 0 ? s1.x : nullptr; p.part1 = s1.c > 0 ? s1.part : nullptr; p.c1 = s1.c; p.np1 = s1.c > 0 ? s1.np : 0;
@@ -495,7 +497,7 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     p.slope = a.slope; p.eps = a.eps;
     // G > 1 configurations (planes narrower than 16) stage whole chunks only
 #define CINE_PLANE_CASE(CK_, CT_, WM_, WN_, MT_, TW_, MODE_, NEEDWHOLE)                                                   \
-    if (ck == CK_ && ct == CT_ && wm == WM_ && wn == WN_ && mt == MT_ && tw == TW_ && mode == MODE_ && (whole || (!(NEEDWHOLE) && one))) { \
+    if (ck == CK_ && ct == CT_ && wm == WM_ && wn == WN_ && mt == MT_ && tw == TW_ && mode == MODE_ && (whole || !(NEEDWHOLE))) { \
         *handled = true;                                                                                                  \
         return launch_plane<CK_, CT_, WM_, WN_, MT_, TW_, MODE_>(p, a.n, st);                                              \
     }
@@ -513,6 +515,7 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 1, true)           // ... and their InstanceNorm + LeakyReLU inner convs (mwcnn.py:143-168)
     CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 1, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 13, 8, 1, true)           // 16 -> 64 before an IWT
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 2, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 1, true)

@@ -382,7 +382,8 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
         if d < 3:
             cases += [("concat", c, c, h, w), ("plain", c, 2 * c, h, w)]          # up path; input gradient of the concat conv
     cases += [("norm", 16, 16, 200, 16), ("pool", 16, 32, 100, 8), ("norm", 128, 128, 25, 2), ("norm", 24, 16, 52, 16)]     # ragged last tiles, 3 chunks
-    cases += [("norm", 16, 16, 100, 8), ("norm", 32, 32, 50, 4), ("norm", 64, 64, 25, 2), ("norm", 64, 32, 48, 4)]          # the MWCNN's inner conv blocks (cfg 3 planes)
+    cases += [("norm", 16, 16, 100, 8), ("norm", 32, 32, 50, 4), ("norm", 64, 64, 25, 2), ("norm", 64, 32, 48, 4),
+              ("norm", 16, 64, 100, 8), ("plain", 10, 16, 200, 16), ("norm", 12, 16, 200, 16)]          # the MWCNN's inner conv blocks (cfg 3 planes), 16 -> 64 before an IWT, 8 + 2 input channels
     cases += [("relu", 16, 16, 208, 8), ("relu", 32, 32, 100, 4), ("relu", 64, 64, 50, 2), ("relu", 16, 16, 200, 16)]       # the MWCNN's conv + bias + ReLU blocks
     try:
         for kind, c0, cout, h, w in cases:
