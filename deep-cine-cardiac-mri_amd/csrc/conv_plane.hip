@@ -50,7 +50,8 @@ __device__ __forceinline__ float add_xor32(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// MODE 0: plain source (no statistics); 1: InstanceNorm + LeakyReLU on load, one source or the concat of two; 2: the same + 2x2 average pool
+// MODE 0: plain source (no statistics); 1: InstanceNorm + LeakyReLU on load, one source or the concat of two; 2: the same + 2x2 average pool;
+// 3: the same + Haar DWT (mwcnn.py:224-236): conv input channel band * c0 + c = that band of source channel c, whole 8-channel chunks of one band
 template <int CK, int CT, int WM, int WN, int MT, int TW, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::MINW)) void conv_plane_kernel(PlaneArgs a) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
@@ -91,11 +92,12 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
     float* const lrow = in_lds + sgc * C::PS + srow * C::COLS + PW * sj;
 
     float4 wraw[NWT];
-    piece_t xraw[MODE == 2 ? 1 : NCI];
+    constexpr bool HALF = MODE == 2 || MODE == 3;          // the source has twice the plane's extent: 2 x 2 input values per staged value
+    piece_t xraw[HALF ? 1 : NCI];
     // pooled source: the first NPRE pieces of a chunk are prefetched like the plain ones (2 PW floats of two source rows each)
-    constexpr int NPRE = MODE == 2 ? (NCI < 2 ? NCI : 2) : 0;
+    constexpr int NPRE = HALF ? (NCI < 2 ? NCI : 2) : 0;
     float4 praw[NPRE > 0 ? NPRE : 1][PW == 4 ? 4 : 2];
-    const float* const pbase = MODE == 2 ? a.x0 + ((long)n * a.c0 + sgc) * a.cs0 + (long)(2 * min(max(gy, 0), a.H - 1)) * (2 * TW) + 2 * PW * sj : nullptr;
+    const float* const pbase = HALF ? a.x0 + ((long)n * a.c0 + sgc) * a.cs0 + (long)(2 * min(max(gy, 0), a.H - 1)) * (2 * TW) + 2 * PW * sj : nullptr;
     auto issue = [&](int chunk) {
         const float* wsrc = wp + (long)chunk * 9 * CK * a.rowsp;
 #pragma unroll
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             if (CK == 4) row = (row / CK) * 8 + row % CK;           // 4-channel chunk over the 8-channel packing
             wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wp);
         }
-        if constexpr (MODE != 2) {
+        if constexpr (!HALF) {
             const int ci0 = chunk * CK;
             const bool first = ci0 < a.c0;
             const int cl0 = first ? ci0 : ci0 - a.c0;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
         } else {
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const float* src = pbase + (long)(chunk * CK + i * G) * a.cs0;
+                const float* src = pbase + (long)((MODE == 3 ? (chunk * CK) % a.c0 : chunk * CK) + i * G) * a.cs0;
                 if constexpr (PW == 4) {
                     praw[i][0] = *reinterpret_cast<const float4*>(src); praw[i][1] = *reinterpret_cast<const float4*>(src + 4);
                     praw[i][2] = *reinterpret_cast<const float4*>(src + 2 * TW); praw[i][3] = *reinterpret_cast<const float4*>(src + 2 * TW + 4);
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = co0 + c4 < a.rowsp ? wraw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int ci0 = chunk * CK;
-        if constexpr (MODE != 2) {
+        if constexpr (!HALF) {
             if (slot && rowok) {
                 const float* stp = st_lds + 2 * (ci0 + sgc);
 #pragma unroll
@@ -219,16 +221,25 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
         } else {
             // pooled source (extent sh0 x 2 TW): 2 PW floats from each of two rows per piece; pieces >= NPRE are loaded here
             if (slot && rowok && 2 * gy + 1 < a.sh0) {
-                const float* sb = pbase + (long)ci0 * a.cs0;
-                const float* stp = st_lds + 2 * (ci0 + sgc);
+                const int cs = MODE == 3 ? ci0 % a.c0 : ci0;          // first source channel of the chunk (uniform)
+                const int band = MODE == 3 ? ci0 / a.c0 : 0;          // DWT: LL, HL, LH, HH (uniform)
+                const float* sb = pbase + (long)cs * a.cs0;
+                const float* stp = st_lds + 2 * (cs + sgc);
                 auto pooled = [&](const float* t0, const float* t1, int i) {
                     const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
                     piece_t o;
                     float* ov = reinterpret_cast<float*>(&o);
 #pragma unroll
-                    for (int u = 0; u < PW; ++u)
-                        ov[u] = 0.25f * (act(t0[2 * u], ss.x, ss.y, a.slope) + act(t0[2 * u + 1], ss.x, ss.y, a.slope) +
-                                         act(t1[2 * u], ss.x, ss.y, a.slope) + act(t1[2 * u + 1], ss.x, ss.y, a.slope));
+                    for (int u = 0; u < PW; ++u) {
+                        if constexpr (MODE == 3) {                    // conv_src.h fetch_scalar's operation order (bit-identical)
+                            const float x1 = 0.5f * act(t0[2 * u], ss.x, ss.y, a.slope), x3 = 0.5f * act(t0[2 * u + 1], ss.x, ss.y, a.slope);
+                            const float x2 = 0.5f * act(t1[2 * u], ss.x, ss.y, a.slope), x4 = 0.5f * act(t1[2 * u + 1], ss.x, ss.y, a.slope);
+                            ov[u] = band == 0 ? x1 + x2 + x3 + x4 : band == 1 ? -x1 - x2 + x3 + x4 : band == 2 ? -x1 + x2 - x3 + x4 : x1 - x2 - x3 + x4;
+                        } else {
+                            ov[u] = 0.25f * (act(t0[2 * u], ss.x, ss.y, a.slope) + act(t0[2 * u + 1], ss.x, ss.y, a.slope) +
+                                             act(t1[2 * u], ss.x, ss.y, a.slope) + act(t1[2 * u + 1], ss.x, ss.y, a.slope));
+                        }
+                    }
                     *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
                 };
 #pragma unroll
@@ -476,8 +487,11 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     if (s0.mode == 0 && s1.c == 0) mode = 0;                            // the 2-channel first layer (4-channel chunk); the input-gradient convs of training
     else if (s0.mode == 1 && (s1.c == 0 || s1.mode == 1) && ck == 8) mode = 1;
     else if (s0.mode == 2 && s1.c == 0 && ck == 8) mode = 2;
+    else if (s0.mode == 3 && (s0.act & 1) && s1.c == 0 && ck == 8 && s0.c % 8 == 0) mode = 3;
     else return CINE_OK;
-    if (mode != 2) {
+    if (mode == 3) {
+        if (s0.w != 2 * a.W || s0.h != 2 * a.H) return CINE_OK;
+    } else if (mode != 2) {
         if (s0.w != a.W || s0.h != a.H || (s1.c > 0 && (s1.w != a.W || s1.h != a.H))) return CINE_OK;
         if (s1.c > 0 && s0.c % ck != 0) return CINE_OK;
     } else {
@@ -516,6 +530,9 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 1, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 8, 1, true)           // 16 -> 64 before an IWT
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 3, true)           // first conv of an MWCNN scale: Haar DWT of the scale above on load
+    CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 3, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 3, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 13, 8, 2, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 1, true)

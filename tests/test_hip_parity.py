@@ -384,16 +384,20 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
     cases += [("norm", 16, 16, 200, 16), ("pool", 16, 32, 100, 8), ("norm", 128, 128, 25, 2), ("norm", 24, 16, 52, 16)]     # ragged last tiles, 3 chunks
     cases += [("norm", 16, 16, 100, 8), ("norm", 32, 32, 50, 4), ("norm", 64, 64, 25, 2), ("norm", 64, 32, 48, 4),
               ("norm", 16, 64, 100, 8), ("plain", 10, 16, 200, 16), ("norm", 12, 16, 200, 16)]          # the MWCNN's inner conv blocks (cfg 3 planes), 16 -> 64 before an IWT, 8 + 2 input channels
+    cases += [("dwt", 16, 16, 100, 8), ("dwt", 16, 32, 50, 4), ("dwt", 32, 64, 25, 2), ("dwt", 8, 16, 96, 8)]              # Haar DWT of the scale above on load (first conv of an MWCNN scale)
     cases += [("relu", 16, 16, 208, 8), ("relu", 32, 32, 100, 4), ("relu", 64, 64, 50, 2), ("relu", 16, 16, 200, 16)]       # the MWCNN's conv + bias + ReLU blocks
     try:
         for kind, c0, cout, h, w in cases:
             g = torch.Generator().manual_seed(c0 * 131 + cout + h)
-            cin = 2 * c0 if kind == "concat" else c0
+            cin = 2 * c0 if kind == "concat" else 4 * c0 if kind == "dwt" else c0
             wa = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
             wb = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
             if kind == "pool":
                 x = torch.randn(n, c0, 2 * h, 2 * w, generator=g).to(dev)
                 srcs = [(x, ops.instnorm_partials(x), 2)]
+            elif kind == "dwt":
+                x = torch.randn(n, c0, 2 * h, 2 * w, generator=g).to(dev)
+                srcs = [(x, ops.instnorm_partials(x), 3 | 8)]                    # mode 3 = DWT on load, bit 3 = the source is raw (normalise + LeakyReLU first)
             elif kind == "concat":
                 x = torch.randn(n, c0, h, w, generator=g).to(dev); x2 = torch.randn(n, c0, h, w, generator=g).to(dev)
                 # `up` comes out of a transpose conv: several statistics records per plane
