@@ -51,7 +51,10 @@ __device__ __forceinline__ float add_xor32(float x) {
 }
 
 // MODE 0: plain source (no statistics); 1: InstanceNorm + LeakyReLU on load, one source or the concat of two; 2: the same + 2x2 average pool;
-// 3: the same + Haar DWT (mwcnn.py:224-236): conv input channel band * c0 + c = that band of source channel c, whole 8-channel chunks of one band
+// 3: the same + Haar DWT (mwcnn.py:224-236): conv input channel band * c0 + c = that band of source channel c, whole 8-channel chunks of one band;
+// 4: Haar IWT of source 0 (4 cin channels at half the extent, mwcnn.py:252-261) PLUS source 1 (cin channels of the plane's extent), both
+//    InstanceNorm + LeakyReLU on load (the additive skips of mwcnn.py:164,172): source 1 rides in the register prefetch, the IWT inputs are
+//    read when the chunk is committed
 template <int CK, int CT, int WM, int WN, int MT, int TW, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::MINW)) void conv_plane_kernel(PlaneArgs a) {
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
         }
         if constexpr (!HALF) {
             const int ci0 = chunk * CK;
-            const bool first = ci0 < a.c0;
-            const int cl0 = first ? ci0 : ci0 - a.c0;
+            const bool first = MODE == 4 ? false : ci0 < a.c0;          // MODE 4: the prefetched pieces are the skip's (source 1, conv channel = its channel)
+            const int cl0 = MODE == 4 ? ci0 : (first ? ci0 : ci0 - a.c0);
             const int sc = first ? a.c0 : a.c1;
             const char* sb = reinterpret_cast<const char*>(first ? a.x0 : a.x1) + ((size_t)n * sc + cl0) * cstride;   // uniform
             const int cmax = sc - 1 - cl0;
@@ -203,7 +206,38 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
         const int ci0 = chunk * CK;
         if constexpr (!HALF) {
             if (slot && rowok) {
-                const float* stp = st_lds + 2 * (ci0 + sgc);
+                const float* stp = st_lds + 2 * ((MODE == 4 ? a.c0 : 0) + ci0 + sgc);
+                if constexpr (MODE == 4) {
+                    constexpr int NS = PW / 2;
+                    const int cq = a.c0 >> 2, hs = a.H >> 1;
+                    const bool ry = gy & 1;
+                    const float* ib = a.x0 + (((long)n * a.c0 + ci0 + sgc) * hs + (gy >> 1)) * (TW / 2) + ((PW * sj) >> 1);
+#pragma unroll 2
+                    for (int i = 0; i < NCI; ++i) {
+                        float v[4][NS];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int c = ci0 + sgc + i * G + k * cq;
+                            const float* src = ib + (long)(i * G + k * cq) * hs * (TW / 2);
+                            if constexpr (NS == 2) { const float2 t2 = *reinterpret_cast<const float2*>(src); v[k][0] = t2.x; v[k][NS - 1] = t2.y; }
+                            else v[k][0] = src[0];
+                            const float2 sk = *reinterpret_cast<const float2*>(st_lds + 2 * c);
+#pragma unroll
+                            for (int e = 0; e < NS; ++e) v[k][e] = 0.5f * act(v[k][e], sk.x, sk.y, a.slope);
+                        }
+                        piece_t o = xraw[i];
+                        float* ov = reinterpret_cast<float*>(&o);
+                        const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
+#pragma unroll
+                        for (int e = 0; e < NS; ++e) {                  // conv_tile's operation order: the IWT value, then += the activated skip
+                            const float e0 = ry ? v[0][e] - v[1][e] + v[2][e] - v[3][e] : v[0][e] - v[1][e] - v[2][e] + v[3][e];
+                            const float e1 = ry ? v[0][e] + v[1][e] + v[2][e] + v[3][e] : v[0][e] + v[1][e] - v[2][e] - v[3][e];
+                            ov[2 * e] = e0 + act(ov[2 * e], ss.x, ss.y, a.slope);
+                            ov[2 * e + 1] = e1 + act(ov[2 * e + 1], ss.x, ss.y, a.slope);
+                        }
+                        *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                    }
+                } else
 #pragma unroll
                 for (int i = 0; i < NCI; ++i) {
                     piece_t o = xraw[i];
@@ -478,19 +512,24 @@ int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
     if (!(g_plane_on.load(std::memory_order_relaxed) & 1)) return CINE_OK;
-    if (a.vol || a.D != 1 || a.add_src1 || a.addend || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
+    if (a.vol || a.D != 1 || a.addend || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
     if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || !al16(a.wp0) || !al16(a.wp1)) return CINE_OK;
     int mode;
-    if (s0.mode == 0 && s1.c == 0) mode = 0;                            // the 2-channel first layer (4-channel chunk); the input-gradient convs of training
+    if (a.add_src1) {                                                   // the MWCNN's IWT + additive skip, nothing else
+        if (!(s0.mode == 4 && (s0.act & 1) && s1.mode == 1 && ck == 8 && s0.c == 4 * s1.c && s1.c == a.cin && a.cin % 8 == 0)) return CINE_OK;
+        mode = 4;
+    } else if (s0.mode == 0 && s1.c == 0) mode = 0;                            // the 2-channel first layer (4-channel chunk); the input-gradient convs of training
     else if (s0.mode == 1 && (s1.c == 0 || s1.mode == 1) && ck == 8) mode = 1;
     else if (s0.mode == 2 && s1.c == 0 && ck == 8) mode = 2;
     else if (s0.mode == 3 && (s0.act & 1) && s1.c == 0 && ck == 8 && s0.c % 8 == 0) mode = 3;
     else return CINE_OK;
     if (mode == 3) {
         if (s0.w != 2 * a.W || s0.h != 2 * a.H) return CINE_OK;
+    } else if (mode == 4) {
+        if (2 * s0.w != a.W || 2 * s0.h != a.H || s1.w != a.W || s1.h != a.H || reinterpret_cast<uintptr_t>(s0.x) % 8 != 0) return CINE_OK;
     } else if (mode != 2) {
         if (s0.w != a.W || s0.h != a.H || (s1.c > 0 && (s1.w != a.W || s1.h != a.H))) return CINE_OK;
         if (s1.c > 0 && s0.c % ck != 0) return CINE_OK;
@@ -530,6 +569,9 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 1, true)
     CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 1, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 8, 1, true)           // 16 -> 64 before an IWT
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 16, 4, true)          // first conv of an MWCNN synthesis scale / its last conv: IWT of the scale below + additive skip
+    CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 4, true)
+    CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 4, true)
     CINE_PLANE_CASE(8, 1, 1, 4, 13, 8, 3, true)           // first conv of an MWCNN scale: Haar DWT of the scale above on load
     CINE_PLANE_CASE(8, 1, 2, 2, 7, 4, 3, true)
     CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 3, true)

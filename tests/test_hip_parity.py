@@ -385,6 +385,7 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
     cases += [("norm", 16, 16, 100, 8), ("norm", 32, 32, 50, 4), ("norm", 64, 64, 25, 2), ("norm", 64, 32, 48, 4),
               ("norm", 16, 64, 100, 8), ("plain", 10, 16, 200, 16), ("norm", 12, 16, 200, 16)]          # the MWCNN's inner conv blocks (cfg 3 planes), 16 -> 64 before an IWT, 8 + 2 input channels
     cases += [("dwt", 16, 16, 100, 8), ("dwt", 16, 32, 50, 4), ("dwt", 32, 64, 25, 2), ("dwt", 8, 16, 96, 8)]              # Haar DWT of the scale above on load (first conv of an MWCNN scale)
+    cases += [("iwt", 16, 16, 100, 8), ("iwt", 32, 32, 50, 4), ("iwt", 16, 10, 200, 16), ("iwt", 8, 16, 96, 8)]             # Haar IWT of the scale below + additive skip on load (last: bias, no statistics)
     cases += [("relu", 16, 16, 208, 8), ("relu", 32, 32, 100, 4), ("relu", 64, 64, 50, 2), ("relu", 16, 16, 200, 16)]       # the MWCNN's conv + bias + ReLU blocks
     try:
         for kind, c0, cout, h, w in cases:
@@ -407,10 +408,26 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
             else:
                 x = torch.randn(n, c0, h, w, generator=g).to(dev)
                 srcs = [(x, ops.instnorm_partials(x) if kind == "norm" else None, 1 if kind == "norm" else 0)]
+            elif_iwt = kind == "iwt"
+            if elif_iwt:
+                cur = torch.randn(n, 4 * c0, h // 2, w // 2, generator=g).to(dev)
+                pc, px = ops.instnorm_partials(cur), ops.instnorm_partials(x)
+                bias_i = torch.randn(cout, generator=g).to(dev) if cout == 10 else None
             outs = []
             for on in (7, 0):
                 assert lib().cine_set_conv_plane(on) == 0
-                if kind == "relu":
+                if elif_iwt:
+                    y = torch.empty(n, cout, h, w, device=dev)
+                    py = None if bias_i is not None else torch.empty((n, cout, lib().cine_conv_stat_partials(cout, h, w, 0), 3), device=dev)
+                    pa, pb = ops.pack_conv3x3(wa), ops.pack_conv3x3(wb)
+                    ptr = lambda t_: None if t_ is None else t_.data_ptr()
+                    rc = lib().cine_conv3x3_ex2(cur.data_ptr(), pc.data_ptr(), pc.shape[2], 4 * c0, 4 | 8, h // 2, w // 2,
+                                                x.data_ptr(), px.data_ptr(), px.shape[2], c0, 1, h, w, 1,
+                                                pa.data_ptr(), ptr(bias_i), pb.data_ptr(), ptr(bias_i), 4, None, 0,
+                                                y.data_ptr(), ptr(py), n, cout, h, w, ops.IN_EPS, ops.LRELU_SLOPE, torch.cuda.current_stream().cuda_stream)
+                    assert rc == 0
+                    outs.append((y, py))
+                elif kind == "relu":
                     bias = torch.randn(cout, generator=torch.Generator().manual_seed(cout)).to(dev)
                     outs.append((ops.conv3x3_sum([x], ops.pack_conv3x3(wa), bias, cout, relu=True), None))
                 else:
