@@ -1026,26 +1026,25 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
             if (pok) {
 #pragma unroll
                 for (int i = 0; i < NCI; ++i) {
-                    if (G == 1 && ci0 + i >= a.cin) break;
                     float4 o = xraw[i];
-                    if constexpr (MODE == 1) {
+                    const bool gone = G == 1 && ci0 + i >= a.cin;       // uniform: the last chunk of a layer whose input is not a multiple of 8 channels
+                    if constexpr (MODE == 1) {                          // (2-channel first layers; the CRNN's 16 + 2) -- zeros over the previous chunk's values
                         const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
                         act_piece<4>(reinterpret_cast<float*>(&o), ss.x, ss.y, a.slope);
                     }
-                    if (!srcok) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (!srcok || gone) o = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(lrow + i * G * C::PS) = o;
                 }
             }
             if (hslot && hok) {
 #pragma unroll
                 for (int i = 0; i < NCI; ++i) {
-                    if (G == 1 && ci0 + i >= a.cin) break;
                     float v = hraw[i];
                     if constexpr (MODE == 1) {
                         const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
                         v = act(v, ss.x, ss.y, a.slope);
                     }
-                    lhalo[i * G * C::PS] = srcok ? v : 0.f;
+                    lhalo[i * G * C::PS] = (srcok && !(G == 1 && ci0 + i >= a.cin)) ? v : 0.f;
                 }
             }
         }
@@ -1259,7 +1258,10 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     // whole 8-channel chunks (two sources: the first one too); a narrower layer only as ONE chunk on the one-channel-group shape
     const bool whole = a.cin % 8 == 0 && (s1.c == 0 || s0.c % 8 == 0);
     const bool narrow_ok = ncc == 1 && s1.c == 0 && ct == 1 && wm == 1 && wn == 4;
-    if (!whole && !narrow_ok) return CINE_OK;
+    // ... or as the LAST chunk of several on the 52-row shape (one channel group: every thread stages all 8 channels of its slot), the
+    // first source ending on a chunk boundary: the CRNN's all-frame conv over cat(hidden 16, image 2)
+    const bool ragged_ok = ct == 1 && wm == 1 && wn == 4 && mt == 13 && (s1.c == 0 || s0.c % 8 == 0);
+    if (!whole && !narrow_ok && !ragged_ok) return CINE_OK;
     WideArgs p{};
     p.x0 = s0.x; p.part0 = s0.part; p.c0 = s0.c; p.np0 = s0.np; p.d0 = d0;
     p.x1 = s1.c > 0 ? s1.x : nullptr; p.part1 = s1.c > 0 ? s1.part : nullptr; p.c1 = s1.c; p.np1 = s1.c > 0 ? s1.np : 0; p.d1 = d1;

@@ -480,17 +480,19 @@ def test_conv_wide_bit_identical_to_general_kernel(dev):
     n = 4                # (>= 4 planes of 200 x 200: the regular 52-row tiles, not the few-sample small-tile configuration)
     try:
         for kind, c0, cout, h, w in (("norm", 8, 8, 208, 208), ("norm", 16, 16, 104, 104), ("norm", 32, 32, 52, 52), ("norm", 64, 64, 26, 28),
-                                     ("plain", 2, 8, 208, 208), ("concat", 8, 8, 120, 200), ("sum", 16, 16, 200, 200), ("sum1", 16, 2, 200, 200)):
+                                     ("plain", 2, 8, 208, 208), ("concat", 8, 8, 120, 200), ("sum", 16, 16, 200, 200), ("sum1", 16, 2, 200, 200),
+                                     ("sum_ragged", 16, 16, 200, 200), ("plain", 10, 8, 200, 200)):     # the BCRNN's all-frame conv over cat(hidden 16, image 2): 8 + 8 + 2
             g = torch.Generator().manual_seed(c0 * 7 + cout + h)
-            cin = 2 * c0 if kind in ("concat", "sum") else c0
+            c2 = 2 if kind == "sum_ragged" else c0
+            cin = c0 + c2 if kind in ("concat", "sum", "sum_ragged") else c0
             wp = ops.pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev))
-            x = torch.randn(n, c0, h, w, generator=g).to(dev); x2 = torch.randn(n, c0, h, w, generator=g).to(dev)
+            x = torch.randn(n, c0, h, w, generator=g).to(dev); x2 = torch.randn(n, c2, h, w, generator=g).to(dev)
             bias = torch.randn(cout, generator=g).to(dev); add = torch.randn(n, cout, h, w, generator=g).to(dev)
             outs = []
             for on in (7, 3):
                 assert lib().cine_set_conv_plane(on) == 0
-                if kind in ("sum", "sum1"):
-                    outs.append((ops.conv3x3_sum([x, x2] if kind == "sum" else [x], wp, bias, cout, addend=add, relu=kind == "sum"), None))
+                if kind in ("sum", "sum1", "sum_ragged"):
+                    outs.append((ops.conv3x3_sum([x, x2] if kind != "sum1" else [x], wp, bias, cout, addend=add, relu=kind == "sum"), None))
                 elif kind == "concat":
                     outs.append(ops.conv3x3_in([(x, ops.instnorm_partials(x), 1), (x2, ops.instnorm_partials(x2), 1)], wp, cout, h, w))
                 else:
