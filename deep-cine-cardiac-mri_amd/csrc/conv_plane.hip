@@ -212,8 +212,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
                     const int cq = a.c0 >> 2, hs = a.H >> 1;
                     const bool ry = gy & 1;
                     const float* ib = a.x0 + (((long)n * a.c0 + ci0 + sgc) * hs + (gy >> 1)) * (TW / 2) + ((PW * sj) >> 1);
-#pragma unroll 2
-                    for (int i = 0; i < NCI; ++i) {
+#pragma unroll
+                    for (int i = 0; i < NCI; ++i) {           // (fully unrolled: xraw[] must stay in registers)
                         float v[4][NS];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
