@@ -742,8 +742,16 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
     CINE_STAMP_RT(10);
 }
 
+// the volume forms' staging (depth offsets, ragged 4-byte-aligned pieces) needs more registers than ConvCfg's estimate: with the small-tile
+// shapes' four waves per SIMD (128 VGPRs) the compiler spilled 172 B per thread in the chunk loop of the coarse 3-D U-Net levels, which
+// run 12 - 156 workgroups per launch and gain nothing from occupancy
+template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3>
+constexpr int conv_minw() {
+    constexpr int m = ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW, cap = WM == 4 ? 2 : 3;      // WM == 4: the 64 / 128-row shapes of the coarse levels
+    return (V3 != 0 && m > cap) ? cap : m;
+}
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS, int V3 = 0>
-__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS>::MINW)) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (conv_minw<CK, CT, WM, WN, MT, TW, TAPS, V3>())) void conv_mfma_kernel(ConvArgs a) {
     extern __shared__ __align__(16) float smem_f[];
     conv_tile<CK, CT, WM, WN, MT, TW, TAPS, V3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem_f);
 }
