@@ -499,6 +499,7 @@ int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
         CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "conv_plane_kernel: hipFuncSetAttribute: %s", hipGetErrorString(status[dev]));
     }
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv_plane_kernel: %d input channels need %zu bytes of LDS", p.cin, lds);
+    CINE_REQUIRE(C::G == 1 || p.cin % CK == 0, CINE_EUNSUPPORTED, "conv_plane_kernel: %d input channels on a shape with %d channel groups", p.cin, C::G);
     const dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
     ProfScope prof(F_CONV3, st);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, p);
@@ -1223,6 +1224,9 @@ int launch_wide(const WideArgs& p, int n, hipStream_t st) {
         CINE_REQUIRE(status[dev] == hipSuccess, CINE_EHIP, "conv_wide_kernel: hipFuncSetAttribute: %s", hipGetErrorString(status[dev]));
     }
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv_wide_kernel: %d input channels need %zu bytes of LDS", p.cin, lds);
+    // the staging map reads channels g, g + G, ... of a chunk unconditionally when G > 1: such shapes take whole 8-channel chunks only
+    CINE_REQUIRE(C::G == 1 || (p.cin % 8 == 0 && p.c0 % 8 == 0), CINE_EUNSUPPORTED,
+                 "conv_wide_kernel: %d (+%d) input channels on a shape with %d channel groups", p.c0, p.c1, C::G);
     const dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
     ProfScope prof(F_CONV3, st);
     hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, p);
@@ -1257,7 +1261,9 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     const int ncc = v3 ? a.ncc : a.nchunks;
     // whole 8-channel chunks (two sources: the first one too); a narrower layer only as ONE chunk on the one-channel-group shape
     const bool whole = a.cin % 8 == 0 && (s1.c == 0 || s0.c % 8 == 0);
-    const bool narrow_ok = ncc == 1 && s1.c == 0 && ct == 1 && wm == 1 && wn == 4;
+    // (mt == 13: ONE channel group, every thread stages channels 0 .. 7 of its slot and clamps the ones that do not exist; the 16-row
+    //  shape has two groups whose second would read channels past the end of the tensor)
+    const bool narrow_ok = ncc == 1 && s1.c == 0 && ct == 1 && wm == 1 && wn == 4 && mt == 13;
     // ... or as the LAST chunk of several on the 52-row shape (one channel group: every thread stages all 8 channels of its slot), the
     // first source ending on a chunk boundary: the CRNN's all-frame conv over cat(hidden 16, image 2)
     const bool ragged_ok = ct == 1 && wm == 1 && wn == 4 && mt == 13 && (s1.c == 0 || s0.c % 8 == 0);
