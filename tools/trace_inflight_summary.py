@@ -1,4 +1,6 @@
-"""Per-kernel time of an in-flight run from a rocprofv3 kernel trace: calls, summed duration, average, and the run's concurrency
+"""(rocprofv3 --kernel-trace serialises the dispatches of different streams on this stack: the concurrency it reports is 1.0 and the
+durations are the isolated ones -- useful only as a per-kernel table of an in-flight COMMAND, not as evidence of overlap.)
+Per-kernel time of an in-flight run from a rocprofv3 kernel trace: calls, summed duration, average, and the run's concurrency
 (summed kernel time / union of busy intervals) over the last `frac` of the trace (the timed region; the first part is warm-up/capture).
   python tools/trace_inflight_summary.py <t_kernel_trace.csv> [frac=0.5]"""
 import csv, sys, collections, re
