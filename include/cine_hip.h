@@ -48,7 +48,9 @@ const char* cine_build_arch(void);      /* "gfx950" */
  * ------------------------------------------------------------------------------------------ */
 
 /* fft2c (fftc.py:59-83) / ifft2c (fftc.py:86-110) over the last two spatial dims of
- * `nimg` images of h x w complex.  inverse = 0 forward, 1 inverse.  in == out allowed. */
+ * `nimg` images of h x w complex.  inverse = 0 forward, 1 inverse.  in == out allowed.
+ * Line lengths (every transform of this header): 200 (the 10 x 20 engine), any 2^a 3^b 5^c <= 512 (mixed-radix Stockham engine),
+ * any other length <= 400 (direct DFT in LDS); CINE_EUNSUPPORTED beyond. */
 int cine_fft2c(const float* in, float* out, int nimg, int h, int w, int inverse, void* stream);
 
 /* fft1c (fftc.py:5-29) / ifft1c (fftc.py:32-56): `nlines` contiguous lines of n complex.
