@@ -658,8 +658,9 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
     const cf* xp = a.img + (long)bt * HW;
     CINE_STAMP(0);
     cf svk[2][10];          // the sensitivities stay in registers for P3: 140 VGPRs, three workgroups per CU (48 vs 56 us re-reading them)
-    // ---- P1
+    // ---- P1: the loads of BOTH items first (40 per thread in flight: one memory latency instead of two), then the two radix-10 items
     if (active) {
+        cf v2[2][10];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int item = tid + r * kDcAct;
@@ -668,13 +669,17 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
             const int colc = min(w0c + line % CW, a.W - 1);                 // clamped: lanes past the edge are never stored
             const cf* sp = a.sens + ((long)b * a.C + min(c0 + slot, a.C - 1)) * HW + colc;
             const cf* xq = xp + colc;
-            cf v[10], sv[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) { sv[j] = sp[rot20(j, c) * a.W]; v[j] = xq[rot20(j, c) * a.W]; }
+            for (int j = 0; j < 10; ++j) { svk[r][j] = sp[rot20(j, c) * a.W]; v2[r][j] = xq[rot20(j, c) * a.W]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 10; ++j) v[j] = cmul(v[j], sv[j]);
+        for (int r = 0; r < 2; ++r) {
+            const int item = tid + r * kDcAct;
+            const int line = item % kDcL, c = item / kDcL;
+            cf v[10];
 #pragma unroll
-            for (int j = 0; j < 10; ++j) svk[r][j] = sv[j];
+            for (int j = 0; j < 10; ++j) v[j] = cmul(v2[r][j], svk[r][j]);
             Fft200::r10_regs<1, false, true>(v, c, TW200);
 #pragma unroll
             for (int j = 0; j < 10; ++j) t[(20 * j + c) * LP + line] = v[j];
