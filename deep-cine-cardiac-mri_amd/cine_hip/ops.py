@@ -179,9 +179,24 @@ def soft_dc_blend(model_term: torch.Tensor, ref_kspace: torch.Tensor, mask: torc
     return (1 - m) * model_term + m * (model_term + v * ref_kspace) / (1 + v)
 
 
+def sens_tile_pack(sens: torch.Tensor) -> Optional[torch.Tensor]:
+    """The maps (b, 1, c, h, w, 2) in the column-tile-major order the h == 200 image-space operators read fastest (cine_sens_tile_pack);
+    None where no kernel reads it.  The maps are constant over a forward pass: pack once after the sens-net, hand it to every
+    ``image_dc`` / ``normal_op`` / ``normal_op_cg_step`` call as ``sens_tiled`` (results are identical with or without it)."""
+    _pair(sens)
+    sens = _dev(sens, "sens_maps")
+    b, _, c, h, w, _ = sens.shape
+    nfl = lib().cine_sens_tile_floats(b, c, h, w)
+    if nfl == 0:
+        return None
+    out = torch.empty(nfl, device=sens.device, dtype=sens.dtype)
+    check(lib().cine_sens_tile_pack(sens.data_ptr(), out.data_ptr(), b, c, h, w, _stream()), "cine_sens_tile_pack")
+    return out
+
+
 def image_dc(img: torch.Tensor, sens: torch.Tensor, zf: Optional[torch.Tensor], mask: torch.Tensor,
              lambda_reg: Optional[torch.Tensor] = None, weights=(1.0, 0.0, 0.0), magnitude: bool = False,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, sens_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """sens_reduce(DC(sens_expand(img))) of reference varnet.py:181-194, 281-282 on the coil-combined image (row masks):
     sum_c conj(S_c) IFFT_h[wgt * FFT_h(S_c img)] + beta * zf.  ``lambda_reg``: soft-DC weights from softplus(lambda);
     else ``weights`` = (w_sampled, w_unsampled, beta).  img (b,t,[1,]h,w,2) -> (b,t,1,h,w,2), or (b,t,h,w) magnitude."""
@@ -201,12 +216,13 @@ def image_dc(img: torch.Tensor, sens: torch.Tensor, zf: Optional[torch.Tensor], 
     w1, w0, beta = (float(v) for v in weights)
     nbytes = lib().cine_image_dc_ws_bytes(b, t, c, h, w)
     ws = torch.empty(nbytes, device=img.device, dtype=torch.uint8) if nbytes else None
-    check(lib().cine_image_dc(img.data_ptr(), sens.data_ptr(), _p(zf), mask.data_ptr(), _p(lam), w1, w0, beta,
-                              out.data_ptr(), b, t, c, h, w, int(magnitude), _p(ws), nbytes, _stream()), "cine_image_dc")
+    check(lib().cine_image_dc_t(img.data_ptr(), sens.data_ptr(), _p(sens_tiled), _p(zf), mask.data_ptr(), _p(lam), w1, w0, beta,
+                                out.data_ptr(), b, t, c, h, w, int(magnitude), _p(ws), nbytes, _stream()), "cine_image_dc")
     return out
 
 
-def normal_op(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor) -> torch.Tensor:
+def normal_op(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor,
+              sens_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """A^H M A img + softplus(lambda) img for a row mask (CineNet's H operator, reference cinenet.py:121-133) -> (b,t,1,h,w,2)."""
     _pair(img); _pair(sens)
     img = _dev(img, "image"); sens = _dev(sens, "sens_maps"); mask = _dev(mask, "mask", torch.uint8)
@@ -218,18 +234,18 @@ def normal_op(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_
     out = torch.empty((b, t, 1, h, w, 2), device=img.device, dtype=img.dtype)
     nbytes = lib().cine_image_dc_ws_bytes(b, t, c, h, w)
     ws = torch.empty(nbytes, device=img.device, dtype=torch.uint8) if nbytes else None
-    check(lib().cine_normal_op(img.data_ptr(), sens.data_ptr(), mask.data_ptr(), lam.data_ptr(), out.data_ptr(), b, t, c, h, w,
-                               _p(ws), nbytes, _stream()), "cine_normal_op")
+    check(lib().cine_normal_op_t(img.data_ptr(), sens.data_ptr(), _p(sens_tiled), mask.data_ptr(), lam.data_ptr(), out.data_ptr(), b, t, c, h, w,
+                                 _p(ws), nbytes, _stream()), "cine_normal_op")
     return out
 
 
 def h_operator(x: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor,
-               _hyb: Optional[torch.Tensor] = None) -> torch.Tensor:
+               _hyb: Optional[torch.Tensor] = None, sens_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """CineNet's H = A^H M A + softplus(lambda) I (reference cinenet.py:121-133) for either mask layout: the one-kernel image-space
     operator for a (b, t, 1, h, 1, 1) row mask, the literal expand -> mask -> reduce chain for a mask that varies along w."""
     full = sens.expand(-1, x.shape[1], -1, -1, -1, -1)
     if is_row_mask(mask, full):
-        return normal_op(x, sens, mask, lambda_reg)
+        return normal_op(x, sens, mask, lambda_reg, sens_tiled)
     if is_general_mask(mask, full):
         k = sens_expand_dc(x, sens)
         k = k * mask.to(k.dtype) + 0.0                       # cinenet.py:129
@@ -489,7 +505,8 @@ def cg_step(x: torch.Tensor, r: torch.Tensor, p: torch.Tensor, d: torch.Tensor, 
     return rr_new
 
 
-def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: Optional[torch.Tensor] = None,
+                      sens_tiled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One conjugate-gradient iteration of reference cinenet.py:153-169 for a row mask: d = H p with the partial sums of p.d produced by
     the operator's last kernel (cine_normal_op_pd), then the alpha / x / r / r.r / beta / p updates (cine_cg_step_pd).  Falls back to
     normal_op + cg_step where the operator has no partial-sum kernel."""
@@ -512,9 +529,9 @@ def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: O
             _no_capture("the conjugate-gradient workspace of this stream")
             fws = _cg_ws[key] = torch.empty(fbytes, device=x.device, dtype=torch.uint8)
         dws = torch.empty(nbytes, device=p.device, dtype=torch.uint8)
-        check(lib().cine_normal_op_cg_fused(x.data_ptr(), r.data_ptr(), p.data_ptr(), _dev(sens, "sens_maps").data_ptr(),
-                                            _dev(mask, "mask", torch.uint8).data_ptr(), lam.data_ptr(), rr_old.data_ptr(), rr_new.data_ptr(),
-                                            _p(pd_out), b, t, c, h, w, dws.data_ptr(), nbytes, fws.data_ptr(), fbytes, _stream()),
+        check(lib().cine_normal_op_cg_fused_t(x.data_ptr(), r.data_ptr(), p.data_ptr(), _dev(sens, "sens_maps").data_ptr(), _p(sens_tiled),
+                                              _dev(mask, "mask", torch.uint8).data_ptr(), lam.data_ptr(), rr_old.data_ptr(), rr_new.data_ptr(),
+                                              _p(pd_out), b, t, c, h, w, dws.data_ptr(), nbytes, fws.data_ptr(), fbytes, _stream()),
               "cine_normal_op_cg_fused")
         return rr_new
     key = (x.device, torch.cuda.current_stream().cuda_stream)

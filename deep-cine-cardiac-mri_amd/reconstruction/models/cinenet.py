@@ -36,17 +36,17 @@ class CineNetBlock(nn.Module):
     def sens_reduce(self, x, sens_maps):
         return ops.sens_reduce(x, sens_maps)
 
-    def HOperator(self, x, mask, sens_maps, _hyb=None):
+    def HOperator(self, x, mask, sens_maps, _hyb=None, _tiled=None):
         """A^H M A x + softplus(lambda) x  (reference cinenet.py:121-133).  With the reference's row mask the normal
         operator is one image-space kernel (cine_image_dc with weights (1, 0, 0)): the mask commutes with the row FFT."""
-        return ops.h_operator(x, sens_maps, mask, self.lambda_reg, _hyb)
+        return ops.h_operator(x, sens_maps, mask, self.lambda_reg, _hyb, _tiled)
 
-    def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int):
+    def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int, _tiled=None):
         """Hx = b with exactly CG_iters iterations (reference cinenet.py:136-171)."""
         bsz, t, _, h, w, _ = x.shape
         rowmask = ops.is_row_mask(mask, sens_maps.expand(-1, t, -1, -1, -1, -1))
         hyb = None if rowmask else torch.empty((bsz, t, sens_maps.shape[2], h, w, 2), device=x.device, dtype=x.dtype)
-        r = ops.axpby_dev(b, self.HOperator(x, mask, sens_maps, hyb), num=_one(x), sign=-1.0)
+        r = ops.axpby_dev(b, self.HOperator(x, mask, sens_maps, hyb, _tiled), num=_one(x), sign=-1.0)
         p = r.clone()
         rr_old = ops.dot(r, r)
         x = x.clone()
@@ -54,7 +54,7 @@ class CineNetBlock(nn.Module):
         for _ in range(CG_iters):
             # d = H p; alpha = rr / p.d; x += alpha p; r -= alpha d; rr' = r.r; p = r + (rr' / rr) p   (:153-169), scalars on the device
             if rowmask:     # the p.d partial sums come out of the operator's own last kernel: four launches per iteration
-                ops.normal_op_cg_step(x, r, p, sens_maps, mask, self.lambda_reg, rr_old, rr_new)
+                ops.normal_op_cg_step(x, r, p, sens_maps, mask, self.lambda_reg, rr_old, rr_new, sens_tiled=_tiled)
             else:
                 ops.cg_step(x, r, p, self.HOperator(p, mask, sens_maps, hyb), rr_old, rr_new)
             rr_old, rr_new = rr_new, rr_old
@@ -102,14 +102,14 @@ class CineNetBlock(nn.Module):
             return ops.normunet3d_unpack(self.model(planes), None, t, h, w).view(b, t, 1, h, w, 2)
         raise ValueError(f"unknown dynamic_type {self.dynamic_type!r}")
 
-    def forward(self, image_pred, image_ref, mask, sens_maps):
+    def forward(self, image_pred, image_ref, mask, sens_maps, _tiled=None):
         if ag.grad_mode(self):
             model_out = self.regularise(image_pred)
             rhs = ag.AxpbyLamFn.apply(image_ref, model_out, self.lambda_reg)
             return ag.ConjGradFn.apply(model_out, rhs, self.lambda_reg, mask, sens_maps, self.CG_iters)
         model_out = self.regularise(image_pred)
         rhs = ops.axpby_dev(image_ref, model_out, lambda_reg=self.lambda_reg)       # x_ref + v x_reg
-        return self.ConjGrad(model_out, rhs, mask, sens_maps, self.CG_iters)
+        return self.ConjGrad(model_out, rhs, mask, sens_maps, self.CG_iters, _tiled)
 
 
 _ones = {}
@@ -151,6 +151,7 @@ class CineNet(nn.Module):
     def _forward_infer(self, masked_kspace, mask, sens_maps):
         image_pred = ops.sens_reduce(masked_kspace, sens_maps)
         image_ref = image_pred.clone()
+        tiled = ops.sens_tile_pack(sens_maps)          # once per forward: 42 applications of the normal operator read it (6 cascades x (1 + 6 CG iterations))
         for cascade in self.cascades:
-            image_pred = cascade(image_pred, image_ref, mask, sens_maps)
+            image_pred = cascade(image_pred, image_ref, mask, sens_maps, tiled)
         return ops.complex_abs(image_pred.squeeze(2))

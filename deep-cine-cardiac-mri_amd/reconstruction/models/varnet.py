@@ -191,6 +191,7 @@ class VarNet(nn.Module):
         ops.kspace_to_hybrid(masked_kspace, out=hyb, mask=mask)
         zf = ops.hybrid_reduce(hyb, sens_maps)                         # sens_reduce(mask * k_ref)
         last = len(self.cascades) - 1
+        tiled = ops.sens_tile_pack(sens_maps)          # the maps in the order the DC kernel reads fastest: once per forward, for every cascade
         for i, cascade in enumerate(self.cascades):
-            image = ops.image_dc(cascade.regularise(image), sens_maps, zf, mask, cascade.lambda_reg, magnitude=(i == last))
+            image = ops.image_dc(cascade.regularise(image), sens_maps, zf, mask, cascade.lambda_reg, magnitude=(i == last), sens_tiled=tiled)
         return image

@@ -122,6 +122,19 @@ int cine_image_dc(const float* img, const float* sens, const float* zf, const ui
  * shapes / workspace as cine_image_dc. */
 int cine_normal_op(const float* img, const float* sens, const uint8_t* mask, const float* lambda_dev,
                    float* out, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
+/* The sensitivities in column-tile-major order [b][c][ceil(w / 5)][200][5] (complex pairs; zero past the last column), for the h == 200
+ * image-space operators: a workgroup of imgdc200_kernel then reads each coil's 200 rows as one contiguous run instead of 40 bytes out of
+ * every 128-byte line (38 -> 34 us per launch at cfg 2 / cfg 4).  The maps are constant over a forward pass (varnet.py:144, cinenet.py
+ * forward's argument), so one pack serves its 6 - 42 operator applications.  cine_sens_tile_floats() == 0 where no kernel reads them
+ * (h != 200); the *_t entry points take the tiled copy beside the plain one (NULL = read the plain maps: identical results either way). */
+size_t cine_sens_tile_floats(int b, int c, int h, int w);
+int cine_sens_tile_pack(const float* sens, float* tiled, int b, int c, int h, int w, void* stream);
+int cine_image_dc_t(const float* img, const float* sens, const float* sens_tiled, const float* zf, const uint8_t* mask,
+                    const float* lambda_dev, float w_sampled, float w_unsampled, float beta,
+                    float* out, int b, int t, int c, int h, int w, int magnitude,
+                    void* ws, size_t ws_bytes, void* stream);
+int cine_normal_op_t(const float* img, const float* sens, const float* sens_tiled, const uint8_t* mask, const float* lambda_dev,
+                     float* out, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
 /* cine_normal_op that also leaves 256 partial sums of <img, out> in pd_part (device floats): the p.d of the conjugate-gradient step that
  * follows (models/cinenet.py:155-159), produced where `out` is produced instead of by a separate pass over both vectors; feed them to
  * cine_cg_step_pd (pd_part = the first 256 floats of its workspace).  CINE_EUNSUPPORTED where cine_image_dc_ws_bytes() is 0. */
@@ -415,6 +428,9 @@ size_t cine_cg_fused_ws_bytes(int b, int t, int c, int h, int w);
 int cine_normal_op_cg_fused(float* x, float* r, float* p, const float* sens, const uint8_t* mask, const float* lambda_dev,
                             const float* rr_old_dev, float* rr_new_dev, float* pd_out_dev, int b, int t, int c, int h, int w,
                             void* ws_dc, size_t ws_dc_bytes, void* ws_cg, size_t ws_cg_bytes, void* stream);
+int cine_normal_op_cg_fused_t(float* x, float* r, float* p, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                              const float* lambda_dev, const float* rr_old_dev, float* rr_new_dev, float* pd_out_dev,
+                              int b, int t, int c, int h, int w, void* ws_dc, size_t ws_dc_bytes, void* ws_cg, size_t ws_cg_bytes, void* stream);
 /* cine_cg_step_pd that also stores p.d into *pd_out_dev (training: the adjoint recurrence needs alpha_k = rr_k / pd_k). */
 int cine_cg_step_pd2(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                      float* pd_out_dev, void* ws, void* stream);

@@ -1226,6 +1226,31 @@ def test_image_dc_batch_and_identities(dev):
     assert rel_err(f(2 * x - 3 * y).cpu(), (2 * f(x) - 3 * f(y)).cpu()) < OP_TOL
 
 
+@pytest.mark.parametrize("t,c,w", [(15, 15, 200), (2, 17, 203), (3, 16, 8), (1, 5, 1), (2, 6, 37)])
+def test_tiled_sensitivities_give_the_same_bits(dev, t, c, w):
+    """cine_sens_tile_pack + the *_t operators (the maps in column-tile-major order, read as contiguous runs) against the plain maps:
+    identical outputs for the soft DC, CineNet's normal operator and a whole CG iteration; ragged last column tiles, 1 - 4 coil groups."""
+    from cine_hip import ops
+    h = 200
+    sens = rnd(2, 1, 1, c, h, w, 2).to(dev)
+    img, zf = rnd(3, 1, t, 1, h, w, 2).to(dev), rnd(4, 1, t, 1, h, w, 2).to(dev)
+    mask = _row_mask(t, h, 5).to(dev)
+    lam = torch.tensor([0.3], device=dev)
+    tiled = ops.sens_tile_pack(sens)
+    assert tiled is not None and ops.sens_tile_pack(rnd(5, 1, 1, 2, 24, 20, 2).to(dev)) is None
+    assert torch.equal(ops.image_dc(img, sens, zf, mask, lam, sens_tiled=tiled), ops.image_dc(img, sens, zf, mask, lam))
+    assert torch.equal(ops.image_dc(img, sens, zf, mask, lam, magnitude=True, sens_tiled=tiled), ops.image_dc(img, sens, zf, mask, lam, magnitude=True))
+    assert torch.equal(ops.normal_op(img, sens, mask, lam, tiled), ops.normal_op(img, sens, mask, lam))
+    outs = []
+    for st in (tiled, None):
+        x, r, p = img.clone(), zf.clone(), zf.clone()
+        rr = [ops.dot(r, r), torch.empty(1, device=dev)]
+        ops.normal_op_cg_step(x, r, p, sens, mask, lam, rr[0], rr[1], sens_tiled=st)
+        outs.append((x, r, p, rr[1]))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("t,c,w", [(15, 15, 200), (3, 7, 36), (2, 6, 7)])
 def test_cg_iteration_three_launch_form_vs_oracle_and_four_launch_form(dev, t, c, w):
     """cine_normal_op_cg_fused (operator with per-workgroup p.Hp partial sums -> update that adds the coil groups itself -> direction)
