@@ -54,10 +54,11 @@ class CineNet_RNN(CRNNBody):
         x_ref = ops.sens_reduce(ref_kspace, sens_maps)
         img = x_ref
         state = self.zero_state(t, b, h, w, img)
+        tiled = ops.sens_tile_pack(sens_maps)             # the maps as the normal operator reads them fastest, once per forward
         for _ in range(self.num_cascades):
             planes, _ = ops.normunet_pack(img.view(t, h, w, 2), norm=False)
             out, state = self.body(planes.view(t, 1, 2, h, w), state, planes)
             x = ops.normunet_unpack(out, None, h, w).view(1, t, 1, h, w, 2)
             rhs = ops.axpby_dev(x_ref, x, lambda_reg=self.lambda_reg)
-            img = self.ConjGrad(x, rhs, mask, sens_maps, self.CG_iters)
+            img = self.ConjGrad(x, rhs, mask, sens_maps, self.CG_iters, tiled)
         return ops.complex_abs(img.squeeze(2))

@@ -55,12 +55,13 @@ class VarNet_RNN(CRNNBody):
             ops.kspace_to_hybrid(ref_kspace, out=hyb, mask=mask)
             zf = ops.hybrid_reduce(hyb, sens_maps)
         state = self.zero_state(t, b, h, w, img)
+        tiled = ops.sens_tile_pack(sens_maps) if rowmask else None               # the maps as the DC kernel reads them fastest, once per forward
         for _ in range(self.num_cascades):
             planes, _ = ops.normunet_pack(img.view(t, h, w, 2), norm=False)      # (t, 2, h, w)
             out, state = self.body(planes.view(t, 1, 2, h, w), state, planes)
             new_img = ops.normunet_unpack(out, None, h, w).view(1, t, 1, h, w, 2)
             if rowmask:
-                img = ops.image_dc(new_img, sens_maps, zf, mask, self.lambda_reg)                  # :80-90 + next reduce
+                img = ops.image_dc(new_img, sens_maps, zf, mask, self.lambda_reg, sens_tiled=tiled)      # :80-90 + next reduce
             else:
                 ops.expand_dc_hybrid(new_img, sens_maps, ref_kspace, mask, self.lambda_reg, out=hyb)   # :80-90
                 img = ops.hybrid_reduce(hyb, sens_maps)

@@ -82,6 +82,7 @@ class XPDNet_RNN(CRNNBody):
         keep = [i for i in range(2 * (n + 1)) if i not in (n, 2 * n + 1)]                  # channels [:n] and [n+1:-1]
         nd = self.k_buffer_size
         kbuf = ops.repeat_complex(ref_kspace, nd) if self.k_buffer_mode else None
+        tiled = ops.sens_tile_pack(sens_maps) if rowmask else None
         for i in range(self.num_cascades):
             x0 = ops.extract_complex(image_buffer, 0, n)
             if self.k_buffer_mode:                                                          # dual buffer + KSpaceCNN
@@ -91,7 +92,7 @@ class XPDNet_RNN(CRNNBody):
                 kbuf = self.kspace_net[i](cat_k).contiguous()
                 bwd = ops.sens_reduce(ops.extract_complex(kbuf, 0, nd) * mask + 0.0, sens_maps)
             elif rowmask:
-                bwd = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0))      # A^H M (A x0 - k_ref) (:110-163)
+                bwd = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0), sens_tiled=tiled)      # A^H M (A x0 - k_ref) (:110-163)
             else:
                 ops.expand_resid_hybrid(x0, sens_maps, ref_kspace, mask, out=hyb)           # K step (:110-140)
                 bwd = ops.hybrid_reduce(hyb, sens_maps)                                     # masked backward op (:142-163)

@@ -202,6 +202,7 @@ class XPDNet(nn.Module):
             zf = ops.hybrid_reduce(ops.kspace_to_hybrid(masked_kspace, mask=mask), sens_maps)
         nd = self.k_buffer_size
         kbuf = ops.repeat_complex(masked_kspace, nd) if self.k_buffer_mode else None          # (:306)
+        tiled = ops.sens_tile_pack(sens_maps) if rowmask else None              # the maps as the DC kernel reads them fastest, once per forward
         for i_domain in range(1, len(self.domain_sequence), 2):                 # each 'K' then 'I' pair (:310-319)
             x0 = ops.extract_complex(image_buffer, 0, n)                        # channel 0 of the buffer (:128)
             if self.k_buffer_mode:
@@ -213,7 +214,7 @@ class XPDNet(nn.Module):
                 k0 = ops.extract_complex(kbuf, 0, nd) * mask + 0.0              # masked backward op (:161-167)
                 backward_img = ops.sens_reduce(k0, sens_maps)
             elif rowmask:
-                backward_img = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0))   # A^H M (A x0 - k_ref)
+                backward_img = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0), sens_tiled=tiled)   # A^H M (A x0 - k_ref)
             else:
                 ops.expand_resid_hybrid(x0, sens_maps, masked_kspace, mask, out=hyb)    # K: M A x0 - k_ref
                 backward_img = ops.hybrid_reduce(hyb, sens_maps)                # I: masked backward op
