@@ -1049,6 +1049,11 @@ static bool vol_small_tiles(int rowsp, int h, int w, int d) {
     return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < kVolSmall;
 }
 
+// 3x3x3 layers that run on conv_coarse.hip: a rule on the layer SHAPE only (the record count of cine_conv_stat_partials3d follows it)
+static bool coarse_shape(int rowsp, int h, int w, int d) {
+    return w > 8 && rowsp > 32 && vol_small_tiles(rowsp, h, w, d) && 32 + 2 * (w + 2) <= 192;
+}
+
 template <int TW, int TAPS, int CK>
 static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
     const long frags = (long)ceil_div(a.H * TW, 16) * ceil_div(a.W, TW);   // fragments per sample
@@ -1143,6 +1148,7 @@ int tiles_for(int rowsp, int h, int w, int d = 1, bool vol3 = false, bool plane3
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
     int nf = regular_nf(rowsp, frags, plane3x3);
+    if (vol3 && coarse_shape(rowsp, h, w, d)) return coarse_tiles(rowsp, d, h, w);
     if (vol3 && vol_small_tiles(rowsp, h, w, d)) nf = 4;          // every small-tile volume configuration has 4 fragments
     const int TH = nf * 16 / TW;
     return ceil_div(w, TW) * ceil_div(h, TH) * d;
@@ -1509,6 +1515,7 @@ extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int 
     a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = a.bias1 = bias; a.addend = addend; a.relu = relu;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.ncc = ceil_div(a.cin, kCK3);
+    if (coarse_shape(a.rowsp, h, w, d)) return launch_conv_coarse(a, as_stream(stream));
     if (conv3d_v3_ok(a)) { a.nchunks = 3 * a.ncc; return dispatch_v3(a, as_stream(stream)); }
     a.nchunks = ceil_div(a.cin, kCK27);
     return dispatch<27, kCK27>(a, as_stream(stream));

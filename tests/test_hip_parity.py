@@ -860,7 +860,8 @@ def test_conv3d_vs_torch(dev, cin, cout, d, h, w):
     assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3, 4), unbiased=False) + 1e-5)) < 1e-4
 
 
-@pytest.mark.parametrize("case", ["plain16", "ragged50", "partial_chunk", "norm_concat", "pooled", "pooled_odd", "concat_unaligned", "bias_relu"])
+@pytest.mark.parametrize("case", ["plain16", "ragged50", "partial_chunk", "norm_concat", "pooled", "pooled_odd", "concat_unaligned", "bias_relu",
+                                  "coarse_l2", "coarse_l2_pooled", "coarse_l2_up", "coarse_l3", "coarse_l3_pooled", "coarse_ragged", "coarse_bias_relu"])
 def test_conv3d_v3_paths_vs_torch(dev, case):
     """The V3 form of the 3x3x3 convolution (three 3x3 passes on the 2-D kernel) at volumes large enough for its regular tiles:
     vectorised staging of plain / normalised / 2x2x2-pooled sources, ragged row widths (4-byte aligned loads, shifted last
@@ -873,12 +874,23 @@ def test_conv3d_v3_paths_vs_torch(dev, case):
     cfgs = {  # c0, mode0, c1, mode1, cout, d, h, w
         "plain16": (16, 0, 0, 0, 16, 16, 104, 64), "ragged50": (8, 1, 0, 0, 32, 16, 104, 50), "partial_chunk": (12, 1, 0, 0, 16, 16, 104, 64),
         "norm_concat": (16, 1, 16, 1, 16, 16, 104, 64), "pooled": (16, 2, 0, 0, 32, 16, 104, 52), "pooled_odd": (8, 2, 0, 0, 32, 16, 104, 25),
-        "concat_unaligned": (12, 1, 4, 0, 16, 16, 104, 64), "bias_relu": (16, 0, 0, 0, 16, 16, 104, 64)}
+        "concat_unaligned": (12, 1, 4, 0, 16, 16, 104, 64), "bias_relu": (16, 0, 0, 0, 16, 16, 104, 64),
+        # the coarse levels of cfg 4's 3-D U-Net (conv_coarse.hip: flattened positions, K split over the waves): 64 -> 64 on 3 x 50 x 50,
+        # the pooled 32 -> 64 from 7 x 100 x 100, the up path's cat(2 x 50 x 50 zero-padded, 3 x 50 x 50), 128 -> 128 and the pooled
+        # 64 -> 128 on 1 x 25 x 25, a ragged layer (44 input channels over two sources, 72 rows, odd sizes), bias + ReLU
+        "coarse_l2": (64, 1, 0, 0, 64, 3, 50, 50), "coarse_l2_pooled": (32, 2, 0, 0, 64, 3, 50, 50), "coarse_l2_up": (64, 1, 64, 1, 64, 3, 50, 50),
+        "coarse_l3": (128, 1, 0, 0, 128, 1, 25, 25), "coarse_l3_pooled": (64, 2, 0, 0, 128, 1, 25, 25), "coarse_ragged": (30, 1, 14, 0, 72, 2, 21, 19),
+        "coarse_bias_relu": (20, 0, 0, 0, 64, 2, 30, 34)}
     c0, m0, c1, m1, cout, d, h, w = cfgs[case]
     def source(seed, c, mode):
         if c == 0:
             return None, None, 0, (0, 0, 0), None
         dd, hh, ww = (2 * d, 2 * h, 2 * w + (1 if case == "pooled_odd" else 0)) if mode == 2 else (d, h, w)
+        if case.startswith("coarse") and mode == 2:
+            dd += 1                                     # avg_pool3d floors: 7 -> 3 slices at cfg 4
+        short = case == "coarse_l2_up" and seed == 11   # the transpose conv's output ends one slice early (unet.py:106-120: zero pad at the end)
+        if short:
+            dd -= 1
         x = rnd(seed, n, c, dd, hh, ww) * 1.5 + 0.3
         part = ops.instnorm_partials(x.to(dev)) if mode else None
         xr = x
@@ -886,12 +898,14 @@ def test_conv3d_v3_paths_vs_torch(dev, case):
             xr = F.leaky_relu(F.instance_norm(x), 0.2)
             if mode == 2:
                 xr = F.avg_pool3d(xr, 2, 2)
+        if short:
+            xr = F.pad(xr, [0, 0, 0, 0, 0, 1])
         return x.to(dev), part, 1 if mode else 0, (dd, hh, ww), xr
     x0, p0, np0, e0, r0 = source(11, c0, m0)
     x1, p1, np1, e1, r1 = source(12, c1, m1)
     cin = c0 + c1
     wt = rnd(13, cout, cin, 3, 3, 3) / (5 * cin ** 0.5)
-    bias = rnd(14, cout) if case == "bias_relu" else None
+    bias = rnd(14, cout) if case.endswith("bias_relu") else None
     wp = ops._pack("c27", wt.to(dev))
     y = torch.empty((n, cout, d, h, w), device=dev)
     part = torch.empty((n, cout, L.cine_conv_stat_partials3d(cout, d, h, w, 0), 3), device=dev)
@@ -907,6 +921,10 @@ def test_conv3d_v3_paths_vs_torch(dev, case):
     assert rel_err(y.cpu(), ref) < 2 * OP_TOL
     st = ops.instnorm_finalize(part)
     assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3, 4))) < 1e-4
+    if case.startswith("coarse"):
+        assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3, 4), unbiased=False) + 1e-5)) < 1e-4
+        want_np = {"coarse_l2": 240, "coarse_l3": 41}.get(case)      # one record per position tile of the flattened slices: the coarse kernel ran
+        assert want_np is None or part.shape[2] == want_np
 
 
 def test_unet3d_and_normunet3d_vs_reference_golden(golden, dev):
