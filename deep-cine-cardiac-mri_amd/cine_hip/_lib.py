@@ -62,13 +62,13 @@ _SIGS = {
                                 P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "cine_conv3x3_ex": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                 P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
-    "cine_crnn_step": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
-    "cine_crnn_step2": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "cine_crnn_step": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_crnn_step2": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_mwcnn_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
-    "cine_mwcnn_forward2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_mwcnn_forward2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_conv3x3_ex2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,
                                  P, P, P, P, c_int, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
-    "cine_mwcnn_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_mwcnn_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_tconv2x2_in": (c_int, [P, P, c_int, c_int, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int,
                                  c_float, c_float, P]),
     "cine_conv1x1_bias": (c_int, [P, P, c_int, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int,
@@ -77,7 +77,7 @@ _SIGS = {
     "cine_instnorm_finalize": (c_int, [P, P, c_long, c_int, c_float, P]),
     "cine_instnorm_lrelu_apply": (c_int, [P, P, c_int, P, c_long, c_long, c_float, c_float, P]),
     "cine_unet2d_ws_bytes": (c_size_t, [c_int] * 7),
-    "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_unet2d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_complex_abs": (c_int, [P, P, c_long, P]),
     "cine_conv3d_packed_floats": (c_size_t, [c_int, c_int]),
     "cine_tconv3d_packed_floats": (c_size_t, [c_int, c_int]),
@@ -90,7 +90,7 @@ _SIGS = {
     "cine_conv1x1x1_bias": (c_int, [P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "cine_instnorm_merge": (c_int, [P, P, c_long, c_int, P]),
     "cine_unet3d_ws_bytes": (c_size_t, [c_int] * 8),
-    "cine_unet3d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_unet3d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_normunet3d_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_normunet3d_unpack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_mwcnn_pad": (c_int, [c_int, c_int, P, P]),
@@ -134,7 +134,7 @@ _SIGS = {
     "cine_tconv2x2_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_conv1x1_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_unet2d_train_ws_bytes": (c_size_t, [c_int] * 7),
-    "cine_unet2d_forward_train": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_unet2d_forward_train": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_complex_mul": (c_int, [P, P, P, c_int, P, P, P, P]),
     "cine_complex_conj": (c_int, [P, P, c_long, P]),
     "cine_complex_abs_sq": (c_int, [P, P, c_long, P]),
@@ -143,13 +143,12 @@ _SIGS = {
     "cine_pad2d": (c_int, [P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_set_side_stream": (c_int, [P]),
     "cine_set_conv_plane": (c_int, [c_int]),
-    "cine_set_lrelu_slope": (c_int, [ctypes.c_float]),
     "cine_unet2d_backward_ws_bytes": (c_size_t, [c_int] * 7),
-    "cine_unet2d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_size_t, P, P]),
+    "cine_unet2d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P]),
     "cine_mwcnn_train_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
-    "cine_mwcnn_forward_train": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_mwcnn_forward_train": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_mwcnn_backward_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
-    "cine_mwcnn_backward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P, c_size_t, P, c_size_t, P, P]),
+    "cine_mwcnn_backward": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_float, P, c_size_t, P, c_size_t, P, P]),
     "cine_relu_mask": (c_int, [P, P, c_long, P]),
     "cine_conv3x3_wgrad_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "cine_conv3x3_wgrad": (c_int, [P, c_int, P, c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_size_t, P]),

@@ -72,8 +72,9 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
     check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(), len(weights.unets), n, h, w, cin,
-                                          weights.out_ch, weights.chans, weights.pools, ws.data_ptr(), ws.numel(), _stream()),
+                                          weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()),
           "cine_unet2d_forward_train")
+    ws.cine_slope = ops.lrelu_slope()                  # the backward pass differentiates the activation the forward pass applied
     ws.cine_training_key = key                       # checked by unet2d_backward
     return y, ws
 
@@ -105,7 +106,7 @@ def unet2d_backward(x: torch.Tensor, gy: torch.Tensor, weights: "ops.UnetWeights
     weights.check_training_key(getattr(fwd_ws, "cine_training_key", None), "cine_unet2d_backward")
     _use_side_stream(x.device)
     check(lib().cine_unet2d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, nsets, n, h, w, cin,
-                                     weights.out_ch, weights.chans, weights.pools, fwd_ws.data_ptr(), fwd_ws.numel(),
+                                     weights.out_ch, weights.chans, weights.pools, getattr(fwd_ws, "cine_slope", ops.lrelu_slope()), fwd_ws.data_ptr(), fwd_ws.numel(),
                                      ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_unet2d_backward")
     return gx, grads
 
@@ -267,7 +268,8 @@ class MwcnnFn(Function):
         y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
         check(L.cine_mwcnn_forward_train(x.data_ptr(), y.data_ptr(), w.pointers(), w2.pointers() if two else None, int(split) if two else n,
                                          n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters,
-                                         int(net.res), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
+                                         int(net.res), ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
+        ctx.slope = ops.lrelu_slope()
         ctx.cfg = (w, w2 if two else None, int(split) if two else n)
         ctx.keys = tuple(tuple((p.data_ptr(), p._version) for p in wt.param_list()) for wt in ((w, w2) if two else (w,)))
         ctx.ws, ctx.params = ws, params
@@ -298,7 +300,7 @@ class MwcnnFn(Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         _use_side_stream(x.device)
         check(L.cine_mwcnn_backward(x.data_ptr(), gy.data_ptr(), w.dgrad_pointers(), w2.dgrad_pointers() if w2 is not None else None, gp1, gp2,
-                                    split, n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters,
+                                    split, n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters, ctx.slope,
                                     ctx.ws.data_ptr(), ctx.ws.numel(), ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_mwcnn_backward")
         out = {}
         for pl, gl in ((p1, g1),) + (((p2, g2),) if w2 is not None else ()):
@@ -411,7 +413,8 @@ class XpdRegFn(Function):
             two = w2 is not None and w2 is not w1
             check(L.cine_mwcnn_forward_train(planes.data_ptr(), y.data_ptr(), w1.pointers(), w2.pointers() if two else None, split if two else nn_,
                                              nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc, net.n_first_convs,
-                                             net.first_conv_n_filters, int(net.res), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
+                                             net.first_conv_n_filters, int(net.res), ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
+            ws.cine_slope = ops.lrelu_slope()
             return y, ws
         if joint:
             planes = torch.as_strided(pxf, (pxf.shape[0] + pyf.shape[0],) + tuple(pxf.shape[1:]), pxf.stride())
@@ -461,7 +464,7 @@ class XpdRegFn(Function):
             gx = torch.empty_like(planes)
             check(L.cine_mwcnn_backward(planes.data_ptr(), gy.data_ptr(), w1.dgrad_pointers(), w2.dgrad_pointers() if two else None, lists[0][2],
                                         lists[1][2] if two else None, split if two else nn_, nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc,
-                                        net.first_conv_n_filters, fws.data_ptr(), fws.numel(), ws.data_ptr(), ws.numel(), gx.data_ptr(), _stream()),
+                                        net.first_conv_n_filters, getattr(fws, "cine_slope", ops.lrelu_slope()), fws.data_ptr(), fws.numel(), ws.data_ptr(), ws.numel(), gx.data_ptr(), _stream()),
                   "cine_mwcnn_backward")
             for pl, gl, _ in lists:
                 for p, g in zip(pl, gl):
@@ -516,7 +519,7 @@ class Unet3dFn(Function):
         if min(dims[P]) < 1:
             raise CineHipError("unet3d: volume too small for the number of pools")
         L = lib()
-        eps, slope = ops.IN_EPS, ops.LRELU_SLOPE
+        eps, slope = ops.IN_EPS, ops.lrelu_slope()
         dev, dt = x.device, x.dtype
 
         def merged(raw_part, cout, np_):
@@ -561,6 +564,7 @@ class Unet3dFn(Function):
                                     weights.out_ch, d, h, w, eps, slope, _stream()), "cine_conv1x1x1_bias")
         ctx.state = (x, A, B, Tc, Cc, Ec, chs, dims, plist)
         ctx.params = params
+        ctx.slope = slope                      # the backward pass runs on an autograd thread: it differentiates what THIS call applied
         return y
 
     @staticmethod
@@ -571,7 +575,7 @@ class Unet3dFn(Function):
         n, cin = x.shape[:2]
         P = len(chs) - 1
         L = lib()
-        eps, slope = ops.IN_EPS, ops.LRELU_SLOPE
+        eps, slope = ops.IN_EPS, ctx.slope
         dev, dt = x.device, x.dtype
         F = torch.nn.functional
 
@@ -721,7 +725,7 @@ def _conv3d_dgrad(g, weight):
     ci = weight.shape[1]
     gx = torch.empty((n, ci, d, h, w), device=g.device, dtype=g.dtype)
     check(lib().cine_conv3d_in(g.data_ptr(), None, 0, cout, 0, d, h, w, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(), None, None, 0,
-                               gx.data_ptr(), None, n, ci, d, h, w, ops.IN_EPS, ops.LRELU_SLOPE, _stream()), "cine_conv3d_in")
+                               gx.data_ptr(), None, n, ci, d, h, w, ops.IN_EPS, ops.lrelu_slope(), _stream()), "cine_conv3d_in")
     return gx
 
 
@@ -747,8 +751,9 @@ class Conv3dBiasReluFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
         x = ops._dev(x, "conv3d input")
-        y = ops.conv3d_bias_relu(x, weight, bias, bool(relu))
-        ctx.relu = bool(relu)
+        relu = bool(relu) and ops.relu_on()
+        y = ops.conv3d_bias_relu(x, weight, bias, relu)
+        ctx.relu = relu
         ctx.save_for_backward(x, weight, y if relu else torch.empty(0))
         return y
 
@@ -850,9 +855,10 @@ class ConvSumFn(Function):
         x0 = ops._dev(x0, "conv input")
         x1 = None if x1 is None else ops._dev(x1, "conv input 1")
         cout = weight.shape[0]
+        relu = bool(relu) and ops.relu_on()
         y = ops.conv3x3_sum([x0] + ([x1] if x1 is not None else []), ops.pack_conv3x3(weight), None if bias is None else ops._dev(bias.detach(), "bias"),
-                            cout, addend=None if addend is None else ops._dev(addend, "addend"), relu=bool(relu))
-        ctx.relu = bool(relu)
+                            cout, addend=None if addend is None else ops._dev(addend, "addend"), relu=relu)
+        ctx.relu = relu
         ctx.has = (x1 is not None, bias is not None, addend is not None)
         ctx.save_for_backward(x0, x1 if x1 is not None else torch.empty(0), weight, y if relu else torch.empty(0))
         return y
@@ -906,6 +912,7 @@ class BcrnnFn(Function):
                 ops.crnn_step2(wph, (hid_f, P[i_f:i_f + 1], hf[i_f:i_f + 1], out[i_f:i_f + 1], first),
                                (hid_b, P[i_b:i_b + 1], hb[i_b:i_b + 1], out[i_b:i_b + 1], first))
             hid_f, hid_b = hf[i_f:i_f + 1], hb[i_b:i_b + 1]
+        ctx.relu = bool(ops.relu_on())            # what crnn_step2 applied
         ctx.save_for_backward(x, hid_iter, w_in, w_hh, hf, hb)
         return out
 
@@ -922,13 +929,15 @@ class BcrnnFn(Function):
                 gf[t:t + 1].copy_(gout[t:t + 1])
             else:
                 ops.conv3x3_sum([gf[t + 1:t + 2]], wdh, None, c, addend=gout[t:t + 1], out=gf[t:t + 1])
-            _relu_mask_(gf[t:t + 1], hf[t:t + 1])
+            if ctx.relu:
+                _relu_mask_(gf[t:t + 1], hf[t:t + 1])
         for t in range(T):                                             # backward-in-time chain
             if t == 0:
                 gb[t:t + 1].copy_(gout[t:t + 1])
             else:
                 ops.conv3x3_sum([gb[t - 1:t]], wdh, None, c, addend=gout[t:t + 1], out=gb[t:t + 1])
-            _relu_mask_(gb[t:t + 1], hb[t:t + 1])
+            if ctx.relu:
+                _relu_mask_(gb[t:t + 1], hb[t:t + 1])
         gP = gf + gb
         need = ctx.needs_input_grad
         gx = ghid = gw_in = gw_hh = gbias = None

@@ -6,13 +6,51 @@ tensors; anything else raises -- there is no CPU path.
 """
 from typing import Optional, Sequence
 
+import contextlib
 import ctypes
+import threading
 import torch
 
 from ._lib import CineHipError, check, lib
 
 IN_EPS = 1e-5       # nn.InstanceNorm2d default eps (reference unet.py:161)
-LRELU_SLOPE = 0.2   # nn.LeakyReLU(0.2)            (reference unet.py:162)
+LRELU_SLOPE = 0.2   # nn.LeakyReLU(0.2)            (reference unet.py:162, mwcnn.py:204)
+RELU_ON = True      # nn.ReLU of the CRNN cells / conv blocks (reference recurrent_varnet.py:126,178); False = identity.  Both are host-side
+                    # defaults that the binding passes as ARGUMENTS of every call (the library keeps no activation state);
+                    # `activation(...)` overrides them for the calling THREAD (the gradient fixtures without activation kinks)
+_act_tls = threading.local()
+
+
+def lrelu_slope() -> float:
+    """The LeakyReLU slope this thread's calls pass to the library."""
+    return getattr(_act_tls, "slope", LRELU_SLOPE)
+
+
+def relu_on() -> bool:
+    """Whether this thread's calls apply the CRNN / k-space-net ReLUs."""
+    return getattr(_act_tls, "relu", RELU_ON)
+
+
+@contextlib.contextmanager
+def activation(slope: Optional[float] = None, relu: Optional[bool] = None):
+    """Override the activations of the CALLING THREAD's calls: ``slope`` = LeakyReLU slope of the U-Net / MWCNN conv blocks (1 = identity),
+    ``relu`` = False turns the nn.ReLU of the CRNN cells and the k-space net into the identity.  Per-call arguments at the C ABI."""
+    old = (getattr(_act_tls, "slope", None), getattr(_act_tls, "relu", None))
+    if slope is not None:
+        if not 0.0 <= float(slope) <= 1.0:
+            raise ValueError("activation: slope outside [0, 1]")
+        _act_tls.slope = float(slope)
+    if relu is not None:
+        _act_tls.relu = bool(relu)
+    try:
+        yield
+    finally:
+        for name, v in zip(("slope", "relu"), old):
+            if v is None:
+                if hasattr(_act_tls, name):
+                    delattr(_act_tls, name)
+            else:
+                setattr(_act_tls, name, v)
 
 
 def _stream() -> int:
@@ -704,7 +742,7 @@ def conv3x3_in(srcs: Sequence, wpacked: torch.Tensor, cout: int, h: int, w: int,
         py = torch.empty((n, cout, lib().cine_conv_stat_partials(cout, h, w, 0), 3), device=x0.device, dtype=x0.dtype)
     check(lib().cine_conv3x3_in(x0.data_ptr(), _p(p0), _np(p0), x0.shape[1], m0, x0.shape[2], x0.shape[3],
                                 _p(x1), _p(p1), _np(p1), c1, m1, h1, w1, wpacked.data_ptr(), _p(wpacked2), set_split,
-                                y.data_ptr(), _p(py), n, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3x3_in")
+                                y.data_ptr(), _p(py), n, cout, h, w, IN_EPS, lrelu_slope(), _stream()), "cine_conv3x3_in")
     return y, py
 
 
@@ -714,7 +752,7 @@ def tconv2x2_in(x, part, mode: int, wpacked: torch.Tensor, cout: int):
     y = torch.empty((n, cout, 2 * h, 2 * w), device=x.device, dtype=x.dtype)
     py = torch.empty((n, cout, lib().cine_conv_stat_partials(cout, h, w, 1), 3), device=x.device, dtype=x.dtype)
     check(lib().cine_tconv2x2_in(x.data_ptr(), _p(part), _np(part), mode, wpacked.data_ptr(), None, 0,
-                                 y.data_ptr(), py.data_ptr(), n, cin, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()),
+                                 y.data_ptr(), py.data_ptr(), n, cin, cout, h, w, IN_EPS, lrelu_slope(), _stream()),
           "cine_tconv2x2_in")
     return y, py
 
@@ -725,7 +763,7 @@ def conv1x1_bias(x, part, mode: int, wpacked: torch.Tensor, bias: torch.Tensor):
     cout = bias.shape[0]
     y = torch.empty((n, cout, h, w), device=x.device, dtype=x.dtype)
     check(lib().cine_conv1x1_bias(x.data_ptr(), _p(part), _np(part), mode, wpacked.data_ptr(), bias.data_ptr(),
-                                  None, None, n, y.data_ptr(), n, cin, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()),
+                                  None, None, n, y.data_ptr(), n, cin, cout, h, w, IN_EPS, lrelu_slope(), _stream()),
           "cine_conv1x1_bias")
     return y
 
@@ -754,7 +792,7 @@ def instnorm_lrelu_apply(x: torch.Tensor, part: torch.Tensor) -> torch.Tensor:
     n, c = x.shape[:2]
     y = torch.empty_like(x)
     check(lib().cine_instnorm_lrelu_apply(x.data_ptr(), part.data_ptr(), part.shape[2], y.data_ptr(), n * c,
-                                          x.numel() // (n * c), IN_EPS, LRELU_SLOPE, _stream()),
+                                          x.numel() // (n * c), IN_EPS, lrelu_slope(), _stream()),
           "cine_instnorm_lrelu_apply")
     return y
 
@@ -886,7 +924,7 @@ def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[to
         workspace = torch.empty(need, device=x.device, dtype=torch.uint8)
     y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
     check(lib().cine_unet2d_forward(x.data_ptr(), y.data_ptr(), weights.pointers(), nsets, n, h, w, cin,
-                                    weights.out_ch, weights.chans, weights.pools, workspace.data_ptr(),
+                                    weights.out_ch, weights.chans, weights.pools, lrelu_slope(), workspace.data_ptr(),
                                     workspace.numel(), _stream()), "cine_unet2d_forward")
     return y
 
@@ -977,11 +1015,11 @@ def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights, w2: Optional[MwcnnWeights] =
                 (net.in_chans, net.out_chans, net.n_scales, list(net.n_filters_per_scale), list(net.n_convs_per_scale), net.first_conv_n_filters):
             raise ValueError("mwcnn_forward: the two networks differ in topology")
         check(lib().cine_mwcnn_forward2(x.data_ptr(), y.data_ptr(), w.pointers(), w2.pointers(), int(split), n, h, wd, cin, net.out_chans,
-                                        net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res),
+                                        net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res), lrelu_slope(),
                                         ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward2")
         return y
     check(lib().cine_mwcnn_forward(x.data_ptr(), y.data_ptr(), w.pointers(), n, h, wd, cin, net.out_chans, net.n_scales,
-                                   w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res),
+                                   w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res), lrelu_slope(),
                                    ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward")
     return y
 
@@ -1081,8 +1119,8 @@ def conv3x3_sum(srcs: Sequence, wpacked: torch.Tensor, bias: Optional[torch.Tens
             raise ValueError("conv3x3_sum: out has the wrong shape")
     check(lib().cine_conv3x3_ex(x0.data_ptr(), None, 0, x0.shape[1], 0, h, w,
                                 _p(x1), None, 0, 0 if x1 is None else x1.shape[1], 0, h, w, 0,
-                                wpacked.data_ptr(), _p(bias), _p(addend), int(relu),
-                                y.data_ptr(), None, n, cout, h, w, IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3x3_ex")
+                                wpacked.data_ptr(), _p(bias), _p(addend), int(bool(relu) and relu_on()),
+                                y.data_ptr(), None, n, cout, h, w, IN_EPS, lrelu_slope(), _stream()), "cine_conv3x3_ex")
     return y
 
 
@@ -1095,7 +1133,7 @@ def crnn_step(x: torch.Tensor, w_hh: torch.Tensor, addend: torch.Tensor, out: to
     for t_, name in ((out, "out"), (accum, "accum")):
         if t_ is not None and not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.shape == x.shape):
             raise ValueError(f"crnn_step: {name} must be a contiguous float32 GPU tensor shaped like x")
-    check(lib().cine_crnn_step(x.data_ptr(), w_hh.data_ptr(), addend.data_ptr(), out.data_ptr(), _p(accum), n, c, h, w, _stream()),
+    check(lib().cine_crnn_step(x.data_ptr(), w_hh.data_ptr(), addend.data_ptr(), out.data_ptr(), _p(accum), n, c, h, w, int(relu_on()), _stream()),
           "cine_crnn_step")
     return out
 
@@ -1120,7 +1158,7 @@ def crnn_step2(w_hh: torch.Tensor, fwd, bwd=None) -> None:
         if xb.shape != xf.shape:
             raise ValueError("crnn_step2: the two directions differ in shape")
     check(lib().cine_crnn_step2(xf.data_ptr(), af.data_ptr(), yf.data_ptr(), _p(cf), sf, _p(xb), _p(ab), _p(yb), _p(cb), sb,
-                                w_hh.data_ptr(), n, c, h, w, _stream()), "cine_crnn_step2")
+                                w_hh.data_ptr(), n, c, h, w, int(relu_on()), _stream()), "cine_crnn_step2")
 
 
 # ------------------------------------------------------------------ 3-D U-Net path (dynamic_type '3D')
@@ -1157,7 +1195,7 @@ def unet3d_forward(x: torch.Tensor, weights: UnetWeights) -> torch.Tensor:
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     y = torch.empty((n, weights.out_ch, d, h, w), device=x.device, dtype=x.dtype)
     check(lib().cine_unet3d_forward(x.data_ptr(), y.data_ptr(), weights.pointers(), n, d, h, w, cin, weights.out_ch,
-                                    weights.chans, weights.pools, ws.data_ptr(), ws.numel(), _stream()), "cine_unet3d_forward")
+                                    weights.chans, weights.pools, lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()), "cine_unet3d_forward")
     return y
 
 
@@ -1170,6 +1208,6 @@ def conv3d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, 
     bias = _dev(bias.detach(), "conv3d bias")
     y = torch.empty((n, cout, d, h, w), device=x.device, dtype=x.dtype)
     check(lib().cine_conv3d_in(x.data_ptr(), None, 0, cin, 0, d, h, w, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(),
-                               bias.data_ptr(), None, int(relu), y.data_ptr(), None, n, cout, d, h, w,
-                               IN_EPS, LRELU_SLOPE, _stream()), "cine_conv3d_in")
+                               bias.data_ptr(), None, int(bool(relu) and relu_on()), y.data_ptr(), None, n, cout, d, h, w,
+                               IN_EPS, lrelu_slope(), _stream()), "cine_conv3d_in")
     return y

@@ -7,8 +7,6 @@
 #include "common.h"
 
 namespace cine {
-std::atomic<float> g_unet_slope{0.2f};          // nn.LeakyReLU(0.2) (unet.py:162); cine_set_lrelu_slope is a test hook
-float unet_slope() { return g_unet_slope.load(std::memory_order_relaxed); }
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -63,12 +61,7 @@ const char* cine_profile_family_name(int i) {
                                   "conv1x1_bias", "pack_unpack", "misc"};
     return (i >= 0 && i < cine::F_COUNT) ? names[i] : "";
 }
-int cine_version(void) { return 1; }
-int cine_set_lrelu_slope(float slope) {
-    if (!(slope >= 0.f && slope <= 1.f)) { cine::set_error("cine_set_lrelu_slope: slope %g outside [0, 1]", (double)slope); return CINE_EINVAL; }
-    cine::g_unet_slope.store(slope, std::memory_order_relaxed);
-    return CINE_OK;
-}
+int cine_version(void) { return 2; }       // 2: the fused U-Net sequences take their LeakyReLU slope per call (round 5)
 const char* cine_last_error(void) { return cine::g_err; }
 const char* cine_build_arch(void) { return "gfx950"; }
 int cine_pad16(int n) { return ((n - 1) | 15) + 1; }

@@ -40,7 +40,6 @@ __device__ unsigned long long g_cine_stamps[1 << 20];
 namespace cine {
 
 void set_error(const char* fmt, ...);   // api.cpp (thread-local buffer)
-float unet_slope();                     // api.cpp: LeakyReLU slope of the fused U-Net sequences (0.2 unless cine_set_lrelu_slope changed it)
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -1282,25 +1282,25 @@ extern "C" int cine_conv3x3_ex2(const float* x0, const float* part0, int np0, in
 // one step of a convolutional-RNN time sweep (reference recurrent_varnet.py:241-254): y = ReLU(conv3x3(x; w) + addend) and,
 // when accum != NULL, accum += y in the same epilogue (the backward sweep adding onto the forward sweep's outputs)
 extern "C" int cine_crnn_step(const float* x, const float* wpacked, const float* addend, float* y, float* accum,
-                              int n, int c, int h, int w, void* stream) {
+                              int n, int c, int h, int w, int relu, void* stream) {
     CINE_REQUIRE(x && wpacked && addend && y, CINE_EINVAL, "cine_crnn_step: null pointer");
     CINE_REQUIRE(y != x && accum != x && accum != y, CINE_EINVAL, "cine_crnn_step: outputs must not alias the input or each other");
     return conv3x3_full(x, nullptr, 0, c, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, 0, wpacked, nullptr, 0,
-                        nullptr, addend, 1, accum, y, nullptr, n, c, h, w, 1e-5f, 0.2f, stream);
+                        nullptr, addend, relu ? 1 : 0, accum, y, nullptr, n, c, h, w, 1e-5f, 0.2f, stream);
 }
 
 // both directions of a BCRNN time sweep (recurrent_varnet.py:241-252: the forward and the backward pass over time are independent
 // chains; only their sum couples them, :254) in ONE launch: set f and set b are two cine_crnn_step calls on different tensors.
 extern "C" int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f,
                                const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b,
-                               const float* wpacked, int n, int c, int h, int w, void* stream) {
+                               const float* wpacked, int n, int c, int h, int w, int relu, void* stream) {
     CINE_REQUIRE(x_f && addend_f && y_f && wpacked, CINE_EINVAL, "cine_crnn_step2: null pointer");
     CINE_REQUIRE(n > 0 && 2 * n <= 65535 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_crnn_step2: bad sizes");
     CINE_REQUIRE(y_f != x_f && accum_f != x_f && accum_f != y_f, CINE_EINVAL, "cine_crnn_step2: outputs must not alias the input or each other");
     ConvArgs a{};
     a.s0 = Src{x_f, nullptr, c, 0, h, w, 0, 0, 1};
     a.s1 = Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
-    a.addend = addend_f; a.relu = 1; a.accum = accum_f; a.accum_store = store_f && accum_f;
+    a.addend = addend_f; a.relu = relu ? 1 : 0; a.accum = accum_f; a.accum_store = store_f && accum_f;
     a.wp0 = a.wp1 = wpacked; a.set_split = 2 * n;
     a.y = y_f; a.ypart = nullptr; a.n = n; a.cin = c; a.rows = c; a.rowsp = ceil_div(c, 16) * 16;
     a.H = h; a.W = w; a.D = 1; a.slope = 0.2f; a.eps = 1e-5f; a.nchunks = ceil_div(c, kCK3);

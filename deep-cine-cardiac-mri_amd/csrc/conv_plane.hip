@@ -25,7 +25,7 @@
 namespace cine {
 namespace {
 
-std::atomic<int> g_plane_on{7};          // bit 0: plane-wide 3x3 convs, bit 1: transpose convs, bit 2: wide planes / volumes
+thread_local int g_plane_on = 7;          // bit 0: plane-wide 3x3 convs, bit 1: transpose convs, bit 2: wide planes / volumes
 
 struct PlaneArgs {
     const float* x0; const float* part0; int c0, np0;
@@ -512,7 +512,7 @@ int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
 // launch when the layer is one of this kernel's shapes.
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
-    if (!(g_plane_on.load(std::memory_order_relaxed) & 1)) return CINE_OK;
+    if (!(g_plane_on & 1)) return CINE_OK;
     if (a.vol || a.D != 1 || a.addend || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
@@ -589,10 +589,11 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
 }  // namespace cine
 
 // Diagnostics: route the plane-wide 3x3 convolutions through the general kernel (0) or the lean one (1, the default).  The two are
-// bit-identical; the switch exists for that test and for A/B timing.  Process-wide.
+// bit-identical; the switch exists for that test and for A/B timing.  State of the CALLING THREAD (like cine_set_side_stream): launches
+// enqueued by other threads keep their own setting (default 7).
 extern "C" int cine_set_conv_plane(int on) {
     cine::set_wgrad_plane((on & 16) ? 0 : 1);       // bit 4 SET: the plane-wide weight gradients (training) on the general kernel
-    cine::g_plane_on.store(on & 7, std::memory_order_relaxed);       // bit 0 plane-wide 3x3 convs, bit 1 transpose convs, bit 2 wide planes / volumes (7 = all, the default)
+    cine::g_plane_on = on & 7;       // bit 0 plane-wide 3x3 convs, bit 1 transpose convs, bit 2 wide planes / volumes (7 = all, the default)
     return CINE_OK;
 }
 
@@ -833,7 +834,7 @@ int launch_tconv(const TconvPlaneArgs& p, int n, hipStream_t st) {
 // Called by the general dispatcher for a 2-D transpose conv with the pixel-tile shape (mt fragments, tw) it chose.
 int launch_tconv_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
-    if (!(g_plane_on.load(std::memory_order_relaxed) & 2)) return CINE_OK;
+    if (!(g_plane_on & 2)) return CINE_OK;
     if (a.vol || a.D != 1 || a.tconv_cout <= 0 || !a.tvec || a.bias || a.addend || a.relu || a.accum || a.s1.c > 0 || a.add_src1) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535 || a.s0.mode > 1 || a.s0.w != a.W || a.s0.h != a.H || (a.H * a.W) % 4 != 0) return CINE_OK;
     if (a.s0.mode == 1 && (!a.s0.part || a.s0.np < 1 || a.s0.np > 16)) return CINE_OK;
@@ -1238,7 +1239,7 @@ int launch_wide(const WideArgs& p, int n, hipStream_t st) {
 // general dispatcher -> wide kernel: 16-wide column tiles of 2-D planes (v3 = 0) or of volumes in the three-pass form (v3 = 1)
 int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, hipStream_t st, bool* handled) {
     *handled = false;
-    if (!(g_plane_on.load(std::memory_order_relaxed) & 4)) return CINE_OK;
+    if (!(g_plane_on & 4)) return CINE_OK;
     if (a.add_src1 || a.tconv_cout > 0 || a.n <= 0 || a.n > 65535) return CINE_OK;
     if ((a.accum || a.pair_n > 0) && (v3 || a.s1.c > 0 || a.s0.mode != 0)) return CINE_OK;
     if ((v3 != 0) != (a.vol != 0) || (!v3 && a.D != 1)) return CINE_OK;
@@ -1429,7 +1430,7 @@ int launch_s2d(const S2dArgs& p, int n, int tiles, hipStream_t st) {
 // general dispatcher -> input gradient of a 2-D transpose conv (TAPS = 1, source mode 5) with the pixel tile (mt, tw) it chose
 int launch_tconv_dgrad_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
-    if (!(g_plane_on.load(std::memory_order_relaxed) & 2)) return CINE_OK;
+    if (!(g_plane_on & 2)) return CINE_OK;
     if (a.vol || a.D != 1 || a.tconv_cout > 0 || a.bias || a.addend || a.relu || a.accum || a.ypart || a.s1.c > 0 || a.add_src1 || a.s0.mode != 5) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535 || a.s0.w != 2 * a.W || a.s0.h != 2 * a.H || (a.H * a.W) % 4 != 0 || a.s0.c % 16 != 0) return CINE_OK;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };

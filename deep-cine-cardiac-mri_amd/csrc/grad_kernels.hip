@@ -869,11 +869,10 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* part, i
 // Runs of work items per launch: ONE resident round of workgroups.  The kernel is register-bound to two workgroups per CU for row blocks of
 // 16 / 32 and one for 64 / 128; a run that covers ~10 tiles amortises its prologue and its K-split reduction, and every extra run is another
 // partial sum to write and re-read (measured on the cfg-2 step, conv family: 2048 runs per set 32.7 ms, 512: 30.4, 256: 28.6, 128: 29.5,
-// 64: 40.0).  CINE_WG_TARGET overrides the total.
+// 64: 40.0).
 static int wgrad_runs(int rows, int cin, int nsets) {
-    static const int env = [] { const char* e = getenv("CINE_WG_TARGET"); return e ? atoi(e) : 0; }();
     const int cob = rows <= 16 ? 16 : rows <= 32 ? 32 : rows <= 64 ? 64 : 128;
-    const long slots = env > 0 ? env : 256L * (cob <= 32 ? 2 : 1);
+    const long slots = 256L * (cob <= 32 ? 2 : 1);
     const long wgs = (long)ceil_div(cin, 16) * ceil_div(rows, cob) * nsets;
     const long per_run = (long)ceil_div(rows, cob) * cob * ceil_div(cin, 16) * 16 * 9 * 4;       // bytes of one partial (3x3)
     const long cap = std::max(8L, (32L << 20) / per_run);                                          // <= 32 MB of partials per weight set
@@ -888,9 +887,9 @@ size_t wgrad_ws_floats(int rows, int cin, int taps, int n) {
     return (size_t)std::max(wgrad_runs(rows, cin, 1), 2 * wgrad_runs(rows, cin, 2)) * rowsb * cinp * taps;
 }
 
-static std::atomic<int> g_wgrad_plane{1};
-bool wgrad_plane_enabled() { return g_wgrad_plane.load(std::memory_order_relaxed) != 0; }
-void set_wgrad_plane(int on) { g_wgrad_plane.store(on, std::memory_order_relaxed); }
+static thread_local int g_wgrad_plane = 1;      // the CALLING THREAD's diagnostic choice (cine_set_conv_plane bit 4), like its side stream
+bool wgrad_plane_enabled() { return g_wgrad_plane != 0; }
+void set_wgrad_plane(int on) { g_wgrad_plane = on; }
 
 template <int TAPS, int TW, int CT, int WM, int NPIX>
 static int launch_wg_cfg(const WgLaunch& L, dim3 grid, hipStream_t st) {

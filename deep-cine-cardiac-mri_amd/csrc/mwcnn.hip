@@ -17,7 +17,7 @@ extern "C" int cine_conv3x3_ex2(const float* x0, const float* part0, int np0, in
                                 float* y, float* part_y, int n, int cout, int h, int w, float eps, float slope, void* stream);
 
 namespace {
-constexpr float kEps = 1e-5f, kSlope = 0.2f;
+constexpr float kEps = 1e-5f;        // (the LeakyReLU slope of the conv blocks, mwcnn.py:204 = 0.2, is an argument of every entry point)
 constexpr int kMaxScales = 6, kMaxConvs = 8;
 enum { M_PLAIN = 0, M_ACT = 1, M_DWT_ACT = 3 | 8, M_IWT_ACT = 4 | 8 };
 
@@ -97,29 +97,30 @@ extern "C" size_t cine_mwcnn_ws_bytes(int n, int h, int w, int in_ch, int out_ch
 // conv_blocks_per_scale[s][i] (packed 3x3), then first_convs[1] weight (packed 3x3) and its bias.
 static int mwcnn_impl(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split, int n, int h, int w,
                       int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                      int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+                      int n_first_convs, int first_filters, int res, float kSlope, void* ws, size_t ws_bytes, void* stream);
 
 extern "C" int cine_mwcnn_forward(const float* x, float* y, const void* const* weights, int n, int h, int w,
                                   int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                                  int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+                                  int n_first_convs, int first_filters, int res, float slope, void* ws, size_t ws_bytes, void* stream) {
     return mwcnn_impl(x, y, weights, nullptr, n, n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, n_first_convs, first_filters, res,
-                      ws, ws_bytes, stream);
+                      slope, ws, ws_bytes, stream);
 }
 
 // two MWCNNs of the same topology in one launch sequence: samples [0, set_split) go through `weights`, the rest through `weights2`
 // (XPDNet's x-t and y-t networks, xpdnet.py:424-446, on planes of equal shape)
 extern "C" int cine_mwcnn_forward2(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
                                    int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                                   int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+                                   int n_first_convs, int first_filters, int res, float slope, void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(weights2 && set_split > 0 && set_split < n, CINE_EINVAL, "cine_mwcnn_forward2: needs a second weight set and 0 < set_split < n");
     return mwcnn_impl(x, y, weights, weights2, set_split, n, h, w, in_ch, out_ch, n_scales, n_filters, n_convs, n_first_convs, first_filters, res,
-                      ws, ws_bytes, stream);
+                      slope, ws, ws_bytes, stream);
 }
 
 static int mwcnn_impl(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split, int n, int h, int w,
                       int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                      int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+                      int n_first_convs, int first_filters, int res, float kSlope, void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(x && y && weights && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_forward: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_mwcnn_forward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(n > 0 && h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && first_filters > 0, CINE_EINVAL, "cine_mwcnn_forward: bad sizes");
     if (int e = check_topology(n_scales, n_filters, n_convs, n_first_convs, res)) return e;
     CINE_REQUIRE(h % (1 << n_scales) == 0 && w % (1 << n_scales) == 0, CINE_EINVAL,
@@ -240,8 +241,9 @@ extern "C" size_t cine_mwcnn_train_ws_bytes(int n, int h, int w, int in_ch, int 
 
 extern "C" int cine_mwcnn_forward_train(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
                                         int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                                        int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream) {
+                                        int n_first_convs, int first_filters, int res, float kSlope, void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(x && y && weights && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_forward_train: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_mwcnn_forward_train: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(n > 0 && h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && first_filters > 0, CINE_EINVAL, "cine_mwcnn_forward_train: bad sizes");
     if (int e = check_topology(n_scales, n_filters, n_convs, n_first_convs, res)) return e;
     CINE_REQUIRE(h % (1 << n_scales) == 0 && w % (1 << n_scales) == 0, CINE_EINVAL, "cine_mwcnn_forward_train: %dx%d is not a multiple of 2^%d", h, w, n_scales);
@@ -319,9 +321,10 @@ extern "C" size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, i
 // module order, the final conv's weight and bias); weights2-style second lists for the second network when set_split < n.
 extern "C" int cine_mwcnn_backward(const float* x, const float* gy, const void* const* wdgrad, const void* const* wdgrad2, void* const* grads,
                                    void* const* grads2, int set_split, int n, int h, int w, int in_ch, int out_ch, int n_scales,
-                                   const int* n_filters, const int* n_convs, int first_filters, const void* fwd_ws, size_t fwd_ws_bytes,
+                                   const int* n_filters, const int* n_convs, int first_filters, float kSlope, const void* fwd_ws, size_t fwd_ws_bytes,
                                    void* ws, size_t ws_bytes, float* gx, void* stream) {
     CINE_REQUIRE(x && gy && wdgrad && grads && fwd_ws && ws && n_filters && n_convs, CINE_EINVAL, "cine_mwcnn_backward: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_mwcnn_backward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(n > 0 && n <= 65535 && h > 0 && w > 0, CINE_EINVAL, "cine_mwcnn_backward: bad sizes");
     if (int e = check_topology(n_scales, n_filters, n_convs, 1, 0)) return e;
     const bool two = wdgrad2 != nullptr;

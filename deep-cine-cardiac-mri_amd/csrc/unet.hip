@@ -17,7 +17,6 @@ extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
 namespace {
 
 constexpr float kEps = 1e-5f;     // nn.InstanceNorm2d default (unet.py:161)
-#define kSlope (::cine::unet_slope())      // nn.LeakyReLU(0.2) (unet.py:162); a function so that the linear-activation test fixtures can change it
 
 struct Bump {
     char* base; size_t off;
@@ -110,24 +109,25 @@ extern "C" size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int
 }
 
 static int unet2d_forward_impl(const float* x, float* y, const void* const* weights, int nsets,
-                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
                                void* ws, size_t ws_bytes, void* stream, bool train);
 
 extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
-                                   int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                                   int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                                    void* ws, size_t ws_bytes, void* stream) {
-    return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, ws, ws_bytes, stream, false);
+    return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, slope, ws, ws_bytes, stream, false);
 }
 extern "C" int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
-                                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                                          void* ws, size_t ws_bytes, void* stream) {
-    return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, ws, ws_bytes, stream, true);
+    return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, slope, ws, ws_bytes, stream, true);
 }
 
 static int unet2d_forward_impl(const float* x, float* y, const void* const* weights, int nsets,
-                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
                                void* ws, size_t ws_bytes, void* stream, bool train) {
     CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet2d_forward: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet2d_forward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_forward: nsets must be 1 or 2");
     CINE_REQUIRE(n > 0 && n % nsets == 0, CINE_EINVAL, "cine_unet2d_forward: n=%d not divisible by nsets=%d", n, nsets);
     CINE_REQUIRE(h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL,
@@ -261,9 +261,10 @@ extern "C" size_t cine_unet2d_backward_ws_bytes(int n, int h, int w, int in_ch, 
 // host array in the same order of device pointers to the weight gradients in the parameters' own layouts ((cout, cin, 3, 3),
 // (cin, cout, 2, 2), (cout, cin), (cout)); they are ACCUMULATED into (+=).  gx (n, in_ch, h, w) may be NULL.
 extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
-                                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
                                     const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream) {
     CINE_REQUIRE(x && gy && wdgrad && grads && fwd_ws && ws, CINE_EINVAL, "cine_unet2d_backward: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet2d_backward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_backward: nsets must be 1 or 2");
     CINE_REQUIRE(n > 0 && n % nsets == 0 && n <= 65535, CINE_EINVAL, "cine_unet2d_backward: n=%d", n);
     CINE_REQUIRE(h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL, "cine_unet2d_backward: bad sizes");

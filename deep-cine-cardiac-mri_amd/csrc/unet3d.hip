@@ -21,7 +21,6 @@ extern "C" int cine_instnorm_merge(const float* part, float* out, long planes, i
 
 namespace {
 constexpr float kEps = 1e-5f;
-#define kSlope (::cine::unet_slope())      // nn.LeakyReLU(0.2) (unet.py:162); see cine_set_lrelu_slope
 struct Bump {
     char* base; size_t off;
     float* take(size_t floats) {
@@ -71,8 +70,9 @@ extern "C" size_t cine_unet3d_ws_bytes(int n, int d, int h, int w, int in_ch, in
 // weights: same order as cine_unet2d_forward, one set: conv3d weights packed with cine_pack_conv3d, transpose convs with
 // cine_pack_tconv3d, the final 1x1x1 with cine_pack_conv1x1, then its bias.
 extern "C" int cine_unet3d_forward(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
-                                   int in_ch, int out_ch, int chans, int pools, void* ws, size_t ws_bytes, void* stream) {
+                                   int in_ch, int out_ch, int chans, int pools, float kSlope, void* ws, size_t ws_bytes, void* stream) {
     CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet3d_forward: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet3d_forward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(n > 0 && d > 0 && h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL,
                  "cine_unet3d_forward: bad sizes");
     CINE_REQUIRE((d >> pools) >= 1 && (h >> pools) >= 1 && (w >> pools) >= 1, CINE_EUNSUPPORTED,

@@ -16,9 +16,14 @@
  *   - `stream` is the caller's hipStream_t passed as void* (NULL = default stream);
  *     every launch goes onto it, so the calls are hipGraph-capturable.
  *   - scratch comes from the caller: `ws`/`ws_bytes` with a matching *_ws_bytes() query.
- *   - re-entrant: per-call state only.  Process-wide state is limited to the thread-local error string, the optional launch
- *     profiler (cine_profile_begin/end: a mutex-guarded event list, off by default), per-(kernel, device) once-flags for the
- *     > 64 KB LDS opt-in, and the calling thread's optional side stream (cine_set_side_stream).  No environment switches.
+ *   - re-entrant: what a call computes depends on its arguments only (activation slopes and ReLU switches are arguments, never
+ *     library state).  State that outlives a call is limited to: the optional launch profiler (cine_profile_begin/end: a
+ *     mutex-guarded event list, off by default) and per-(kernel, device) once-flags for the > 64 KB LDS opt-in -- process-wide,
+ *     neither changes a result; and three settings of the CALLING THREAD, invisible to every other thread: its error string
+ *     (cine_last_error), its optional side stream (cine_set_side_stream) and its diagnostic kernel-selection mask
+ *     (cine_set_conv_plane: which of two bit-identical kernels a launch uses).  The library reads no environment variable.
+ *     tests/test_hip_parity.py::test_two_threads_two_streams_are_independent runs two models on two threads and streams while
+ *     one of them flips the diagnostic mask and uses another slope.
  *   - the library creates no streams.  The two backward entry points that overlap weight gradients with the input-gradient
  *     chain (cine_unet2d_backward, cine_mwcnn_backward) create and destroy hipEvents (no timing) to order the two streams.
  */
@@ -280,14 +285,16 @@ int cine_conv3x3_ex2(const float* x0, const float* part0, int np0, int c0, int m
  * adding onto the forward sweep's outputs, :254).  x, addend, y, accum (n, c, h, w); wpacked = cine_pack_conv3x3 of the
  * (c, c, 3, 3) hidden-to-hidden weight (its bias belongs in addend).  y / accum must not alias x or each other. */
 int cine_crnn_step(const float* x, const float* wpacked, const float* addend, float* y, float* accum,
-                   int n, int c, int h, int w, void* stream);
+                   int n, int c, int h, int w, int relu, void* stream);
 /* Both directions of the BCRNN time sweep in one launch (recurrent_varnet.py:241-252: two independent chains, summed at :254):
  * set f and set b are each a cine_crnn_step on their own tensors; store_* != 0 writes accum_* = y_* instead of adding (the
  * first direction to reach a frame).  x_b == NULL runs set f alone.  The sets must not write what the other reads, and must
  * not accumulate into the same tensor. */
 int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f,
                     const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b,
-                    const float* wpacked, int n, int c, int h, int w, void* stream);
+                    const float* wpacked, int n, int c, int h, int w, int relu, void* stream);
+/* `relu`: 1 = the cell's nn.ReLU (recurrent_varnet.py:178), 0 = no activation (the identity-activation gradient fixtures of
+ * tests/test_hip_grad.py, made by the reference with F.relu patched out). */
 
 /* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)
  * and the partial statistics of y.  x mode 0|1 as above. */
@@ -322,8 +329,10 @@ int cine_instnorm_lrelu_apply(const float* x, const float* part, int np, float* 
  * back to back. */
 size_t cine_unet2d_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
 int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
-                        int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                        int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                         void* ws, size_t ws_bytes, void* stream);
+/* `slope`: the LeakyReLU slope of every ConvBlock (unet.py:162 hard-wires 0.2; 0 <= slope <= 1, 1 = identity -- how
+ * tests/test_hip_grad.py compares full-size gradients with reference fixtures made without activation kinks). */
 
 /* ---- 3-D variants (reference unet.py with dims = 3, norm_unet.py:117-219; VarNet / CineNet dynamic_type '3D') ----
  * Volumes are (n, c, d, h, w).  Conv3d 3x3x3 pad 1 (unet.py:48-49), ConvTranspose3d k2 s2 as a GEMM with 8*cout rows,
@@ -350,7 +359,7 @@ int cine_instnorm_merge(const float* part, float* out, long planes, int np, void
  * cine_pack_conv3d / cine_pack_tconv3d / cine_pack_conv1x1. */
 size_t cine_unet3d_ws_bytes(int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools);
 int cine_unet3d_forward(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
-                        int in_ch, int out_ch, int chans, int pools, void* ws, size_t ws_bytes, void* stream);
+                        int in_ch, int out_ch, int chans, int pools, float slope, void* ws, size_t ws_bytes, void* stream);
 /* NormUnet3D front / back halves (norm_unet.py:149-219): x (n, t, h, w, 2) -> planes (n, 2, pad16(t), pad16(h),
  * pad16(w)) with group norm (unbiased std) and stats (n, 2, 2); norm == 0 / stats == NULL: plain unpadded repack
  * (CineNet's bare 3-D Unet, cinenet.py:251-253). */
@@ -366,13 +375,14 @@ size_t cine_mwcnn_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_sca
                            const int* n_convs, int first_filters);
 int cine_mwcnn_forward(const float* x, float* y, const void* const* weights, int n, int h, int w,
                        int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                       int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+                       int n_first_convs, int first_filters, int res, float slope, void* ws, size_t ws_bytes, void* stream);
+/* `slope`: the LeakyReLU slope of every conv block (mwcnn.py:204 hard-wires 0.2; 0 <= slope <= 1, 1 = identity). */
 /* Two MWCNNs of one topology in ONE launch sequence: samples [0, set_split) through `weights`, the rest through `weights2`
  * (same pointer-array order).  XPDNet's image networks for the x-t and the y-t planes (xpdnet.py:424-446) when both plane sets
  * have the same shape. */
 int cine_mwcnn_forward2(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
                         int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                        int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+                        int n_first_convs, int first_filters, int res, float slope, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * XPDNet primal-buffer plumbing                reference: models/xpdnet.py:301-326, 406-509
@@ -507,7 +517,7 @@ int cine_conv1x1_dgrad(const float* gy, const float* wpacked, const float* wpack
  * pass; same arguments and results as cine_unet2d_forward. */
 size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
 int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
-                              int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                              int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                               void* ws, size_t ws_bytes, void* stream);
 /* The reference's small tensor helpers as device kernels, for user code written against its utils (the fused path never calls
  * them).  utils/math.py:20-44: complex_mul with broadcasting -- `shape` = the broadcast result's dimensions WITHOUT the trailing
@@ -523,19 +533,14 @@ int cine_rss(const float* x, float* out, long outer, int k, long inner, int is_c
 int cine_roll(const float* x, float* out, long outer, int n, long inner, int shift, void* stream);
 int cine_pad2d(const float* x, float* out, long planes, int h, int w, int top, int left, int hp, int wp, void* stream);
 
-/* Test hook.  LeakyReLU slope used INSIDE the fused U-Net sequences (cine_unet2d_forward / _forward_train / _backward,
- * cine_unet3d_forward; reference unet.py:162 hard-wires 0.2, and so does this library by default).  slope = 1 makes the
- * activation the identity: tests/test_hip_grad.py compares full-size gradients with reference fixtures generated the same way
- * (no LeakyReLU kinks -> the comparison is sharp).  The per-layer entry points take their slope as an argument.  Process-wide. */
-int cine_set_lrelu_slope(float slope);
-
 /* Diagnostics.  3x3 convolutions whose tile spans the plane's width (the x-f / y-f planes of the cascade U-Nets, reference
  * denoisers/unet.py:159-168) and the k2 s2 transpose convs between them (unet.py:212-218) run on lean kernels (csrc/conv_plane.hip)
  * that are BIT-IDENTICAL to the general one, and so do the 3x3 (x3) convolutions of wider planes and volumes in 16-wide column
  * tiles (sensitivity network, CRNN cells, 3-D U-Net); `on` is a mask -- bit 0 the plane-wide 3x3 convolutions, bit 1 the
  * transpose convolutions, bit 2 the wide planes / volumes; a cleared bit routes that kind through the general kernel (the
  * bit-identity tests, A/B timing).  Bit 4 SET routes the plane-wide weight gradients of training (grad_kernels.hip:
- * wgrad_plane_kernel, also bit-identical) through the general weight-gradient kernel.  Process-wide, default 7. */
+ * wgrad_plane_kernel, also bit-identical) through the general weight-gradient kernel.  A setting of the CALLING THREAD (default 7
+ * in every thread): it selects kernels for the launches that thread enqueues afterwards and never changes a result. */
 int cine_set_conv_plane(int on);
 
 /* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_mwcnn_backward (they
@@ -553,7 +558,7 @@ int cine_set_side_stream(void* side_stream);
  * ws: cine_unet2d_backward_ws_bytes() of scratch. */
 size_t cine_unet2d_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
 int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
-                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools,
+                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                          const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream);
 
 /* The same for the wavelet CNN (denoisers/mwcnn.py:135-179): a forward that keeps every feature map, and the backward pass -- InstanceNorm +
@@ -565,12 +570,12 @@ size_t cine_mwcnn_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int
                                  const int* n_convs, int first_filters);
 int cine_mwcnn_forward_train(const float* x, float* y, const void* const* weights, const void* const* weights2, int set_split,
                              int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters, const int* n_convs,
-                             int n_first_convs, int first_filters, int res, void* ws, size_t ws_bytes, void* stream);
+                             int n_first_convs, int first_filters, int res, float slope, void* ws, size_t ws_bytes, void* stream);
 size_t cine_mwcnn_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int n_scales, const int* n_filters,
                                     const int* n_convs, int first_filters);
 int cine_mwcnn_backward(const float* x, const float* gy, const void* const* wdgrad, const void* const* wdgrad2, void* const* grads,
                         void* const* grads2, int set_split, int n, int h, int w, int in_ch, int out_ch, int n_scales,
-                        const int* n_filters, const int* n_convs, int first_filters, const void* fwd_ws, size_t fwd_ws_bytes,
+                        const int* n_filters, const int* n_convs, int first_filters, float slope, const void* fwd_ws, size_t fwd_ws_bytes,
                         void* ws, size_t ws_bytes, float* gx, void* stream);
 
 /* Adjoints of cine_normunet_unpack / cine_normunet_pack (norm_unet.py:59-96).

@@ -777,18 +777,19 @@ def _linear_activation():
 
     @contextlib.contextmanager
     def cm():
-        orig = F.leaky_relu
+        orig, orig_relu = F.leaky_relu, F.relu
         F.leaky_relu = lambda x, *a, **k: x
+        F.relu = lambda x, *a, **k: x          # nn.ReLU.forward calls F.relu: the CRNN cells (recurrent_varnet.py:126-134,198)
         try:
             yield
         finally:
-            F.leaky_relu = orig
+            F.leaky_relu, F.relu = orig, orig_relu
     return cm()
 
 
 def _grad_fingerprint_linear(name, make, ex, extra=()):
-    """Full-size gradient fingerprints with the LeakyReLUs replaced by the identity (the HIP path: cine_set_lrelu_slope(1) + slope 1 at the
-    per-layer calls): the reference's float32 gradients, its float64 gradients, and their distance (the float32 floor) per parameter."""
+    """Full-size gradient fingerprints with the LeakyReLUs replaced by the identity (the HIP path: slope 1 / ReLU off as per-call
+    arguments): the reference's float32 gradients, its float64 gradients, and their distance (the float32 floor) per parameter."""
     target = ex["target"].contiguous()
     mk = ex["masked_kspace"]
     with _linear_activation():
@@ -830,6 +831,29 @@ def g_cinenet_grad_cfg4_linear():
 
 
 
+def g_xpdnet_grad_cfg3_linear():
+    """cfg 3 (XT-XPDNet, 10 cascades; MWCNN conv blocks = conv + InstanceNorm + LeakyReLU, mwcnn.py:199-208) with identity activations."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=8, seed=0, noise_std=0.01)
+
+    def make():
+        net = RM.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT")
+        synth.fill_parameters_(net, 6, keep=())
+        return net
+    _grad_fingerprint_linear("xpdnet_grad_cfg3_linear", make, ex)
+
+
+def g_rnn_grad_cfg5_linear():
+    """cfg 5 (CRNN-VarNet, 5 cascades, 15-frame bidirectional time sweeps) with identity activations: nn.ReLU of the cells and conv blocks
+    (recurrent_varnet.py:126-134,198) and the sensitivity U-Net's LeakyReLU."""
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=8, seed=0)
+
+    def make():
+        net = RM.VarNet_RNN(5, 8, 3, 16)
+        synth.fill_parameters_(net, 9)
+        return net
+    _grad_fingerprint_linear("rnn_grad_cfg5_linear", make, ex)
+
+
 def g_fft_smooth():
     """fftc.py:13-117 on the lengths the mixed-radix line engine serves (2^a 3^b 5^c, not 200): inputs regenerated from the seed,
     outputs stored whole for the small planes and on a strided lattice for the large ones (every sample of a transform depends on
@@ -853,7 +877,7 @@ def g_fft_smooth():
     save("fft_smooth", **a)
 
 
-GENERATORS = dict(varnet_grad_cfg2_linear=g_varnet_grad_cfg2_linear, cinenet_grad_cfg4_linear=g_cinenet_grad_cfg4_linear, xpdnet_grad_cfg3=g_xpdnet_grad_cfg3, cinenet_grad_cfg4=g_cinenet_grad_cfg4, rnn_grad_cfg5=g_rnn_grad_cfg5, rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
+GENERATORS = dict(xpdnet_grad_cfg3_linear=g_xpdnet_grad_cfg3_linear, rnn_grad_cfg5_linear=g_rnn_grad_cfg5_linear, varnet_grad_cfg2_linear=g_varnet_grad_cfg2_linear, cinenet_grad_cfg4_linear=g_cinenet_grad_cfg4_linear, xpdnet_grad_cfg3=g_xpdnet_grad_cfg3, cinenet_grad_cfg4=g_cinenet_grad_cfg4, rnn_grad_cfg5=g_rnn_grad_cfg5, rnn_grad=g_rnn_grad, xpdnet_grad=g_xpdnet_grad, cinenet_grad=g_cinenet_grad, lightning=g_lightning, varnet_grad=g_varnet_grad, varnet_grad_cfg2=g_varnet_grad_cfg2, rnn=g_rnn, xpdnet=g_xpdnet, cinenet=g_cinenet, ops=g_ops, unet=g_unet, varnet_block=g_varnet_block,
                   varnet_tiny=g_varnet_tiny, masks=g_masks, varnet_full=g_varnet_full,
                   varnet_cfg1=g_varnet_cfg1, xpdnet_cfg3=g_xpdnet_cfg3,
                   cinenet_cfg4=g_cinenet_cfg4, rnn_cfg5=g_rnn_cfg5, metrics=g_metrics, frontend=g_frontend, fft_smooth=g_fft_smooth)

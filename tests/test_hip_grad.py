@@ -506,13 +506,16 @@ def test_plane_wgrad_kernel_bit_identical_to_general_kernel(dev):
 _LINEAR = {
     "varnet_grad_cfg2_linear": (lambda M: M.VarNet(6, 8, 3, 16, 3, "XF"), 1, 4, False),
     "cinenet_grad_cfg4_linear": (lambda M: M.CineNet(6, 6, 16, 3, "3D"), 7, 6, True),
+    # cfg 3: the MWCNN backward (DWT / IWT adjoints, 200 x 16 planes); cfg 5: back-propagation through the 15-frame BCRNN time sweeps
+    "xpdnet_grad_cfg3_linear": (lambda M: M.XPDNet(num_cascades=10, sens_chans=8, sens_pools=3, n_primal=5, dynamic_type="XT"), 6, 8, False),
+    "rnn_grad_cfg5_linear": (lambda M: M.VarNet_RNN(5, 8, 3, 16), 9, 8, False),
 }
 
 
 @pytest.mark.parametrize("name", sorted(_LINEAR))
 def test_full_size_gradients_with_identity_activations_vs_reference(dev, golden, name, monkeypatch):
     """The sharp full-size pin of the backward pass.  With the LeakyReLUs replaced by the identity on BOTH sides (the reference run of
-    make_golden.py patches F.leaky_relu; here cine_set_lrelu_slope(1) + slope 1 at the per-layer calls) the networks have no kinks: the
+    make_golden.py patches F.leaky_relu; here slope 1 as the per-call argument of every entry point) the networks have no kinks: the
     reference's float32 gradients are a smooth function of the input and their distance from its own float64 gradients (stored per
     parameter) is pure rounding.  An indexing or staging error in a full-size code path (200-wide planes, 15 x 200 x 200 volumes) moves a
     gradient by O(1) of its size; the bar is 1e-4 of each tensor's largest entry, or twice the reference's own float32 floor where that
@@ -522,18 +525,16 @@ def test_full_size_gradients_with_identity_activations_vs_reference(dev, golden,
     from cine_hip._lib import lib
     make, wseed, accel, needs_sens = _LINEAR[name]
     g = golden(name)
-    ex = synth.make_cine_slice(15, 15, 200, 200, accel=accel, seed=0)
+    cfg3 = name.startswith("xpdnet")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=accel, seed=0, noise_std=0.01 if cfg3 else 0.0)
     net = make(M)
-    synth.fill_parameters_(net, wseed)
+    synth.fill_parameters_(net, wseed, **(dict(keep=()) if cfg3 else {}))
     net = net.to(dev).train()
-    monkeypatch.setattr(ops, "LRELU_SLOPE", 1.0)
-    assert lib().cine_set_lrelu_slope(1.0) == 0
-    try:
-        with torch.enable_grad():
-            loss, grads, out = _training_step(net, ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev),
-                                              extra=(ex["sens_maps"].to(dev),) if needs_sens else ())
-    finally:
-        lib().cine_set_lrelu_slope(0.2)
+    # identity activations as per-call arguments (no library state): LeakyReLU slope 1, nn.ReLU of the CRNN cells off -- what
+    # make_golden.py's F.leaky_relu / F.relu patches do on the reference side
+    with ops.activation(slope=1.0, relu=False), torch.enable_grad():
+        loss, grads, out = _training_step(net, ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev),
+                                          extra=(ex["sens_maps"].to(dev),) if needs_sens else ())
     assert rel_err(out[:, :, ::4, ::4].cpu(), g["out_strided"]) < TOL
     assert abs(float(loss) - float(g["loss64"])) < 1e-4
     bad, worst = {}, 0.0

@@ -424,7 +424,7 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
                     rc = lib().cine_conv3x3_ex2(cur.data_ptr(), pc.data_ptr(), pc.shape[2], 4 * c0, 4 | 8, h // 2, w // 2,
                                                 x.data_ptr(), px.data_ptr(), px.shape[2], c0, 1, h, w, 1,
                                                 pa.data_ptr(), ptr(bias_i), pb.data_ptr(), ptr(bias_i), 4, None, 0,
-                                                y.data_ptr(), ptr(py), n, cout, h, w, ops.IN_EPS, ops.LRELU_SLOPE, torch.cuda.current_stream().cuda_stream)
+                                                y.data_ptr(), ptr(py), n, cout, h, w, ops.IN_EPS, ops.lrelu_slope(), torch.cuda.current_stream().cuda_stream)
                     assert rc == 0
                     outs.append((y, py))
                 elif kind == "relu":
@@ -858,6 +858,75 @@ def test_conv3d_vs_torch(dev, cin, cout, d, h, w):
     st = ops.instnorm_finalize(part)
     assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3, 4))) < 1e-4
     assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3, 4), unbiased=False) + 1e-5)) < 1e-4
+
+
+def test_two_threads_two_streams_are_independent(dev):
+    """include/cine_hip.h, "re-entrant": what a call computes depends on its arguments only, and the settings that outlive a call (error
+    string, side stream, diagnostic kernel-selection mask) belong to the calling thread.  The contract behind it is the reference's
+    Lightning `dp` strategy (traintest_scripts/varnet/train_test_varnet.py:148,290: one Python thread per device in one process).
+    Two threads, each with its own model and stream, run concurrently: thread A reconstructs with ANOTHER LeakyReLU slope and flips
+    cine_set_conv_plane between iterations (general <-> lean kernels, bit-identical by construction); thread B runs forward + backward
+    training steps with the defaults.  Every result must equal, bit for bit, what the same work gives alone on the main thread."""
+    import threading
+    import reconstruction.models as M
+    from cine_hip import ops, synth
+    from cine_hip._lib import lib
+    exa = synth.make_cine_slice(5, 3, 24, 20, accel=4, center_lines=4, seed=0)
+    exb = synth.make_cine_slice(6, 4, 32, 24, accel=4, center_lines=4, seed=1)
+    exa = {k: v.to(dev) for k, v in exa.items() if torch.is_tensor(v)}
+    exb = {k: v.to(dev) for k, v in exb.items() if torch.is_tensor(v)}
+    neta = M.VarNet(2, 4, 2, 4, 2, "XF").eval(); synth.fill_parameters_(neta, 1); neta.to(dev)
+    netb = M.CineNet(2, 3, 4, 2, "XT").train(); synth.fill_parameters_(netb, 2); netb.to(dev)
+    iters = 6
+
+    def work_a(flip):
+        outs = []
+        with torch.no_grad(), ops.activation(slope=0.5):
+            for i in range(iters):
+                if flip:
+                    assert lib().cine_set_conv_plane(0 if i % 2 == 0 else 7) == 0
+                outs.append(neta(exa["masked_kspace"], exa["mask"]).clone())
+        return outs
+
+    def work_b():
+        outs = []
+        for _ in range(iters):
+            netb.zero_grad()
+            with torch.enable_grad():
+                y = netb(exb["masked_kspace"], exb["mask"], exb["sens_maps"])
+                ((y - exb["target"]) ** 2).sum().backward()
+            outs.append([y.detach().clone()] + [p.grad.detach().clone() for p in netb.parameters()])
+        return outs
+
+    want_a = work_a(False)
+    want_b = work_b()
+    with torch.no_grad():
+        default_a = neta(exa["masked_kspace"], exa["mask"])
+    assert not torch.equal(default_a, want_a[0])             # the slope argument does change the result
+    torch.cuda.synchronize()
+    res, errs, gate = {}, [], threading.Barrier(2)
+
+    def runner(name, fn, *args):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                gate.wait(timeout=60)
+                res[name] = fn(*args)
+                st.synchronize()
+        except Exception as e:                                # noqa: BLE001 -- reported by the main thread
+            errs.append((name, repr(e)))
+    ta = threading.Thread(target=runner, args=("a", work_a, True))
+    tb = threading.Thread(target=runner, args=("b", work_b))
+    ta.start(); tb.start(); ta.join(300); tb.join(300)
+    assert not errs and not ta.is_alive() and not tb.is_alive(), errs
+    for got, want in zip(res["a"], want_a):
+        assert torch.equal(got, want)
+    for got, want in zip(res["b"], want_b):
+        for g_, w_ in zip(got, want):
+            assert torch.equal(g_, w_)
+    # thread A's mask and slope died with it: the main thread still reconstructs with its defaults
+    with torch.no_grad():
+        assert torch.equal(neta(exa["masked_kspace"], exa["mask"]), default_a)
 
 
 @pytest.mark.parametrize("case", ["plain16", "ragged50", "partial_chunk", "norm_concat", "pooled", "pooled_odd", "concat_unaligned", "bias_relu",
@@ -1465,7 +1534,7 @@ def test_dwt_iwt_alone_vs_reference_golden(golden, dev):
         y = torch.empty((n, cin, ho, wo), device=dev)
         check(lib().cine_conv3x3_ex(src.data_ptr(), None, 0, src.shape[1], mode, hs, ws, None, None, 0, 0, 0, 0, 0, 0,
                                     ops.pack_conv3x3(wt).data_ptr(), None, None, 0, y.data_ptr(), None, n, cin, ho, wo,
-                                    ops.IN_EPS, ops.LRELU_SLOPE, ops._stream()), "cine_conv3x3_ex")
+                                    ops.IN_EPS, ops.lrelu_slope(), ops._stream()), "cine_conv3x3_ex")
         return y
     dwt = delta_conv(x, 3, 4 * c, h, w, h // 2, w // 2)
     assert rel_err(dwt.cpu(), g["dwt_y"]) < 1e-6
