@@ -8,11 +8,12 @@
 //     right halo of row y and the left halo of row y + 1), so a 16-position MFMA fragment is any 16 consecutive P and tap (dy, dx)
 //     reads position P + (dy - 1)(W + 1) + (dx - 1): no fragment is cut at the row end (W = 50: 2 % padding instead of the 22 % of
 //     16-wide column tiles);
-//   * one workgroup = 64 output rows x 16 MT positions of one slice; its four waves split the K dimension (8-channel chunks
-//     round-robin, every depth offset) and each holds the whole 64 x 16 MT accumulator tile: per (tap, 4 channels) a wave reads
-//     MT A operands from ITS OWN staged run in LDS (wave-private: no workgroup barrier in the chunk loop) and streams 4 B operands
-//     straight from the packed weights in L2, three taps ahead -- 4 MT MFMAs per 4 + MT operand loads;
-//   * the four partial tiles meet in LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic), then bias / addend / ReLU, the
+//   * one workgroup = 64 output rows x 16 MT positions of one slice; its eight waves split the K dimension ((depth offset, 8-channel
+//     chunk) units dealt round-robin) and each holds the whole 64 x 16 MT accumulator tile: per (tap, 4 channels) a wave reads
+//     MT A operands from ITS OWN staged run in LDS (wave-private: no workgroup barrier in the chunk loop) and streams its 4 B operands
+//     straight from the packed weights in L2 -- ONE 16-byte load (the row tiles interleave the rows: tile ct = rows 4 q + ct), requested
+//     a whole unit (9 taps) ahead -- 4 MT MFMAs per 1 + MT operand loads;
+//   * the eight partial tiles meet in LDS in a fixed order (wave 0 + 1 + ... + 7: deterministic), then bias / addend / ReLU, the
 //     stores, and this layer's InstanceNorm record {count, mean, M2} per (row, tile).
 // 240 workgroups for cfg 4's 3 x 50 x 50 level (was 156 with 24 barrier pairs each), 82 for 1 x 25 x 25 (was 14 - 28).
 // Sources: plain / InstanceNorm + LeakyReLU / the same + 2x2x2 average pool (unet.py:88,97), one or two of them (concat, unet.py:122),
@@ -31,29 +32,36 @@ struct CoarseArgs {
     const float* wp; const float* bias; const float* addend; int relu;
     float* y; float* ypart;
     int cin, rows, rowsp, D, H, W, Wp, ncc, tiles_z, tiles;
-    int nph, ps;                         // staged positions per channel (16 MT + 2 (Wp + 1)); LDS channel stride, == 16 (mod 32)
+    int nph;                             // staged positions per channel: 16 MT + 2 (Wp + 1)
     float slope, eps;
 };
 
-constexpr int kNS = 3;                   // position slots per lane of a staged run (<= 192 positions)
-
-template <int MT>
-__global__ __launch_bounds__(256, 2) void conv_coarse_kernel(CoarseArgs a) {
+// NS: 64-position slots per lane of a staged run (2 or 3); POOL: some source is 2x2x2-pooled on load (its eight loads per value happen in
+// commit); RAGGED: a chunk may hold fewer than 8 channels or channels of both sources (per-channel source selection).  The common
+// instantiation (whole chunks, one source per chunk, no pooling) has a branch-free unit loop with ~150 vector instructions of staging
+// per unit; the first version selected the source per channel and masked every LDS write: ~1 000 instructions per unit on a SIMD
+// that runs ONE wave (240 workgroups on 256 CUs) -- as long as the unit's 144 MFMAs.
+constexpr int kCoarseWaves = 8;          // K-split width = waves per workgroup: two per SIMD, so one wave's staging and load latency run under the other's MFMAs
+template <int MT, int NS, bool POOL, bool RAGGED>
+__global__ __launch_bounds__(64 * kCoarseWaves, 1) void conv_coarse_kernel(CoarseArgs a) {
+    constexpr int NW = kCoarseWaves;
     constexpr int NP = 16 * MT;          // output positions of the workgroup
     constexpr int RS = NP + 4;           // row stride of the partial tiles in LDS
     constexpr int PPT = NP / 4;          // positions per thread in the final pass
+    constexpr int PS = 64 * NS + 16;     // LDS channel stride of a staged unit: every slot of every lane exists, == 16 (mod 32)
     extern __shared__ __align__(16) float smem_c[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: the unit list, source selection and modes stay scalar
     const int q = lane & 15, kk = lane >> 4;
     const int n = blockIdx.z, co0 = blockIdx.y * 64, tile = blockIdx.x;
     const int z0 = tile / a.tiles_z, P0 = (tile - z0 * a.tiles_z) * NP;
     const int nch = a.s0.c + a.s1.c, nchp = (nch + 1) & ~1;
     float* st_lds = smem_c;                                  // {scale, shift} per input channel (act())
-    float* xw = smem_c + 2 * nchp + wave * (8 * a.ps);       // this wave's staged unit: 8 channels x nph positions
-    float* red = smem_c + 2 * nchp + 4 * 8 * a.ps;           // [4 waves][64 rows][RS]
+    float* xw = smem_c + 2 * nchp + wave * (8 * PS);         // this wave's staged unit: 8 channels x 64 NS positions
+    float* red = smem_c + 2 * nchp + NW * 8 * PS;            // [NW waves][64 rows][RS]
 
     // ---- InstanceNorm table of the input channels (records are usually merged already: np = 1)
-    for (int ci = tid; ci < nch; ci += 256) {
+    for (int ci = tid; ci < nch; ci += 64 * NW) {
         const bool first = ci < a.s0.c;
         const Src& s = first ? a.s0 : a.s1;
         const int cl = first ? ci : ci - a.s0.c;
@@ -63,9 +71,9 @@ __global__ __launch_bounds__(256, 2) void conv_coarse_kernel(CoarseArgs a) {
     }
 
     // ---- my position slots of a staged run: run position p <-> padded position P0 - (Wp + 1) + p of the slice
-    int off0[kNS], off1[kNS];            // element offset inside a (channel, slice) plane of source 0 / 1; -1: reads as zero
+    int off0[NS], off1[NS];              // element offset inside a (channel, slice) plane of source 0 / 1; -1: reads as zero
 #pragma unroll
-    for (int j = 0; j < kNS; ++j) {
+    for (int j = 0; j < NS; ++j) {
         const int p = lane + 64 * j;
         const int pin = P0 - (a.Wp + 1) + p + 2 * a.Wp;      // >= 0
         const int yy = pin / a.Wp - 2, xx = pin - (yy + 2) * a.Wp;
@@ -78,74 +86,127 @@ __global__ __launch_bounds__(256, 2) void conv_coarse_kernel(CoarseArgs a) {
         off0[j] = soff(a.s0); off1[j] = soff(a.s1);
     }
 
-    // ---- units of this wave: (depth offset, 8-channel chunk), chunks wave, wave + 4, ...; dead depth offsets are skipped
+    // ---- units of this wave: the live (depth offset, 8-channel chunk) pairs k = dz * ncc + cc of the tile, dealt round-robin: k = wave, wave + NW, ...
     const int dz_lo = z0 == 0 ? 1 : 0, dz_hi = z0 == a.D - 1 ? 1 : 2;
-    const int nccw = wave < a.ncc ? (a.ncc - wave + 3) / 4 : 0;
-    const int nunits = (dz_hi - dz_lo + 1) * nccw;
-    auto unit_dz = [&](int u) { return dz_lo + u / nccw; };
-    auto unit_cc = [&](int u) { return wave + 4 * (u % nccw); };
+    const int nk = (dz_hi - dz_lo + 1) * a.ncc;
+    const int nunits = wave < nk ? (nk - wave + NW - 1) / NW : 0;
+    auto unit_dz = [&](int u) { return dz_lo + (wave + NW * u) / a.ncc; };
+    auto unit_cc = [&](int u) { return (wave + NW * u) % a.ncc; };
 
     // channel ci of the layer input -> source, channel inside it (uniform)
     auto chan = [&](int ci, int& cl) -> const Src& { const bool f = ci < a.s0.c; cl = f ? ci : ci - a.s0.c; return f ? a.s0 : a.s1; };
 
-    float xraw[kNS][8];
-    // raw loads of unit u (plain / normalised sources; pooled ones are fetched in commit)
+    float xraw[NS][8];
+    // raw loads of unit u (plain / normalised sources; pooled ones are fetched in commit).  Every load is UNCONDITIONAL (clamped address,
+    // the value is selected in commit): a conditional load is a branch, and a branch makes the compiler wait for every load in flight
     auto issue = [&](int u) {
         const int zs = z0 + unit_dz(u) - 1, ci0 = unit_cc(u) * 8;
+        if constexpr (!RAGGED) {
+            const bool f0 = ci0 < a.s0.c;                        // the whole chunk lies in one source
+            const Src& s = f0 ? a.s0 : a.s1;
+            const long plane = (long)s.h * s.w;
+            const char* sb = reinterpret_cast<const char*>(s.x + (((long)n * s.c + (f0 ? ci0 : ci0 - a.s0.c)) * s.d + min(zs, s.d - 1)) * plane);
+            const long cstr = (long)s.d * plane * 4;
+            unsigned vo[NS];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int ci = ci0 + c;
-            int cl;
-            const Src& s = chan(min(ci, a.cin - 1), cl);
-            const bool live = ci < a.cin && s.mode != 2 && zs < s.d;
-            const float* sb = s.x + (((long)n * s.c + cl) * s.d + min(zs, s.d - 1)) * (long)s.h * s.w;
-            const bool f0 = ci < a.s0.c;
+            for (int j = 0; j < NS; ++j) vo[j] = (unsigned)max(f0 ? off0[j] : off1[j], 0) * 4u;
 #pragma unroll
-            for (int j = 0; j < kNS; ++j) {
-                const int o = f0 ? off0[j] : off1[j];
-                xraw[j][c] = (live && o >= 0) ? sb[o] : 0.f;
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) xraw[j][c] = *reinterpret_cast<const float*>(sb + c * cstr + vo[j]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ci = min(ci0 + c, a.cin - 1);
+                int cl;
+                const Src& s = chan(ci, cl);
+                const bool f0 = ci < a.s0.c;
+                const float* sb = s.x + (((long)n * s.c + cl) * s.d + min(zs, s.d - 1)) * (long)s.h * s.w;     // (a pooled source: a valid address, the value is not used)
+#pragma unroll
+                for (int j = 0; j < NS; ++j) xraw[j][c] = sb[max(f0 ? off0[j] : off1[j], 0)];
             }
+        }
+    };
+    // avg_pool3d 2x2x2 of act(x) (unet.py:88,97) for channel cl of source s into LDS channel c: two source slices x two rows x two
+    // columns, fetch_scalar's summation order; invalid slots load one valid element eight times
+    auto commit_pooled = [&](const Src& s, int cl, bool f0, int c, int zs, bool cok, float sc, float sh) {
+        const bool zok = cok && 2 * zs + 1 < s.d;
+        const float* sb = s.x + (((long)n * s.c + cl) * s.d + (zok ? 2 * zs : 0)) * (long)s.h * s.w;
+        const long zstr = zok ? (long)s.h * s.w : 0;
+        float t[NS][8];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int o = f0 ? off0[j] : off1[j];
+            const float* p = sb + max(o, 0);
+            const int dw = o >= 0 ? s.w : 0, d1 = o >= 0 ? 1 : 0;
+#pragma unroll
+            for (int dzz = 0; dzz < 2; ++dzz) {
+                t[j][4 * dzz] = p[dzz * zstr]; t[j][4 * dzz + 1] = p[dzz * zstr + d1];
+                t[j][4 * dzz + 2] = p[dzz * zstr + dw]; t[j][4 * dzz + 3] = p[dzz * zstr + dw + d1];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int o = f0 ? off0[j] : off1[j];
+            float acc8 = 0.f;
+#pragma unroll
+            for (int dzz = 0; dzz < 2; ++dzz)
+                acc8 += act(t[j][4 * dzz], sc, sh, a.slope) + act(t[j][4 * dzz + 1], sc, sh, a.slope) +
+                        act(t[j][4 * dzz + 2], sc, sh, a.slope) + act(t[j][4 * dzz + 3], sc, sh, a.slope);
+            xw[c * PS + lane + 64 * j] = (zok && o >= 0) ? 0.125f * acc8 : 0.f;
         }
     };
     auto commit = [&](int u) {
         const int zs = z0 + unit_dz(u) - 1, ci0 = unit_cc(u) * 8;
+        if constexpr (!RAGGED) {
+            const bool f0 = ci0 < a.s0.c;
+            const Src& s = f0 ? a.s0 : a.s1;
+            if (POOL && s.mode == 2) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int ci = ci0 + c;
-            int cl;
-            const Src& s = chan(min(ci, a.cin - 1), cl);
-            const bool f0 = ci < a.s0.c;
-            const float sc = st_lds[2 * min(ci, a.cin - 1)], sh = st_lds[2 * min(ci, a.cin - 1) + 1];
-            if (ci < a.cin && s.mode == 2) {
-                // avg_pool3d 2x2x2 of act(x) (unet.py:88,97): two source slices x two rows x two columns, fetch_scalar's summation order
-                const bool zok = 2 * zs + 1 < s.d;
-                const float* sb = s.x + (((long)n * s.c + cl) * s.d + (zok ? 2 * zs : 0)) * (long)s.h * s.w;
-                const long zstr = (long)s.h * s.w;
-#pragma unroll
-                for (int j = 0; j < kNS; ++j) {
-                    const int o = f0 ? off0[j] : off1[j];
-                    float v = 0.f;
-                    if (zok && o >= 0) {
-                        float acc8 = 0.f;
-#pragma unroll
-                        for (int dzz = 0; dzz < 2; ++dzz) {
-                            const float* p = sb + dzz * zstr + o;
-                            acc8 += act(p[0], sc, sh, a.slope) + act(p[1], sc, sh, a.slope) + act(p[s.w], sc, sh, a.slope) + act(p[s.w + 1], sc, sh, a.slope);
-                        }
-                        v = 0.125f * acc8;
-                    }
-                    if (lane + 64 * j < a.nph) xw[c * a.ps + lane + 64 * j] = v;
+                for (int c = 0; c < 8; ++c) {
+                    const float2 ss = *reinterpret_cast<const float2*>(st_lds + 2 * (ci0 + c));
+                    commit_pooled(s, (f0 ? ci0 : ci0 - a.s0.c) + c, f0, c, zs, true, ss.x, ss.y);
                 }
-            } else {
-                const bool live = ci < a.cin && zs < s.d;
-                const bool plain = s.mode == 0;
+                return;
+            }
+            const bool live = zs < s.d;                          // a shorter `up` volume reads as zero behind its end (unet.py:106-120)
+            bool ok[NS];
 #pragma unroll
-                for (int j = 0; j < kNS; ++j) {
-                    const int o = f0 ? off0[j] : off1[j];
-                    float v = xraw[j][c];
-                    if (!plain) v = act(v, sc, sh, a.slope);
-                    if (!(live && o >= 0)) v = 0.f;
-                    if (lane + 64 * j < a.nph) xw[c * a.ps + lane + 64 * j] = v;
+            for (int j = 0; j < NS; ++j) ok[j] = live && (f0 ? off0[j] : off1[j]) >= 0;
+            if (s.mode == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) xw[c * PS + lane + 64 * j] = ok[j] ? xraw[j][c] : 0.f;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float2 ss = *reinterpret_cast<const float2*>(st_lds + 2 * (ci0 + c));
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) xw[c * PS + lane + 64 * j] = ok[j] ? act(xraw[j][c], ss.x, ss.y, a.slope) : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ci = min(ci0 + c, a.cin - 1);
+                const bool cok = ci0 + c < a.cin;
+                int cl;
+                const Src& s = chan(ci, cl);
+                const bool f0 = ci < a.s0.c;
+                const float sc = st_lds[2 * ci], sh = st_lds[2 * ci + 1];
+                if (POOL && s.mode == 2) {
+                    commit_pooled(s, cl, f0, c, zs, cok, sc, sh);
+                } else {
+                    const bool live = cok && zs < s.d;
+                    const bool plain = s.mode == 0;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) {
+                        const int o = f0 ? off0[j] : off1[j];
+                        float v = xraw[j][c];
+                        if (!plain) v = act(v, sc, sh, a.slope);
+                        xw[c * PS + lane + 64 * j] = (live && o >= 0) ? v : 0.f;
+                    }
                 }
             }
         }
@@ -157,58 +218,66 @@ __global__ __launch_bounds__(256, 2) void conv_coarse_kernel(CoarseArgs a) {
 #pragma unroll
         for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // B operands: lane (q, kk) of k-step ks, row tile ct reads W[row co0 + 16 ct + q][channel 4 ks + kk][tap] of the packed weights
-    // [dz][8-channel chunk][3x3 tap][8 channels][rowsp] (cine_pack_conv3d)
-    bool ctl[4];
+    // B operands from the packed weights [dz][8-channel chunk][3x3 tap][8 channels][rowsp] (cine_pack_conv3d): lane (q, kk) of row tile
+    // ct works on output row co0 + 4 q + ct, so its four B operands of a k-step are ONE 16-byte load (rows 4 q .. 4 q + 3 of channel
+    // 4 ks + kk; a wave-load = four 256-byte runs).  All nine taps of a unit sit in registers; tap t of the NEXT unit is requested as
+    // soon as tap t of this one has been consumed -- a prefetch distance of a whole unit (288 MFMAs at MT = 2).
+    // (row quads past the padded row count read the last quad again: their accumulators are never stored)
+    const unsigned wlane = (unsigned)(kk * a.rowsp + min(co0 + 4 * q, a.rowsp - 4)) * 4u;     // my byte offset inside a (unit, tap) block; the block base is scalar
+    const unsigned wks = (unsigned)(4 * a.rowsp) * 4u;
+    float4 wr[9][2];
+    auto loadw = [&](int u, int tap, float4 (&w)[2]) {
+        const char* wu = reinterpret_cast<const char*>(a.wp + (((long)unit_dz(u) * a.ncc + unit_cc(u)) * 9 + tap) * 8 * a.rowsp);
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) ctl[ct] = co0 + 16 * ct < a.rowsp;
-    float wr[3][2][4];
-    auto loadw = [&](int u, int tap, float (&w)[2][4]) {
-        const float* wu = a.wp + ((((long)unit_dz(u) * a.ncc + unit_cc(u)) * 9 + tap) * 8 + kk) * a.rowsp + co0 + q;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct) w[ks][ct] = ctl[ct] ? wu[(long)(4 * ks) * a.rowsp + 16 * ct] : 0.f;
+        for (int ks = 0; ks < 2; ++ks) w[ks] = *reinterpret_cast<const float4*>(wu + (wlane + ks * wks));
     };
 
     __syncthreads();                     // the statistics table (the only workgroup-wide dependency before the final pass)
     if (nunits > 0) {
-        loadw(0, 0, wr[0]); loadw(0, 1, wr[1]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) loadw(0, tap, wr[tap]);
         issue(0);
     }
-    const int xbase = kk * a.ps + q;
+    const int xbase = kk * PS + q;
     for (int u = 0; u < nunits; ++u) {
+        const int un = min(u + 1, nunits - 1);      // the prefetches are unconditional (the last unit re-reads itself): no branch, no lost wait counts
         commit(u);
-        if (u + 1 < nunits) issue(u + 1);
+        issue(un);
         __builtin_amdgcn_sched_barrier(0);
+        // 18 operand groups (tap, k-step); the A operands of group g + 1 are read from LDS before the MFMAs of group g are issued (this
+        // wave is alone on its SIMD: nobody else hides the LDS latency)
+        float xa[2][MT];
+        auto loadx = [&](int g, float (&x)[MT]) {
+            const int tap = g >> 1, ks = g & 1, toff = (tap / 3) * a.Wp + tap % 3;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 2 < 9) loadw(u, tap + 2, wr[(tap + 2) % 3]);
-            else if (u + 1 < nunits) loadw(u + 1, tap + 2 - 9, wr[(tap + 2) % 3]);
-            const int toff = (tap / 3) * a.Wp + tap % 3;
+            for (int f = 0; f < MT; ++f) x[f] = xw[xbase + (4 * ks) * PS + 16 * f + toff];
+        };
+        loadx(0, xa[0]);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float xa[MT];
+        for (int g = 0; g < 18; ++g) {
+            const int tap = g >> 1, ks = g & 1;
+            if (g + 1 < 18) loadx(g + 1, xa[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise sinks these reads behind the MFMAs, next to their use)
+            const float wv[4] = {wr[tap][ks].x, wr[tap][ks].y, wr[tap][ks].z, wr[tap][ks].w};
 #pragma unroll
-                for (int f = 0; f < MT; ++f) xa[f] = xw[xbase + (4 * ks) * a.ps + 16 * f + toff];
+            for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                    for (int f = 0; f < MT; ++f)
-                        acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[f], wr[tap % 3][ks][ct], acc[ct][f], 0, 0, 0);
-            }
+                for (int f = 0; f < MT; ++f)
+                    acc[ct][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g & 1][f], wv[ct], acc[ct][f], 0, 0, 0);
+            if (ks == 1) loadw(un, tap, wr[tap]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // ---- the four K-split partial tiles meet in LDS; lane (q, kk) holds rows 16 ct + q, positions 16 f + 4 kk .. + 3
+    // ---- the K-split partial tiles meet in LDS; lane (q, kk) holds rows 4 q + ct, positions 16 f + 4 kk .. + 3
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
         for (int f = 0; f < MT; ++f)
-            *reinterpret_cast<float4*>(red + (wave * 64 + 16 * ct + q) * RS + 16 * f + 4 * kk) =
+            *reinterpret_cast<float4*>(red + (wave * 64 + 4 * q + ct) * RS + 16 * f + 4 * kk) =
                 make_float4(acc[ct][f][0], acc[ct][f][1], acc[ct][f][2], acc[ct][f][3]);
     __syncthreads();
+    if (tid >= 256) return;              // (no barrier behind this point)
     // ---- final pass: thread = (row, PPT consecutive positions); partials added in wave order
     const int row = tid >> 2, pos0 = (tid & 3) * PPT;
     const int m = co0 + row;
@@ -217,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_coarse_kernel(CoarseArgs a) {
 #pragma unroll
     for (int i = 0; i < PPT; ++i) v[i] = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
         for (int i = 0; i < PPT; i += 4) {
             const float4 t = *reinterpret_cast<const float4*>(red + (w * 64 + row) * RS + pos0 + i);
@@ -256,11 +325,11 @@ __global__ __launch_bounds__(256, 2) void conv_coarse_kernel(CoarseArgs a) {
     }
 }
 
-template <int MT>
+template <int MT, int NS, bool POOL, bool RAGGED>
 int launch_coarse(const CoarseArgs& p, int n, hipStream_t st) {
-    auto kern = conv_coarse_kernel<MT>;
+    auto kern = conv_coarse_kernel<MT, NS, POOL, RAGGED>;
     const int nch = p.s0.c + p.s1.c, nchp = (nch + 1) & ~1;
-    const size_t lds = (size_t)(2 * nchp + 4 * 8 * p.ps + 4 * 64 * (16 * MT + 4)) * sizeof(float);
+    const size_t lds = (size_t)(2 * nchp + kCoarseWaves * 8 * (64 * NS + 16) + kCoarseWaves * 64 * (16 * MT + 4)) * sizeof(float);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv_coarse_kernel: %d input channels need %zu bytes of LDS", p.cin, lds);
     if (lds > 64 * 1024) {
         static std::once_flag once[64];
@@ -275,8 +344,13 @@ int launch_coarse(const CoarseArgs& p, int n, hipStream_t st) {
     }
     const dim3 grid(p.tiles, ceil_div(p.rowsp, 64), n);
     ProfScope prof(F_CONV3, st);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * kCoarseWaves), lds, st, p);
     return check_launch("conv_coarse_kernel");
+}
+template <int MT, int NS>
+int launch_coarse_variant(const CoarseArgs& p, int n, bool pool, bool ragged, hipStream_t st) {
+    if (ragged) return pool ? launch_coarse<MT, NS, true, true>(p, n, st) : launch_coarse<MT, NS, false, true>(p, n, st);
+    return pool ? launch_coarse<MT, NS, true, false>(p, n, st) : launch_coarse<MT, NS, false, false>(p, n, st);
 }
 
 }  // namespace
@@ -304,10 +378,12 @@ int launch_conv_coarse(const ConvArgs& a, hipStream_t st) {
     p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.D = a.D; p.H = a.H; p.W = a.W; p.Wp = a.W + 1; p.ncc = a.ncc;
     p.tiles_z = ceil_div(a.H * p.Wp, 16 * mt); p.tiles = p.tiles_z * a.D;
     p.nph = 16 * mt + 2 * (p.Wp + 1);
-    CINE_REQUIRE(p.nph <= 64 * kNS, CINE_EUNSUPPORTED, "conv_coarse_kernel: rows of %d voxels are too wide", a.W);
-    p.ps = ((p.nph + 15) / 32) * 32 + 16;           // >= nph, == 16 (mod 32): the four channels of a k-step land on disjoint banks
+    CINE_REQUIRE(p.nph <= 192, CINE_EUNSUPPORTED, "conv_coarse_kernel: rows of %d voxels are too wide", a.W);
     p.slope = a.slope; p.eps = a.eps;
-    return mt == 2 ? launch_coarse<2>(p, a.n, st) : launch_coarse<1>(p, a.n, st);
+    const bool pool = a.s0.mode == 2 || (a.s1.c > 0 && a.s1.mode == 2);
+    const bool ragged = a.cin % 8 != 0 || (a.s1.c > 0 && a.s0.c % 8 != 0);
+    if (p.nph <= 128) return mt == 2 ? launch_coarse_variant<2, 2>(p, a.n, pool, ragged, st) : launch_coarse_variant<1, 2>(p, a.n, pool, ragged, st);
+    return mt == 2 ? launch_coarse_variant<2, 3>(p, a.n, pool, ragged, st) : launch_coarse_variant<1, 3>(p, a.n, pool, ragged, st);
 }
 
 }  // namespace cine
