@@ -8,12 +8,12 @@
 //     right halo of row y and the left halo of row y + 1), so a 16-position MFMA fragment is any 16 consecutive P and tap (dy, dx)
 //     reads position P + (dy - 1)(W + 1) + (dx - 1): no fragment is cut at the row end (W = 50: 2 % padding instead of the 22 % of
 //     16-wide column tiles);
-//   * one workgroup = 64 output rows x 16 MT positions of one slice; its eight waves split the K dimension ((depth offset, 8-channel
+//   * one workgroup = 64 output rows x 16 MT positions of one slice; its four waves split the K dimension ((depth offset, 8-channel
 //     chunk) units dealt round-robin) and each holds the whole 64 x 16 MT accumulator tile: per (tap, 4 channels) a wave reads
 //     MT A operands from ITS OWN staged run in LDS (wave-private: no workgroup barrier in the chunk loop) and streams its 4 B operands
 //     straight from the packed weights in L2 -- ONE 16-byte load (the row tiles interleave the rows: tile ct = rows 4 q + ct), requested
 //     a whole unit (9 taps) ahead -- 4 MT MFMAs per 1 + MT operand loads;
-//   * the eight partial tiles meet in LDS in a fixed order (wave 0 + 1 + ... + 7: deterministic), then bias / addend / ReLU, the
+//   * the four partial tiles meet in LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic), then bias / addend / ReLU, the
 //     stores, and this layer's InstanceNorm record {count, mean, M2} per (row, tile).
 // 240 workgroups for cfg 4's 3 x 50 x 50 level (was 156 with 24 barrier pairs each), 82 for 1 x 25 x 25 (was 14 - 28).
 // Sources: plain / InstanceNorm + LeakyReLU / the same + 2x2x2 average pool (unet.py:88,97), one or two of them (concat, unet.py:122),
@@ -41,9 +41,15 @@ struct CoarseArgs {
 // instantiation (whole chunks, one source per chunk, no pooling) has a branch-free unit loop with ~150 vector instructions of staging
 // per unit; the first version selected the source per channel and masked every LDS write: ~1 000 instructions per unit on a SIMD
 // that runs ONE wave (240 workgroups on 256 CUs) -- as long as the unit's 144 MFMAs.
-constexpr int kCoarseWaves = 8;          // K-split width = waves per workgroup: two per SIMD, so one wave's staging and load latency run under the other's MFMAs
+#ifndef CINE_COARSE_WAVES                // (diagnostic builds: tools/build_variant.sh ... -DCINE_COARSE_WAVES=8)
+#define CINE_COARSE_WAVES 4
+#endif
+// K-split width = waves per workgroup.  Measured on cfg 4 (tools/ab_variants.sh): 8 waves (two per SIMD, 128 KB of LDS, one workgroup per CU)
+// 23.4 / 43.6 us per 64 -> 64 / 128 -> 64 layer alone and 159.4 slices/s with ten slices in flight; 4 waves (55 KB: a second stream's
+// workgroup fits beside it) 24.8 / 47.4 us and 163.3 slices/s -- the same latency for one slice (100.4 slices/s either way)
+constexpr int kCoarseWaves = CINE_COARSE_WAVES;
 template <int MT, int NS, bool POOL, bool RAGGED>
-__global__ __launch_bounds__(64 * kCoarseWaves, 1) void conv_coarse_kernel(CoarseArgs a) {
+__global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void conv_coarse_kernel(CoarseArgs a) {
     constexpr int NW = kCoarseWaves;
     constexpr int NP = 16 * MT;          // output positions of the workgroup
     constexpr int RS = NP + 4;           // row stride of the partial tiles in LDS
