@@ -17,12 +17,13 @@ timed region.  Time = max over ranks, value = N*K / time.
 
 Rank 0 prints ONE JSON line.  `roofline` = the dominant kernel family (3x3 conv on fp32 MFMA).  `roofline.frac` =
 `frac_timed_mode`: the family's algorithmic FLOPs of the K timed slices over the TIMED REGION's wall time (the mode `ms_per_step`
-comes from: graphs of several slices overlap, so this is the whole-chip fp32-MFMA utilisation and a lower bound on the family's
-own rate); `frac_isolated` = the same FLOPs over the kernels' own duration with ONE slice in flight (eager launches, hipEvent
+comes from: graphs of several slices overlap, so no per-launch duration exists there -- it is the WHOLE-CHIP fp32-MFMA utilisation
+over the timed region, the figure the driver's clock anchors; rounds 1-3 printed the isolated per-launch figure under this key);
+`frac_isolated` = the same FLOPs over the kernels' own duration with ONE slice in flight (eager launches, hipEvent
 pairs on the launch stream -- agrees with profiles/rNN_rocprofv3_kernel_stats_isolated.csv).  `roofline_fft_dc` = the FFT +
 data-consistency family, both in SURVEY 8(d)'s algorithmic bytes and in real (PMC) bytes.  `latency_ms_one_slice` = one graph
-replay on one stream (what run_inference.py:53-61 times); `sustained_value` = one >= 10 s region of the same steps with the
-slowest / fastest 1-s window.  `cpu_baseline` = the CPU oracle on this host's cores (thread sweep, then >= 3 forwards at the
+replay on one stream (what run_inference.py:53-61 times); `sustained_value` = one >= 60 s region of the same steps with the
+slices finished in every 1-s window and the GPU's shader clock / power sampled beside them.  `cpu_baseline` = the CPU oracle on this host's cores (thread sweep, then >= 3 forwards at the
 best setting); `oracle/` is imported by that leg (and the parity check it feeds) only.
 """
 import argparse
@@ -153,9 +154,10 @@ def parse():
                     help="initialise RCCL (backend nccl), the device barrier and the all-gather of the volume assembly even at --gpus 1 "
                          "(start under `python -m torch.distributed.run --nproc-per-node=1`, or alone: rank 0 of a world of 1)")
     ap.add_argument("--no-conv-plane", action="store_true", help="A/B: route the plane-wide 3x3 / transpose convs through the general kernel (cine_set_conv_plane(0))")
-    ap.add_argument("--conv-plane-mask", type=int, default=-1, help="A/B: cine_set_conv_plane(mask): bit 0 the 3x3 convs, bit 1 the transpose convs")
+    ap.add_argument("--conv-plane-mask", type=int, default=-1, help="A/B: cine_set_conv_plane(mask) of the bench's thread: bit 0 the plane-wide 3x3 convs, bit 1 the transpose convs, bit 2 the wide-plane / volume kernel "
+                         "(conv_wide_kernel: cfg 4, cfg 5, the sensitivity net), bit 4 SET = the general weight-gradient kernel; 7 = all lean kernels (the default)")
     ap.add_argument("--pin-numa", action="store_true", help="pin this process to its GPU's NUMA node at --gpus 1 too (always done for N > 1)")
-    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="length of the extra sustained region (0 = skip)")
+    ap.add_argument("--sustained-seconds", type=float, default=60.0, help="length of the extra sustained region (0 = skip)")
     ap.add_argument("--headline-only", action="store_true", help="skip the latency / sustained regions and the other_configs / train_step extras of the default 1-GPU line")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the launcher, sharding, timed region and all-gather on "
@@ -217,7 +219,11 @@ def gpu_numa_cpus(local_rank, sysfs="/sys"):
         with open(os.path.join(dev, "numa_node")) as f:
             node = int(f.read().strip())
         if node < 0:
-            return None, None
+            # a box whose firmware does not name the node (numa_node = -1, seen on the driver's GPU boxes): the PCI function still
+            # exports the CPUs local to it (local_cpulist = the root complex's cpumask); node id -1 marks this path in the result
+            with open(os.path.join(dev, "local_cpulist")) as f:
+                cpus = _parse_cpulist(f.read())
+            return (-1, cpus) if cpus else (None, None)
         with open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")) as f:
             cpus = _parse_cpulist(f.read())
         return node, (cpus or None)
@@ -229,20 +235,25 @@ def pin_rank_to_gpu_numa(local_rank, world, sysfs="/sys"):
     """os.sched_setaffinity to the GPU's NUMA node, intersected with what this process may use (cgroup / taskset).  Never a
     re-exec.  With N ranks on one node that would otherwise all inherit every CPU, the host side of a rank (graph launches,
     pinned buffers, the phantom generator) stays next to its GPU."""
-    info = {"numa_node": None, "cpus": None, "applied": False}
+    info = {"numa_node": None, "cpus": None, "applied": False, "why": None}
     node, cpus = gpu_numa_cpus(local_rank, sysfs)
     if node is None:
+        info["why"] = "sysfs names neither a NUMA node nor local CPUs for this GPU"
         return info
     try:
         allowed = os.sched_getaffinity(0)
         want = cpus & allowed
         info["numa_node"] = node
+        info["source"] = "numa_node + node cpulist" if node >= 0 else "local_cpulist of the PCI function (numa_node = -1)"
         if want and want != allowed:
             os.sched_setaffinity(0, want)
             info["applied"] = True
+        else:
+            info["why"] = ("the GPU's local CPUs are every CPU this process may use (one node, or a cpuset that is already local)" if want
+                           else "none of the GPU's local CPUs is in this process's cpuset")
         info["cpus"] = len(want or allowed)
-    except (OSError, AttributeError):
-        pass
+    except (OSError, AttributeError) as e:
+        info["why"] = f"sched_setaffinity: {e}"
     return info
 
 
@@ -493,15 +504,18 @@ class Workload:
             st.wait_stream(torch.cuda.current_stream())
         ev0.record(self.streams[0])
         t0 = time.perf_counter()
-        for k in range(n):
-            i = k % S
-            with torch.cuda.stream(self.streams[i]):
-                if self.use_graph:
-                    self.graphs[i].replay()
-                else:
-                    self.forward(i)
-                evs[k].record()
-        torch.cuda.synchronize()
+        with GpuTelemetry(self.dev.index or 0) as tele:
+            for k in range(n):
+                i = k % S
+                with torch.cuda.stream(self.streams[i]):
+                    if self.use_graph:
+                        self.graphs[i].replay()
+                    else:
+                        self.forward(i)
+                    evs[k].record()
+                if k % (8 * S) == 8 * S - 1 and k >= 64 * S:      # keep the host at most ~64 rounds ahead: the sampler thread needs the GIL now and then
+                    evs[k - 64 * S].synchronize()
+            torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         done = sorted(ev0.elapsed_time(e) * 1e-3 for e in evs)              # completion times, seconds after the start
         total = done[-1]
@@ -509,8 +523,9 @@ class Workload:
         per = [sum(1 for d in done if w <= d < w + 1) * B for w in range(nwin)]
         return {"value": n * B / total, "unit": "cine slices/sec", "steps": n, "seconds": total, "host_wall_s": wall,
                 "window_s": 1.0, "window_min": min(per) if per else None, "window_max": max(per) if per else None,
-                "windows": per,
-                "note": "same graphs / streams as the timed region, one event per finished slice on its stream; no volume assembly inside"}
+                "windows": per, "gpu_telemetry": tele.summary(),
+                "note": "same graphs / streams as the timed region, one event per finished slice on its stream; no volume assembly inside; "
+                        "gpu_telemetry = shader clock / power / busy sampled from sysfs once per second beside the windows"}
 
     def replayed_output(self):
         """Output of stream 0's slice through the timed mode (a graph replay when graphs are in use)."""
@@ -525,6 +540,91 @@ class Workload:
         for name in ("mks", "masks", "senss", "outs", "net", "host_mk", "exs"):
             setattr(self, name, None)
         torch.cuda.empty_cache()
+
+
+class GpuTelemetry:
+    """Shader clock / power / busy samples of the GPU under test while a region runs, read from the amdgpu sysfs files (no child
+    process, no HIP call): pp_dpm_sclk (the level marked '*'), hwmon power1_average (uW), gpu_busy_percent.  The card is the one
+    whose PCI address torch reports for the device; failing that, the busiest card at the first sample.  Every field is optional:
+    a box that hides sysfs gives an empty series and the bench line says so."""
+
+    def __init__(self, dev_index=0, period_s=1.0):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thr = period_s, [], threading.Event(), None
+        self.cards = [d for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")) if os.path.exists(os.path.join(d, "pp_dpm_sclk"))]
+        self.card, self.how = None, None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for d in self.cards:
+                if os.path.basename(os.path.realpath(d)).startswith(bdf):
+                    self.card, self.how = d, "pci address of the torch device"
+        except Exception:
+            pass
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except OSError:
+            return None
+
+    def _sample(self, d):
+        import glob
+        out = {}
+        txt = self._read(os.path.join(d, "pp_dpm_sclk"))
+        if txt:
+            cur = [ln for ln in txt.splitlines() if ln.rstrip().endswith("*")]
+            if cur:
+                try:
+                    out["sclk_mhz"] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit()))
+                except (IndexError, ValueError):
+                    pass
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_input")):
+            txt = self._read(hw)
+            if txt and txt.strip().isdigit():
+                out["power_w"] = round(int(txt) / 1e6, 1)
+                break
+        txt = self._read(os.path.join(d, "gpu_busy_percent"))
+        if txt and txt.strip().isdigit():
+            out["busy_pct"] = int(txt)
+        return out
+
+    def _loop(self, t0):
+        while not self._stop.is_set():
+            if self.card is None and self.cards:
+                busy = [(self._sample(d).get("busy_pct", -1), d) for d in self.cards]
+                if max(busy)[0] > 0:
+                    self.card, self.how = max(busy)[1], "the busiest card at the first sample"
+            if self.card is not None:
+                smp = self._sample(self.card)
+                if smp:
+                    smp["t_s"] = round(time.perf_counter() - t0, 2)
+                    self.samples.append(smp)
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        self._thr = threading.Thread(target=self._loop, args=(time.perf_counter(),), daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thr.join(timeout=5)
+
+    def summary(self):
+        if not self.samples:
+            return {"samples": 0, "note": "no readable amdgpu sysfs telemetry on this box (pp_dpm_sclk / hwmon power1_average / gpu_busy_percent)"}
+        out = {"samples": len(self.samples), "period_s": self.period, "card": self.card, "card_chosen_by": self.how}
+        for k in ("sclk_mhz", "power_w", "busy_pct"):
+            v = [x[k] for x in self.samples if k in x]
+            if v:
+                out[k] = {"min": min(v), "max": max(v), "mean": round(sum(v) / len(v), 1), "series": v}
+        out["t_s"] = [x["t_s"] for x in self.samples]
+        return out
 
 
 def pmc_families(cfg_id):
@@ -543,7 +643,8 @@ def pmc_families(cfg_id):
 def conv_roofline(wl, fam, dt, slices):
     """`achieved` / `frac` describe the TIMED mode (the family's algorithmic FLOPs of the timed slices over the timed region's
     wall time: kernels of several slices overlap there, so no per-launch duration exists -- this is the whole-chip fp32-MFMA
-    utilisation, a lower bound on the family's own rate); the *_isolated keys are the per-launch view (one slice in flight,
+    utilisation over the timed region; it can exceed the isolated figure, whose launches leave half-empty last rounds that
+    the other slices in flight fill); the *_isolated keys are the per-launch view (one slice in flight,
     hipEvent pairs around every launch of the family)."""
     cfg = wl.cfg
     conv_ms, conv_n = fam["conv3x3_mfma"]
@@ -561,12 +662,20 @@ def conv_roofline(wl, fam, dt, slices):
 
 
 def measure_other_config(cfg_id, args, dev, threads):
-    """A shorter run of another BASELINE configuration for the default line's `other_configs`: 12 steps of the same timed region,
-    the conv family's isolated and in-flight MFMA fractions, and the parity of a replayed output against ONE CPU-oracle forward."""
+    """Another BASELINE configuration for the default line's `other_configs`: the same timed region, long enough to last >= 1 s
+    (a 12-step region is 0.03 - 0.08 s: inside one clock / power state), the conv family's isolated and in-flight MFMA fractions,
+    and the parity of a replayed output against the CPU oracle (1 warm-up forward, then as many timed ones as fit ~30 s, at most 3)."""
     from cine_hip import synth
     steps = 12
     wl = Workload(cfg_id, args, 1, 0, 0, dev, steps)
     wl.run(2, False)
+    est = wl.timed(steps) / steps
+    reps = max(1, int(1.05 / (est * steps)) + 1)              # whole rounds of the S streams, >= 1 s in total
+    steps_short = steps
+    steps = steps * reps
+    short_dt = min(wl.timed(steps_short) for _ in range(2))
+    wl.outs = torch.empty((steps * wl.B,) + tuple(wl.outs.shape[1:]), device=dev)     # the long region keeps every output too
+    wl.steps = steps
     dt = min(wl.timed(steps) for _ in range(2))
     fam = profile_families(wl.forward, iters=2)
     roof = conv_roofline(wl, fam, dt, steps * wl.B)
@@ -575,7 +684,8 @@ def measure_other_config(cfg_id, args, dev, threads):
         roof["traffic"] = tr["conv3x3_mfma"]["hbm_MB_per_launch"] * 1e6
         roof["traffic_unit"] = f"HBM bytes per launch, PMC FETCH_SIZE x2 + WRITE_SIZE, {tr_src}"
     res = {"workload": wl.cfg["name"], "metric": wl.cfg["metric"], "value": steps * wl.B / dt, "unit": "cine slices/sec", "steps": steps,
-           "ms_per_step": dt / steps * 1e3, "slices_in_flight": wl.S, "launch": "hipGraph replay" if wl.use_graph else "eager",
+           "ms_per_step": dt / steps * 1e3, "timed_region_s": dt, "value_12_step_region": steps_short * wl.B / short_dt,
+           "slices_in_flight": wl.S, "launch": "hipGraph replay" if wl.use_graph else "eager",
            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_timed_mode", "frac_isolated", "traffic",
                                              "ms_per_slice_isolated", "launches_per_slice")},
            "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items() if v[1]}}
@@ -589,9 +699,14 @@ def measure_other_config(cfg_id, args, dev, threads):
         with torch.no_grad():
             t0 = time.perf_counter()
             ref_out = net(*cargs)
-            cdt = time.perf_counter() - t0
+            warm = time.perf_counter() - t0
+            nfw = max(1, min(3, int(30.0 / warm) - 1))             # ~30 s of CPU work per configuration, the warm-up included
+            t0 = time.perf_counter()
+            for _ in range(nfw):
+                ref_out = net(*cargs)
+            cdt = (time.perf_counter() - t0) / nfw
         res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "cine slices/sec", "cores": threads, "kind": "port",
-                               "sample": f"ONE forward of the CPU oracle at {threads} threads, no warm-up: {cdt:.1f} s"}
+                               "sample": f"1 warm-up forward ({warm:.1f} s), then {nfw} timed forward(s) of the CPU oracle at {threads} threads: {cdt:.1f} s/slice"}
         res["parity_max_rel_err_vs_cpu_oracle"] = float((chk - ref_out).abs().max() / ref_out.abs().max())
         if cfg_id == 3:
             res["parity_note"] = ("10-cascade XPDNet with random weights: the reference's own fp32 output is 7.0e-4 of the peak from its fp64 "

@@ -1023,6 +1023,75 @@ class AbsFn(Function):
         return gx
 
 
+class ConjFn(Function):
+    """complex_conj (utils/math.py:36-45): the adjoint of conjugation is conjugation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.complex_conj(ops._dev(x, "complex_conj input"))
+
+    @staticmethod
+    def backward(ctx, gy):
+        return ops.complex_conj(ops._dev(_c(gy), "complex_conj output gradient"))
+
+
+class RollFn(Function):
+    """fftc.roll (utils/fftc.py:141-163): the adjoint of a circular shift is the opposite shift."""
+
+    @staticmethod
+    def forward(ctx, x, shifts, dims):
+        ctx.sd = (tuple(shifts), tuple(dims))
+        return ops.roll(ops._dev(x, "roll input"), list(shifts), list(dims))
+
+    @staticmethod
+    def backward(ctx, gy):
+        shifts, dims = ctx.sd
+        return ops.roll(ops._dev(_c(gy), "roll output gradient"), [-s for s in shifts], list(dims)), None, None
+
+
+class Pad2dFn(Function):
+    """F.pad(x, [left, right, top, bottom]) of padding.pad_for_mwcnn (utils/padding.py:46): the adjoint crops."""
+
+    @staticmethod
+    def forward(ctx, x, left, right, top, bottom):
+        ctx.pad = (int(left), int(right), int(top), int(bottom))
+        return ops.pad2d(ops._dev(x, "pad input"), *ctx.pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        left, right, top, bottom = ctx.pad
+        h, w = gy.shape[-2], gy.shape[-1]
+        return gy[..., top:h - bottom, left:w - right].contiguous(), None, None, None, None
+
+
+class CenteredFftFn(Function):
+    """utils.fftc fft1c / ifft1c / fft2c / ifft2c (fftc.py:13-117) times a scalar: the centered orthonormal transform is unitary, so the
+    adjoint of s F is s F^-1 -- the same kernel in the other direction on the output gradient."""
+
+    @staticmethod
+    def forward(ctx, x, two_d, inverse, scale):
+        ctx.cfg = (bool(two_d), bool(inverse), float(scale))
+        x = ops._dev(x, "fft input")
+        out = ops.fft2c(x, inverse=inverse) if two_d else ops.fft1c(x, inverse=inverse)
+        if scale != 1.0:
+            ops.scale_(out, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        two_d, inverse, scale = ctx.cfg
+        g = ops._dev(_c(gy), "fft output gradient")
+        gx = ops.fft2c(g, inverse=not inverse) if two_d else ops.fft1c(g, inverse=not inverse)
+        if scale != 1.0:
+            ops.scale_(gx, scale)
+        return gx, None, None, None
+
+
+def needs_grad(*xs) -> bool:
+    """True when autograd has to see this call: the utils shims then take a differentiable form (the raw kernels would cut the graph)."""
+    return torch.is_grad_enabled() and any(torch.is_tensor(x) and x.requires_grad for x in xs)
+
+
 def _axpby_lam(a, b, lam, kind, sign=1.0):
     out = torch.empty_like(b)
     check(lib().cine_axpby_lam(out.data_ptr(), _p(a), b.data_ptr(), b.numel(), lam.detach().data_ptr(), kind, float(sign), _stream()),

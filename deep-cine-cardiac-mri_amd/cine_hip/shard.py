@@ -60,7 +60,10 @@ class GradientAllReduce:
             if broadcast:
                 dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
                 with torch.no_grad():
-                    torch._foreach_copy_([p.data for p in self.params],
+                    # into the parameters THEMSELVES (not p.data): the copy bumps p._version, which is what the packed-weight caches
+                    # (UnetWeights.pointers, the MWCNN / CRNN packs) and the stale-weight training key are keyed on -- a forward that
+                    # ran before this constructor must not leave pre-broadcast packed weights behind
+                    torch._foreach_copy_(list(self.params),
                                          [c.view_as(p) for c, p in zip(flat.split([p.numel() for p in self.params]), self.params)])
             else:
                 ck = torch.stack([flat.double().sum(), flat.double().abs().sum()])
@@ -80,16 +83,23 @@ class GradientAllReduce:
             return
         world = dist.get_world_size(self.group)
         # A parameter without a gradient (a sub-network this step did not use, e.g. the sensitivity network when sens_maps are
-        # passed in) contributes zeros and keeps grad None afterwards -- every rank runs the same graph, so the slots line up.
-        # Ranks that disagree about WHICH parameters are unused would still exchange equally sized buffers; they get the average
-        # over all ranks with zeros for the missing ones (what DDP's find_unused_parameters does).
+        # passed in) contributes zeros.  The reduced gradient is written on EVERY rank where ANY rank had one (what DDP's
+        # find_unused_parameters does): the `have` bitmap rides at the end of the same buffer (a SUM of 0 / 1 flags), so ranks that
+        # disagree about which parameters are unused still take the same optimiser step and the replicas cannot drift apart.
         have = [p.grad is not None for p in self.params]
+        dev, dt = self.params[0].device, self.params[0].dtype
         flat = torch.cat([p.grad.reshape(-1) if h else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
-                          for p, h in zip(self.params, have)])          # one gather kernel, one collective, one scatter
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / world)
+                          for p, h in zip(self.params, have)] + [torch.tensor([float(h) for h in have], dtype=dt, device=dev)])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # one gather kernel, one collective, one scatter
+        nparam = len(self.params)
+        any_have = (flat[-nparam:] > 0).tolist()
+        flat = flat[:-nparam].mul_(1.0 / world)
         pieces = flat.split([p.numel() for p in self.params])
-        dst = [p.grad for p, h in zip(self.params, have) if h]
-        src = [c.view_as(p.grad) for c, p, h in zip(pieces, self.params, have) if h]
+        dst, src = [], []
+        for c, p, h, ah in zip(pieces, self.params, have, any_have):
+            if h:
+                dst.append(p.grad); src.append(c.view_as(p.grad))
+            elif ah:
+                p.grad = c.view_as(p).clone()                 # unused here, used on another rank: take the average like everybody else
         if dst:
             torch._foreach_copy_(dst, src)

@@ -10,6 +10,7 @@ from typing import List, Optional
 import torch
 
 from cine_hip import ops
+from cine_hip import autograd as ag
 
 
 def _check(data: torch.Tensor) -> None:
@@ -36,6 +37,9 @@ def _run(data: torch.Tensor, two_d: bool, inverse: bool, norm: Optional[str]) ->
     # the reference's callers also hand over CPU tensors (run_inference.py:66): they are staged through the GPU -- the
     # arithmetic still runs in the HIP kernels; without a GPU ops raises (no CPU fallback)
     x = data if data.is_cuda or not torch.cuda.is_available() else data.cuda()
+    if ag.needs_grad(x):                           # a tensor that requires grad: the same kernels behind an autograd Function
+        out = ag.CenteredFftFn.apply(x, two_d, inverse, s)
+        return out if out.device == data.device else out.to(data.device)
     out = ops.fft2c(x, inverse=inverse) if two_d else ops.fft1c(x, inverse=inverse)
     if s != 1.0:
         ops.scale_(out, s)
@@ -62,6 +66,8 @@ def roll(x: torch.Tensor, shift: List[int], dim: List[int]) -> torch.Tensor:
     if len(shift) != len(dim):
         raise ValueError("len(shift) must match len(dim)")
     if x.is_cuda and x.dtype == torch.float32:                 # csrc/ew_kernels.hip: cine_roll, one launch per rolled dimension
+        if ag.needs_grad(x):
+            return ag.RollFn.apply(x, tuple(int(s) for s in shift), tuple(int(d) for d in dim))
         return ops.roll(x, [int(s) for s in shift], [int(d) for d in dim])
     return torch.roll(x, shifts=tuple(int(s) for s in shift), dims=tuple(int(d) for d in dim))
 

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from cine_hip import ops
+from cine_hip import autograd as ag
 
 
 def pad_for_mwcnn(x: torch.Tensor, n_scales: int) -> Tuple[torch.Tensor, List[int]]:
@@ -22,8 +23,8 @@ def pad_for_mwcnn(x: torch.Tensor, n_scales: int) -> Tuple[torch.Tensor, List[in
         n_pad = 0 if d % m == 0 else (d // m + 1) * m - d
         left = n_pad // 2 if (d % 2 == 0 or n_pad == 0) else 1 + n_pad // 2
         paddings += [left, n_pad // 2]
-    if x.is_cuda and x.dtype == torch.float32:             # csrc/ew_kernels.hip: cine_pad2d
-        return ops.pad2d(x, *paddings), paddings
+    if x.is_cuda and x.dtype == torch.float32:             # csrc/ew_kernels.hip: cine_pad2d (an autograd Function when x requires grad)
+        return (ag.Pad2dFn.apply(x, *paddings) if ag.needs_grad(x) else ops.pad2d(x, *paddings)), paddings
     return F.pad(x, paddings), paddings
 
 

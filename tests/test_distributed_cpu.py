@@ -62,7 +62,11 @@ def _train_worker(rank, world, port, q):
     shared = torch.nn.Conv2d(2, 3, 3, padding=1)
     unused = torch.nn.Conv2d(1, 1, 1)                          # a sub-network this step does not use (VarNet with explicit sens_maps)
     net = torch.nn.ModuleList([shared, shared, torch.nn.Conv2d(3, 1, 1), unused])     # an aliased module, like the cascades' networks
+    versions = [p._version for p in net.parameters()]
     sync = shard.GradientAllReduce(net)
+    # the broadcast writes the parameters themselves: their version counters move, so packed-weight caches keyed on
+    # (data_ptr, _version) that a forward BEFORE this constructor filled are invalidated on every rank
+    bumped = all(p._version > v for p, v in zip(net.parameters(), versions))
     assert len(sync.params) == 6
     w0 = [torch.empty_like(p) for p in sync.params]
     for w, p in zip(w0, sync.params):
@@ -80,7 +84,19 @@ def _train_worker(rank, world, port, q):
     got = [p.grad.clone() for p in used]
     net.zero_grad()
     (sum(loss_of(r) for r in range(world)) / world).backward()                 # the same average on one rank
-    ok = same_start and len(used) == 4 and all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, used))
+    ok = bumped and same_start and len(used) == 4 and all(torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7) for a, p in zip(got, used))
+    # ranks that DISAGREE about which parameters are unused: only rank 0 runs the extra sub-network; every rank must end up with the
+    # same (averaged) gradient for it, or the optimiser would update it on one replica only
+    net.zero_grad(set_to_none=True)
+    extra = unused(torch.ones(1, 1, 2, 2)).sum() if rank == 0 else 0.0
+    (loss_of(rank) + extra).backward()
+    sync()
+    gu = [p.grad for p in unused.parameters()]
+    ok = ok and all(g is not None for g in gu)
+    if ok:
+        want_w = torch.full_like(gu[0], 4.0 / world)          # d(sum of the conv over four ones)/dw = 4 on rank 0, nothing elsewhere
+        want_b = torch.full_like(gu[1], 4.0 / world)
+        ok = torch.allclose(gu[0], want_w) and torch.allclose(gu[1], want_b)
     try:                                                                        # broadcast=False only checks: equal now ...
         shard.GradientAllReduce(net, broadcast=False)
         with torch.no_grad():
@@ -160,8 +176,9 @@ def test_bench_selftest_eight_ranks_gloo():
     assert len(line["per_rank_timed_region_s"]) == 8 and line["timed_region_s"] == max(line["per_rank_timed_region_s"])
 
 
-def _fake_sysfs(root, gpus):
-    """gpus: list of (bus, numa_node); node 0 of the KFD topology is the CPU (simd_count 0), as on a real box."""
+def _fake_sysfs(root, gpus, local_cpulists=None):
+    """gpus: list of (bus, numa_node); node 0 of the KFD topology is the CPU (simd_count 0), as on a real box.  local_cpulists: per-GPU
+    text of the PCI function's local_cpulist (None = the file does not exist)."""
     import pathlib
     root = pathlib.Path(root)
     nodes = root / "class/kfd/kfd/topology/nodes"
@@ -173,6 +190,8 @@ def _fake_sysfs(root, gpus):
         dev = root / "bus/pci/devices" / f"0000:{bus:02x}:00.0"
         dev.mkdir(parents=True)
         (dev / "numa_node").write_text(f"{numa}\n")
+        if local_cpulists and local_cpulists[i] is not None:
+            (dev / "local_cpulist").write_text(local_cpulists[i] + "\n")
     for n, cl in ((0, "0-3,64-67"), (1, "4-7")):
         d = root / f"devices/system/node/node{n}"
         d.mkdir(parents=True)
@@ -186,7 +205,7 @@ def test_rank_numa_affinity_from_sysfs(tmp_path):
     _fake_sysfs(tmp_path, [(0x05, 0), (0x85, 1), (0xc5, -1)])
     assert bench.gpu_numa_cpus(0, str(tmp_path)) == (0, {0, 1, 2, 3, 64, 65, 66, 67})
     assert bench.gpu_numa_cpus(1, str(tmp_path)) == (1, {4, 5, 6, 7})
-    assert bench.gpu_numa_cpus(2, str(tmp_path)) == (None, None)          # numa_node -1: no pinning
+    assert bench.gpu_numa_cpus(2, str(tmp_path)) == (None, None)          # numa_node -1 and no local_cpulist either: no pinning
     assert bench.gpu_numa_cpus(7, str(tmp_path)) == (None, None)          # no such GPU
     assert bench.gpu_numa_cpus(0, str(tmp_path / "missing")) == (None, None)
     # applied in a child process (the affinity of the test runner itself stays untouched)
@@ -201,4 +220,26 @@ def test_rank_numa_affinity_from_sysfs(tmp_path):
     if want and want != before:
         assert after == want and info["applied"] and info["numa_node"] == 1
     else:
-        assert after == before and not info["applied"]
+        assert after == before and not info["applied"] and info["why"]
+
+
+def test_rank_numa_affinity_falls_back_to_local_cpulist(tmp_path):
+    """A box whose firmware does not name the GPU's node (numa_node = -1, what the driver's GPU boxes report: `cpu_affinity.applied`
+    was false there): the PCI function's local_cpulist gives the CPUs next to the GPU, marked as node -1."""
+    sys.path.insert(0, ROOT)
+    import bench
+    _fake_sysfs(tmp_path, [(0x05, -1), (0x85, -1)], local_cpulists=["0-3", ""])
+    assert bench.gpu_numa_cpus(0, str(tmp_path)) == (-1, {0, 1, 2, 3})
+    assert bench.gpu_numa_cpus(1, str(tmp_path)) == (None, None)          # an empty mask: nothing to pin to
+    import json
+    import subprocess
+    code = ("import os, sys, json; sys.path.insert(0, %r); import bench; before = os.sched_getaffinity(0); "
+            "info = bench.pin_rank_to_gpu_numa(0, 2, %r); print(json.dumps([sorted(before), sorted(os.sched_getaffinity(0)), info]))" % (ROOT, str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-1500:]
+    before, after, info = json.loads(out.stdout.strip().splitlines()[-1])
+    want = sorted(set(before) & {0, 1, 2, 3})
+    if want and want != before:
+        assert after == want and info["applied"] and info["numa_node"] == -1 and "local_cpulist" in info["source"]
+    else:
+        assert after == before and not info["applied"] and info["why"]

@@ -1166,6 +1166,53 @@ def test_cfg2_graph_replay_bitexact_and_vs_golden(golden, dev):
     _check_full_fingerprint(gout.cpu(), g, ex)
 
 
+def test_utils_helpers_backpropagate_on_gpu_tensors(dev):
+    """User code written against the reference (a loss built from rss_complex, complex_mul, fft2c ...) differentiates through its utils:
+    on a GPU tensor that requires grad every shim must return a tensor with a grad_fn, and the gradient must equal what torch.autograd
+    derives from the reference's tensor expressions (utils/math.py:20-62, coil_combine.py, fftc.py:13-163, padding.py:22-47) on the CPU."""
+    import torch.nn.functional as F
+    import reconstruction.utils as U
+
+    def ref_fft(x, two_d, inverse):
+        c = torch.view_as_complex(x.contiguous())
+        dims = (-2, -1) if two_d else (-1,)
+        c = torch.fft.ifftshift(c, dim=dims)
+        c = (torch.fft.ifftn if inverse else torch.fft.fftn)(c, dim=dims, norm="ortho")
+        return torch.view_as_real(torch.fft.fftshift(c, dim=dims))
+    cmul = lambda a, b: torch.view_as_real(torch.view_as_complex(a.contiguous()) * torch.view_as_complex(b.contiguous()))
+    cases = {
+        "complex_mul": (lambda x, y: U.complex_mul(x, y), lambda x, y: cmul(x, y.expand(3, 4, 6, 5, 2)), ((3, 4, 6, 5, 2), (1, 4, 1, 5, 2))),
+        "complex_conj": (lambda x: U.complex_conj(x), lambda x: x * x.new_tensor([1.0, -1.0]), ((3, 6, 5, 2),)),
+        "complex_abs": (lambda x: U.complex_abs(x), lambda x: (x * x).sum(-1).sqrt(), ((3, 6, 5, 2),)),
+        "complex_abs_sq": (lambda x: U.complex_abs_sq(x), lambda x: (x * x).sum(-1), ((3, 6, 5, 2),)),
+        "rss": (lambda x: U.rss(x, 1), lambda x: (x * x).sum(1).sqrt(), ((2, 4, 6, 5),)),
+        "rss_complex": (lambda x: U.rss_complex(x, 1), lambda x: (x * x).sum(-1).sum(1).sqrt(), ((2, 4, 6, 5, 2),)),
+        "fftshift": (lambda x: U.fftshift(x, [-3, -2]), lambda x: torch.roll(x, (3, 2), (-3, -2)), ((2, 7, 5, 2),)),
+        "ifftshift": (lambda x: U.ifftshift(x, [-3, -2]), lambda x: torch.roll(x, (4, 3), (-3, -2)), ((2, 7, 5, 2),)),
+        "pad_for_mwcnn": (lambda x: U.pad_for_mwcnn(x, 3)[0], lambda x: F.pad(x, [2, 1, 3, 3]), ((2, 3, 10, 13),)),
+        "fft2c": (lambda x: U.fft2c(x), lambda x: ref_fft(x, True, False), ((3, 12, 10, 2),)),
+        "ifft2c": (lambda x: U.ifft2c(x), lambda x: ref_fft(x, True, True), ((3, 9, 10, 2),)),
+        "fft1c": (lambda x: U.fft1c(x), lambda x: ref_fft(x, False, False), ((4, 15, 2),)),
+        "ifft1c": (lambda x: U.ifft1c(x, norm=None), lambda x: ref_fft(x, False, True) * 15 ** -0.5, ((4, 15, 2),)),
+    }
+    for name, (hip_fn, ref_fn, shapes) in cases.items():
+        xs = [rnd(700 + i, *sh) + 0.1 for i, sh in enumerate(shapes)]
+        cpu = [x.clone().requires_grad_(True) for x in xs]
+        gpu = [x.to(dev).requires_grad_(True) for x in xs]
+        want = ref_fn(*cpu)
+        got = hip_fn(*gpu)
+        assert got.grad_fn is not None, f"{name}: the result is cut off the autograd graph"
+        assert rel_err(got.detach().cpu(), want.detach()) < OP_TOL, name
+        w = rnd(720, *want.shape)
+        (want * w).sum().backward()
+        (got * w.to(dev)).sum().backward()
+        for a, b in zip(gpu, cpu):
+            assert a.grad is not None and rel_err(a.grad.cpu(), b.grad) < 2 * OP_TOL, name
+    # without requires_grad (inference, Lightning's validation) the raw kernels run: no graph
+    with torch.no_grad():
+        assert U.complex_abs(xs[0].to(dev)).grad_fn is None
+
+
 # ------------------------------------------------------------------ utils.math / coil_combine vs the reference's cm_* vectors
 def test_complex_math_helpers_vs_reference_golden(golden, dev):
     import reconstruction.utils as U

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/ab_mask.sh MASK ...: bench.py headline-only per cine_set_conv_plane mask (3 = all lean kernels, 1 = 3x3 only, 0 = general kernels)
+# tools/ab_mask.sh MASK ...: bench.py headline-only per cine_set_conv_plane mask (bit 0 plane-wide 3x3, bit 1 transpose convs, bit 2 wide planes / volumes: 7 = all lean kernels, 0 = general kernels)
 CFG=${CFG:-2}; INF=${INF:-0}; STEPS=${STEPS:-40}
 for m in "$@"; do
   for inf in $INF; do
