@@ -1199,13 +1199,14 @@ def test_utils_helpers_backpropagate_on_gpu_tensors(dev):
         xs = [rnd(700 + i, *sh) + 0.1 for i, sh in enumerate(shapes)]
         cpu = [x.clone().requires_grad_(True) for x in xs]
         gpu = [x.to(dev).requires_grad_(True) for x in xs]
-        want = ref_fn(*cpu)
-        got = hip_fn(*gpu)
-        assert got.grad_fn is not None, f"{name}: the result is cut off the autograd graph"
-        assert rel_err(got.detach().cpu(), want.detach()) < OP_TOL, name
-        w = rnd(720, *want.shape)
-        (want * w).sum().backward()
-        (got * w.to(dev)).sum().backward()
+        with torch.enable_grad():                                 # (the suite runs with autograd off by default: conftest.py)
+            want = ref_fn(*cpu)
+            got = hip_fn(*gpu)
+            assert got.grad_fn is not None, f"{name}: the result is cut off the autograd graph"
+            assert rel_err(got.detach().cpu(), want.detach()) < OP_TOL, name
+            w = rnd(720, *want.shape)
+            (want * w).sum().backward()
+            (got * w.to(dev)).sum().backward()
         for a, b in zip(gpu, cpu):
             assert a.grad is not None and rel_err(a.grad.cpu(), b.grad) < 2 * OP_TOL, name
     # without requires_grad (inference, Lightning's validation) the raw kernels run: no graph
