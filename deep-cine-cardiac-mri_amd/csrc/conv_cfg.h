@@ -91,9 +91,10 @@ int launch_tconv_dgrad_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, 
 // 3x3 convolutions over 16-wide column tiles of wider planes (v3 = 0) / volumes in the three-pass form (v3 = 1)
 int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, hipStream_t st, bool* handled);
 
-// conv_coarse.hip: 3x3x3 convolutions of small volumes with >= 48 output rows (the coarse levels of the 3-D U-Net) -- flattened
+// conv_coarse.hip: 3x3(x3) convolutions of small volumes / planes with >= 48 output rows (the coarse levels of the 3-D U-Net, the 26 x 26
+// level of the sensitivity network) -- flattened
 // positions, K split over the waves of a workgroup.  coarse_tiles() = its statistics records per (sample, channel).
-int launch_conv_coarse(const ConvArgs& a, hipStream_t st);
-int coarse_tiles(int rowsp, int d, int h, int w);
+int launch_conv_coarse(const ConvArgs& a, hipStream_t st, bool* handled);
+int coarse_tiles(int rowsp, int d, int h, int w, bool vol);
 
 }  // namespace cine

@@ -29,9 +29,12 @@ namespace {
 
 struct CoarseArgs {
     Src s0, s1;
-    const float* wp; const float* bias; const float* addend; int relu;
+    const float* wp; const float* wp1; const float* bias; const float* bias1; int set_split;     // samples >= set_split: the second weight set
+    const float* addend; int relu;
     float* y; float* ypart;
     int cin, rows, rowsp, D, H, W, Wp, ncc, tiles_z, tiles;
+    int wz_off;                          // 1: 2-D weights [chunk][tap][8][rowsp] (no depth-offset blocks); 0: the 3-D packing [dz][chunk][tap][8][rowsp]
+    int add_src1;                        // GEN staging only: source 1 is added to source 0 (mwcnn.py:164,172)
     int nph;                             // staged positions per channel: 16 MT + 2 (Wp + 1)
     float slope, eps;
 };
@@ -48,8 +51,11 @@ struct CoarseArgs {
 // 23.4 / 43.6 us per 64 -> 64 / 128 -> 64 layer alone and 159.4 slices/s with ten slices in flight; 4 waves (55 KB: a second stream's
 // workgroup fits beside it) 24.8 / 47.4 us and 163.3 slices/s -- the same latency for one slice (100.4 slices/s either way)
 constexpr int kCoarseWaves = CINE_COARSE_WAVES;
-template <int MT, int NS, bool POOL, bool RAGGED>
+// STAGE: 0 whole chunks of one source, 1 = RAGGED, 2 = GEN: any source cine_conv3x3_ex accepts (Haar DWT / IWT on load, added skips, narrower
+// extents) element by element through fetch_scalar -- the fallback that keeps the statistics-record count a function of the layer SHAPE
+template <int MT, int NS, bool POOL, int STAGE>
 __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void conv_coarse_kernel(CoarseArgs a) {
+    constexpr bool RAGGED = STAGE == 1, GEN = STAGE == 2;
     constexpr int NW = kCoarseWaves;
     constexpr int NP = 16 * MT;          // output positions of the workgroup
     constexpr int RS = NP + 4;           // row stride of the partial tiles in LDS
@@ -72,18 +78,21 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
         const Src& s = first ? a.s0 : a.s1;
         const int cl = first ? ci : ci - a.s0.c;
         float2 mr = make_float2(0.f, 1.f);
-        if (s.mode != 0) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
+        if (s.mode == 1 || s.mode == 2 || (s.mode >= 3 && (s.act & 1))) mr = merge_partials(s.part + ((long)n * s.c + cl) * s.np * 3, s.np, a.eps);
         st_lds[2 * ci] = mr.y; st_lds[2 * ci + 1] = -mr.x * mr.y;
     }
+    const float* const wpn = n >= a.set_split ? a.wp1 : a.wp;
 
     // ---- my position slots of a staged run: run position p <-> padded position P0 - (Wp + 1) + p of the slice
     int off0[NS], off1[NS];              // element offset inside a (channel, slice) plane of source 0 / 1; -1: reads as zero
+    int pyy[GEN ? NS : 1], pxx[GEN ? NS : 1];                 // GEN: the slot's (row, column), -1: outside the plane
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const int p = lane + 64 * j;
         const int pin = P0 - (a.Wp + 1) + p + 2 * a.Wp;      // >= 0
         const int yy = pin / a.Wp - 2, xx = pin - (yy + 2) * a.Wp;
         const bool in = p < a.nph && yy >= 0 && yy < a.H && xx < a.W;
+        if constexpr (GEN) { pyy[j] = in ? yy : -1; pxx[j] = xx; }
         auto soff = [&](const Src& s) {
             if (!in || s.c == 0) return -1;
             if (s.mode == 2) return (2 * yy + 1 < s.h && 2 * xx + 1 < s.w) ? 2 * yy * s.w + 2 * xx : -1;
@@ -107,7 +116,9 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
     // the value is selected in commit): a conditional load is a branch, and a branch makes the compiler wait for every load in flight
     auto issue = [&](int u) {
         const int zs = z0 + unit_dz(u) - 1, ci0 = unit_cc(u) * 8;
-        if constexpr (!RAGGED) {
+        if constexpr (GEN) {
+            (void)zs; (void)ci0;
+        } else if constexpr (!RAGGED) {
             const bool f0 = ci0 < a.s0.c;                        // the whole chunk lies in one source
             const Src& s = f0 ? a.s0 : a.s1;
             const long plane = (long)s.h * s.w;
@@ -136,9 +147,10 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
     // avg_pool3d 2x2x2 of act(x) (unet.py:88,97) for channel cl of source s into LDS channel c: two source slices x two rows x two
     // columns, fetch_scalar's summation order; invalid slots load one valid element eight times
     auto commit_pooled = [&](const Src& s, int cl, bool f0, int c, int zs, bool cok, float sc, float sh) {
-        const bool zok = cok && 2 * zs + 1 < s.d;
-        const float* sb = s.x + (((long)n * s.c + cl) * s.d + (zok ? 2 * zs : 0)) * (long)s.h * s.w;
-        const long zstr = zok ? (long)s.h * s.w : 0;
+        const bool vol = s.act & 2;                              // a 2-D plane pools 2 x 2 (unet.py:97 with dims = 2): the second "slice" is the first again, weight 1/8 each
+        const bool zok = cok && (!vol || 2 * zs + 1 < s.d);
+        const float* sb = s.x + (((long)n * s.c + cl) * s.d + (zok && vol ? 2 * zs : 0)) * (long)s.h * s.w;
+        const long zstr = zok && vol ? (long)s.h * s.w : 0;
         float t[NS][8];
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -164,7 +176,23 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
     };
     auto commit = [&](int u) {
         const int zs = z0 + unit_dz(u) - 1, ci0 = unit_cc(u) * 8;
-        if constexpr (!RAGGED) {
+        if constexpr (GEN) {
+            const int c0n = src_cin(a.s0);
+#pragma unroll 1
+            for (int c = 0; c < 8; ++c) {
+                const int ci = ci0 + c;
+                const bool f0 = a.add_src1 || ci < c0n;
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    float v = 0.f;
+                    if (ci < a.cin && pyy[j] >= 0) {
+                        v = fetch_scalar(f0 ? a.s0 : a.s1, n, f0 ? ci : ci - c0n, zs, pyy[j], pxx[j], st_lds + (f0 ? 0 : 2 * a.s0.c), a.slope);
+                        if (a.add_src1) v += fetch_scalar(a.s1, n, ci, zs, pyy[j], pxx[j], st_lds + 2 * a.s0.c, a.slope);
+                    }
+                    xw[c * PS + lane + 64 * j] = v;
+                }
+            }
+        } else if constexpr (!RAGGED) {
             const bool f0 = ci0 < a.s0.c;
             const Src& s = f0 ? a.s0 : a.s1;
             if (POOL && s.mode == 2) {
@@ -233,7 +261,7 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
     const unsigned wks = (unsigned)(4 * a.rowsp) * 4u;
     float4 wr[9][2];
     auto loadw = [&](int u, int tap, float4 (&w)[2]) {
-        const char* wu = reinterpret_cast<const char*>(a.wp + (((long)unit_dz(u) * a.ncc + unit_cc(u)) * 9 + tap) * 8 * a.rowsp);
+        const char* wu = reinterpret_cast<const char*>(wpn + (((long)(unit_dz(u) - a.wz_off) * a.ncc + unit_cc(u)) * 9 + tap) * 8 * a.rowsp);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) w[ks] = *reinterpret_cast<const float4*>(wu + (wlane + ks * wks));
     };
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
             const float4 t = *reinterpret_cast<const float4*>(red + (w * 64 + row) * RS + pos0 + i);
             v[i] += t.x; v[i + 1] += t.y; v[i + 2] += t.z; v[i + 3] += t.w;
         }
-    const float bv = (a.bias && mok) ? a.bias[m] : 0.f;
+    const float bv = (a.bias && mok) ? (n >= a.set_split ? a.bias1 : a.bias)[m] : 0.f;
     const long plane = (((long)n * a.rows + (mok ? m : 0)) * a.D + z0) * (long)a.H * a.W;
     float cnt = 0.f, sum = 0.f;
     bool ok[PPT];
@@ -331,9 +359,9 @@ __global__ __launch_bounds__(64 * kCoarseWaves, (kCoarseWaves > 4 ? 1 : 2)) void
     }
 }
 
-template <int MT, int NS, bool POOL, bool RAGGED>
+template <int MT, int NS, bool POOL, int STAGE>
 int launch_coarse(const CoarseArgs& p, int n, hipStream_t st) {
-    auto kern = conv_coarse_kernel<MT, NS, POOL, RAGGED>;
+    auto kern = conv_coarse_kernel<MT, NS, POOL, STAGE>;
     const int nch = p.s0.c + p.s1.c, nchp = (nch + 1) & ~1;
     const size_t lds = (size_t)(2 * nchp + kCoarseWaves * 8 * (64 * NS + 16) + kCoarseWaves * 64 * (16 * MT + 4)) * sizeof(float);
     CINE_REQUIRE(lds <= 160 * 1024, CINE_EUNSUPPORTED, "conv_coarse_kernel: %d input channels need %zu bytes of LDS", p.cin, lds);
@@ -354,42 +382,59 @@ int launch_coarse(const CoarseArgs& p, int n, hipStream_t st) {
     return check_launch("conv_coarse_kernel");
 }
 template <int MT, int NS>
-int launch_coarse_variant(const CoarseArgs& p, int n, bool pool, bool ragged, hipStream_t st) {
-    if (ragged) return pool ? launch_coarse<MT, NS, true, true>(p, n, st) : launch_coarse<MT, NS, false, true>(p, n, st);
-    return pool ? launch_coarse<MT, NS, true, false>(p, n, st) : launch_coarse<MT, NS, false, false>(p, n, st);
+int launch_coarse_variant(const CoarseArgs& p, int n, bool pool, int stage, hipStream_t st) {
+    if (stage == 2) return launch_coarse<MT, NS, false, 2>(p, n, st);
+    if (stage == 1) return pool ? launch_coarse<MT, NS, true, 1>(p, n, st) : launch_coarse<MT, NS, false, 1>(p, n, st);
+    return pool ? launch_coarse<MT, NS, true, 0>(p, n, st) : launch_coarse<MT, NS, false, 0>(p, n, st);
 }
 
 }  // namespace
 
-// fragments per workgroup of the coarse kernel for a layer shape: two unless that leaves fewer than 128 workgroups
-int coarse_mt(int rowsp, int d, int h, int w) {
+// fragments per workgroup of the coarse kernel for a layer shape: two unless that leaves fewer than 128 workgroups per volume (2-D planes
+// come many to a launch -- the sensitivity network's 15 coil planes: always two)
+int coarse_mt(int rowsp, int d, int h, int w, bool vol) {
+    if (!vol) return 2;
     const long tiles2 = (long)ceil_div(h * (w + 1), 32) * d * ceil_div(rowsp, 64);
     return tiles2 >= 128 ? 2 : 1;
 }
-// statistics records per (sample, channel) = position tiles of the volume
-int coarse_tiles(int rowsp, int d, int h, int w) {
-    return ceil_div(h * (w + 1), 16 * coarse_mt(rowsp, d, h, w)) * d;
+// statistics records per (sample, channel) = position tiles of the volume / plane
+int coarse_tiles(int rowsp, int d, int h, int w, bool vol) {
+    return ceil_div(h * (w + 1), 16 * coarse_mt(rowsp, d, h, w, vol)) * d;
+}
+// what the fast staging paths cover; everything else that reaches a coarse SHAPE runs the GEN staging (or, without a statistics record to
+// keep in step, the general kernel: launch_conv_coarse returns *handled = false)
+static bool coarse_fast_ok(const ConvArgs& a) {
+    auto ok = [&](const Src& s) { return s.c == 0 || s.mode <= 2; };
+    return !a.add_src1 && ok(a.s0) && ok(a.s1);
 }
 
-int launch_conv_coarse(const ConvArgs& a, hipStream_t st) {
-    CINE_REQUIRE(a.vol && !a.add_src1 && a.tconv_cout == 0 && !a.accum && a.pair_n == 0, CINE_EUNSUPPORTED, "conv_coarse_kernel: not a plain 3x3x3 convolution");
-    CINE_REQUIRE(a.s0.mode <= 2 && (a.s1.c == 0 || a.s1.mode <= 2), CINE_EUNSUPPORTED, "conv_coarse_kernel: source modes 0..2 only");
-    CINE_REQUIRE(a.set_split >= a.n, CINE_EUNSUPPORTED, "conv_coarse_kernel: one weight set");
-    const int mt = coarse_mt(a.rowsp, a.D, a.H, a.W);
+int launch_conv_coarse(const ConvArgs& a, hipStream_t st, bool* handled) {
+    *handled = false;
+    if (a.tconv_cout != 0 || a.accum || a.pair_n != 0 || a.n <= 0 || a.n > 65535) {
+        CINE_REQUIRE(!a.ypart, CINE_EUNSUPPORTED, "conv_coarse_kernel: this epilogue has no statistics-compatible fallback");
+        return CINE_OK;                                   // (CRNN second outputs / pair launches on a coarse shape: the general kernel, no records involved)
+    }
+    const bool fast = coarse_fast_ok(a);
+    if (!fast && !a.ypart) return CINE_OK;
+    *handled = true;
+    const bool vol = a.vol != 0;
+    const int mt = coarse_mt(a.rowsp, a.D, a.H, a.W, vol);
     CoarseArgs p{};
     p.s0 = a.s0; p.s1 = a.s1;
     if (p.s1.c == 0) { p.s1 = p.s0; p.s1.c = 0; }
-    p.wp = a.wp0; p.bias = a.bias; p.addend = a.addend; p.relu = a.relu;
+    p.wp = a.wp0; p.wp1 = a.wp1 ? a.wp1 : a.wp0; p.bias = a.bias; p.bias1 = a.bias1 ? a.bias1 : a.bias; p.set_split = a.set_split;
+    p.addend = a.addend; p.relu = a.relu;
     p.y = a.y; p.ypart = a.ypart;
-    p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.D = a.D; p.H = a.H; p.W = a.W; p.Wp = a.W + 1; p.ncc = a.ncc;
+    p.cin = a.cin; p.rows = a.rows; p.rowsp = a.rowsp; p.D = a.D; p.H = a.H; p.W = a.W; p.Wp = a.W + 1;
+    p.ncc = ceil_div(a.cin, 8); p.wz_off = vol ? 0 : 1; p.add_src1 = a.add_src1;
     p.tiles_z = ceil_div(a.H * p.Wp, 16 * mt); p.tiles = p.tiles_z * a.D;
     p.nph = 16 * mt + 2 * (p.Wp + 1);
     CINE_REQUIRE(p.nph <= 192, CINE_EUNSUPPORTED, "conv_coarse_kernel: rows of %d voxels are too wide", a.W);
     p.slope = a.slope; p.eps = a.eps;
-    const bool pool = a.s0.mode == 2 || (a.s1.c > 0 && a.s1.mode == 2);
-    const bool ragged = a.cin % 8 != 0 || (a.s1.c > 0 && a.s0.c % 8 != 0);
-    if (p.nph <= 128) return mt == 2 ? launch_coarse_variant<2, 2>(p, a.n, pool, ragged, st) : launch_coarse_variant<1, 2>(p, a.n, pool, ragged, st);
-    return mt == 2 ? launch_coarse_variant<2, 3>(p, a.n, pool, ragged, st) : launch_coarse_variant<1, 3>(p, a.n, pool, ragged, st);
+    const bool pool = fast && (a.s0.mode == 2 || (a.s1.c > 0 && a.s1.mode == 2));
+    const int stage = !fast ? 2 : ((a.cin % 8 != 0 || (a.s1.c > 0 && a.s0.c % 8 != 0)) ? 1 : 0);
+    if (p.nph <= 128) return mt == 2 ? launch_coarse_variant<2, 2>(p, a.n, pool, stage, st) : launch_coarse_variant<1, 2>(p, a.n, pool, stage, st);
+    return mt == 2 ? launch_coarse_variant<2, 3>(p, a.n, pool, stage, st) : launch_coarse_variant<1, 3>(p, a.n, pool, stage, st);
 }
 
 }  // namespace cine

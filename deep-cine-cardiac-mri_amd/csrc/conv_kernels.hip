@@ -1053,6 +1053,11 @@ static bool vol_small_tiles(int rowsp, int h, int w, int d) {
 static bool coarse_shape(int rowsp, int h, int w, int d) {
     return w > 8 && rowsp > 32 && vol_small_tiles(rowsp, h, w, d) && 32 + 2 * (w + 2) <= 192;
 }
+// ... and the 2-D planes that do: wider than the plane-wide tiles of conv_plane.hip, small, > 32 output rows (the sensitivity network's
+// 26 x 26 x 64-channel level: round 4's conv_mfma_kernel<8, 1, 4, 1, 13, 16, 9, 0>, PMC MFMA 0.039)
+static bool coarse_shape2d(int rowsp, int h, int w) {
+    return w > 16 && rowsp > 32 && 32 + 2 * (w + 2) <= 192 && (long)h * (w + 1) <= 4096;
+}
 
 template <int TW, int TAPS, int CK>
 static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
@@ -1148,7 +1153,8 @@ int tiles_for(int rowsp, int h, int w, int d = 1, bool vol3 = false, bool plane3
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
     int nf = regular_nf(rowsp, frags, plane3x3);
-    if (vol3 && coarse_shape(rowsp, h, w, d)) return coarse_tiles(rowsp, d, h, w);
+    if (vol3 && coarse_shape(rowsp, h, w, d)) return coarse_tiles(rowsp, d, h, w, true);
+    if (plane3x3 && d == 1 && coarse_shape2d(rowsp, h, w)) return coarse_tiles(rowsp, 1, h, w, false);
     if (vol3 && vol_small_tiles(rowsp, h, w, d)) nf = 4;          // every small-tile volume configuration has 4 fragments
     const int TH = nf * 16 / TW;
     return ceil_div(w, TW) * ceil_div(h, TH) * d;
@@ -1349,6 +1355,11 @@ static int conv3x3_full(const float* x0, const float* part0, int np0, int c0, in
     a.cin = a.add_src1 ? src_cin(a.s0) : src_cin(a.s0) + src_cin(a.s1);
     a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.D = 1; a.slope = slope; a.eps = eps; a.nchunks = ceil_div(a.cin, kCK3);
+    if (coarse_shape2d(a.rowsp, h, w)) {
+        bool handled = false;
+        const int e = launch_conv_coarse(a, as_stream(stream), &handled);
+        if (e || handled) return e;
+    }
     return dispatch<9, kCK3>(a, as_stream(stream));
 }
 
@@ -1515,7 +1526,11 @@ extern "C" int cine_conv3d_in(const float* x0, const float* part0, int np0, int 
     a.wp0 = a.wp1 = wpacked; a.set_split = n; a.bias = a.bias1 = bias; a.addend = addend; a.relu = relu;
     a.y = y; a.ypart = part_y; a.n = n; a.cin = c0 + c1; a.rows = cout; a.rowsp = ceil_div(cout, 16) * 16;
     a.H = h; a.W = w; a.D = d; a.slope = slope; a.eps = eps; a.ncc = ceil_div(a.cin, kCK3);
-    if (coarse_shape(a.rowsp, h, w, d)) return launch_conv_coarse(a, as_stream(stream));
+    if (coarse_shape(a.rowsp, h, w, d)) {
+        bool handled = false;
+        const int e = launch_conv_coarse(a, as_stream(stream), &handled);
+        if (e || handled) return e;
+    }
     if (conv3d_v3_ok(a)) { a.nchunks = 3 * a.ncc; return dispatch_v3(a, as_stream(stream)); }
     a.nchunks = ceil_div(a.cin, kCK27);
     return dispatch<27, kCK27>(a, as_stream(stream));

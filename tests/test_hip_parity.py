@@ -302,6 +302,61 @@ def test_conv3x3_fused_sources_vs_torch(dev):
         assert rel_err(y.cpu(), ref) < BLOCK_TOL
 
 
+def test_conv3x3_coarse_planes_vs_torch(dev):
+    """2-D planes on the flattened-position K-split kernel (conv_coarse.hip: wider than the plane-wide tiles, small, > 32 output rows --
+    the sensitivity network's 26 x 26 level with 64 channels on 15 coil planes): normalised source, pooled source, concat with a short
+    `up` extent, a ragged channel count, two weight sets in one launch, and the element-wise staging that serves the sources the fast
+    paths do not (Haar DWT on load, an added skip).  One statistics record per 32-position tile of the flattened plane."""
+    from cine_hip import ops
+    from cine_hip._lib import lib
+    import torch.nn.functional as F
+    act = lambda t: F.leaky_relu(F.instance_norm(t, eps=1e-5), 0.2)
+    n, h, w = 15, 26, 26
+    assert lib().cine_conv_stat_partials(64, h, w, 0) == -(-h * (w + 1) // 32)
+
+    def check(y, part, ref, tol=BLOCK_TOL):
+        assert rel_err(y.cpu(), ref) < tol
+        assert part.shape[2] == lib().cine_conv_stat_partials(ref.shape[1], ref.shape[2], ref.shape[3], 0)
+        assert float(part[..., 0].sum(dim=2).min()) == ref.shape[2] * ref.shape[3] == float(part[..., 0].sum(dim=2).max())
+        st = ops.instnorm_finalize(part)
+        assert rel_err(st[..., 0].cpu(), ref.mean(dim=(2, 3))) < 1e-4
+        assert rel_err(st[..., 1].cpu(), 1 / torch.sqrt(ref.var(dim=(2, 3), unbiased=False) + 1e-5)) < 1e-4
+    x = rnd(31, n, 64, h, w) * 1.3 + 0.2
+    wt = rnd(32, 64, 64, 3, 3) / 24
+    px = ops.instnorm_partials(x.to(dev))
+    y, part = ops.conv3x3_in([(x.to(dev), px, 1)], ops.pack_conv3x3(wt.to(dev)), 64, h, w)
+    check(y, part, F.conv2d(act(x), wt, padding=1))
+    y, part = ops.conv3x3_in([(x.to(dev), None, 0)], ops.pack_conv3x3(wt.to(dev)), 64, h, w)       # plain source
+    check(y, part, F.conv2d(x, wt, padding=1), OP_TOL)
+    big = rnd(33, n, 32, 2 * h, 2 * w + 1)                                                      # pooled (avg_pool2d floors)
+    wp = rnd(34, 64, 32, 3, 3) / 17
+    y, part = ops.conv3x3_in([(big.to(dev), ops.instnorm_partials(big.to(dev)), 2)], ops.pack_conv3x3(wp.to(dev)), 64, h, w)
+    check(y, part, F.conv2d(F.avg_pool2d(act(big), 2), wp, padding=1))
+    up, skip = rnd(35, 4, 24, h - 1, w), rnd(36, 4, 20, h, w)                                   # ragged concat, `up` one row short, 72 rows
+    wc = rnd(37, 72, 44, 3, 3) / 20
+    y, part = ops.conv3x3_in([(up.to(dev), ops.instnorm_partials(up.to(dev)), 1), (skip.to(dev), None, 0)], ops.pack_conv3x3(wc.to(dev)), 72, h, w)
+    check(y, part, F.conv2d(torch.cat([F.pad(act(up), [0, 0, 0, 1]), skip], 1), wc, padding=1))
+    wb = rnd(38, 64, 64, 3, 3) / 24                                                             # two weight sets
+    y, part = ops.conv3x3_in([(x.to(dev), px, 1)], ops.pack_conv3x3(wt.to(dev)), 64, h, w, wpacked2=ops.pack_conv3x3(wb.to(dev)), set_split=6)
+    check(y, part, torch.cat([F.conv2d(act(x[:6]), wt, padding=1), F.conv2d(act(x[6:]), wb, padding=1)]))
+    # sources outside the fast staging paths, through cine_conv3x3_ex: Haar DWT of a normalised tensor + an added plain skip
+    src = rnd(39, 3, 16, 2 * h, 2 * w); skp = rnd(40, 3, 64, h, w)
+    wd = rnd(41, 48, 64, 3, 3) / 24
+    src_d, skp_d, wd_p = src.to(dev), skp.to(dev), ops.pack_conv3x3(wd.to(dev))      # (kept alive: raw pointers go to the call below)
+    psrc = ops.instnorm_partials(src_d)
+    a_ = act(src) * 0.5
+    x1, x2, x3, x4 = a_[:, :, 0::2, 0::2], a_[:, :, 1::2, 0::2], a_[:, :, 0::2, 1::2], a_[:, :, 1::2, 1::2]      # mwcnn.py:224-236
+    dwt = torch.cat([x1 + x2 + x3 + x4, -x1 - x2 + x3 + x4, -x1 + x2 - x3 + x4, x1 - x2 - x3 + x4], 1)
+    yd = torch.empty((3, 48, h, w), device=dev)
+    pd = torch.empty((3, 48, lib().cine_conv_stat_partials(48, h, w, 0), 3), device=dev)
+    P = lambda t_: None if t_ is None else t_.data_ptr()
+    from cine_hip import _lib
+    _lib.check(lib().cine_conv3x3_ex(src_d.data_ptr(), psrc.data_ptr(), psrc.shape[2], 16, 3 | 8, 2 * h, 2 * w,
+                                     skp_d.data_ptr(), None, 0, 64, 0, h, w, 1, wd_p.data_ptr(), None, None, 0,
+                                     yd.data_ptr(), pd.data_ptr(), 3, 48, h, w, ops.IN_EPS, ops.lrelu_slope(), ops._stream()), "cine_conv3x3_ex")
+    check(yd, pd, F.conv2d(dwt + skp, wd, padding=1))
+
+
 @pytest.mark.parametrize("cin,cout,h,w", [(128, 64, 26, 2), (64, 32, 52, 4), (32, 16, 104, 8), (8, 4, 6, 5), (16, 8, 26, 26)])
 def test_tconv_and_conv1x1_vs_torch(dev, cin, cout, h, w):
     from cine_hip import ops
