@@ -118,7 +118,7 @@ def _cfg4():
     return dict(name="BASELINE.json configs[3]: 3D CineNet, 6 cascades, CG 6, U-Net3D 16ch/3 pools, 15 coils x 15 frames x 200x200, R=6",
                 metric="cine slices/sec, 3D CineNet R=6 15-coil 200x200x15t", accel=6, noise=0.0, wseed=7, keep=("lambda",),
                 hip=lambda: M.CineNet(6, 6, 16, 3, "3D"), ref=lambda: oracle_model(4), needs_sens=True,
-                conv_flop=365.2e9, conv_kernel="cine::conv_wide_kernel<..., V3 = 1> (3x3x3 convs as three 3x3 passes, levels 0 / 1) + conv_mfma_kernel<8, ..., 9, 1> (coarse levels)", fft_bytes=None)
+                conv_flop=365.2e9, conv_kernel="cine::conv_wide_kernel<..., V3 = 1> (3x3x3 convs as three 3x3 passes, levels 0 / 1) + conv_coarse_kernel (coarse levels: flattened positions, K split over the waves)", fft_bytes=None)
 
 
 def _cfg5():
@@ -631,7 +631,7 @@ def pmc_families(cfg_id):
     """HBM-side bytes / MFMA busy fractions per kernel family from the committed rocprofv3 --pmc passes of this same command
     (tools/collect_profiles.sh -> tools/pmc_traffic.py / pmc_mfma.py; PMC collection cannot run inside the bench itself)."""
     sfx = "" if cfg_id == 2 else f"_cfg{cfg_id}"
-    for rnd_ in ("r04", "r03", "r02", "r01"):
+    for rnd_ in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", f"{rnd_}_pmc_traffic{sfx}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:

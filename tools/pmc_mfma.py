@@ -30,7 +30,7 @@ for k, c in sorted(per.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYC
               "active_inst_valu_cycles": c.get("SQ_ACTIVE_INST_VALU", 0), "busy_cu_cycles": c.get("SQ_BUSY_CU_CYCLES", 0), "waves": c.get("SQ_WAVES", 0)}
     print(f"{k[:70]:70s} n={n:4d} mfma_util={out[k]['mfma_util']} clock={out[k]['clock_GHz']} GHz")
 def is_conv3(k):
-    return ("conv_plane_kernel" in k and "tconv" not in k) or "conv_wide_kernel" in k or ("conv_mfma_kernel" in k and re.search(r", (9|27)(, \d)?>", k))
+    return ("conv_plane_kernel" in k and "tconv" not in k) or "conv_wide_kernel" in k or "conv_coarse_kernel" in k or ("conv_mfma_kernel" in k and re.search(r", (9|27)(, \d)?>", k))
 tot_busy = sum(v["mfma_busy_cycles"] for k, v in out.items() if is_conv3(k))
 tot_gui = sum(v["gui_active_cycles"] for k, v in out.items() if is_conv3(k))
 summary = {"conv3x3_family_mfma_util": round(tot_busy / (tot_gui / 8.0 * 1024.0), 4) if tot_gui else None}

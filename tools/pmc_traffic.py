@@ -7,7 +7,7 @@ import csv, re, collections, json, sys
 
 def fam(k):
     if "tconv_plane_kernel" in k or "s2d_gemm_plane_kernel" in k: return "tconv_conv1x1_mfma"      # the lean kernels of csrc/conv_plane.hip
-    if "conv_plane_kernel" in k or "conv_wide_kernel" in k: return "conv3x3_mfma"
+    if "conv_plane_kernel" in k or "conv_wide_kernel" in k or "conv_coarse_kernel" in k: return "conv3x3_mfma"
     if "conv_mfma" in k and re.search(r", (9|27)(, \d)?>", k): return "conv3x3_mfma"
     if "conv_mfma" in k: return "tconv_conv1x1_mfma"
     if "conv1x1_stream" in k: return "conv1x1_stream"
