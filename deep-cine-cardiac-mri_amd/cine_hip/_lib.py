@@ -89,6 +89,8 @@ _SIGS = {
     "cine_tconv3d_in": (c_int, [P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "cine_conv1x1x1_bias": (c_int, [P, P, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "cine_instnorm_merge": (c_int, [P, P, c_long, c_int, P]),
+    "cine_pool3d_act": (c_int, [P, P, c_int, P, c_long, c_int, c_int, c_int, c_float, c_float, P]),
+    "cine_conv3d_pools_on_load": (c_int, [c_int, c_int, c_int, c_int]),
     "cine_unet3d_ws_bytes": (c_size_t, [c_int] * 8),
     "cine_unet3d_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_normunet3d_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P]),

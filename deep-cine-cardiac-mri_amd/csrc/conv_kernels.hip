@@ -938,6 +938,52 @@ __global__ void instnorm_lrelu_apply_kernel(const float* x, const float* part, i
 }
 
 
+// y (planes, d/2, h/2, w/2) = avg_pool3d(LeakyReLU(InstanceNorm(x)), 2) (unet.py:88,97 with dims = 3), fetch_scalar's summation order: the
+// pooled level-1 input of the 3-D U-Net materialised once (38 MB read, 4.5 MB written at cfg 4) so that its consumer stages a plain
+// tensor with 16-byte pieces; the coarse levels pool inside conv_coarse.hip and do not use this.  VEC: 4 outputs per thread.
+template <bool VEC>
+__global__ __launch_bounds__(256) void pool3d_act_kernel(const float* x, const float* part, int np, float* y, long planes,
+                                                         int d, int h, int w, float eps, float slope) {
+    const int od = d / 2, oh = h / 2, ow = w / 2;
+    const int owv = VEC ? ow / 4 : ow;
+    const long per = (long)od * oh * owv, total = planes * per;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long plane = e / per;
+        long r = e - plane * per;
+        const int ox = (int)(r % owv); r /= owv;
+        const int oy = (int)(r % oh), oz = (int)(r / oh);
+        const float2 mr = merge_partials(part + plane * np * 3, np, eps);
+        const float sc = mr.y, sh = -mr.x * mr.y;
+        const float* src = x + ((plane * d + 2 * oz) * h + 2 * oy) * (long)w + (VEC ? 8 * ox : 2 * ox);
+        if constexpr (VEC) {
+            float acc8[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const float* p0 = src + (long)dz * h * w;
+                float t0[8], t1[8];
+#pragma unroll
+                for (int u = 0; u < 8; u += 4) {
+                    *reinterpret_cast<float4*>(t0 + u) = *reinterpret_cast<const float4*>(p0 + u);
+                    *reinterpret_cast<float4*>(t1 + u) = *reinterpret_cast<const float4*>(p0 + w + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc8[u] += act(t0[2 * u], sc, sh, slope) + act(t0[2 * u + 1], sc, sh, slope) + act(t1[2 * u], sc, sh, slope) + act(t1[2 * u + 1], sc, sh, slope);
+            }
+            *reinterpret_cast<float4*>(y + ((plane * od + oz) * oh + oy) * (long)ow + 4 * ox) =
+                make_float4(0.125f * acc8[0], 0.125f * acc8[1], 0.125f * acc8[2], 0.125f * acc8[3]);
+        } else {
+            float acc8 = 0.f;
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz) {
+                const float* p0 = src + (long)dz * h * w;
+                acc8 += act(p0[0], sc, sh, slope) + act(p0[1], sc, sh, slope) + act(p0[w], sc, sh, slope) + act(p0[w + 1], sc, sh, slope);
+            }
+            y[((plane * od + oz) * oh + oy) * (long)ow + ox] = 0.125f * acc8;
+        }
+    }
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is per device: raise it once per (kernel, device) and KEEP the result -- a failed
 // first call must fail every later launch with its own message instead of a generic launch error
 template <typename K>
@@ -1448,6 +1494,26 @@ extern "C" int cine_instnorm_lrelu_apply(const float* x, const float* part, int 
     hipLaunchKernelGGL(instnorm_lrelu_apply_kernel, dim3(grid1d(planes * plane_elems, 256)), dim3(256), 0,
                        as_stream(stream), x, part, np, y, planes, plane_elems, eps, slope);
     return check_launch("instnorm_lrelu_apply_kernel");
+}
+
+extern "C" int cine_pool3d_act(const float* x, const float* part, int np, float* y, long planes, int d, int h, int w,
+                               float eps, float slope, void* stream) {
+    if (int e = check_slope(slope, "cine_pool3d_act")) return e;
+    CINE_REQUIRE(x && part && y && planes > 0 && np > 0 && d >= 2 && h >= 2 && w >= 2, CINE_EINVAL, "cine_pool3d_act: bad arguments");
+    const bool vec = w % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0;
+    const long total = planes * (long)(d / 2) * (h / 2) * (vec ? w / 8 : w / 2);
+    ProfScope prof(F_PACK, as_stream(stream));
+    if (vec) hipLaunchKernelGGL(pool3d_act_kernel<true>, dim3(grid1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), x, part, np, y, planes, d, h, w, eps, slope);
+    else hipLaunchKernelGGL(pool3d_act_kernel<false>, dim3(grid1d(total, 256, 16384)), dim3(256), 0, as_stream(stream), x, part, np, y, planes, d, h, w, eps, slope);
+    return check_launch("pool3d_act_kernel");
+}
+
+// 1 when cine_conv3d_in pools a mode-2 source inside an efficient kernel for this layer shape (conv_coarse.hip); 0 when the layer runs on
+// the 16-wide tile kernels, whose pooled staging is element-wise: a caller then does better to materialise the pooled tensor once
+// (cine_pool3d_act) and hand it over as a plain source -- what cine_unet3d_forward does for its level 1
+extern "C" int cine_conv3d_pools_on_load(int cout, int d, int h, int w) {
+    if (cout <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
+    return coarse_shape(ceil_div(cout, 16) * 16, h, w, d) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------- input gradients (training)

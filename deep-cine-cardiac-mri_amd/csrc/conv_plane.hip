@@ -913,6 +913,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
     for (int dx = 0; dx < 3; ++dx) base_in[dx] = kk * C::PS + (wn * MT) * C::COLS + (q + dx - 1 + C::COLS) % C::COLS;
     const int base_w = kk * C::COTP + 16 * (wm * CT) + q;
     __builtin_amdgcn_s_setprio(2);
+    CINE_STAMP_RT(9);
+    CINE_STAMP(0);
     // ---- my slot: row srow, piece sj of channel group sg; the first / last piece of a row also carries the row's left / right halo column
     const int sg = tid / RP, srp = tid - sg * RP;
     const bool slot = sg < G;
@@ -1010,9 +1012,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
 #pragma unroll
         for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    CINE_STAMP(1);
     for (int chunk = first_live; chunk < a.nchunks; ++chunk) {
         if (V3 && !chunk_live(chunk)) break;           // the live chunks of a tile are one run: the dead ones behind it are skipped
         __syncthreads();
+        if (chunk == first_live) CINE_STAMP(2);
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int e = tid + i * NT;
@@ -1050,7 +1054,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
                 }
             }
         }
+        if (chunk == first_live) CINE_STAMP(3);
         __syncthreads();
+        if (chunk == first_live) CINE_STAMP(4);
         if (chunk + 1 < a.nchunks) issue(chunk + 1);
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -1078,7 +1084,9 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
             }
             __builtin_amdgcn_s_setprio(2);
         }
+        if (chunk == first_live) CINE_STAMP(5);
     }
+    CINE_STAMP(6);
 
     // ---- epilogue: fragment f = image row fr0 + f, my 4 pixels at columns gx0 .. gx0 + 3 (inside or outside the plane as a whole)
     const int fr0 = r0 + wn * MT, gx0 = c0 + 4 * kk;
@@ -1136,6 +1144,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
                 }
             }
     }
+    CINE_STAMP(7);
     if (a.ypart) {
         const int rows_w = min(max(a.H - fr0, 0), MT);
         const float cnt_w = (float)(rows_w * min(TW, a.W - c0));
@@ -1206,6 +1215,8 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
             }
         }
     }
+    CINE_STAMP(8);
+    CINE_STAMP_RT(10);
 }
 
 template <int CT, int WM, int WN, int MT, int MODE, int V3>

@@ -2,6 +2,7 @@
 // Conv3d 3x3x3 + InstanceNorm3d + LeakyReLU, avg_pool3d 2, ConvTranspose3d k2 s2, 1x1x1 conv).
 // Same storage discipline as unet.hip.  A volume emits one statistics record per (tile, depth slice); they are
 // merged into one record per (sample, channel) right after each launch.
+#include <algorithm>
 #include "common.h"
 
 using namespace cine;
@@ -18,6 +19,9 @@ extern "C" int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x
                                    const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
                                    float eps, float slope, void* stream);
 extern "C" int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream);
+extern "C" int cine_pool3d_act(const float* x, const float* part, int np, float* y, long planes, int d, int h, int w,
+                               float eps, float slope, void* stream);
+extern "C" int cine_conv3d_pools_on_load(int cout, int d, int h, int w);
 
 namespace {
 constexpr float kEps = 1e-5f;
@@ -33,6 +37,7 @@ struct Bump {
 struct Plan {
     int P; int ds[8], hs[8], wsz[8], ch[8];
     float *skip[8], *pskip[8], *scr[3], *pscr[3], *raw_part;
+    float* pooled;                      // the materialised avg_pool3d(act(.)) input of the levels whose conv kernel does not pool on load
 };
 void build(Plan& p, Bump& b, int n, int d, int h, int w, int chans, int pools) {
     p.P = pools;
@@ -56,6 +61,11 @@ void build(Plan& p, Bump& b, int n, int d, int h, int w, int chans, int pools) {
     }
     for (int i = 0; i < 3; ++i) { p.scr[i] = b.take((size_t)n * big); p.pscr[i] = b.take((size_t)n * bigc * 3); }
     p.raw_part = b.take((size_t)n * bignp * 3);
+    size_t pool = 0;
+    for (int l = 1; l <= pools; ++l)
+        if (!cine_conv3d_pools_on_load(p.ch[l], p.ds[l], p.hs[l], p.wsz[l]))
+            pool = std::max(pool, (size_t)p.ch[l - 1] * p.ds[l] * p.hs[l] * p.wsz[l]);
+    p.pooled = pool ? b.take((size_t)n * pool) : nullptr;
 }
 }  // namespace
 
@@ -101,8 +111,13 @@ extern "C" int cine_unet3d_forward(const float* x, float* y, const void* const* 
         float* pout = last ? p.pscr[1] : p.pskip[l];
         const float* w1 = W();
         if (l == 0) e = conv(x, nullptr, in_ch, 0, d, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, w1, p.scr[0], p.pscr[0], p.ch[0], 0);
-        else e = conv(p.skip[l - 1], p.pskip[l - 1], p.ch[l - 1], 2, p.ds[l - 1], p.hs[l - 1], p.wsz[l - 1],
-                      nullptr, nullptr, 0, 0, 0, 0, 0, w1, p.scr[0], p.pscr[0], p.ch[l], l);
+        else if (p.pooled && !cine_conv3d_pools_on_load(p.ch[l], p.ds[l], p.hs[l], p.wsz[l])) {
+            // the 16-wide tile kernels stage a pooled source element by element (80 us for cfg 4's level 1): pool once, then a plain source
+            if ((e = cine_pool3d_act(p.skip[l - 1], p.pskip[l - 1], 1, p.pooled, (long)n * p.ch[l - 1], p.ds[l - 1], p.hs[l - 1], p.wsz[l - 1],
+                                     kEps, kSlope, stream))) return e;
+            e = conv(p.pooled, nullptr, p.ch[l - 1], 0, p.ds[l], p.hs[l], p.wsz[l], nullptr, nullptr, 0, 0, 0, 0, 0, w1, p.scr[0], p.pscr[0], p.ch[l], l);
+        } else e = conv(p.skip[l - 1], p.pskip[l - 1], p.ch[l - 1], 2, p.ds[l - 1], p.hs[l - 1], p.wsz[l - 1],
+                        nullptr, nullptr, 0, 0, 0, 0, 0, w1, p.scr[0], p.pscr[0], p.ch[l], l);
         if (e) return e;
         if ((e = conv(p.scr[0], p.pscr[0], p.ch[l], 1, p.ds[l], p.hs[l], p.wsz[l], nullptr, nullptr, 0, 0, 0, 0, 0, W(),
                       out, pout, p.ch[l], l))) return e;

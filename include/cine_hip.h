@@ -355,6 +355,13 @@ int cine_conv1x1x1_bias(const float* x, const float* part_x, int np_x, int mode,
                         const float* bias, float* y, int n, int cin, int cout, int d, int h, int w,
                         float eps, float slope, void* stream);
 int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream);
+/* y (planes, d/2, h/2, w/2) = avg_pool3d(LeakyReLU(InstanceNorm3d(x)), 2) (unet.py:88,97 with dims = 3; part: np statistics records per
+ * plane), and the planning query that goes with it: cine_conv3d_pools_on_load() == 1 when cine_conv3d_in serves a mode-2 source of this
+ * layer shape inside an efficient kernel (the coarse levels), 0 when the caller does better to pool once with cine_pool3d_act and pass
+ * the result as a plain source (what cine_unet3d_forward does for its level 1; same arithmetic, same summation order). */
+int cine_pool3d_act(const float* x, const float* part, int np, float* y, long planes, int d, int h, int w,
+                    float eps, float slope, void* stream);
+int cine_conv3d_pools_on_load(int cout, int d, int h, int w);
 /* Whole 3-D U-Net (unet.py:73-125, dims = 3); weights ordered as for cine_unet2d_forward (one set), packed with
  * cine_pack_conv3d / cine_pack_tconv3d / cine_pack_conv1x1. */
 size_t cine_unet3d_ws_bytes(int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools);

@@ -1051,6 +1051,24 @@ def test_conv3d_v3_paths_vs_torch(dev, case):
         assert want_np is None or part.shape[2] == want_np
 
 
+@pytest.mark.parametrize("shape", [(3, 15, 200, 200), (2, 7, 10, 13), (5, 4, 6, 16)])
+def test_pool3d_act_vs_torch(dev, shape):
+    """cine_pool3d_act: avg_pool3d(LeakyReLU(InstanceNorm3d(x)), 2) materialised (the 3-D U-Net's level-1 input at cfg 4: 15 x 200 x 200 ->
+    7 x 100 x 100; odd extents floor), vectorised and element-wise forms, against torch."""
+    from cine_hip import ops, _lib
+    import torch.nn.functional as F
+    c, d, h, w = shape
+    x = rnd(61, 1, c, d, h, w) * 1.7 + 0.4
+    xd = x.to(dev)
+    part = ops.instnorm_partials(xd)
+    y = torch.empty((1, c, d // 2, h // 2, w // 2), device=dev)
+    _lib.check(_lib.lib().cine_pool3d_act(xd.data_ptr(), part.data_ptr(), part.shape[2], y.data_ptr(), c, d, h, w, 1e-5, 0.2, ops._stream()), "cine_pool3d_act")
+    ref = F.avg_pool3d(F.leaky_relu(F.instance_norm(x), 0.2), 2, 2)
+    assert rel_err(y.cpu(), ref) < OP_TOL
+    L = _lib.lib()
+    assert L.cine_conv3d_pools_on_load(64, 3, 50, 50) == 1 and L.cine_conv3d_pools_on_load(32, 7, 100, 100) == 0
+
+
 def test_unet3d_and_normunet3d_vs_reference_golden(golden, dev):
     from reconstruction.models.denoisers import NormUnet3D
     g = golden("unet")

@@ -4,6 +4,7 @@
 #include "conv_plane.hip"
 #include <vector>
 #include <algorithm>
+namespace cine { void set_wgrad_plane(int) {} }      // (grad_kernels.hip is not linked into this tool)
 extern "C" int cine_conv_stat_partials(int, int, int, int);
 extern "C" size_t cine_conv3x3_packed_floats(int, int);
 extern "C" int cine_pack_conv3x3(const float*, float*, int, int, void*);
