@@ -524,6 +524,7 @@ def dot(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 
 _cg_ws = {}
+CG_SOLVER = True     # A/B switch: False = one normal_op_cg_step call per iteration (3 launches each) instead of cine_conj_grad (2 launches each)
 FUSED_CG = True      # A/B switch of the diagnostics (tools/whatif_cfg4.py): False = operator + partial-sum pass + update + direction (4 launches)
 
 
@@ -588,6 +589,26 @@ def normal_op_cg_step(x, r, p, sens, mask, lambda_reg, rr_old, rr_new, pd_out: O
     check(lib().cine_cg_step_pd(x.data_ptr(), r.data_ptr(), p.data_ptr(), d.data_ptr(), x.numel(), rr_old.data_ptr(), rr_new.data_ptr(),
                                 ws.data_ptr(), _stream()), "cine_cg_step_pd")
     return rr_new
+
+
+def conj_grad(x: torch.Tensor, rhs: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor, iters: int,
+              sens_tiled: Optional[torch.Tensor] = None, rhs_is_ref: bool = False) -> Optional[torch.Tensor]:
+    """reference cinenet.py:136-171 for a row mask: the whole solve in 2 + 2 * iters launches (cine_conj_grad), x updated IN PLACE and
+    returned.  rhs_is_ref: `rhs` is x_ref and the right-hand side x_ref + softplus(lambda) x is formed inside (cinenet.py:106-107).
+    None when the shape has no such path (h != 200 or <= 5 coils): the caller iterates normal_op_cg_step."""
+    b, _, c, h, w, _ = sens.shape
+    t = x.shape[1]
+    nbytes = lib().cine_conj_grad_ws_bytes(b, t, c, h, w)
+    if nbytes == 0:
+        return None
+    for t_, name in ((x, "x"), (rhs, "rhs")):
+        if not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.numel() == b * t * h * w * 2):
+            raise ValueError(f"conj_grad: {name} must be a contiguous float32 GPU tensor of (b, t, 1, h, w, 2)")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    check(lib().cine_conj_grad(x.data_ptr(), rhs.data_ptr(), int(rhs_is_ref), _dev(sens, "sens_maps").data_ptr(), _p(sens_tiled), _dev(mask, "mask", torch.uint8).data_ptr(),
+                               _dev(lambda_reg.detach(), "lambda_reg").data_ptr(), int(iters), b, t, c, h, w, ws.data_ptr(), nbytes, _stream()),
+          "cine_conj_grad")
+    return x
 
 
 def axpby_dev(a: torch.Tensor, b: torch.Tensor, num: Optional[torch.Tensor] = None, den: Optional[torch.Tensor] = None,

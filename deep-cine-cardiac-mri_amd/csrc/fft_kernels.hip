@@ -594,6 +594,9 @@ struct ImgDcArgs {
     int BT, ntx, nz;                 // H == 200: frames x batch, column tiles, coil groups
     float* pd_wg;                    // optional (H == 200, nz > 1): one partial sum of <img, sum_z partial_z + beta img> per WORKGROUP of imgdc200_kernel
                                      // (cine_normal_op_cg_fused: the conjugate-gradient step then needs no imgdc_sum pass)
+    // imgdc200_kernel<true> (cine_conj_grad): the operator's input is the NEW conjugate-gradient direction p = r + (sum num / sum den) p_old
+    // (cinenet.py:165-169), formed on load from the interleaved {p_old, r} pairs the update kernel left; coil group 0 writes it to cg_p_out
+    const float4* cg_pr; const float* cg_num; const float* cg_den; cf* cg_p_out;
 };
 
 __device__ __forceinline__ void imgdc_weights(const ImgDcArgs& a, float& w1, float& w0, float& beta) {
@@ -626,6 +629,7 @@ __device__ __forceinline__ void imgdc_store(const ImgDcArgs& a, long o, cf s, fl
     if (a.out_abs) a.out_abs[o] = sqrtf(s.x * s.x + s.y * s.y);
     else a.out[o] = s;
 }
+template <bool CG>
 __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs a) {
     constexpr int CS = kDcCS, CW = kDcCW, LP = kDcL;
     constexpr int NOUT = (200 * CW + kDcT - 1) / kDcT;         // outputs per thread
@@ -657,7 +661,21 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
 #pragma unroll
         for (int k2 = 0; k2 < 20; ++k2) mbits |= (mrow[rot10(k2, g2)] ? 1u : 0u) << k2;
     }
-    const cf* xp = a.img + (long)bt * HW;
+    const cf* xp = CG ? nullptr : a.img + (long)bt * HW;
+    float bcg = 0.f;                 // CG: beta = r.r (new) / r.r (old), both from the update kernels' 256 partial sums (block_sum's order: what cg_direction_kernel computes)
+    if constexpr (CG) {
+        __shared__ float cgred[8];
+        float vn = a.cg_num[tid], vd = a.cg_den[tid];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) { vn += __shfl_xor(vn, o2, 64); vd += __shfl_xor(vd, o2, 64); }
+        if ((tid & 63) == 0) { cgred[tid >> 6] = vn; cgred[4 + (tid >> 6)] = vd; }
+        __syncthreads();
+        float sn = 0.f, sd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sn += cgred[i]; sd += cgred[4 + i]; }
+        bcg = sn / sd;
+    }
+    const float4* prp = CG ? a.cg_pr + (long)bt * HW : nullptr;
     CINE_STAMP(0);
     cf svk[2][10];          // the sensitivities stay in registers for P3: 140 VGPRs, three workgroups per CU (48 vs 56 us re-reading them)
     // ---- P1: the loads of BOTH items first (40 per thread in flight: one memory latency instead of two), then the two radix-10 items
@@ -672,9 +690,19 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
             const cf* sp = a.sens_t ? a.sens_t + (((long)b * a.C + min(c0 + slot, a.C - 1)) * a.ntx + w0c / CW) * (200L * CW) + line % CW
                                     : a.sens + ((long)b * a.C + min(c0 + slot, a.C - 1)) * HW + colc;
             const int sstr = a.sens_t ? CW : a.W;                           // (the tiled copy is zero past the last column)
-            const cf* xq = xp + colc;
+            if constexpr (CG) {
+                const float4* pq = prp + colc;
 #pragma unroll
-            for (int j = 0; j < 10; ++j) { svk[r][j] = sp[rot20(j, c) * sstr]; v2[r][j] = xq[rot20(j, c) * a.W]; }
+                for (int j = 0; j < 10; ++j) {
+                    svk[r][j] = sp[rot20(j, c) * sstr];
+                    const float4 u = pq[rot20(j, c) * a.W];                 // {p_old, r}
+                    v2[r][j] = mk(u.z + bcg * u.x, u.w + bcg * u.y);        // p = r + beta p_old (the expression of cg_direction_kernel)
+                }
+            } else {
+                const cf* xq = xp + colc;
+#pragma unroll
+                for (int j = 0; j < 10; ++j) { svk[r][j] = sp[rot20(j, c) * sstr]; v2[r][j] = xq[rot20(j, c) * a.W]; }
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -748,7 +776,12 @@ __global__ __launch_bounds__(kDcT, CINE_DC_MINW) void imgdc200_kernel(ImgDcArgs 
         if (single) imgdc_store(a, o, s, beta);
         else part[o] = s;
         if (a.pd_wg) {                  // <p, this group's share of H p>; the regulariser term beta <p, p> rides with group 0
-            const cf pv = a.img[o];
+            cf pv;
+            if constexpr (CG) {
+                const float4 u = a.cg_pr[o];
+                pv = mk(u.z + bcg * u.x, u.w + bcg * u.y);
+                if (zg == 0) a.cg_p_out[o] = pv;                            // the new direction, for the update kernel that follows
+            } else pv = a.img[o];
             pdl += pv.x * s.x + pv.y * s.y;
             if (zg == 0) pdl += beta * (pv.x * pv.x + pv.y * pv.y);
         }
@@ -1228,6 +1261,68 @@ extern "C" int cine_normal_op_cg_fused_t(float* x, float* r, float* p, const flo
                                   rr_old_dev, rr_new_dev, pd_wg + nb, pd_out_dev, as_stream(stream));
 }
 
+// ---- the whole conjugate-gradient solve of CineNet's DC block (cinenet.py:136-171) for a row mask, TWO launches per iteration:
+//   set-up    imgdc200_kernel (H x0, coil-group sums) -> cg_init_kernel: r = b - H x0, {p_old = 0, r} pairs, partial sums of r.r
+//   iteration imgdc200_kernel<true>: beta = r.r / r.r_old from the two partial-sum arrays, p = r + beta p_old formed ON LOAD (one 16-byte
+//             {p_old, r} element where the plain kernel reads an 8-byte one), coil-group sums of A^H M A p, p.Hp per workgroup, p written
+//             by coil group 0  ->  cg_update2_kernel: alpha, x += alpha p, r -= alpha (sum_z partial_z + v p), new {p, r} pairs, r.r partials
+// The direction update of round 4's three-launch form (cg_direction_kernel) needs the global r.r, i.e. a kernel boundary behind the update;
+// here that boundary is the one in front of the next operator anyway.  No direction is computed behind the last iteration (p is not used
+// again), and the set-up is 2 launches instead of 7 (operator, coil sums, b - Hx, two copies, dot, dot): 14 launches per solve of 6
+// iterations instead of 25.  Same arithmetic as the three-launch form except for the summation order of the first r.r.
+namespace cine {
+int launch_cg_init(const float* x, const float* rhs, int rhs_ref, const cf* partial, int nz, long part_stride, const float* lam, long ncf,
+                   float4* pr, float* rr_part, hipStream_t st);                                                    // pack_kernels.hip
+int launch_cg_update2(float* x, float4* pr, const cf* p, const cf* partial, int nz, long part_stride, const float* lam, long ncf,
+                      const float* pd_wg, int npd, const float* rr_prev, float* rr_cur, int last, hipStream_t st);
+}
+extern "C" size_t cine_conj_grad_ws_bytes(int b, int t, int c, int h, int w) {
+    const long nb = cg_fused_blocks(b, t, c, h, w);
+    if (!nb) return 0;
+    const size_t ncf = (size_t)b * t * h * w;
+    return cine_image_dc_ws_bytes(b, t, c, h, w) + (size_t)(nb + 512) * sizeof(float) + 256 + ncf * (sizeof(float4) + sizeof(cf));
+}
+extern "C" int cine_conj_grad(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                              const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    CINE_REQUIRE(x && rhs && sens && mask && lambda_dev && ws, CINE_EINVAL, "cine_conj_grad: null pointer");
+    CINE_REQUIRE(iters >= 0 && x != rhs, CINE_EINVAL, "cine_conj_grad: bad arguments");
+    const long nb = cg_fused_blocks(b, t, c, h, w);
+    CINE_REQUIRE(nb > 0 && nb <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_conj_grad: needs h == 200 and more than %d coils", kDcCS);
+    CINE_REQUIRE((long)b * t <= 65535, CINE_EUNSUPPORTED, "cine_conj_grad: b*t > 65535");
+    CINE_REQUIRE(ws_bytes >= cine_conj_grad_ws_bytes(b, t, c, h, w), CINE_EWORKSPACE, "cine_conj_grad: workspace too small");
+    const long ncf = (long)b * t * h * w;
+    const int nz = ceil_div(c, kDcCS);
+    char* wp = reinterpret_cast<char*>(ws);
+    cf* partial = reinterpret_cast<cf*>(wp); wp += cine_image_dc_ws_bytes(b, t, c, h, w);
+    float* pd_wg = reinterpret_cast<float*>(wp); wp += (size_t)nb * sizeof(float);
+    float* rr[2] = {reinterpret_cast<float*>(wp), reinterpret_cast<float*>(wp) + 256}; wp += 512 * sizeof(float);
+    wp = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(wp) + 255) & ~uintptr_t(255));
+    float4* pr = reinterpret_cast<float4*>(wp); wp += (size_t)ncf * sizeof(float4);
+    cf* pbuf = reinterpret_cast<cf*>(wp);
+    hipStream_t st = as_stream(stream);
+    // H x0: the plain operator kernel; asking for its per-workgroup dot partials keeps the coil-group sums for cg_init_kernel
+    if (int e = image_dc_impl(x, sens, x, mask, lambda_dev, 1, 1.f, 0.f, 0.f, nullptr, b, t, c, h, w, 0, partial, cine_image_dc_ws_bytes(b, t, c, h, w),
+                              stream, nullptr, pd_wg, sens_tiled)) return e;
+    if (int e = launch_cg_init(x, rhs, rhs_is_ref ? 1 : 0, partial, nz, ncf, lambda_dev, ncf, pr, rr[0], st)) return e;
+    ImgDcArgs a{};
+    a.sens = reinterpret_cast<const cf*>(sens); a.sens_t = reinterpret_cast<const cf*>(sens_tiled); a.mask = mask;
+    a.lam = lambda_dev; a.lam_beta = 1; a.w1 = 1.f; a.w0 = 0.f; a.beta = 0.f;
+    a.T = t; a.C = c; a.H = h; a.W = w; a.partial = partial; a.part_stride = ncf; a.BT = b * t; a.ntx = ceil_div(w, kDcCW); a.nz = nz;
+    a.pd_wg = pd_wg; a.cg_pr = pr; a.cg_p_out = pbuf;
+    for (int k = 0; k < iters; ++k) {
+        // beta_k = r.r after update k-1 / r.r before it; k = 0: both are the set-up's sums and p_old = 0, i.e. p = r exactly
+        a.cg_num = k == 0 ? rr[0] : rr[k & 1];
+        a.cg_den = k == 0 ? rr[0] : rr[(k - 1) & 1];
+        {
+            ProfScope prof(F_FFT_COL, st);
+            hipLaunchKernelGGL(imgdc200_kernel<true>, dim3((unsigned)nb), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
+            if (int e = check_launch("imgdc200_kernel<cg>")) return e;
+        }
+        if (int e = launch_cg_update2(x, pr, pbuf, partial, nz, ncf, lambda_dev, ncf, pd_wg, (int)nb, rr[k & 1], rr[(k + 1) & 1], k + 1 == iters, st)) return e;
+    }
+    return CINE_OK;
+}
+
 static int image_dc_impl(const float* img, const float* sens, const float* zf, const uint8_t* mask,
                          const float* lambda_dev, int lam_beta, float w_sampled, float w_unsampled, float beta,
                          float* out, int b, int t, int c, int h, int w, int magnitude,
@@ -1257,7 +1352,7 @@ static int image_dc_impl(const float* img, const float* sens, const float* zf, c
         CINE_REQUIRE(nblk <= 0x7fffffffL, CINE_EUNSUPPORTED, "cine_image_dc: grid too large");
         CINE_REQUIRE(!pd_wg || nz > 1, CINE_EUNSUPPORTED, "cine_image_dc: per-workgroup dot partials need more than one coil group");
         a.pd_wg = pd_wg;
-        hipLaunchKernelGGL(imgdc200_kernel, dim3((unsigned)nblk), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
+        hipLaunchKernelGGL(imgdc200_kernel<false>, dim3((unsigned)nblk), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
         if (int e = check_launch("imgdc200_kernel")) return e;
         if (nz > 1 && !pd_wg) {           // (with pd_wg the caller's next kernel adds the coil groups itself: cine_normal_op_cg_fused)
             const long n = a.part_stride;

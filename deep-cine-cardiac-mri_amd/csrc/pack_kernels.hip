@@ -548,6 +548,74 @@ __global__ __launch_bounds__(256) void cg_update_fused_kernel(cfp* x, cfp* r, co
     s = block_sum(s, red);
     if (threadIdx.x == 0) rr_part[blockIdx.x] = s;
 }
+// cine_conj_grad (fft_kernels.hip): the set-up and update kernels of the two-launch conjugate-gradient iteration.  The residual lives
+// next to the direction it was computed with, as {p.x, p.y, r.x, r.y}: the next operator forms p_new = r + beta p on load from ONE element.
+// rhs_ref != 0: `rhs` holds x_ref and the right-hand side is x_ref + softplus(lambda) x (cinenet.py:106-107 with x = the regulariser's
+// output, which is also the start value: cine_axpby_dev's expression, one launch less per DC block)
+__global__ __launch_bounds__(256) void cg_init_kernel(const cfp* x, const cfp* rhs, int rhs_ref, const cfp* partial, int nz, long part_stride, const float* lam,
+                                                      long ncf, float4* pr, float* rr_part) {
+    __shared__ float red[16];
+    const float l = *lam;
+    const float beta = l > 20.f ? l : log1pf(expf(l));                 // softplus, as imgdc_weights reads it
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncf; i += (long)gridDim.x * blockDim.x) {
+        cfp d = partial[i];
+        for (int z = 1; z < nz; ++z) { const cfp u = partial[z * part_stride + i]; d.x += u.x; d.y += u.y; }
+        const cfp xv = x[i];
+        cfp bv = rhs[i];
+        if (rhs_ref) { bv.x = bv.x + beta * xv.x; bv.y = bv.y + beta * xv.y; }
+        d.x = fmaf(beta, xv.x, d.x); d.y = fmaf(beta, xv.y, d.y);        // H x0 (imgdc_sum_kernel's arithmetic)
+        const float rx = bv.x + -1.0f * d.x, ry = bv.y + -1.0f * d.y;    // b - H x0 (cine_axpby_dev's expression)
+        pr[i] = make_float4(0.f, 0.f, rx, ry);
+        s += rx * rx; s += ry * ry;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) rr_part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void cg_update2_kernel(cfp* x, float4* pr, const cfp* p, const cfp* partial, int nz, long part_stride,
+                                                         const float* lam, long ncf, const float* pd_wg, int npd,
+                                                         const float* rr_prev, float* rr_cur, int last) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < npd; i += 256) acc += pd_wg[i];
+    const float pd = block_sum(acc, red);
+    const float rr_old = block_sum(rr_prev[threadIdx.x], red);
+    const float alpha = rr_old / pd;
+    const float nalpha = alpha * -1.0f;
+    const float l = *lam;
+    const float beta = l > 20.f ? l : log1pf(expf(l));
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ncf; i += (long)gridDim.x * blockDim.x) {
+        cfp d = partial[i];
+        for (int z = 1; z < nz; ++z) { const cfp u = partial[z * part_stride + i]; d.x += u.x; d.y += u.y; }
+        const cfp pv = p[i];
+        d.x = fmaf(beta, pv.x, d.x); d.y = fmaf(beta, pv.y, d.y);
+        cfp xv = x[i];
+        const float4 old = pr[i];
+        xv.x = xv.x + alpha * pv.x; xv.y = xv.y + alpha * pv.y;
+        const float rx = old.z + nalpha * d.x, ry = old.w + nalpha * d.y;
+        x[i] = xv;
+        if (!last) pr[i] = make_float4(pv.x, pv.y, rx, ry);
+        s += rx * rx; s += ry * ry;
+    }
+    __syncthreads();
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) rr_cur[blockIdx.x] = s;
+}
+int launch_cg_init(const float* x, const float* rhs, int rhs_ref, const float2* partial, int nz, long part_stride, const float* lam, long ncf,
+                   float4* pr, float* rr_part, hipStream_t st) {
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_init_kernel, dim3(kDotBlocks), dim3(256), 0, st, reinterpret_cast<const cfp*>(x), reinterpret_cast<const cfp*>(rhs), rhs_ref,
+                       partial, nz, part_stride, lam, ncf, pr, rr_part);
+    return check_launch("cg_init_kernel");
+}
+int launch_cg_update2(float* x, float4* pr, const float2* p, const float2* partial, int nz, long part_stride, const float* lam, long ncf,
+                      const float* pd_wg, int npd, const float* rr_prev, float* rr_cur, int last, hipStream_t st) {
+    ProfScope prof(F_MISC, st);
+    hipLaunchKernelGGL(cg_update2_kernel, dim3(kDotBlocks), dim3(256), 0, st, reinterpret_cast<cfp*>(x), pr, p, partial, nz, part_stride, lam, ncf,
+                       pd_wg, npd, rr_prev, rr_cur, last);
+    return check_launch("cg_update2_kernel");
+}
 int launch_cg_update_fused(float* x, float* r, float* p, const float2* partial, int nz, long part_stride, const float* lam, long ncf,
                            const float* pd_wg, int npd, const float* rr_old, float* rr_new, float* rr_part, float* pd_out, hipStream_t st) {
     ProfScope prof(F_MISC, st);

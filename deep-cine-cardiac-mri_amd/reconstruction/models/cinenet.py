@@ -41,10 +41,15 @@ class CineNetBlock(nn.Module):
         operator is one image-space kernel (cine_image_dc with weights (1, 0, 0)): the mask commutes with the row FFT."""
         return ops.h_operator(x, sens_maps, mask, self.lambda_reg, _hyb, _tiled)
 
-    def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int, _tiled=None):
+    def ConjGrad(self, x, b, mask, sens_maps, CG_iters: int, _tiled=None, _inplace=False):
         """Hx = b with exactly CG_iters iterations (reference cinenet.py:136-171)."""
         bsz, t, _, h, w, _ = x.shape
         rowmask = ops.is_row_mask(mask, sens_maps.expand(-1, t, -1, -1, -1, -1))
+        if rowmask and ops.FUSED_CG and ops.CG_SOLVER:
+            # the whole solve in 2 + 2 * CG_iters launches (cine_conj_grad): the direction update rides in the next operator's loads
+            out = ops.conj_grad(x if _inplace else x.clone(), b, sens_maps, mask, self.lambda_reg, CG_iters, _tiled)
+            if out is not None:
+                return out
         hyb = None if rowmask else torch.empty((bsz, t, sens_maps.shape[2], h, w, 2), device=x.device, dtype=x.dtype)
         r = ops.axpby_dev(b, self.HOperator(x, mask, sens_maps, hyb, _tiled), num=_one(x), sign=-1.0)
         p = r.clone()
@@ -108,8 +113,13 @@ class CineNetBlock(nn.Module):
             rhs = ag.AxpbyLamFn.apply(image_ref, model_out, self.lambda_reg)
             return ag.ConjGradFn.apply(model_out, rhs, self.lambda_reg, mask, sens_maps, self.CG_iters)
         model_out = self.regularise(image_pred)
+        if ops.FUSED_CG and ops.CG_SOLVER and ops.is_row_mask(mask, sens_maps.expand(-1, image_pred.shape[1], -1, -1, -1, -1)):
+            # one call = the whole DC block: rhs = x_ref + v x_reg formed in the solver's set-up kernel, 2 + 2 * CG_iters launches
+            out = ops.conj_grad(model_out, image_ref, sens_maps, mask, self.lambda_reg, self.CG_iters, _tiled, rhs_is_ref=True)
+            if out is not None:
+                return out
         rhs = ops.axpby_dev(image_ref, model_out, lambda_reg=self.lambda_reg)       # x_ref + v x_reg
-        return self.ConjGrad(model_out, rhs, mask, sens_maps, self.CG_iters, _tiled)
+        return self.ConjGrad(model_out, rhs, mask, sens_maps, self.CG_iters, _tiled, _inplace=True)       # (model_out is this call's own tensor)
 
 
 _ones = {}

@@ -448,6 +448,16 @@ int cine_normal_op_cg_fused(float* x, float* r, float* p, const float* sens, con
 int cine_normal_op_cg_fused_t(float* x, float* r, float* p, const float* sens, const float* sens_tiled, const uint8_t* mask,
                               const float* lambda_dev, const float* rr_old_dev, float* rr_new_dev, float* pd_out_dev,
                               int b, int t, int c, int h, int w, void* ws_dc, size_t ws_dc_bytes, void* ws_cg, size_t ws_cg_bytes, void* stream);
+/* The WHOLE conjugate-gradient solve of CineNet's data-consistency block (models/cinenet.py:136-171: H x = b with exactly `iters`
+ * iterations, H = A^H M A + softplus(lambda) I, row mask) in 2 + 2 * iters launches: x (b, t, 1, h, w, 2) holds the start value and
+ * receives the solution, rhs = b -- or, with rhs_is_ref != 0, `rhs` holds x_ref and b = x_ref + softplus(lambda) x is formed inside
+ * (cinenet.py:106-107: x is then the regulariser's output, start value and regularisation target at once).  Per iteration one operator kernel -- which forms the new direction p = r + beta p on load and
+ * needs no direction pass -- and one update kernel (alpha, x, r, the partial sums of r.r).  Same arithmetic as cine_normal_op_cg_fused
+ * iterated, except for the summation order of the first r.r.  h == 200 and more than 5 coils (else CINE_EUNSUPPORTED: iterate
+ * cine_normal_op / cine_cg_step); sens_tiled: cine_sens_tile_pack's copy or NULL.  ws: cine_conj_grad_ws_bytes(). */
+size_t cine_conj_grad_ws_bytes(int b, int t, int c, int h, int w);
+int cine_conj_grad(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                   const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
 /* cine_cg_step_pd that also stores p.d into *pd_out_dev (training: the adjoint recurrence needs alpha_k = rr_k / pd_k). */
 int cine_cg_step_pd2(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                      float* pd_out_dev, void* ws, void* stream);

@@ -1459,6 +1459,50 @@ def test_tiled_sensitivities_give_the_same_bits(dev, t, c, w):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("t,c,w,iters", [(15, 15, 200, 6), (3, 8, 23, 4), (2, 6, 5, 1)])
+def test_conj_grad_two_launches_per_iteration_vs_oracle_and_three_launch_form(dev, t, c, w, iters):
+    """cine_conj_grad: the whole solve of reference cinenet.py:136-171 (set-up + `iters` iterations, two launches each: the operator forms
+    the new direction on load) against the reference's ConjGrad in float64 and against the three-launch iteration of round 4 on the same
+    start value and right-hand side."""
+    from cine_hip import ops
+    from oracle import cinenet_ref as C
+    import reconstruction.models as M
+    h = 200
+    sens = rnd(2, 1, 1, c, h, w, 2)
+    sens = sens / sens.pow(2).sum(dim=(2, 5), keepdim=True).sqrt()
+    mask = _row_mask(t, h, 5)
+    lam = torch.tensor([0.37])
+    x0, b0 = rnd(3, 1, t, 1, h, w, 2), rnd(4, 1, t, 1, h, w, 2)
+    blk = C.CineNetBlock(torch.nn.Identity(), iters, "XF", True).double()
+    with torch.no_grad():
+        blk.lambda_reg.copy_(lam.double())
+        want = blk.ConjGrad(x0.double(), b0.double(), mask, sens.double(), iters)
+    hipb = M.CineNetBlock(torch.nn.Identity(), iters, "XF", True).to(dev)
+    with torch.no_grad():
+        hipb.lambda_reg.copy_(lam.to(dev))
+    xd = x0.to(dev)
+    got2 = ops.conj_grad(xd.clone(), b0.to(dev), sens.to(dev), mask.to(dev), hipb.lambda_reg, iters)
+    assert got2 is not None and rel_err(got2.cpu(), want.float()) < 2e-5
+    try:
+        ops.CG_SOLVER = False                                  # the model's own loop: operator + update + direction per iteration
+        got3 = hipb.ConjGrad(xd, b0.to(dev), mask.to(dev), sens.to(dev), iters)
+    finally:
+        ops.CG_SOLVER = True
+    assert torch.equal(xd.cpu(), x0)                           # the public method leaves its start value alone
+    assert rel_err(got3.cpu(), want.float()) < 2e-5 and rel_err(got2.cpu(), got3.cpu()) < 1e-5
+    got = hipb.ConjGrad(xd, b0.to(dev), mask.to(dev), sens.to(dev), iters)         # the default route = cine_conj_grad
+    assert torch.equal(got, got2) and torch.equal(xd.cpu(), x0)
+    # the DC block's own call: the right-hand side x_ref + softplus(lambda) x0 formed inside the set-up kernel (cinenet.py:106-107)
+    v = float(torch.nn.functional.softplus(lam))
+    rhs = ops.axpby_dev(b0.to(dev), xd, lambda_reg=hipb.lambda_reg)
+    sep = ops.conj_grad(xd.clone(), rhs, sens.to(dev), mask.to(dev), hipb.lambda_reg, iters)
+    folded = ops.conj_grad(xd.clone(), b0.to(dev), sens.to(dev), mask.to(dev), hipb.lambda_reg, iters, rhs_is_ref=True)
+    assert torch.equal(sep, folded)
+    with torch.no_grad():
+        want_blk = blk.ConjGrad(x0.double(), b0.double() + v * x0.double(), mask, sens.double(), iters)
+    assert rel_err(folded.cpu(), want_blk.float()) < 2e-5
+
+
 @pytest.mark.parametrize("t,c,w", [(15, 15, 200), (3, 7, 36), (2, 6, 7)])
 def test_cg_iteration_three_launch_form_vs_oracle_and_four_launch_form(dev, t, c, w):
     """cine_normal_op_cg_fused (operator with per-workgroup p.Hp partial sums -> update that adds the coil groups itself -> direction)
