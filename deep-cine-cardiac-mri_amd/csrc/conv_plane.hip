@@ -98,9 +98,14 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
     constexpr bool HALF = MODE == 2 || MODE == 3;          // the source has twice the plane's extent: 2 x 2 input values per staged value
     piece_t xraw[HALF ? 1 : NCI];
     // pooled source: the first NPRE pieces of a chunk are prefetched like the plain ones (2 PW floats of two source rows each)
-    constexpr int NPRE = HALF ? (NCI < 2 ? NCI : 2) : 0;
+    // MODE 3 (Haar DWT on load): a chunk = the FOUR BANDS of TWO source channels, LDS channel ck = 2 band + s -- the weights of conv channel
+    // band * C + 2 chunk + s are gathered to match -- so a thread reads each 2 x 2 PW source block once and activates it once for all the
+    // bands it stages (round 4: a chunk = 8 source channels of one band, every block read and activated in four chunks; 540 vector
+    // instructions per MFMA against 300 for a plain source).  NB3 = source blocks per thread and chunk, all prefetched.
+    constexpr int NB3 = G == 1 ? 2 : 1;
+    constexpr int NPRE = MODE == 3 ? NB3 : (HALF ? (NCI < 2 ? NCI : 2) : 0);
     float4 praw[NPRE > 0 ? NPRE : 1][PW == 4 ? 4 : 2];
-    const float* const pbase = HALF ? a.x0 + ((long)n * a.c0 + sgc) * a.cs0 + (long)(2 * min(max(gy, 0), a.H - 1)) * (2 * TW) + 2 * PW * sj : nullptr;
+    const float* const pbase = HALF ? a.x0 + ((long)n * a.c0 + (MODE == 3 ? 0 : sgc)) * a.cs0 + (long)(2 * min(max(gy, 0), a.H - 1)) * (2 * TW) + 2 * PW * sj : nullptr;
     auto issue = [&](int chunk) {
         const float* wsrc = wp + (long)chunk * 9 * CK * a.rowsp;
 #pragma unroll
@@ -110,6 +115,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             const int c4 = (e % (C::COT / 4)) * 4;
             const bool v = e < 9 * CK * (C::COT / 4) && co0 + c4 < a.rowsp;
             if (CK == 4) row = (row / CK) * 8 + row % CK;           // 4-channel chunk over the 8-channel packing
+            if constexpr (MODE == 3) {      // LDS row (tap, ck) <- packed row of conv channel (ck >> 1) C + 2 chunk + (ck & 1)
+                const int tap = row >> 3, ckk = row & 7;
+                const int ci = (ckk >> 1) * a.c0 + 2 * chunk + (ckk & 1);
+                wraw[i] = *reinterpret_cast<const float4*>(v ? wp + (long)(((ci >> 3) * 9 + tap) * 8 + (ci & 7)) * a.rowsp + co0 + c4 : wp);
+            } else
             wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wp);
         }
         if constexpr (!HALF) {
@@ -127,7 +137,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
         } else {
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const float* src = pbase + (long)((MODE == 3 ? (chunk * CK) % a.c0 : chunk * CK) + i * G) * a.cs0;
+                const float* src = pbase + (long)(MODE == 3 ? 2 * chunk + (G == 1 ? i : (sgc & 1)) : chunk * CK + i * G) * a.cs0;
                 if constexpr (PW == 4) {
                     praw[i][0] = *reinterpret_cast<const float4*>(src); praw[i][1] = *reinterpret_cast<const float4*>(src + 4);
                     praw[i][2] = *reinterpret_cast<const float4*>(src + 2 * TW); praw[i][3] = *reinterpret_cast<const float4*>(src + 2 * TW + 4);
@@ -254,9 +264,43 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             }
         } else {
             // pooled source (extent sh0 x 2 TW): 2 PW floats from each of two rows per piece; pieces >= NPRE are loaded here
+            if constexpr (MODE == 3) {
+                if (slot && rowok) {
+#pragma unroll
+                    for (int b = 0; b < NB3; ++b) {
+                        const int sch = 2 * chunk + (G == 1 ? b : (sgc & 1));       // this block's source channel
+                        const float2 ss = *reinterpret_cast<const float2*>(st_lds + 2 * sch);
+                        float t0[2 * PW], t1[2 * PW];
+                        if constexpr (PW == 4) {
+                            *reinterpret_cast<float4*>(t0) = praw[b][0]; *reinterpret_cast<float4*>(t0 + 4) = praw[b][1];
+                            *reinterpret_cast<float4*>(t1) = praw[b][2]; *reinterpret_cast<float4*>(t1 + 4) = praw[b][3];
+                        } else {
+                            *reinterpret_cast<float4*>(t0) = praw[b][0]; *reinterpret_cast<float4*>(t1) = praw[b][1];
+                        }
+                        float x1[PW], x2[PW], x3[PW], x4[PW];                       // mwcnn.py:224-236: x1 even/even, x2 odd row, x3 odd column, x4 odd/odd, halved
+#pragma unroll
+                        for (int u = 0; u < PW; ++u) {
+                            x1[u] = 0.5f * act(t0[2 * u], ss.x, ss.y, a.slope); x3[u] = 0.5f * act(t0[2 * u + 1], ss.x, ss.y, a.slope);
+                            x2[u] = 0.5f * act(t1[2 * u], ss.x, ss.y, a.slope); x4[u] = 0.5f * act(t1[2 * u + 1], ss.x, ss.y, a.slope);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NCI; ++i) {
+                            if (G == 1 && (i & 1) != b) continue;                   // G == 1: LDS channel i = 2 band + s
+                            const int band = (sgc + i * G) >> 1;                    // LL, HL, LH, HH: (+ + + +), (- - + +), (- + - +), (+ - - +)
+                            const float s1 = (band == 0 || band == 3) ? 1.f : -1.f, s2 = (band == 0 || band == 2) ? 1.f : -1.f,
+                                        s3 = (band == 0 || band == 1) ? 1.f : -1.f;
+                            piece_t o;
+                            float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+                            for (int u = 0; u < PW; ++u) ov[u] = fmaf(s3, x3[u], fmaf(s2, x2[u], s1 * x1[u])) + x4[u];      // ((+-x1 +- x2) +- x3) + x4: fetch_scalar's order
+                            *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                        }
+                    }
+                }
+            } else
             if (slot && rowok && 2 * gy + 1 < a.sh0) {
-                const int cs = MODE == 3 ? ci0 % a.c0 : ci0;          // first source channel of the chunk (uniform)
-                const int band = MODE == 3 ? ci0 / a.c0 : 0;          // DWT: LL, HL, LH, HH (uniform)
+                const int cs = ci0;                                   // first source channel of the chunk (uniform)
+                constexpr int band = 0;
                 const float* sb = pbase + (long)cs * a.cs0;
                 const float* stp = st_lds + 2 * (cs + sgc);
                 auto pooled = [&](const float* t0, const float* t1, int i) {
