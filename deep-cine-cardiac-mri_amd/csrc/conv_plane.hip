@@ -96,7 +96,19 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
 
     float4 wraw[NWT];
     constexpr bool HALF = MODE == 2 || MODE == 3;          // the source has twice the plane's extent: 2 x 2 input values per staged value
-    piece_t xraw[HALF ? 1 : NCI];
+    // MODE 4 (Haar IWT of the scale below + additive skip): a slot is a PAIR of image rows (2 sy, 2 sy + 1) x one piece -- both rows come from the
+    // same source row sy of the four bands, which round 4's (row, piece) slots read and activated once per row.  RPAIR pair slots cover the tile's
+    // ROWS rows (the first / last one only half: the tile starts on an odd image row); G4 channel groups, NCI4 channels per thread.
+    constexpr int RPAIR = C::ROWS / 2 + 1, SLOTS4 = RPAIR * PR;
+    constexpr int G4 = SLOTS4 * 8 <= NT ? 8 : SLOTS4 * 4 <= NT ? 4 : SLOTS4 * 2 <= NT ? 2 : 1, NCI4 = CK / G4;
+    static_assert(MODE != 4 || (C::ROWS % 2 == 0 && SLOTS4 <= NT && PW == 4), "MODE 4: even tile rows, one slot per thread, 16-byte pieces");
+    const int sg4 = tid / SLOTS4, sp4 = tid - sg4 * SLOTS4;
+    const bool slot4 = sg4 < G4;
+    const int sg4c = min(sg4, G4 - 1);
+    const int ps4 = sp4 / PR, sj4 = sp4 % PR;
+    const int sy4 = (r0 >> 1) - 1 + ps4;                    // source row; image rows 2 sy4, 2 sy4 + 1 = LDS rows 2 ps4 - 1, 2 ps4 (r0 is even)
+    const bool srcok4 = slot4 && sy4 >= 0 && 2 * sy4 < a.H;
+    piece_t xraw[HALF ? 1 : (MODE == 4 ? 2 * NCI4 : NCI)];
     // pooled source: the first NPRE pieces of a chunk are prefetched like the plain ones (2 PW floats of two source rows each)
     // MODE 3 (Haar DWT on load): a chunk = the FOUR BANDS of TWO source channels, LDS channel ck = 2 band + s -- the weights of conv channel
     // band * C + 2 chunk + s are gathered to match -- so a thread reads each 2 x 2 PW source block once and activates it once for all the
@@ -122,10 +134,18 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             } else
             wraw[i] = *reinterpret_cast<const float4*>(v ? wsrc + (long)row * a.rowsp + co0 + c4 : wp);
         }
-        if constexpr (!HALF) {
+        if constexpr (MODE == 4) {      // the skip's pieces of my two rows (source 1, conv channel = its channel)
+            const char* sb = reinterpret_cast<const char*>(a.x1) + ((size_t)n * a.c1 + chunk * CK + sg4c) * cstride;
+            const int g0 = min(max(2 * sy4, 0), a.H - 2);
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < NCI4; ++i)
+                    xraw[r * NCI4 + i] = *reinterpret_cast<const piece_t*>(sb + (size_t)(i * G4) * cstride + (unsigned)((g0 + r) * TW + PW * sj4) * 4u);
+        } else if constexpr (!HALF) {
             const int ci0 = chunk * CK;
-            const bool first = MODE == 4 ? false : ci0 < a.c0;          // MODE 4: the prefetched pieces are the skip's (source 1, conv channel = its channel)
-            const int cl0 = MODE == 4 ? ci0 : (first ? ci0 : ci0 - a.c0);
+            const bool first = ci0 < a.c0;
+            const int cl0 = first ? ci0 : ci0 - a.c0;
             const int sc = first ? a.c0 : a.c1;
             const char* sb = reinterpret_cast<const char*>(first ? a.x0 : a.x1) + ((size_t)n * sc + cl0) * cstride;   // uniform
             const int cmax = sc - 1 - cl0;
@@ -214,40 +234,42 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, 9>::
             *reinterpret_cast<float4*>(w_lds + row * C::COTP + c4) = co0 + c4 < a.rowsp ? wraw[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const int ci0 = chunk * CK;
-        if constexpr (!HALF) {
-            if (slot && rowok) {
-                const float* stp = st_lds + 2 * ((MODE == 4 ? a.c0 : 0) + ci0 + sgc);
-                if constexpr (MODE == 4) {
-                    constexpr int NS = PW / 2;
-                    const int cq = a.c0 >> 2, hs = a.H >> 1;
-                    const bool ry = gy & 1;
-                    const float* ib = a.x0 + (((long)n * a.c0 + ci0 + sgc) * hs + (gy >> 1)) * (TW / 2) + ((PW * sj) >> 1);
+        if constexpr (MODE == 4) {
+            if (srcok4) {
+                constexpr int NS = PW / 2;
+                const int cq = a.c0 >> 2, hs = a.H >> 1;
+                const float* ib = a.x0 + (((long)n * a.c0 + ci0 + sg4c) * hs + sy4) * (TW / 2) + ((PW * sj4) >> 1);
+                const float* stp = st_lds + 2 * (a.c0 + ci0 + sg4c);
+                const bool w0 = ps4 >= 1, w1 = 2 * ps4 < C::ROWS;                 // which of my two LDS rows exist in this tile
+                float* const l0 = in_lds + sg4c * C::PS + (2 * ps4 - 1) * C::COLS + PW * sj4;
 #pragma unroll
-                    for (int i = 0; i < NCI; ++i) {           // (fully unrolled: xraw[] must stay in registers)
-                        float v[4][NS];
+                for (int i = 0; i < NCI4; ++i) {
+                    float v[4][NS];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int c = ci0 + sgc + i * G + k * cq;
-                            const float* src = ib + (long)(i * G + k * cq) * hs * (TW / 2);
-                            if constexpr (NS == 2) { const float2 t2 = *reinterpret_cast<const float2*>(src); v[k][0] = t2.x; v[k][NS - 1] = t2.y; }
-                            else v[k][0] = src[0];
-                            const float2 sk = *reinterpret_cast<const float2*>(st_lds + 2 * c);
-#pragma unroll
-                            for (int e = 0; e < NS; ++e) v[k][e] = 0.5f * act(v[k][e], sk.x, sk.y, a.slope);
-                        }
-                        piece_t o = xraw[i];
-                        float* ov = reinterpret_cast<float*>(&o);
-                        const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G);
-#pragma unroll
-                        for (int e = 0; e < NS; ++e) {                  // conv_tile's operation order: the IWT value, then += the activated skip
-                            const float e0 = ry ? v[0][e] - v[1][e] + v[2][e] - v[3][e] : v[0][e] - v[1][e] - v[2][e] + v[3][e];
-                            const float e1 = ry ? v[0][e] + v[1][e] + v[2][e] + v[3][e] : v[0][e] + v[1][e] - v[2][e] - v[3][e];
-                            ov[2 * e] = e0 + act(ov[2 * e], ss.x, ss.y, a.slope);
-                            ov[2 * e + 1] = e1 + act(ov[2 * e + 1], ss.x, ss.y, a.slope);
-                        }
-                        *reinterpret_cast<piece_t*>(lrow + i * G * C::PS) = o;
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = ci0 + sg4c + i * G4 + k * cq;
+                        const float2 t2 = *reinterpret_cast<const float2*>(ib + (long)(i * G4 + k * cq) * hs * (TW / 2));
+                        const float2 sk = *reinterpret_cast<const float2*>(st_lds + 2 * c);
+                        v[k][0] = 0.5f * act(t2.x, sk.x, sk.y, a.slope); v[k][1] = 0.5f * act(t2.y, sk.x, sk.y, a.slope);
                     }
-                } else
+                    const float2 ss = *reinterpret_cast<const float2*>(stp + 2 * i * G4);
+                    piece_t o0 = xraw[i], o1 = xraw[NCI4 + i];
+                    float* a0 = reinterpret_cast<float*>(&o0);
+                    float* a1 = reinterpret_cast<float*>(&o1);
+#pragma unroll
+                    for (int e = 0; e < NS; ++e) {          // conv_tile's operation order per output: the IWT value, then += the activated skip (mwcnn.py:252-261)
+                        a0[2 * e] = (v[0][e] - v[1][e] - v[2][e] + v[3][e]) + act(a0[2 * e], ss.x, ss.y, a.slope);
+                        a0[2 * e + 1] = (v[0][e] + v[1][e] - v[2][e] - v[3][e]) + act(a0[2 * e + 1], ss.x, ss.y, a.slope);
+                        a1[2 * e] = (v[0][e] - v[1][e] + v[2][e] - v[3][e]) + act(a1[2 * e], ss.x, ss.y, a.slope);
+                        a1[2 * e + 1] = (v[0][e] + v[1][e] + v[2][e] + v[3][e]) + act(a1[2 * e + 1], ss.x, ss.y, a.slope);
+                    }
+                    if (w0) *reinterpret_cast<piece_t*>(l0 + i * G4 * C::PS) = o0;
+                    if (w1) *reinterpret_cast<piece_t*>(l0 + C::COLS + i * G4 * C::PS) = o1;
+                }
+            }
+        } else if constexpr (!HALF) {
+            if (slot && rowok) {
+                const float* stp = st_lds + 2 * (ci0 + sgc);
 #pragma unroll
                 for (int i = 0; i < NCI; ++i) {
                     piece_t o = xraw[i];
