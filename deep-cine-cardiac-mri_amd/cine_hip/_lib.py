@@ -147,6 +147,10 @@ _SIGS = {
     "cine_pad2d": (c_int, [P, P, c_long, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_set_side_stream": (c_int, [P]),
     "cine_set_conv_plane": (c_int, [c_int]),
+    "cine_unet3d_train_ws_bytes": (c_size_t, [c_int] * 8),
+    "cine_unet3d_forward_train": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P]),
+    "cine_unet3d_backward_ws_bytes": (c_size_t, [c_int] * 8),
+    "cine_unet3d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P]),
     "cine_unet2d_backward_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P]),
     "cine_mwcnn_train_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),

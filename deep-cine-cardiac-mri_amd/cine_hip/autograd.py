@@ -495,13 +495,10 @@ def xpd_regularise(buf, extra, n, n_scales, xf, wx, wy):
 
 # ---- 3-D U-Net (denoisers/unet.py with dims = 3) -----------------------------------------------------------------------------------------
 class Unet3dFn(Function):
-    """y = Unet(x), dims = 3, on (n, in_ch, d, h, w).  The forward is cine_unet3d_forward's launch sequence layer by layer (raw outputs + merged
-    InstanceNorm records kept); the backward pass is composed per layer from the same hand-written kernels as the 2-D one:
-      d / d raw        cine_in_lrelu_bwd on the (n, c) volumes
-      input gradient   the forward conv kernel on the flipped / transposed packing (3x3x3), the 1x1x1 kernel on the space-to-depth view
-                       (transpose conv) or the transposed matrix (final conv)
-      weight gradient  the MFMA weight-gradient kernel, one launch per depth offset with the depth slices as samples
-    torch only re-lays out gradient tensors between them (depth-major copies, space-to-depth, the pool / pad / concat adjoints)."""
+    """y = Unet(x), dims = 3, on (n, in_ch, d, h, w): cine_unet3d_forward_train keeps every raw layer output with its merged InstanceNorm record,
+    cine_unet3d_backward walks them in reverse with the kernels of the 2-D backward pass (InstanceNorm + LeakyReLU backward on (d h, w) planes with
+    the 2x2x2 pool adjoint / zero-pad crop gathered on load; input gradients on the forward 3x3x3 / 1x1x1 kernels; the 3x3x3 weight gradient as
+    three 3x3 weight gradients over depth-shifted slice pairs, on the side stream)."""
 
     @staticmethod
     def forward(ctx, x, weights, *params):
@@ -510,207 +507,37 @@ class Unet3dFn(Function):
         if len(weights.unets) != 1 or cin != weights.in_ch:
             raise ValueError("unet3d: one weight set, input channels as built")
         ctx.training_key = weights.training_key()    # raises for Dropout in training mode
-        ctx.weights_obj = weights
-        weights.pointers()
-        packs, plist = weights._keep, weights.param_lists()[0]
-        P = weights.pools
-        chs = [weights.chans * 2 ** l for l in range(P + 1)]
-        dims = [(d >> l, h >> l, w >> l) for l in range(P + 1)]
-        if min(dims[P]) < 1:
-            raise CineHipError("unet3d: volume too small for the number of pools")
         L = lib()
-        eps, slope = ops.IN_EPS, ops.lrelu_slope()
-        dev, dt = x.device, x.dtype
-
-        def merged(raw_part, cout, np_):
-            part = torch.empty((n, cout, 1, 3), device=dev, dtype=dt)
-            check(L.cine_instnorm_merge(raw_part.data_ptr(), part.data_ptr(), n * cout, np_, _stream()), "cine_instnorm_merge")
-            return part
-
-        def conv(s0, s1, wp, cout, dim):
-            """s = (x, part | None, c, mode, (d, h, w)) -> raw output, merged record."""
-            np_ = L.cine_conv_stat_partials3d(cout, dim[0], dim[1], dim[2], 0)
-            raw_part = torch.empty((n, cout, np_, 3), device=dev, dtype=dt)
-            y = torch.empty((n, cout) + tuple(dim), device=dev, dtype=dt)
-            x1, p1, c1, m1, d1 = s1 if s1 is not None else (None, None, 0, 0, (0, 0, 0))
-            check(L.cine_conv3d_in(s0[0].data_ptr(), _p(s0[1]), 1, s0[2], s0[3], s0[4][0], s0[4][1], s0[4][2],
-                                   _p(x1), _p(p1), 1, c1, m1, d1[0], d1[1], d1[2], wp.data_ptr(), None, None, 0,
-                                   y.data_ptr(), raw_part.data_ptr(), n, cout, dim[0], dim[1], dim[2], eps, slope, _stream()), "cine_conv3d_in")
-            return y, merged(raw_part, cout, np_)
-        wi = 0
-        A, B = [], []                       # per level: (raw, part) of the block's two convs (B[l] = skip for l < P, bottleneck for l = P)
-        for l in range(P + 1):
-            src = (x, None, cin, 0, dims[0]) if l == 0 else (B[l - 1][0], B[l - 1][1], chs[l - 1], 2, dims[l - 1])
-            a = conv(src, None, packs[wi], chs[l], dims[l]); wi += 1
-            b = conv((a[0], a[1], chs[l], 1, dims[l]), None, packs[wi], chs[l], dims[l]); wi += 1
-            A.append(a); B.append(b)
-        Tc, Cc, Ec = [None] * P, [None] * P, [None] * P
-        cur = B[P]
-        for l in range(P - 1, -1, -1):
-            lo = dims[l + 1]
-            up = (2 * lo[0], 2 * lo[1], 2 * lo[2])
-            npt = L.cine_conv_stat_partials3d(chs[l], lo[0], lo[1], lo[2], 1)
-            raw_part = torch.empty((n, chs[l], npt, 3), device=dev, dtype=dt)
-            t = torch.empty((n, chs[l]) + up, device=dev, dtype=dt)
-            check(L.cine_tconv3d_in(cur[0].data_ptr(), cur[1].data_ptr(), 1, 1, packs[wi].data_ptr(), t.data_ptr(), raw_part.data_ptr(), n, chs[l + 1], chs[l],
-                                    lo[0], lo[1], lo[2], eps, slope, _stream()), "cine_tconv3d_in")
-            wi += 1
-            Tc[l] = (t, merged(raw_part, chs[l], npt))
-            Cc[l] = conv((Tc[l][0], Tc[l][1], chs[l], 1, up), (B[l][0], B[l][1], chs[l], 1, dims[l]), packs[wi], chs[l], dims[l]); wi += 1
-            Ec[l] = conv((Cc[l][0], Cc[l][1], chs[l], 1, dims[l]), None, packs[wi], chs[l], dims[l]); wi += 1
-            cur = Ec[l]
-        y = torch.empty((n, weights.out_ch, d, h, w), device=dev, dtype=dt)
-        check(L.cine_conv1x1x1_bias(cur[0].data_ptr(), cur[1].data_ptr(), 1, 1, packs[wi].data_ptr(), packs[wi + 1].data_ptr(), y.data_ptr(), n, chs[0],
-                                    weights.out_ch, d, h, w, eps, slope, _stream()), "cine_conv1x1x1_bias")
-        ctx.state = (x, A, B, Tc, Cc, Ec, chs, dims, plist)
-        ctx.params = params
+        need = L.cine_unet3d_train_ws_bytes(n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools)
+        if need == 0 or min(d >> weights.pools, h >> weights.pools, w >> weights.pools) < 1:
+            raise CineHipError("unet3d: volume too small for the number of pools")
+        ws = torch.empty(need, device=x.device, dtype=torch.uint8)
+        y = torch.empty((n, weights.out_ch, d, h, w), device=x.device, dtype=x.dtype)
+        slope = ops.lrelu_slope()
+        check(L.cine_unet3d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(), n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools,
+                                          slope, ws.data_ptr(), ws.numel(), _stream()), "cine_unet3d_forward_train")
+        ctx.weights, ctx.ws, ctx.params = weights, ws, params
         ctx.slope = slope                      # the backward pass runs on an autograd thread: it differentiates what THIS call applied
+        ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, A, B, Tc, Cc, Ec, chs, dims, plist = ctx.state
-        ctx.weights_obj.check_training_key(ctx.training_key, "unet3d backward")
+        (x,) = ctx.saved_tensors
+        weights = ctx.weights
+        weights.check_training_key(ctx.training_key, "unet3d backward")
         gy = ops._dev(_c(gy), "unet3d output gradient")
-        n, cin = x.shape[:2]
-        P = len(chs) - 1
+        n, cin, d, h, w = x.shape
         L = lib()
-        eps, slope = ops.IN_EPS, ctx.slope
-        dev, dt = x.device, x.dtype
-        F = torch.nn.functional
-
-        def act(t):                                               # LeakyReLU(InstanceNorm(raw)) materialised
-            raw, part = t
-            y = torch.empty_like(raw)
-            planes = raw.shape[0] * raw.shape[1]
-            check(L.cine_instnorm_lrelu_apply(raw.data_ptr(), part.data_ptr(), 1, y.data_ptr(), planes, raw.numel() // planes, eps, slope, _stream()),
-                  "cine_instnorm_lrelu_apply")
-            return y
-
-        def inbwd(t, g):                                          # d / d raw from d / d act
-            raw, part = t
-            g = _c(g)
-            out = torch.empty_like(raw)
-            nn_, c, dd, hh, ww = raw.shape
-            nb = L.cine_in_lrelu_bwd_ws_bytes(nn_, c, dd * hh, ww)
-            ws = torch.empty(nb, device=dev, dtype=torch.uint8) if nb else None
-            check(L.cine_in_lrelu_bwd(raw.data_ptr(), part.data_ptr(), 1, g.data_ptr(), out.data_ptr(), nn_, c, dd * hh, ww, eps, slope,
-                                      _p(ws), nb, _stream()), "cine_in_lrelu_bwd")
-            return out
-
-        def dgrad3(g, weight):                                    # (n, cout, d, h, w) -> (n, cin, d, h, w)
-            wp = ops._pack("c27", weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous())
-            nn_, cout, dd, hh, ww = g.shape
-            ci = weight.shape[1]
-            gx = torch.empty((nn_, ci, dd, hh, ww), device=dev, dtype=dt)
-            check(L.cine_conv3d_in(g.data_ptr(), None, 0, cout, 0, dd, hh, ww, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(), None, None, 0,
-                                   gx.data_ptr(), None, nn_, ci, dd, hh, ww, eps, slope, _stream()), "cine_conv3d_in")
-            return gx
-
-        def wgrad3(x0, x1, g, weight):                            # weight gradient of a 3x3x3 conv over cat(x0, x1)
-            gwz = torch.zeros((3,) + tuple(weight.shape[:2]) + (3, 3), device=dev, dtype=dt)      # [kz][cout][cin][3][3]: one plain 2-D gradient per depth tap
-            dd = g.shape[2]
-            for i in range(g.shape[0]):                           # depth slices become the samples of the 2-D weight-gradient kernel
-                xs = [t[i].transpose(0, 1).contiguous() for t in (x0, x1) if t is not None]
-                gs = g[i].transpose(0, 1).contiguous()
-                for kz in range(3):
-                    dz = kz - 1
-                    z0, z1 = max(0, -dz), dd - max(0, dz)
-                    if z1 > z0:
-                        _conv_wgrad_(gwz[kz], None, xs[0][z0 + dz:z1 + dz], xs[1][z0 + dz:z1 + dz] if len(xs) > 1 else None, gs[z0:z1])
-            return gwz.permute(1, 2, 0, 3, 4).contiguous()
-
-        def wgrad1(xa, g, cout):                                  # (cout, cin) of a 1x1x1 conv; bias gradient too when asked
-            nn_, ci = xa.shape[:2]
-            plane = xa.numel() // (nn_ * ci)
-            ww = xa.shape[-1]
-            gw = torch.zeros((cout, ci), device=dev, dtype=dt)
-            ws = torch.empty(L.cine_conv1x1_wgrad_ws_bytes(cout, ci, nn_), device=dev, dtype=torch.uint8)
-            return gw, ws, (nn_, ci, plane // ww, ww)
-
-        grads = {}
-
-        def put(p, g):
-            grads[id(p)] = g if id(p) not in grads else grads[id(p)] + g
-        # parameters in module order (UnetWeights._params): down blocks + bottleneck (2 each), per up level (tconv, conv1, conv2), final w, b
-        W = list(plist)
-        i_down = lambda l, k: 2 * l + k
-        i_up = lambda l, k: 2 * P + 2 + 3 * (P - 1 - l) + k
-        i_fin, i_bias = 5 * P + 2, 5 * P + 3
-        zero_bias = {}
-
-        def conv1(g, w2d, cout):                                  # 1x1x1 conv of plain g with matrix w2d (cout, cin_g), no bias
-            nn_, ci, dd, hh, ww = g.shape
-            wp = ops._pack("c1", w2d.contiguous().view(cout, ci, 1, 1))
-            zb = zero_bias.setdefault(cout, torch.zeros(cout, device=dev, dtype=dt))
-            y = torch.empty((nn_, cout, dd, hh, ww), device=dev, dtype=dt)
-            check(L.cine_conv1x1x1_bias(g.data_ptr(), None, 0, 0, wp.data_ptr(), zb.data_ptr(), y.data_ptr(), nn_, ci, cout, dd, hh, ww, eps, slope, _stream()),
-                  "cine_conv1x1x1_bias")
-            return y
-
-        # ---- final 1x1x1 conv + bias
-        e0 = act(Ec[0] if P > 0 else B[0])
-        wf = W[i_fin]
-        out_ch = wf.shape[0]
-        gw, ws, (nn_, ci, hh, ww) = wgrad1(e0, gy, out_ch)
-        gb = torch.zeros(out_ch, device=dev, dtype=dt)
-        check(L.cine_conv1x1_wgrad(e0.data_ptr(), ci, gy.data_ptr(), gw.data_ptr(), gb.data_ptr(), nn_, out_ch, hh, ww, ws.data_ptr(), ws.numel(), _stream()),
-              "cine_conv1x1_wgrad")
-        put(wf, gw.view(wf.shape)); put(W[i_bias], gb)
-        g_act = conv1(gy, wf.detach().reshape(out_ch, -1).t(), chs[0])          # d / d act(e_0)
-        del e0
-        g_skip, g_bott = [None] * P, None
-        # ---- up path, level 0 first
-        for l in range(P):
-            c = chs[l]
-            g_raw = inbwd(Ec[l], g_act)                                           # second conv
-            put(W[i_up(l, 2)], wgrad3(act(Cc[l]), None, g_raw, W[i_up(l, 2)]))
-            g_act = dgrad3(g_raw, W[i_up(l, 2)])
-            g_raw = inbwd(Cc[l], g_act)                                           # first conv on cat(pad(act(t)), act(skip))
-            t_ext, s_ext = Tc[l][0].shape[2:], dims[l]
-            ta = act(Tc[l])
-            if tuple(t_ext) != tuple(s_ext):
-                ta = F.pad(ta, (0, s_ext[2] - t_ext[2], 0, s_ext[1] - t_ext[1], 0, s_ext[0] - t_ext[0]))
-            put(W[i_up(l, 1)], wgrad3(ta, act(B[l]), g_raw, W[i_up(l, 1)]))
-            del ta
-            gcat = dgrad3(g_raw, W[i_up(l, 1)])
-            g_skip[l] = gcat[:, c:]
-            g_t = gcat[:, :c, :t_ext[0], :t_ext[1], :t_ext[2]]
-            g_raw = inbwd(Tc[l], g_t)                                             # transpose conv of act(cur)
-            lo = dims[l + 1]
-            s2d = g_raw.view(n, c, lo[0], 2, lo[1], 2, lo[2], 2).permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(n, c * 8, lo[0], lo[1], lo[2]).contiguous()
-            cur = Ec[l + 1] if l + 1 < P else B[P]
-            wt = W[i_up(l, 0)]                                                    # (cin = chs[l + 1], cout = c, 2, 2, 2)
-            ca = act(cur)
-            gw, ws, (nn_, ci, hh, ww) = wgrad1(ca, s2d, c * 8)
-            check(L.cine_conv1x1_wgrad(ca.data_ptr(), ci, s2d.data_ptr(), gw.data_ptr(), None, nn_, c * 8, hh, ww, ws.data_ptr(), ws.numel(), _stream()),
-                  "cine_conv1x1_wgrad")
-            put(wt, gw.t().reshape(wt.shape))
-            del ca
-            g_act = conv1(s2d, wt.detach().reshape(chs[l + 1], c * 8), chs[l + 1])     # d / d act(cur)
-        g_bott = g_act
-        # ---- bottleneck and down path
-        g_pool = None
-        gx = None
-        for l in range(P, -1, -1):
-            if l == P:
-                g_b = g_bott
-            else:
-                up = g_pool.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4) * 0.125      # avg_pool3d(2, 2) adjoint
-                e = dims[l]
-                up = F.pad(up, (0, e[2] - up.shape[4], 0, e[1] - up.shape[3], 0, e[0] - up.shape[2]))
-                g_b = g_skip[l] + up
-            g_raw = inbwd(B[l], g_b)
-            put(W[i_down(l, 1)], wgrad3(act(A[l]), None, g_raw, W[i_down(l, 1)]))
-            g_act = dgrad3(g_raw, W[i_down(l, 1)])
-            g_raw = inbwd(A[l], g_act)
-            xin = x if l == 0 else F.avg_pool3d(act(B[l - 1]), 2)
-            put(W[i_down(l, 0)], wgrad3(xin, None, g_raw, W[i_down(l, 0)]))
-            if l > 0:
-                g_pool = dgrad3(g_raw, W[i_down(l, 0)])
-            elif ctx.needs_input_grad[0]:
-                gx = dgrad3(g_raw, W[i_down(0, 0)])
-        return (gx, None) + tuple(grads.get(id(p)) for p in ctx.params)
+        ws = torch.empty(L.cine_unet3d_backward_ws_bytes(n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools), device=x.device, dtype=torch.uint8)
+        plists = weights.param_lists()
+        grads = _zero_grads(plists, x.device)
+        gptr = (ctypes.c_void_p * len(plists[0]))(*[g.data_ptr() for g in grads[0]])
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        _use_side_stream(x.device)
+        check(L.cine_unet3d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools,
+                                     ctx.slope, ctx.ws.data_ptr(), ctx.ws.numel(), ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_unet3d_backward")
+        return (gx, None) + _param_grads(weights, grads, ctx.params)
 
 
 def unet3d(x: torch.Tensor, weights: "ops.UnetWeights") -> torch.Tensor:

@@ -57,10 +57,34 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _no_capture(what: str) -> None:
+_PACK_IN_CAPTURE = False      # inside training_capture(): the weight-pack kernels BELONG to the captured step (the weights change every replay)
+_cache_epoch = 0              # part of every packed-weight cache key: bumped when a training capture ends
+
+
+def cache_epoch() -> int:
+    return _cache_epoch
+
+
+@contextlib.contextmanager
+def training_capture():
+    """Around the hipGraph capture of a whole TRAINING step (cine_hip.train.GraphedTrainingStep): the parameters change at every replay, so
+    the kernels that re-pack them must be part of the graph -- the capture guard of the packed-weight caches is lifted.  The packs made inside
+    belong to the graph's memory pool and are refreshed only by its replays: when the capture ends every cache is invalidated (the epoch in
+    their keys moves), so a later eager call (validation) packs the parameters' current values into memory of its own."""
+    global _PACK_IN_CAPTURE, _cache_epoch
+    _PACK_IN_CAPTURE = True
+    try:
+        yield
+    finally:
+        _PACK_IN_CAPTURE = False
+        _cache_epoch += 1
+
+
+def _no_capture(what: str, pack: bool = False) -> None:
     """Caches that outlive a call (packed weights, per-stream scratch) must not be filled during hipGraph capture: the
-    tensors would come from the graph's private pool yet stay referenced afterwards."""
-    if torch.cuda.is_current_stream_capturing():
+    tensors would come from the graph's private pool yet stay referenced afterwards.  (pack: a packed-weight cache, allowed inside
+    ``training_capture()``.)"""
+    if torch.cuda.is_current_stream_capturing() and not (pack and _PACK_IN_CAPTURE):
         raise CineHipError(f"{what} would be created during hipGraph capture; run one eager forward on this stream first "
                            "(and re-capture after changing weights)")
 
@@ -858,9 +882,9 @@ class UnetWeights:
 
     def pointers(self):
         params = self._params()
-        key = tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
+        key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
         if key != self._key:
-            _no_capture("packed U-Net weights")
+            _no_capture("packed U-Net weights", pack=True)
             # graphs captured earlier still hold the old pointers: keep the superseded packs alive only when a capture has
             # taken place since they were made (a training loop re-packs every step and must not pile them up)
             if self._captured:
@@ -914,17 +938,25 @@ class UnetWeights:
     def dgrad_pointers(self):
         """Input-gradient packings in the order of ``pointers()`` (NULL in the bias slot); re-packed when a parameter changes."""
         params = self._params()
-        key = tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
+        key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
         if key != self._dkey:
-            _no_capture("packed U-Net gradient weights")
+            _no_capture("packed U-Net gradient weights", pack=True)
             keep, ptrs = [], []
             for seq in params:
                 for kind, p in seq:
                     if kind == "raw":
                         ptrs.append(None); continue
-                    if kind not in ("c3", "tc", "c1"):
-                        raise CineHipError("training through the 3-D U-Net is not on the HIP path")
-                    t = _pack(kind + "d", p)
+                    if kind in ("c3", "tc"):
+                        t = _pack(kind + "d", p)
+                    elif kind == "c1":
+                        # 2-D: the dgrad packing; 3-D (cine_unet3d_backward): the forward 1x1x1 kernel on the transposed matrix
+                        t = _pack("c1d", p) if p.dim() == 4 else _pack("c1", p.detach().reshape(p.shape[0], -1).t().contiguous())
+                    elif kind == "c27":      # the forward 3x3x3 kernel on the flipped taps, (cout, cin) transposed
+                        t = _pack("c27", p.detach().flip(2, 3, 4).transpose(0, 1).contiguous())
+                    elif kind == "tc3":      # (cin, cout, 2, 2, 2) read as the (cin, 8 cout) matrix of a 1x1x1 conv over the space-to-depth view
+                        t = _pack("c1", p.detach().reshape(p.shape[0], -1))
+                    else:
+                        raise CineHipError(f"no input-gradient packing for weight kind {kind}")
                     keep.append(t); ptrs.append(t.data_ptr())
             self._dkeep, self._dkey = keep, key
             self._dptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
@@ -983,9 +1015,9 @@ class MwcnnWeights:
 
     def pointers(self):
         params = self._params()
-        key = tuple((p.data_ptr(), p._version) for _, p in params)
+        key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for _, p in params)
         if key != self._key:
-            _no_capture("packed MWCNN weights")
+            _no_capture("packed MWCNN weights", pack=True)
             if getattr(self, "_captured", False):                    # graphs captured earlier still hold the old pointers
                 self._old = getattr(self, "_old", []) + [self._keep]
             self._captured = False
@@ -1005,9 +1037,9 @@ class MwcnnWeights:
 
     def dgrad_pointers(self):
         params = self._params()
-        key = tuple((p.data_ptr(), p._version) for _, p in params)
+        key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for _, p in params)
         if key != getattr(self, "_dkey", None):
-            _no_capture("packed MWCNN gradient weights")
+            _no_capture("packed MWCNN gradient weights", pack=True)
             keep, ptrs = [], []
             for kind, p in params:
                 if kind == "raw":

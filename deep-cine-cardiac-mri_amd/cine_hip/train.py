@@ -1,0 +1,72 @@
+"""Training-loop helpers that have no counterpart in the reference (its Lightning modules step eagerly, pl_modules/varnet_module.py:97-113).
+
+``GraphedTrainingStep``: one training step of a FIXED shape -- forward through the drop-in model, loss, ``loss.backward()`` through the
+HIP gradient kernels, the optional gradient all-reduce and the optimiser step -- captured into ONE hipGraph and replayed.  A step is
+1 300 - 2 900 launches; where the host cannot enqueue them as fast as the GPU retires them (the layer-by-layer 3-D backward
+of cfg 4, the MWCNN backward of cfg 3) the replay removes the host from the step.  Numerically it is the eager step: the same kernels in
+the same order on the same stream(s).
+"""
+from typing import Callable, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class GraphedTrainingStep:
+    """Capture ``loss = loss_fn(model(*inputs, **forward_kwargs), target); loss.backward(); [grad_sync();] optimizer.step()``.
+
+    ``optimizer`` must be capturable (``torch.optim.Adam(..., capturable=True)``: its step counter lives on the device).  ``inputs`` /
+    ``target`` give the shapes; ``step()`` copies new data into the static buffers and replays.  ``warmup`` eager steps run first on the
+    capture stream (they are real training steps: ``warmup_losses``) -- they size every cached workspace, which must not be allocated
+    during capture.  Anything that reads the device from the host inside ``forward`` (the ACS window of a sampling mask, varnet.py:64-68)
+    has to be passed in precomputed (``forward_kwargs={"acs": SensitivityModel.acs_window(mask)}``).
+    """
+
+    def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer, inputs: Sequence[torch.Tensor],
+                 target: torch.Tensor, forward_kwargs: Optional[dict] = None, warmup: int = 3, grad_sync: Optional[Callable] = None):
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("GraphedTrainingStep: the optimiser must be constructed with capturable=True")
+        self.model, self.loss_fn, self.opt, self.sync = model, loss_fn, optimizer, grad_sync
+        self.kw = dict(forward_kwargs or {})
+        self.inputs = [t.clone() for t in inputs]
+        self.target = target.clone()
+        self.stream = torch.cuda.Stream(device=self.target.device)
+        self.warmup_losses = []
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream), torch.enable_grad():
+            for _ in range(max(1, warmup)):
+                self.warmup_losses.append(self._eager_step().detach().clone())
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        # (ops.training_capture: the kernels that re-pack the changing weights are part of the step; the packs made here belong to the
+        #  graph and every packed-weight cache is invalidated when the capture ends)
+        with ops.training_capture(), torch.cuda.graph(self.graph, stream=self.stream), torch.enable_grad():
+            self.loss = self._eager_step(zero=False).detach()
+        torch.cuda.synchronize()
+
+    def _eager_step(self, zero: bool = True) -> torch.Tensor:
+        if zero:
+            self.opt.zero_grad(set_to_none=True)
+        out = self.model(*self.inputs, **self.kw)
+        loss = self.loss_fn(out, self.target)
+        loss.backward()
+        if self.sync is not None:
+            self.sync()
+        self.opt.step()
+        return loss
+
+    def step(self, *inputs: torch.Tensor, target: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Copy the new example into the static buffers (skipped for tensors that ARE the buffers), replay, return the static loss tensor
+        (valid until the next ``step``; stream-ordered on the current stream)."""
+        if inputs and len(inputs) != len(self.inputs):
+            raise ValueError("GraphedTrainingStep.step: as many inputs as the step was captured with")
+        for dst, src in zip(self.inputs, inputs):
+            if src is not dst:
+                dst.copy_(src, non_blocking=True)
+        if target is not None and target is not self.target:
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.loss

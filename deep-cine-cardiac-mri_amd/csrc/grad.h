@@ -15,7 +15,11 @@ namespace cine {
 //                    of channel ch at c_off + band * c + ch -- the adjoint is the inverse transform of the four band gradients
 //   type 4  IWT    : the consumer read the Haar IWT of act(r) (mwcnn.py:252-261): g (n, c_total >= c / 4, 2 h, 2 w); channel ch = k c/4 + cc
 //                    collects the 2x2 block of output channel c_off + cc with the signs of sub-band k
-struct GradPiece { const float* g; int type, c_total, c_off, gh, gw; };
+//   Volumes (the 3-D U-Net, unet.py with dims = 3) pass their tensors as planes of (d h, w); a piece whose in-plane extents equal the tensor's is a
+//   type 1 window of (gd gh, gw), and
+//   type 5  window3: a (n, c_total, gd, gh, gw) tensor whose front-top-left (d, vh, w) window belongs to this tensor (vh = the tensor's own height)
+//   type 6  pool3  : the consumer read the 2x2x2 average pool of act(r) (unet.py:88,97): g (n, c, gd, gh, gw), 0.125 g[z/2][y/2][x/2]
+struct GradPiece { const float* g; int type, c_total, c_off, gh, gw, gd, vh; };
 struct InBwdArgs {
     const float* r; const float* part; int np;
     GradPiece a, b;
@@ -36,7 +40,8 @@ int launch_in_lrelu_bwd_fast(const InBwdArgs& a, hipStream_t st, bool* handled);
 //   taps 9: 3x3 pad 1; taps 1: 1x1 (also the k2 s2 transpose conv, whose rows are the 4 sub-positions x cout of G's
 //   space-to-depth view: g_mode 5, g (n, g_c, 2H, 2W), rows = 4 g_c).
 // Samples [0, set_split) accumulate into grad0, the rest into grad1 (two networks in one launch).  grad layouts (natural,
-// `+=`): kind 0 (rows, cin, 3, 3); kind 1 transpose conv (cin, rows / 4, 2, 2); kind 2 (rows, cin).
+// `+=`): kind 0 (rows, cin, 3, 3); kind 1 transpose conv (cin, rows / 4, 2, 2) -- in general (cin, rows); kind 2 (rows, cin); kind 3 + kz: depth tap kz of a
+// (rows, cin, 3, 3, 3) weight (the 3x3x3 conv's gradient is three 3x3 gradients over depth-shifted slice pairs, unet3d.hip).
 struct WgArgs {
     Src s0, s1;
     int add_src1;          // 1: source 1 is ADDED to source 0 channel-wise (the MWCNN skips) instead of concatenated

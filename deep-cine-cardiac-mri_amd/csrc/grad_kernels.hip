@@ -59,12 +59,19 @@ __device__ __forceinline__ float in_bwd_g(const InBwdArgs& a, int n, int ch, int
 }
 // window / pooled pieces (the U-Net's): the plane's base pointer once, then one multiply-add per element
 __device__ __forceinline__ const float* piece_plane(const GradPiece& p, int n, int ch) {
-    return p.type ? p.g + ((long)n * p.c_total + p.c_off + ch) * p.gh * p.gw : nullptr;
+    return p.type ? p.g + ((long)n * p.c_total + p.c_off + ch) * p.gh * p.gw * (p.type >= 5 ? p.gd : 1) : nullptr;
 }
 __device__ __forceinline__ float piece_at(const GradPiece& p, const float* q, int y, int x) {
     if (p.type == 1) return q[y * p.gw + x];
-    const int py = y >> 1, px = x >> 1;
-    return (py < p.gh && px < p.gw) ? 0.25f * q[py * p.gw + px] : 0.f;
+    if (p.type == 2) {
+        const int py = y >> 1, px = x >> 1;
+        return (py < p.gh && px < p.gw) ? 0.25f * q[py * p.gw + px] : 0.f;
+    }
+    // volumes as (d vh, w) planes: row y = z vh + yy
+    const int z = y / p.vh, yy = y - z * p.vh;
+    if (p.type == 5) return q[((long)z * p.gh + yy) * p.gw + x];
+    const int pz = z >> 1, py = yy >> 1, px = x >> 1;
+    return (pz < p.gd && py < p.gh && px < p.gw) ? 0.125f * q[((long)pz * p.gh + py) * p.gw + px] : 0.f;
 }
 
 // WAVE = true: one wave per plane (small planes), else one workgroup per plane.  HAAR: a piece is a wavelet adjoint (MWCNN)
@@ -116,18 +123,23 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
 }
 
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st) {
-    CINE_REQUIRE(a.r && a.part && a.gr && a.a.g && a.a.type >= 1 && a.a.type <= 4 && a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.np > 0, CINE_EINVAL,
+    CINE_REQUIRE(a.r && a.part && a.gr && a.a.g && a.a.type >= 1 && a.a.type <= 6 && a.n > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.np > 0, CINE_EINVAL,
                  "in_lrelu_bwd: bad arguments");
+    const bool haar = a.a.type == 3 || a.a.type == 4 || a.b.type == 3 || a.b.type == 4;
     for (const GradPiece* p : {&a.a, &a.b}) {
         if (!p->type) continue;
-        CINE_REQUIRE(p->g && p->type >= 1 && p->type <= 4 && p->c_off >= 0, CINE_EINVAL, "in_lrelu_bwd: bad gradient piece");
+        CINE_REQUIRE(p->g && p->type >= 1 && p->type <= 6 && p->c_off >= 0, CINE_EINVAL, "in_lrelu_bwd: bad gradient piece");
+        if (p->type >= 5) {
+            CINE_REQUIRE(!haar && p->vh > 0 && a.h % p->vh == 0 && p->gd > 0, CINE_EINVAL, "in_lrelu_bwd: volume piece (vh %d, gd %d) of a (%d, %d) plane", p->vh, p->gd, a.h, a.w);
+            CINE_REQUIRE(p->type != 5 || (p->gd >= a.h / p->vh && p->gh >= p->vh && p->gw >= a.w), CINE_EINVAL, "in_lrelu_bwd: volume window smaller than the tensor");
+            CINE_REQUIRE((long)p->gd * p->gh * p->gw < (1L << 31), CINE_EUNSUPPORTED, "in_lrelu_bwd: volume piece too large");
+        }
         const int need_c = p->type == 3 ? 3 * a.c + a.c : (p->type == 4 ? a.c / 4 : a.c);
         CINE_REQUIRE(p->c_off + need_c <= p->c_total && (p->type != 4 || a.c % 4 == 0), CINE_EINVAL, "in_lrelu_bwd: gradient piece channels");
         CINE_REQUIRE(p->type != 1 || (p->gh >= a.h && p->gw >= a.w), CINE_EINVAL,
                      "in_lrelu_bwd: gradient window (%d, %d) smaller than the tensor (%d, %d)", p->gh, p->gw, a.h, a.w);
     }
     const long planes = (long)a.n * a.c;
-    const bool haar = a.a.type >= 3 || a.b.type >= 3;
     if (!haar) {
         ProfScope prof(F_STATS, st);
         bool handled = false;
@@ -209,11 +221,16 @@ size_t in_lrelu_bwd_ws_floats(int n, int c, int h, int w) {
 }
 int launch_in_lrelu_bwd_split(const InBwdArgs& a, float* ws, size_t ws_floats, hipStream_t st) {
     const size_t need = in_lrelu_bwd_ws_floats(a.n, a.c, a.h, a.w);
-    const bool haar = a.a.type >= 3 || a.b.type >= 3;
+    const bool haar = a.a.type == 3 || a.a.type == 4 || a.b.type == 3 || a.b.type == 4;
     if (!need || !ws || haar || (long)a.n * a.c >= 2048) return launch_in_lrelu_bwd(a, st);
     CINE_REQUIRE(ws_floats >= need, CINE_EWORKSPACE, "in_lrelu_bwd: workspace too small");
     CINE_REQUIRE(a.r && a.part && a.gr && a.a.g && a.np > 0 && (long)a.n * a.c <= 65535, CINE_EINVAL, "in_lrelu_bwd: bad arguments");
     CINE_REQUIRE(a.a.type != 1 || (a.a.gh >= a.h && a.a.gw >= a.w), CINE_EINVAL, "in_lrelu_bwd: gradient window smaller than the tensor");
+    for (const GradPiece* p : {&a.a, &a.b})
+        if (p->type >= 5) {
+            CINE_REQUIRE(p->g && p->type <= 6 && p->vh > 0 && a.h % p->vh == 0 && p->gd > 0 && (long)p->gd * p->gh * p->gw < (1L << 31), CINE_EINVAL, "in_lrelu_bwd: bad volume piece");
+            CINE_REQUIRE(p->type != 5 || (p->gd >= a.h / p->vh && p->gh >= p->vh && p->gw >= a.w), CINE_EINVAL, "in_lrelu_bwd: volume window smaller than the tensor");
+        }
     const int nchunk = (int)ceil_div((long)a.h * a.w, (long)kInBwdChunk);
     ProfScope prof(F_STATS, st);
     const dim3 grid((unsigned)nchunk, (unsigned)((long)a.n * a.c));
@@ -855,6 +872,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* part, i
         const float* p = p0 + ((long)row * cinp + ci) * taps + t;
         for (int c = sub; c < nchunks; c += 16) s += p[c * pstride];
         o = kind == 1 ? (long)ci * rows + row : e;            // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
+        if (kind >= 3) o = r2 * 27 + (kind - 3) * 9 + t;      // depth tap kind - 3 of a (rows, cin, 3, 3, 3) weight
     }
     red[sub][lane] = s;
     __syncthreads();

@@ -59,9 +59,9 @@ class BCRNNlayer(nn.Module):
     def _packed(self):
         cell = self.CRNN_model
         params = (cell.i2h.weight, cell.h2h.weight, cell.ih2ih.weight, cell.i2h.bias, cell.h2h.bias, cell.ih2ih.bias)
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (ops.cache_epoch(),) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self._key:
-            ops._no_capture("packed CRNN weights")
+            ops._no_capture("packed CRNN weights", pack=True)
             self._w_in = ops.pack_conv3x3(torch.cat([cell.ih2ih.weight, cell.i2h.weight], dim=1))
             self._w_hh = ops.pack_conv3x3(cell.h2h.weight)
             self._bias = (cell.i2h.bias + cell.h2h.bias + cell.ih2ih.bias).detach().contiguous()
@@ -120,9 +120,9 @@ class CRNNBody(nn.Module):
 
     def _body_packed(self):
         convs = [getattr(self, f"conv{k}_{s}") for k in (1, 2, 3) for s in ("x", "h")] + [self.conv4_x]
-        key = tuple((p.data_ptr(), p._version) for c in convs for p in (c.weight, c.bias))
+        key = (ops.cache_epoch(),) + tuple((p.data_ptr(), p._version) for c in convs for p in (c.weight, c.bias))
         if key != self._body_key:
-            ops._no_capture("packed CRNN weights")
+            ops._no_capture("packed CRNN weights", pack=True)
             self._pairs = []
             for k in (1, 2, 3):
                 cx, chh = getattr(self, f"conv{k}_x"), getattr(self, f"conv{k}_h")

@@ -25,7 +25,7 @@
  *     tests/test_hip_parity.py::test_two_threads_two_streams_are_independent runs two models on two threads and streams while
  *     one of them flips the diagnostic mask and uses another slope.
  *   - the library creates no streams.  The two backward entry points that overlap weight gradients with the input-gradient
- *     chain (cine_unet2d_backward, cine_mwcnn_backward) create and destroy hipEvents (no timing) to order the two streams.
+ *     chain (cine_unet2d_backward, cine_unet3d_backward, cine_mwcnn_backward) create and destroy hipEvents (no timing) to order the two streams.
  */
 #ifndef CINE_HIP_H
 #define CINE_HIP_H
@@ -560,7 +560,7 @@ int cine_pad2d(const float* x, float* out, long planes, int h, int w, int top, i
  * in every thread): it selects kernels for the launches that thread enqueues afterwards and never changes a result. */
 int cine_set_conv_plane(int on);
 
-/* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_mwcnn_backward (they
+/* A second stream of the CALLING THREAD for the weight-gradient launches of cine_unet2d_backward / cine_unet3d_backward / cine_mwcnn_backward (they
  * depend only on a layer's output gradient, not on the input-gradient chain behind it): the calls fork onto it with events
  * and join before returning, so on return everything is ordered on `stream` again and the results do not depend on timing.
  * NULL (the default) or the same stream as `stream`: every launch stays on `stream`.  Replaces nothing in the reference
@@ -576,6 +576,21 @@ int cine_set_side_stream(void* side_stream);
 size_t cine_unet2d_backward_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools);
 int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
                          int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
+                         const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream);
+
+/* The same for the 3-D U-Net (unet.py:73-125 with dims = 3; CineNet's regulariser, cinenet.py:98-116): cine_unet3d_forward_train is
+ * cine_unet3d_forward with every raw layer output and its merged statistics record kept in `ws` (cine_unet3d_train_ws_bytes), and
+ * cine_unet3d_backward walks it in reverse.  `wdgrad` (order of `weights`, bias slot ignored): cine_pack_conv3d of each 3x3x3 weight with its taps
+ * flipped and (cout, cin) transposed; cine_pack_conv1x1 of a transpose conv's weight (cin, cout, 2, 2, 2) read as the (cin, 8 cout) matrix;
+ * cine_pack_conv1x1 of the final conv's matrix transposed (chans, out_ch).  `grads`: the parameters' own layouts ((cout, cin, 3, 3, 3) /
+ * (cin, cout, 2, 2, 2) / (out_ch, chans) / (out_ch)), accumulated into.  One weight set.  gx (n, in_ch, d, h, w) may be NULL.
+ * Weight gradients run on the calling thread's side stream (cine_set_side_stream) when it has one. */
+size_t cine_unet3d_train_ws_bytes(int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools);
+int cine_unet3d_forward_train(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
+                              int in_ch, int out_ch, int chans, int pools, float slope, void* ws, size_t ws_bytes, void* stream);
+size_t cine_unet3d_backward_ws_bytes(int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools);
+int cine_unet3d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads,
+                         int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                          const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream);
 
 /* The same for the wavelet CNN (denoisers/mwcnn.py:135-179): a forward that keeps every feature map, and the backward pass -- InstanceNorm +

@@ -357,10 +357,13 @@ def test_in_lrelu_bwd_large_planes_vs_torch_autograd(dev):
     assert rel_err(out2.cpu(), x64.grad) < 2e-5
 
 
-@pytest.mark.parametrize("shape,chans,pools", [((1, 2, 5, 12, 10), 4, 2), ((2, 2, 7, 9, 11), 3, 1), ((1, 2, 6, 88, 80), 2, 1)])
+@pytest.mark.parametrize("shape,chans,pools", [((1, 2, 5, 12, 10), 4, 2), ((2, 2, 7, 9, 11), 3, 1), ((1, 2, 6, 88, 80), 2, 1),
+                                               ((1, 2, 6, 24, 24), 16, 2)])
 def test_unet3d_backward_vs_oracle_autograd(dev, shape, chans, pools):
-    """Unet3dFn (3x3x3 convs as depth-offset passes of the 2-D weight-gradient kernel, transpose conv through the space-to-depth view, odd
-    extents with the up-path zero pad, 2x2x2 pooling adjoint) against the oracle's float64 autograd."""
+    """Unet3dFn = cine_unet3d_forward_train + cine_unet3d_backward (3x3x3 weight gradients as depth-offset passes of the 2-D weight-gradient kernel over
+    depth-major slices, transpose conv through the space-to-depth copy, odd extents with the up-path zero pad -- depth-only crops as shorter planes,
+    in-plane crops as volume windows --, the 2x2x2 pooling adjoint gathered on load; two samples; 16-channel levels on the coarse conv kernel)
+    against the oracle's float64 autograd."""
     import reconstruction.models as M
     from oracle import regularisers as R
     from cine_hip import synth
