@@ -40,8 +40,7 @@ int launch_in_lrelu_bwd_fast(const InBwdArgs& a, hipStream_t st, bool* handled);
 //   taps 9: 3x3 pad 1; taps 1: 1x1 (also the k2 s2 transpose conv, whose rows are the 4 sub-positions x cout of G's
 //   space-to-depth view: g_mode 5, g (n, g_c, 2H, 2W), rows = 4 g_c).
 // Samples [0, set_split) accumulate into grad0, the rest into grad1 (two networks in one launch).  grad layouts (natural,
-// `+=`): kind 0 (rows, cin, 3, 3); kind 1 transpose conv (cin, rows / 4, 2, 2) -- in general (cin, rows); kind 2 (rows, cin); kind 3 + kz: depth tap kz of a
-// (rows, cin, 3, 3, 3) weight (the 3x3x3 conv's gradient is three 3x3 gradients over depth-shifted slice pairs, unet3d.hip).
+// `+=`): kind 0 (rows, cin, 3, 3); kind 1 transpose conv (cin, rows / 4, 2, 2) -- in general (cin, rows); kind 2 (rows, cin).
 struct WgArgs {
     Src s0, s1;
     int add_src1;          // 1: source 1 is ADDED to source 0 channel-wise (the MWCNN skips) instead of concatenated
@@ -56,6 +55,9 @@ struct WgArgs {
 };
 size_t wgrad_ws_floats(int rows, int cin, int taps, int n);
 int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1, float* ws, size_t ws_floats, hipStream_t st);
+// grad (rows, cin, 3, 3, 3) += the weight gradient of a 3x3x3 conv as its three depth taps: a[kz] = the one-set 3x3 problem of tap kz over the
+// depth-shifted slice pairs (x[z + kz - 1], g[z]), depth slices as samples (a[kz].n == 0: a dead tap); ws: 3 x wgrad_ws_floats(rows, cin, 9, .)
+int launch_wgrad27(const WgArgs (&a)[3], float* grad, float* ws, size_t ws_floats, hipStream_t st);
 
 // gb[co] += sum_{n in set, pixels} g[n][co][p]   (bias of the final 1x1 conv, unet.py:69)
 int launch_bias_grad(const float* g, int n, int cout, long hw, int set_split, float* gb0, float* gb1, float* ws, size_t ws_floats, hipStream_t st);   // ws: n * cout floats

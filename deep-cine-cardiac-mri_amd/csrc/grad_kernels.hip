@@ -215,6 +215,93 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(InBwdArgs a, co
         gr[e] = scale * (g - m1 - xh * m2);
     }
 }
+// The same two passes with 16-byte accesses for what the 3-D U-Net's large levels hand over: the consumer's gradient as wide as the tensor (a type 1
+// window with gw == w: the plane is contiguous), optionally plus the 2x2x2 pool adjoint (type 6); w % 4 == 0.  One thread = four consecutive elements
+// of one row (the scalar kernels moved 2.1 TB/s on cfg 4's level 0: 90 us per layer for 192 MB).
+template <bool POOL>
+__device__ __forceinline__ float4 in_bwd_g4(const InBwdArgs& a, const float4* qa4, const float* qb, int e4) {
+    float4 g = qa4[e4];
+    if constexpr (POOL) {
+        const int e = 4 * e4, y = e / a.w, x = e - y * a.w;
+        const int z = y / a.b.vh, yy = y - z * a.b.vh;
+        const int pz = z >> 1, py = yy >> 1, px = x >> 1;
+        const bool ok = pz < a.b.gd && py < a.b.gh;
+        const float* q = qb + ((long)min(pz, a.b.gd - 1) * a.b.gh + min(py, a.b.gh - 1)) * a.b.gw;
+        const float v0 = (ok && px < a.b.gw) ? 0.125f * q[min(px, a.b.gw - 1)] : 0.f;
+        const float v1 = (ok && px + 1 < a.b.gw) ? 0.125f * q[min(px + 1, a.b.gw - 1)] : 0.f;
+        g.x += v0; g.y += v0; g.z += v1; g.w += v1;
+    }
+    return g;
+}
+template <bool POOL>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_sums_vec_kernel(InBwdArgs a, float* __restrict__ ws, int nchunk) {
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long pl = blockIdx.y;
+    const int n = (int)(pl / a.c), c = (int)(pl - (long)n * a.c);
+    const int pe = a.h * a.w;
+    const float2 mr = merge_partials(a.part + pl * a.np * 3, a.np, a.eps);
+    const float scale = mr.y, shift = -mr.x * mr.y;
+    const float4* r4 = reinterpret_cast<const float4*>(a.r + pl * pe);
+    const float4* qa4 = reinterpret_cast<const float4*>(piece_plane(a.a, n, c));
+    const float* qb = POOL ? piece_plane(a.b, n, c) : nullptr;
+    const int e0 = blockIdx.x * (kInBwdChunk / 4), e1 = min(pe / 4, e0 + kInBwdChunk / 4);
+    float s1 = 0.f, s2 = 0.f;
+    for (int e4 = e0 + threadIdx.x; e4 < e1; e4 += 256) {
+        const float4 rv = r4[e4];
+        const float4 gv = in_bwd_g4<POOL>(a, qa4, qb, e4);
+        const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = fmaf(rr[u], scale, shift);
+            const float g = xh > 0.f ? gg[u] : gg[u] * a.slope;
+            s1 += g; s2 = fmaf(g, xh, s2);
+        }
+    }
+    s1 = wave_sum_g(s1); s2 = wave_sum_g(s2);
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = ws + (pl * nchunk + blockIdx.x) * 2;
+        o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+template <bool POOL>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_apply_vec_kernel(InBwdArgs a, const float* __restrict__ ws, int nchunk) {
+    const long pl = blockIdx.y;
+    const int n = (int)(pl / a.c), c = (int)(pl - (long)n * a.c);
+    const int pe = a.h * a.w;
+    const float2 mr = merge_partials(a.part + pl * a.np * 3, a.np, a.eps);
+    const float scale = mr.y, shift = -mr.x * mr.y;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) { s1 += ws[(pl * nchunk + k) * 2]; s2 += ws[(pl * nchunk + k) * 2 + 1]; }
+    const float m1 = s1 / pe, m2 = s2 / pe;
+    const float4* r4 = reinterpret_cast<const float4*>(a.r + pl * pe);
+    float4* gr4 = reinterpret_cast<float4*>(a.gr + pl * pe);
+    const float4* qa4 = reinterpret_cast<const float4*>(piece_plane(a.a, n, c));
+    const float* qb = POOL ? piece_plane(a.b, n, c) : nullptr;
+    const int e0 = blockIdx.x * (kInBwdChunk / 4), e1 = min(pe / 4, e0 + kInBwdChunk / 4);
+    for (int e4 = e0 + threadIdx.x; e4 < e1; e4 += 256) {
+        const float4 rv = r4[e4];
+        const float4 gv = in_bwd_g4<POOL>(a, qa4, qb, e4);
+        const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, gg[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = fmaf(rr[u], scale, shift);
+            const float g = xh > 0.f ? gg[u] : gg[u] * a.slope;
+            o[u] = scale * (g - m1 - xh * m2);
+        }
+        gr4[e4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+static bool in_bwd_vec_ok(const InBwdArgs& a) {
+    auto al = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    if (a.a.type != 1 || a.a.gw != a.w || (a.w & 3) || (((long)a.a.gh * a.a.gw) & 3)) return false;
+    if (a.b.type != 0 && a.b.type != 6) return false;
+    return al(a.r) && al(a.gr) && al(a.a.g) && (((long)a.a.c_off * a.a.gh * a.a.gw) & 3) == 0;
+}
 size_t in_lrelu_bwd_ws_floats(int n, int c, int h, int w) {
     const long pe = (long)h * w;
     return pe > 4 * kInBwdChunk ? (size_t)n * c * ceil_div(pe, (long)kInBwdChunk) * 2 : 0;
@@ -234,6 +321,16 @@ int launch_in_lrelu_bwd_split(const InBwdArgs& a, float* ws, size_t ws_floats, h
     const int nchunk = (int)ceil_div((long)a.h * a.w, (long)kInBwdChunk);
     ProfScope prof(F_STATS, st);
     const dim3 grid((unsigned)nchunk, (unsigned)((long)a.n * a.c));
+    if (in_bwd_vec_ok(a)) {
+        if (a.b.type == 6) {
+            hipLaunchKernelGGL(in_lrelu_bwd_sums_vec_kernel<true>, grid, dim3(256), 0, st, a, ws, nchunk);
+            hipLaunchKernelGGL(in_lrelu_bwd_apply_vec_kernel<true>, grid, dim3(256), 0, st, a, ws, nchunk);
+        } else {
+            hipLaunchKernelGGL(in_lrelu_bwd_sums_vec_kernel<false>, grid, dim3(256), 0, st, a, ws, nchunk);
+            hipLaunchKernelGGL(in_lrelu_bwd_apply_vec_kernel<false>, grid, dim3(256), 0, st, a, ws, nchunk);
+        }
+        return check_launch("in_lrelu_bwd_apply_vec_kernel");
+    }
     hipLaunchKernelGGL(in_lrelu_bwd_sums_kernel, grid, dim3(256), 0, st, a, ws, nchunk);
     hipLaunchKernelGGL(in_lrelu_bwd_apply_kernel, grid, dim3(256), 0, st, a, ws, nchunk);
     return check_launch("in_lrelu_bwd_apply_kernel");
@@ -872,7 +969,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* part, i
         const float* p = p0 + ((long)row * cinp + ci) * taps + t;
         for (int c = sub; c < nchunks; c += 16) s += p[c * pstride];
         o = kind == 1 ? (long)ci * rows + row : e;            // transpose conv (cin, cout, 2, 2): row = 4 co + 2 a + b
-        if (kind >= 3) o = r2 * 27 + (kind - 3) * 9 + t;      // depth tap kind - 3 of a (rows, cin, 3, 3, 3) weight
     }
     red[sub][lane] = s;
     __syncthreads();
@@ -942,6 +1038,9 @@ static int launch_wg_tw(const WgLaunch& L, int cob, dim3 grid, hipStream_t st) {
     return launch_wg_cfg<TAPS, TW, 2, 4, 64>(L, grid, st);
 }
 
+// the partial sums of one weight-gradient launch into `ws` (everything but the reduction); L: the launch's geometry for the reduction
+static int launch_wgrad_partials(const WgArgs& a, int taps, int kind, float* ws, size_t ws_floats, hipStream_t st, WgLaunch& L);
+
 int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1, float* ws, size_t ws_floats, hipStream_t st) {
     CINE_REQUIRE(a.g && a.s0.x && ws && grad0 && a.n > 0 && a.rows > 0 && a.cin > 0 && a.H > 0 && a.W > 0, CINE_EINVAL, "wgrad: bad arguments");
     CINE_REQUIRE(taps == 9 || taps == 1, CINE_EINVAL, "wgrad: taps %d", taps);
@@ -975,6 +1074,17 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
         }
     }
     WgLaunch L{};
+    if (int e = launch_wgrad_partials(a, taps, kind, ws, ws_floats, st, L)) return e;
+    const int nsets = a.n - a.set_split > 0 ? 2 : 1;
+    const long total = (long)a.rows * a.cin * taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 64L), nsets), dim3(1024), 0, st,
+                       ws, L.nchunks, a.rows, a.cin, L.rowsp, L.cinp, taps, kind, grad0, grad1);
+    return check_launch("wgrad_reduce_kernel");
+}
+
+static int launch_wgrad_partials(const WgArgs& a, int taps, int kind, float* ws, size_t ws_floats, hipStream_t st, WgLaunch& L) {
+    const int TW = a.W > 8 ? 16 : a.W > 4 ? 8 : a.W > 2 ? 4 : 2;
+    L = WgLaunch{};
     L.a = a;
     L.rowsp = ceil_div(a.rows, 16) * 16; L.cinp = ceil_div(a.cin, 16) * 16;
     const int cob = a.rows <= 16 ? 16 : a.rows <= 32 ? 32 : a.rows <= 64 ? 64 : 128;
@@ -1016,11 +1126,55 @@ int launch_wgrad(const WgArgs& a, int taps, int kind, float* grad0, float* grad1
         else if (TW == 4) e = launch_wg_tw<1, 4>(L, cob, grid, st);
         else e = launch_wg_tw<1, 2>(L, cob, grid, st);
     }
-    if (e) return e;
-    const long total = (long)a.rows * a.cin * taps;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 64L), nsets), dim3(1024), 0, st,
-                       ws, L.nchunks, a.rows, a.cin, L.rowsp, L.cinp, taps, kind, grad0, grad1);
-    return check_launch("wgrad_reduce_kernel");
+    return e;
+}
+
+// grad (rows, cin, 3, 3, 3) += the three depth taps' partial sums (regions of `stride` floats, nchunks[kz] partials each; 0: a dead tap)
+__global__ __launch_bounds__(1024) void wgrad_reduce27_kernel(const float* part, long stride, int nc0, int nc1, int nc2, int rows, int cin, int rowsp, int cinp, float* grad) {
+    __shared__ float red[16][64];
+    const long total = (long)rows * cin * 27;
+    const long pstride = (long)rowsp * cinp * 9;
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (e < total) {
+        const int t = (int)(e % 9), kz = (int)((e / 9) % 3);
+        const long r2 = e / 27;
+        const int ci = (int)(r2 % cin), row = (int)(r2 / cin);
+        const int nchunks = kz == 0 ? nc0 : (kz == 1 ? nc1 : nc2);
+        const float* p = part + kz * stride + ((long)row * cinp + ci) * 9 + t;
+        for (int c = sub; c < nchunks; c += 16) s += p[c * pstride];
+    }
+    red[sub][lane] = s;
+    __syncthreads();
+    if (sub == 0 && e < total) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tsum += red[i][lane];
+        grad[e] += tsum;
+    }
+}
+
+// The 3x3x3 weight gradient from its three depth taps: a[kz] = the 3x3 weight-gradient problem of tap kz (a[kz].n == 0: a dead tap), one set each;
+// three launches of partial sums into thirds of `ws`, ONE reduction (the per-tap form paid three: 15 us each on cfg 4's level 0).
+int launch_wgrad27(const WgArgs (&a)[3], float* grad, float* ws, size_t ws_floats, hipStream_t st) {
+    const WgArgs* first = nullptr;
+    for (const WgArgs& t : a) if (t.n > 0 && !first) first = &t;
+    CINE_REQUIRE(first && grad && ws, CINE_EINVAL, "wgrad27: bad arguments");
+    const size_t stride = ws_floats / 3;
+    int nc[3] = {0, 0, 0}, rowsp = 0, cinp = 0;
+    for (int kz = 0; kz < 3; ++kz) {
+        if (a[kz].n <= 0) continue;
+        CINE_REQUIRE(a[kz].g && a[kz].s0.x && a[kz].rows == first->rows && a[kz].cin == first->cin && a[kz].set_split == a[kz].n && !a[kz].mat && !a[kz].add_src1 &&
+                     a[kz].H > 0 && a[kz].W > 0, CINE_EINVAL, "wgrad27: the taps are one-set problems of one layer");
+        WgLaunch L{};
+        if (int e = launch_wgrad_partials(a[kz], 9, 0, ws + kz * stride, stride, st, L)) return e;
+        nc[kz] = L.nchunks; rowsp = L.rowsp; cinp = L.cinp;
+    }
+    const long total = (long)first->rows * first->cin * 27;
+    hipLaunchKernelGGL(wgrad_reduce27_kernel, dim3((unsigned)ceil_div(total, 64L)), dim3(1024), 0, st, ws, (long)stride, nc[0], nc[1], nc[2],
+                       first->rows, first->cin, rowsp, cinp, grad);
+    return check_launch("wgrad_reduce27_kernel");
 }
 
 // ---------------------------------------------------------------- bias gradient

@@ -187,7 +187,7 @@ extern "C" int cine_unet3d_forward_train(const float* x, float* y, const void* c
 //  * InstanceNorm + LeakyReLU backward sees a volume as a plane of (d h, w); the depth crop of the zero-padded transpose-conv output is a
 //    shorter plane, an in-plane crop (odd extents) and the 2x2x2 pool adjoint are the volume pieces of grad.h (types 5 / 6);
 //  * the 3x3x3 weight gradient is three 3x3 weight gradients -- one per depth tap kz, over the slice pairs (x[z + kz - 1], g[z]) with the depth
-//    slices as the samples of the MFMA weight-gradient kernel (wgrad_reduce_kernel kind 3 + kz writes tap kz of the (cout, cin, 3, 3, 3) gradient).
+//    slices as the samples of the MFMA weight-gradient kernel, and one reduction of the three taps' partial sums (launch_wgrad27).
 //    The kernel addresses (sample, channel, h, w): the (re-activated, concatenated, zero-padded, pooled) conv input and the output gradient are
 //    written once per layer in depth-major order (vol_slices_kernel) -- on the side stream, beside the input-gradient chain;
 //  * the k2 s2 transpose conv: one space-to-depth copy of its output gradient (rows 8 c + 4 dz + 2 dy + dx), then the 1x1x1 kernels.
@@ -277,12 +277,12 @@ void build_bwd(BwdPlan& q, const Plan& p, Bump& b, int n, int in_ch, int out_ch)
     size_t wg = (size_t)n * out_ch, xs = 16, gs = 16, inb = 16;
     for (int l = 0; l <= P; ++l) {
         const int cin1 = l ? p.ch[l - 1] : in_ch;
-        wg = std::max(wg, wgrad_ws_floats(p.ch[l], cin1, 9, p.ds[l]));
-        wg = std::max(wg, wgrad_ws_floats(p.ch[l], p.ch[l], 9, p.ds[l]));
+        wg = std::max(wg, 3 * wgrad_ws_floats(p.ch[l], cin1, 9, p.ds[l]));            // (three depth taps: launch_wgrad27)
+        wg = std::max(wg, 3 * wgrad_ws_floats(p.ch[l], p.ch[l], 9, p.ds[l]));
         xs = std::max(xs, (size_t)std::max(cin1, p.ch[l]) * p.vol(l));
         gs = std::max(gs, (size_t)p.ch[l] * p.vol(l));
         if (l < P) {
-            wg = std::max(wg, wgrad_ws_floats(p.ch[l], 2 * p.ch[l], 9, p.ds[l]));
+            wg = std::max(wg, 3 * wgrad_ws_floats(p.ch[l], 2 * p.ch[l], 9, p.ds[l]));
             wg = std::max(wg, wgrad_ws_floats(8 * p.ch[l], p.ch[l + 1], 1, n));
             xs = std::max(xs, (size_t)2 * p.ch[l] * p.vol(l));
         }
@@ -356,15 +356,15 @@ extern "C" int cine_unet3d_backward(const float* x, const float* gy, const void*
                 if (int r = launch_vol_slices(s0, s1, q.xs, v, cin, D, H, W, kEps, kSlope, sw)) return r;
                 const Src gsrc{g + (long)v * rows * D * hw, nullptr, rows, 0, H, W, 0, 2, D};
                 if (int r = launch_vol_slices(gsrc, none, q.gs, 0, rows, D, H, W, kEps, kSlope, sw)) return r;
+                WgArgs a[3] = {};
                 for (int kz = 0; kz < 3; ++kz) {
                     const int dz = kz - 1, z0 = std::max(0, -dz), z1 = D - std::max(0, dz);
                     if (z1 <= z0) continue;
-                    WgArgs a{};
-                    a.s0 = Src{q.xs + (long)(z0 + dz) * cin * hw, nullptr, cin, 0, H, W, 0, 0, 1}; a.s1 = none; a.cin = cin;
-                    a.g = q.gs + (long)z0 * rows * hw; a.g_mode = 0; a.rows = rows;
-                    a.n = z1 - z0; a.H = H; a.W = W; a.set_split = z1 - z0; a.eps = kEps; a.slope = kSlope;
-                    if (int r = launch_wgrad(a, 9, 3 + kz, gr(wi), nullptr, q.wg, q.wg_floats, sw)) return r;
+                    a[kz].s0 = Src{q.xs + (long)(z0 + dz) * cin * hw, nullptr, cin, 0, H, W, 0, 0, 1}; a[kz].s1 = none; a[kz].cin = cin;
+                    a[kz].g = q.gs + (long)z0 * rows * hw; a[kz].g_mode = 0; a[kz].rows = rows;
+                    a[kz].n = z1 - z0; a[kz].H = H; a[kz].W = W; a[kz].set_split = z1 - z0; a[kz].eps = kEps; a[kz].slope = kSlope;
                 }
+                if (int r = launch_wgrad27(a, gr(wi), q.wg, q.wg_floats, sw)) return r;
             }
             return CINE_OK;
         });

@@ -51,6 +51,15 @@ print(f"training step: {dt * 1e3:.1f} ms   loss {float(l):.5f}   peak mem {torch
       (f"   [{world} rank(s), RCCL gradient all-reduce of {sum(p.numel() for p in sync.params) * 4 / 2**20:.1f} MiB per step: {world / dt:.1f} slices/s]" if dist.is_initialized() else ""))
 if rank != 0:
     sys.exit(0)
+if os.environ.get("CINE_TRAIN_REGIONS"):      # more regions of the same length: the spread between them, and how long the HOST needs to enqueue a step
+    regs, enq = [], []
+    for _ in range(int(os.environ["CINE_TRAIN_REGIONS"])):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): step()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        regs.append((time.perf_counter() - t0) / n * 1e3); enq.append((t1 - t0) / n * 1e3)
+    print("regions (ms per step):", " ".join(f"{r:.2f}" for r in regs), "  host enqueue per step:", " ".join(f"{r:.2f}" for r in enq))
 with torch.no_grad():
     for _ in range(2): net(mk, mask, *extra)
     torch.cuda.synchronize(); t0 = time.time()
