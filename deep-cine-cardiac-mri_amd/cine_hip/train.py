@@ -1,10 +1,14 @@
 """Training-loop helpers that have no counterpart in the reference (its Lightning modules step eagerly, pl_modules/varnet_module.py:97-113).
 
 ``GraphedTrainingStep``: one training step of a FIXED shape -- forward through the drop-in model, loss, ``loss.backward()`` through the
-HIP gradient kernels, the optional gradient all-reduce and the optimiser step -- captured into ONE hipGraph and replayed.  A step is
-1 300 - 2 900 launches; where the host cannot enqueue them as fast as the GPU retires them (the layer-by-layer 3-D backward
-of cfg 4, the MWCNN backward of cfg 3) the replay removes the host from the step.  Numerically it is the eager step: the same kernels in
-the same order on the same stream(s).
+HIP gradient kernels, the optional gradient all-reduce and the optimiser step -- captured into ONE hipGraph and replayed.  Numerically it is
+the eager step: the same kernels in the same order (``tests/test_hip_grad.py::test_training_step_captured_in_one_hipgraph_matches_the_eager_step``).
+
+MEASURED (MI355X, ROCm 7.2, ``tools/train_graph_probe.py``): replaying the graph is NOT faster than launching eagerly on this runtime --
+cfg 2: 51 ms against 33.6 eager, cfg 3: 78 against 42, cfg 4: 72 against 34.8, cfg 5: 35.7 against 34.5.  The eager steps are GPU-bound already (the union of
+busy intervals of the two queues equals the step), and the captured weight-gradient side lane becomes fork / join edges that the graph
+executor serialises; with the side lane off the graph is the one-stream step (cfg 2: 43 ms of kernel time).  The class stays as the way to take the
+host out of a step should a later runtime execute multi-stream graphs well; the benchmarks and the tests' timing use the eager step.
 """
 from typing import Callable, Optional, Sequence
 

@@ -779,6 +779,50 @@ def test_training_loop_tracks_the_oracle_and_learns(dev):
         assert abs(a - b) < 2e-3 * max(abs(b), 1e-3), (lh, lr_)
 
 
+@pytest.mark.parametrize("family", ["varnet_XF", "cinenet_3D"])
+def test_training_step_captured_in_one_hipgraph_matches_the_eager_step(dev, family):
+    """cine_hip.train.GraphedTrainingStep: forward + SSIMLoss + backward (two streams: the weight gradients' side lane is captured as a branch) + a
+    capturable Adam in ONE hipGraph.  Replaying it is the eager step -- the same loss sequence from the same start -- and the parameters move;
+    the weight packs the step makes are nodes of the graph (ops.training_capture), and the caches they bypass are invalidated afterwards."""
+    import reconstruction.models as M
+    from reconstruction.models.varnet import SensitivityModel
+    from reconstruction.utils import SSIMLoss
+    from cine_hip import synth, train, ops
+    ex = synth.make_cine_slice(6, 3, 24, 16, accel=4, center_lines=4, seed=3, noise_std=0.01)
+    mk, mask, target = ex["masked_kspace"].to(dev), ex["mask"].to(dev), ex["target"].to(dev)
+    if family == "varnet_XF":
+        make, extra, kw = (lambda: M.VarNet(2, 4, 2, 4, 2, "XF")), (), {"acs": SensitivityModel.acs_window(mask)}
+    else:
+        make, extra, kw = (lambda: M.CineNet(2, 2, 4, 2, "3D")), (ex["sens_maps"].to(dev),), {}
+    lossf = SSIMLoss().to(dev)
+    loss_fn = lambda out, tgt: lossf(out.unsqueeze(1), tgt.unsqueeze(1), tgt.max())
+
+    def fresh(capturable):
+        net = make(); synth.fill_parameters_(net, 4); net = net.to(dev).train()
+        return net, torch.optim.Adam(net.parameters(), lr=1e-3, capturable=capturable)
+    net, opt = fresh(True)
+    eager = []
+    with torch.enable_grad():
+        for _ in range(6):
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(net(mk, mask, *extra, **kw), target)
+            loss.backward(); opt.step()
+            eager.append(float(loss.detach()))
+    net, opt = fresh(True)
+    w0 = [p.detach().clone() for p in net.parameters()]
+    epoch = ops.cache_epoch()
+    gs = train.GraphedTrainingStep(net, loss_fn, opt, (mk, mask) + extra, target, forward_kwargs=kw, warmup=2)
+    assert ops.cache_epoch() > epoch                                   # packs made during the capture are not served to later eager calls
+    graphed = [float(l) for l in gs.warmup_losses] + [float(gs.step(mk, mask, *extra, target=target).clone()) for _ in range(4)]
+    for a, b in zip(graphed, eager):
+        assert abs(a - b) < 5e-4 * max(abs(b), 1e-3), (graphed, eager)
+    assert graphed[-1] < graphed[0]
+    assert any(float((p.detach() - q).abs().max()) > 0 for p, q in zip(net.parameters(), w0))
+    with torch.no_grad():                                              # and the model is usable eagerly afterwards (re-packed weights)
+        out = net.eval()(mk, mask, *extra)
+    assert torch.isfinite(out).all()
+
+
 @pytest.mark.parametrize("n,in_ch,out_ch,scales,nf,nc,first,h,w", [(3, 6, 4, 2, [8, 16], [2, 1], 8, 16, 8), (4, 12, 10, 3, [16, 32, 64], [2, 2, 2], 16, 32, 16)])
 def test_mwcnn_backward_vs_oracle(dev, n, in_ch, out_ch, scales, nf, nc, first, h, w):
     """cine_mwcnn_backward (reference denoisers/mwcnn.py:135-179 under autograd): every weight / bias gradient and the input gradient,
