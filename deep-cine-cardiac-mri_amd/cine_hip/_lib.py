@@ -45,6 +45,8 @@ _SIGS = {
     "cine_image_metrics": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int, c_double,
                                    P, P, c_size_t, P]),
     "cine_sens_prologue": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_acs_window": (c_int, [P, c_int, c_int, P, P]),
+    "cine_sens_prologue_win": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
     "cine_rss_normalise": (c_int, [P, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_pack": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
     "cine_normunet_unpack": (c_int, [P, P, P, c_int, c_int, c_int, P]),

@@ -360,11 +360,31 @@ def expand_mask_hybrid(img: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor
     return out
 
 
-def sens_prologue(masked_kspace: torch.Tensor, row_lo: int, row_hi: int) -> torch.Tensor:
-    """reference varnet.py:71-74: ifft2c(mask_center(mean_t(k)))."""
+def acs_window_dev(mask: torch.Tensor) -> torch.Tensor:
+    """The ACS window {first kept row, one past the last} of a row mask (b, t, 1, h, 1, 1) as an int32 tensor of two ON THE DEVICE
+    (cine_acs_window; reference varnet.py:64-68 reads the mask on the host): nothing here waits for the GPU, so a forward pass can be
+    enqueued -- or captured into a hipGraph -- straight from (masked_kspace, mask)."""
+    if mask.shape[-2] != 1 or mask.shape[-1] != 1:
+        raise ValueError("the ACS window is read from a row mask (reference varnet.py:64-68 indexes the mask's h axis); with a mask that "
+                         "varies along w pass acs=(pad, n_low) or sens_maps")
+    h = mask.shape[-3]
+    rows = mask[:, 0].reshape(-1)
+    rows = _dev(rows if rows.dtype == torch.float32 else rows.float(), "mask")
+    win = torch.empty(2, device=rows.device, dtype=torch.int32)
+    check(lib().cine_acs_window(rows.data_ptr(), rows.numel(), h, win.data_ptr(), _stream()), "cine_acs_window")
+    return win
+
+
+def sens_prologue(masked_kspace: torch.Tensor, row_lo, row_hi: Optional[int] = None) -> torch.Tensor:
+    """reference varnet.py:71-74: ifft2c(mask_center(mean_t(k))).  row_lo: an int (with row_hi) or the device window of ``acs_window_dev``."""
     k = _dev(masked_kspace, "masked_kspace")
     b, t, c, h, w, _ = k.shape
     out = torch.empty((b, c, h, w, 2), device=k.device, dtype=k.dtype)
+    if isinstance(row_lo, torch.Tensor):
+        if row_lo.dtype != torch.int32 or row_lo.numel() != 2 or row_lo.device != k.device:
+            raise ValueError("sens_prologue: the device window is an int32 tensor of two on the k-space's device")
+        check(lib().cine_sens_prologue_win(k.data_ptr(), out.data_ptr(), b, t, c, h, w, row_lo.data_ptr(), _stream()), "cine_sens_prologue_win")
+        return out
     check(lib().cine_sens_prologue(k.data_ptr(), out.data_ptr(), b, t, c, h, w, int(row_lo), int(row_hi), _stream()),
           "cine_sens_prologue")
     return out

@@ -23,8 +23,8 @@ class GraphedTrainingStep:
     ``optimizer`` must be capturable (``torch.optim.Adam(..., capturable=True)``: its step counter lives on the device).  ``inputs`` /
     ``target`` give the shapes; ``step()`` copies new data into the static buffers and replays.  ``warmup`` eager steps run first on the
     capture stream (they are real training steps: ``warmup_losses``) -- they size every cached workspace, which must not be allocated
-    during capture.  Anything that reads the device from the host inside ``forward`` (the ACS window of a sampling mask, varnet.py:64-68)
-    has to be passed in precomputed (``forward_kwargs={"acs": SensitivityModel.acs_window(mask)}``).
+    during capture.  Nothing inside ``forward`` may read the device from the host (the models' own data-dependent read -- the ACS window of a
+    sampling mask, varnet.py:64-68 -- is found on the device, ``ops.acs_window_dev``).
     """
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable, optimizer: torch.optim.Optimizer, inputs: Sequence[torch.Tensor],

@@ -291,7 +291,9 @@ __global__ void xfyf_unpack_kernel(UnpackArgs a) {
 
 // ---------------------------------------------------------------- sens-map prologue
 // mean over frames of the rows kept by mask_center (varnet.py:71, transforms.py:95-108)
-__global__ void time_mean_center_kernel(const cf* k, cf* out, int T, int C, int H, int W, int lo, int hi) {
+// (win != NULL: the window {lo, hi} is read from device memory -- cine_acs_window -- so that a forward pass needs no host read-back of the mask)
+__global__ void time_mean_center_kernel(const cf* k, cf* out, int T, int C, int H, int W, int lo, int hi, const int* __restrict__ win) {
+    if (win) { lo = win[0]; hi = win[1]; }
     const long HW = (long)H * W;
     const long total = (long)C * HW;                // per batch element
     const int b = blockIdx.y;
@@ -427,15 +429,51 @@ extern "C" int cine_xfyf_unpack(const float* planes_xf, const float* planes_yf, 
     return check_launch("xfyf_unpack_kernel");
 }
 
-extern "C" int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,
-                                  int row_lo, int row_hi, void* stream) {
+static int sens_prologue_impl(const float* k, float* out, int b, int t, int c, int h, int w, int row_lo, int row_hi, const int* win, void* stream) {
     CINE_REQUIRE(k && out, CINE_EINVAL, "cine_sens_prologue: null pointer");
     CINE_REQUIRE(b > 0 && b <= 65535 && t > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_sens_prologue: bad sizes");
     { ProfScope prof(F_MISC, as_stream(stream));
     hipLaunchKernelGGL(time_mean_center_kernel, dim3(grid_for((long)c * h * w, 256), b), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const cf*>(k), reinterpret_cast<cf*>(out), t, c, h, w, row_lo, row_hi); }
+                       reinterpret_cast<const cf*>(k), reinterpret_cast<cf*>(out), t, c, h, w, row_lo, row_hi, win); }
     if (int e = check_launch("time_mean_center_kernel")) return e;
     return cine_fft2c(out, out, b * c, h, w, 1, stream);
+}
+extern "C" int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,
+                                  int row_lo, int row_hi, void* stream) {
+    return sens_prologue_impl(k, out, b, t, c, h, w, row_lo, row_hi, nullptr, stream);
+}
+// The same with the window {row_lo, row_hi} in DEVICE memory (cine_acs_window wrote it): no host read-back of the mask between the caller and the launch.
+extern "C" int cine_sens_prologue_win(const float* k, float* out, int b, int t, int c, int h, int w, const int* window, void* stream) {
+    CINE_REQUIRE(window, CINE_EINVAL, "cine_sens_prologue_win: null window");
+    return sens_prologue_impl(k, out, b, t, c, h, w, 0, 0, window, stream);
+}
+
+// The fully sampled centre rows of a row mask, found on the device (reference varnet.py:64-68 reads the mask on the host): rows = the 1-D
+// pattern of frame 0 (n >= h entries, 0 = not sampled), cent = h / 2, left = the last unsampled row below cent (-1: none), right = the first
+// one at or above it (n: none), n_low = right - left, pad = (h - n_low + 1) / 2; window = {pad, pad + n_low}.
+namespace cine {
+__global__ __launch_bounds__(256) void acs_window_kernel(const float* __restrict__ rows, int n, int h, int* __restrict__ win) {
+    __shared__ int sl[4], sr[4];
+    const int cent = h / 2;
+    int l = -1, r = n;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (rows[i] == 0.f) { if (i < cent) l = max(l, i); else r = min(r, i); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { l = max(l, __shfl_xor(l, o, 64)); r = min(r, __shfl_xor(r, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = l; sr[threadIdx.x >> 6] = r; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        l = max(max(sl[0], sl[1]), max(sl[2], sl[3])); r = min(min(sr[0], sr[1]), min(sr[2], sr[3]));
+        const int n_low = r - l, pad = (h - n_low + 1) / 2;
+        win[0] = pad; win[1] = pad + n_low;
+    }
+}
+}  // namespace cine
+extern "C" int cine_acs_window(const float* mask_rows, int n, int h, int* window, void* stream) {
+    CINE_REQUIRE(mask_rows && window && h > 0 && n >= h, CINE_EINVAL, "cine_acs_window: bad arguments");
+    ProfScope prof(F_MISC, as_stream(stream));
+    hipLaunchKernelGGL(cine::acs_window_kernel, dim3(1), dim3(256), 0, as_stream(stream), mask_rows, n, h, window);
+    return check_launch("acs_window_kernel");
 }
 
 extern "C" int cine_rss_normalise(float* x, int b, int c, int h, int w, void* stream) {

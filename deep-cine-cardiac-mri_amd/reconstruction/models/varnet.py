@@ -39,8 +39,8 @@ class SensitivityModel(nn.Module):
 
     @staticmethod
     def acs_window(mask: torch.Tensor):
-        """Rows [pad, pad + n_low) to keep (reference varnet.py:64-68: frame 0's mask only).
-        Data dependent, so it reads the 1-D mask back to the host."""
+        """Rows [pad, pad + n_low) to keep (reference varnet.py:64-68: frame 0's mask only) as host integers: it reads the 1-D mask back to
+        the host and so waits for the GPU.  ``forward`` without ``acs`` uses the device form (``ops.acs_window_dev``: same arithmetic, no wait)."""
         if mask.shape[-2] != 1:
             raise ValueError("the ACS window is read from a row mask (reference varnet.py:64-68 indexes the mask's h axis); with a mask that "
                              "varies along w pass acs=(pad, n_low) or sens_maps")
@@ -52,8 +52,11 @@ class SensitivityModel(nn.Module):
         return (mask.shape[-3] - n_low + 1) // 2, n_low
 
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
-        pad, n_low = self.acs_window(mask) if acs is None else acs
-        x = ops.sens_prologue(masked_kspace, pad, pad + n_low)            # (b, c, h, w, 2)
+        if acs is None:      # the window is found on the device: no host read-back between the caller and the launches (acs_window is the host form)
+            x = ops.sens_prologue(masked_kspace, ops.acs_window_dev(mask))      # (b, c, h, w, 2)
+        else:
+            pad, n_low = acs
+            x = ops.sens_prologue(masked_kspace, pad, pad + n_low)
         b, c, h, w, _ = x.shape
         x = self.norm_unet(x.view(b * c, 1, h, w, 2)).view(b, c, h, w, 2)
         if x.requires_grad:

@@ -33,8 +33,11 @@ class SensitivityModel(nn.Module):
         self.unet_model = Unet(chans, num_pools, in_chans=in_chans, out_chans=out_chans, drop_prob=drop_prob)
 
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, acs=None) -> torch.Tensor:
-        pad, n_low = _VarnetSens.acs_window(mask) if acs is None else acs
-        x = ops.sens_prologue(masked_kspace, pad, pad + n_low)                 # (b, c, h, w, 2)
+        if acs is None:      # the window is found on the device: no host read-back between the caller and the launches (acs_window is the host form)
+            x = ops.sens_prologue(masked_kspace, ops.acs_window_dev(mask))      # (b, c, h, w, 2)
+        else:
+            pad, n_low = acs
+            x = ops.sens_prologue(masked_kspace, pad, pad + n_low)
         b, c, h, w, _ = x.shape
         if ag.grad_mode(self):
             # unpack(unet(planes) + planes) = unpack(unet(planes)) + x: the repacks are linear and x is data (no gradient)

@@ -182,6 +182,12 @@ int cine_image_metrics(const float* gt, const float* pred, int t, int hg, int wg
  * dim h (transforms.mask_center, data/transforms.py:95-108), ifft2c.  k (b,t,c,h,w,2) -> out (b,c,h,w,2). */
 int cine_sens_prologue(const float* k, float* out, int b, int t, int c, int h, int w,
                        int row_lo, int row_hi, void* stream);
+/* The same without a host read-back of the mask (the reference finds the window on the host, varnet.py:64-68): cine_acs_window finds the fully
+ * sampled centre rows of a row mask on the device -- mask_rows: the 1-D pattern of frame 0, n >= h float32 entries, 0 = not sampled;
+ * window[0..1] = {pad, pad + n_low} with left = the last unsampled row below h / 2 (-1: none), right = the first one at or above it (n: none),
+ * n_low = right - left, pad = (h - n_low + 1) / 2 -- and cine_sens_prologue_win reads {row_lo, row_hi} from that device buffer. */
+int cine_acs_window(const float* mask_rows, int n, int h, int* window, void* stream);
+int cine_sens_prologue_win(const float* k, float* out, int b, int t, int c, int h, int w, const int* window, void* stream);
 
 /* SensitivityModel.divide_root_sum_of_squares (varnet.py:58-59, coil_combine.py:21-34), in place
  * on x (b, c, h, w, 2). */

@@ -1473,6 +1473,26 @@ def test_tiled_sensitivities_give_the_same_bits(dev, t, c, w):
         assert torch.equal(a_, b_)
 
 
+def test_acs_window_found_on_the_device_equals_the_host_form(dev):
+    """cine_acs_window (the forward pass without ``acs=``: no host read-back of the mask, reference varnet.py:64-68) against SensitivityModel.acs_window
+    on the synthetic generator's masks and on hand-made ones (asymmetric centre block, odd height, several batch entries), and the two
+    prologues -- host integers / device window -- give the same bits."""
+    from reconstruction.models.varnet import SensitivityModel
+    from cine_hip import ops, synth
+    masks = [synth.make_cine_slice(3, 2, h, 8, accel=a, center_lines=cl, seed=s)["mask"] for h, a, cl, s in [(200, 4, 24, 0), (96, 8, 8, 1), (33, 4, 5, 2)]]
+    m = torch.zeros(1, 2, 1, 40, 1, 1); m[:, :, :, 14:29] = 1; m[:, :, :, 3] = 1; m[:, :, :, 37] = 1
+    masks.append(m)
+    masks.append(torch.cat([masks[1], masks[1]], 0))                 # b = 2: frame 0 of every batch entry, the first centre
+    for mk in masks:
+        want = SensitivityModel.acs_window(mk)
+        win = ops.acs_window_dev(mk.to(dev)).cpu().tolist()
+        assert win == [want[0], want[0] + want[1]], (win, want, tuple(mk.shape))
+    ex = synth.make_cine_slice(4, 3, 48, 40, accel=4, center_lines=6, seed=5)
+    k, mk = ex["masked_kspace"].to(dev), ex["mask"].to(dev)
+    pad, n_low = SensitivityModel.acs_window(mk)
+    assert torch.equal(ops.sens_prologue(k, pad, pad + n_low), ops.sens_prologue(k, ops.acs_window_dev(mk)))
+
+
 @pytest.mark.parametrize("t,c,w,iters", [(15, 15, 200, 6), (3, 8, 23, 4), (2, 6, 5, 1)])
 def test_conj_grad_two_launches_per_iteration_vs_oracle_and_three_launch_form(dev, t, c, w, iters):
     """cine_conj_grad: the whole solve of reference cinenet.py:136-171 (set-up + `iters` iterations, two launches each: the operator forms
