@@ -136,6 +136,9 @@ _SIGS = {
     "cine_pack_conv3x3_dgrad": (c_int, [P, P, c_int, c_int, P]),
     "cine_pack_tconv2x2_dgrad": (c_int, [P, P, c_int, c_int, P]),
     "cine_pack_conv1x1_dgrad": (c_int, [P, P, c_int, c_int, P]),
+    "cine_pack_desc_bytes": (c_size_t, []),
+    "cine_pack_desc": (c_int, [P, c_int, P, P, c_int, c_int]),
+    "cine_pack_batch": (c_int, [P, c_int, c_long, P]),
     "cine_conv3x3_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_tconv2x2_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_conv1x1_dgrad": (c_int, [P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -71,7 +71,7 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
         raise CineHipError("cine_unet2d_train_ws_bytes rejected the shape")
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
-    check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(), len(weights.unets), n, h, w, cin,
+    check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(train=True), len(weights.unets), n, h, w, cin,
                                           weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()),
           "cine_unet2d_forward_train")
     ws.cine_slope = ops.lrelu_slope()                  # the backward pass differentiates the activation the forward pass applied
@@ -266,7 +266,7 @@ class MwcnnFn(Function):
         need = L.cine_mwcnn_train_ws_bytes(n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters)
         ws = torch.empty(max(need, 1), device=x.device, dtype=torch.uint8)
         y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
-        check(L.cine_mwcnn_forward_train(x.data_ptr(), y.data_ptr(), w.pointers(), w2.pointers() if two else None, int(split) if two else n,
+        check(L.cine_mwcnn_forward_train(x.data_ptr(), y.data_ptr(), w.pointers(train=True), w2.pointers(train=True) if two else None, int(split) if two else n,
                                          n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.n_first_convs, net.first_conv_n_filters,
                                          int(net.res), ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
         ctx.slope = ops.lrelu_slope()
@@ -411,7 +411,7 @@ class XpdRegFn(Function):
             ws = torch.empty(max(need, 1), device=planes.device, dtype=torch.uint8)
             y = torch.empty((nn_, net.out_chans, hh, ww), device=planes.device, dtype=planes.dtype)
             two = w2 is not None and w2 is not w1
-            check(L.cine_mwcnn_forward_train(planes.data_ptr(), y.data_ptr(), w1.pointers(), w2.pointers() if two else None, split if two else nn_,
+            check(L.cine_mwcnn_forward_train(planes.data_ptr(), y.data_ptr(), w1.pointers(train=True), w2.pointers(train=True) if two else None, split if two else nn_,
                                              nn_, hh, ww, cin, net.out_chans, net.n_scales, w1.nf, w1.nc, net.n_first_convs,
                                              net.first_conv_n_filters, int(net.res), ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward_train")
             ws.cine_slope = ops.lrelu_slope()

@@ -779,6 +779,66 @@ def _pack(kind: str, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _BatchedPacks:
+    """Packed copies of a network's 2-D conv weights in PERSISTENT buffers, re-packed by ONE launch when a parameter's version moves (training:
+    every optimiser step; per tensor that was 596 launches of 4 us in a cfg-3 step).  ``pointers(items)``: items = (kind, parameter) in pointer-list
+    order, kind in _OPS or "raw" (the parameter itself, e.g. a bias) or None (a NULL slot).  The descriptor table goes to the device once per
+    (parameter addresses, cache epoch); inside a hipGraph capture only the re-pack launch is enqueued, so a captured training step packs in place.
+    Inference keeps its own per-tensor packs (UnetWeights.pointers()): graphs captured from those never see these buffers change."""
+    _OPS = {"c3": 0, "tc": 1, "c1": 2, "c3d": 3, "tcd": 4, "c1d": 5}
+
+    def __init__(self):
+        self.idkey = self.vkey = None
+        self.keep = []                       # superseded buffers stay alive: a captured graph may still re-pack into them
+
+    @classmethod
+    def supports(cls, items) -> bool:
+        return all(k is None or k == "raw" or (k in cls._OPS and p.dim() == 4) for k, p in items)
+
+    def pointers(self, items):
+        L = lib()
+        live = [(k, p) for k, p in items if k is not None]
+        idkey = (_cache_epoch,) + tuple((k, p.data_ptr(), tuple(p.shape)) for k, p in live)
+        vkey = tuple(p._version for _, p in live)
+        if idkey != self.idkey:
+            _no_capture("packed training weights", pack=False)      # the table is built by an eager step (GraphedTrainingStep's warm-up)
+            dev = live[0][1].device
+            sizes, dims = [], []
+            for k, p in live:
+                if k == "raw":
+                    sizes.append(0); dims.append(None); continue
+                a, b = int(p.shape[0]), int(p.shape[1])
+                fl = {"c3": L.cine_conv3x3_packed_floats, "tc": L.cine_tconv2x2_packed_floats, "c1": L.cine_conv1x1_packed_floats,
+                      "c3d": L.cine_conv3x3_dgrad_packed_floats, "tcd": L.cine_tconv2x2_dgrad_packed_floats, "c1d": L.cine_conv1x1_dgrad_packed_floats}[k](a, b)
+                sizes.append((int(fl) + 63) // 64 * 64); dims.append((a, b))
+            flat = torch.empty(max(sum(sizes), 1), device=dev, dtype=torch.float32)
+            nb = L.cine_pack_desc_bytes()
+            host = ctypes.create_string_buffer(nb * max(1, sum(1 for s_ in sizes if s_)))
+            ptrs, off, nd = [], 0, 0
+            params = []
+            for (k, p), sz, dm in zip(live, sizes, dims):
+                src = _dev(p.detach(), "weight")
+                params.append(src)
+                if k == "raw":
+                    ptrs.append(src.data_ptr()); continue
+                dst = flat.data_ptr() + 4 * off
+                check(L.cine_pack_desc(ctypes.addressof(host) + nb * nd, self._OPS[k], src.data_ptr(), dst, dm[0], dm[1]), "cine_pack_desc")
+                ptrs.append(dst); off += sz; nd += 1
+            desc = torch.frombuffer(bytearray(host.raw), dtype=torch.uint8).to(dev) if nd else None
+            out, it = [], iter(ptrs)
+            for k, _ in items:
+                out.append(None if k is None else next(it))
+            self.keep.append((flat, desc))
+            self.flat, self.desc, self.nd, self.max_total = flat, desc, nd, max(sizes) if sizes else 0
+            self.ptrs = (ctypes.c_void_p * len(out))(*out)
+            self.idkey, self.vkey = idkey, None
+        if vkey != self.vkey:
+            if self.nd:
+                check(L.cine_pack_batch(self.desc.data_ptr(), self.nd, self.max_total, _stream()), "cine_pack_batch")
+            self.vkey = vkey
+        return self.ptrs
+
+
 def pack_conv3x3(w): return _pack("c3", w)
 def pack_tconv2x2(w): return _pack("tc", w)
 def pack_conv1x1(w): return _pack("c1", w)
@@ -900,8 +960,15 @@ class UnetWeights:
             out.append(seq)
         return out
 
-    def pointers(self):
+    def pointers(self, train: bool = False):
+        """train=True (the training forward): persistent packs re-packed by one launch per optimiser step (_BatchedPacks)."""
         params = self._params()
+        if train:
+            items = [(k, p) for seq in params for k, p in seq]
+            if _BatchedPacks.supports(items):
+                if self.__dict__.get("_tp") is None:
+                    self._tp = _BatchedPacks()
+                return self._tp.pointers(items)
         key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
         if key != self._key:
             _no_capture("packed U-Net weights", pack=True)
@@ -958,6 +1025,11 @@ class UnetWeights:
     def dgrad_pointers(self):
         """Input-gradient packings in the order of ``pointers()`` (NULL in the bias slot); re-packed when a parameter changes."""
         params = self._params()
+        items = [(None if k == "raw" else k + "d", p) for seq in params for k, p in seq]
+        if _BatchedPacks.supports(items):
+            if self.__dict__.get("_tdp") is None:
+                self._tdp = _BatchedPacks()
+            return self._tdp.pointers(items)
         key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for seq in params for _, p in seq)
         if key != self._dkey:
             _no_capture("packed U-Net gradient weights", pack=True)
@@ -1033,8 +1105,12 @@ class MwcnnWeights:
         seq += [("c3", n.first_convs[-1].weight), ("raw", n.first_convs[-1].bias)]
         return seq
 
-    def pointers(self):
+    def pointers(self, train: bool = False):
         params = self._params()
+        if train and _BatchedPacks.supports(params):
+            if self.__dict__.get("_tp") is None:
+                self._tp = _BatchedPacks()
+            return self._tp.pointers(params)
         key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for _, p in params)
         if key != self._key:
             _no_capture("packed MWCNN weights", pack=True)
@@ -1057,6 +1133,11 @@ class MwcnnWeights:
 
     def dgrad_pointers(self):
         params = self._params()
+        items = [(None if k == "raw" else "c3d", p) for k, p in params]
+        if _BatchedPacks.supports(items):
+            if self.__dict__.get("_tdp") is None:
+                self._tdp = _BatchedPacks()
+            return self._tdp.pointers(items)
         key = (_cache_epoch,) + tuple((p.data_ptr(), p._version) for _, p in params)
         if key != getattr(self, "_dkey", None):
             _no_capture("packed MWCNN gradient weights", pack=True)

@@ -832,10 +832,10 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(Conv1Args a) {
 // tconv   (cin, cout, 2, 2)        -> [chunk][1][ck][rowsp]       rows = 4*cout, row = 2*(a*cout + co) + b: the two x-parities
 //                                     of one output channel sit in adjacent lanes, which pair up for 16-byte stores
 // conv1x1 (cout, cin)              -> [chunk][1][ck][rowsp]       rows = cout
-__global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout, int cin, int rows, int rowsp,
-                                    int taps, int ck_, int nchunks) {
+__device__ __forceinline__ void pack_weights_body(const float* w, float* p, int kind, int cout, int cin, int rows, int rowsp,
+                                                  int taps, int ck_, int nchunks, long e0, long stride) {
     const long total = (long)nchunks * taps * ck_ * rowsp;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    for (long e = e0; e < total; e += stride) {
         const int m = (int)(e % rowsp);
         long r = e / rowsp;
         const int ck = (int)(r % ck_); r /= ck_;
@@ -854,6 +854,17 @@ __global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout
         }
         p[e] = v;
     }
+}
+__global__ void pack_weights_kernel(const float* w, float* p, int kind, int cout, int cin, int rows, int rowsp,
+                                    int taps, int ck_, int nchunks) {
+    pack_weights_body(w, p, kind, cout, cin, rows, rowsp, taps, ck_, nchunks, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+// Every 2-D conv weight of a network in ONE launch (training re-packs after every optimiser step: 596 launches of 4 us per cfg-3 step): blockIdx.y
+// picks a descriptor -- the arguments pack_weights_kernel would get for that tensor -- from device memory (cine_pack_desc / cine_pack_batch).
+struct PackDesc { const float* w; float* p; int kind, cout, cin, rows, rowsp, taps, ck, nchunks; };
+__global__ void pack_weights_batch_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    pack_weights_body(d.w, d.p, d.kind, d.cout, d.cin, d.rows, d.rowsp, d.taps, d.ck, d.nchunks, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // conv3d (cout, cin, 3, 3, 3) -> [dz][8-channel chunk][3x3 tap][8 channels][rowsp]: the chunk order of the V3 kernels (the
@@ -1541,6 +1552,38 @@ extern "C" int cine_pack_tconv2x2_dgrad(const float* w, float* packed, int cin, 
 }
 extern "C" int cine_pack_conv1x1_dgrad(const float* w, float* packed, int cout, int cin, void* stream) {
     return pack_general(w, packed, 7, cin, cout, 1, kCK1, stream, "cine_pack_conv1x1_dgrad");
+}
+
+// Batched packing.  cine_pack_desc writes, into HOST memory, the descriptor of one tensor: op 0 = cine_pack_conv3x3 (n1 = cout, n2 = cin), 1 = cine_pack_tconv2x2
+// (cin, cout), 2 = cine_pack_conv1x1 (cout, cin), 3 = cine_pack_conv3x3_dgrad (cout, cin), 4 = cine_pack_tconv2x2_dgrad (cin, cout), 5 = cine_pack_conv1x1_dgrad
+// (cout, cin) -- the same arguments, the same packed layout and size.  The caller copies an array of them to the device once (the parameters and their
+// packed buffers keep their addresses across optimiser steps) and cine_pack_batch re-packs all of them in one launch.
+extern "C" size_t cine_pack_desc_bytes(void) { return sizeof(PackDesc); }
+extern "C" int cine_pack_desc(void* desc_host, int op, const float* w, float* packed, int n1, int n2) {
+    CINE_REQUIRE(desc_host && w && packed && n1 > 0 && n2 > 0 && op >= 0 && op <= 5, CINE_EINVAL, "cine_pack_desc: bad arguments");
+    PackDesc d{};
+    d.w = w; d.p = packed;
+    if (op <= 2) {                       // pack(): kind = op, (cout, cin) = (n1, n2) except the transpose conv's (cin, cout)
+        const int cout = op == 1 ? n2 : n1, cin = op == 1 ? n1 : n2;
+        d.kind = op; d.cout = cout; d.cin = cin;
+        d.rows = op == 1 ? 4 * cout : cout; d.taps = op == 0 ? 9 : 1; d.ck = op == 0 ? kCK3 : kCK1;
+        d.rowsp = ceil_div(d.rows, 16) * 16; d.nchunks = ceil_div(cin, d.ck);
+    } else {                             // pack_general(kind, rows, kdim): the kernel's `cin` is the K dimension
+        if (op == 3) { d.kind = 5; d.rows = n2; d.cin = n1; d.taps = 9; d.ck = kCK3; }              // (cout, cin): rows = cin, K = cout
+        else if (op == 4) { d.kind = 2; d.rows = n1; d.cin = 4 * n2; d.taps = 1; d.ck = kCK1; }     // (cin, cout): rows = cin, K = 4 cout
+        else { d.kind = 7; d.rows = n2; d.cin = n1; d.taps = 1; d.ck = kCK1; }                      // (cout, cin): rows = cin, K = cout
+        d.cout = 0;
+        d.rowsp = ceil_div(d.rows, 16) * 16; d.nchunks = ceil_div(d.cin, d.ck);
+    }
+    *reinterpret_cast<PackDesc*>(desc_host) = d;
+    return CINE_OK;
+}
+extern "C" int cine_pack_batch(const void* descs_dev, int n, long max_total, void* stream) {
+    CINE_REQUIRE(descs_dev && n > 0 && n <= 65535 && max_total > 0, CINE_EINVAL, "cine_pack_batch: bad arguments");
+    ProfScope prof(F_MISC, as_stream(stream));
+    const unsigned gx = (unsigned)std::max(1L, std::min(64L, ceil_div(max_total, 256L)));
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(gx, (unsigned)n), dim3(256), 0, as_stream(stream), reinterpret_cast<const PackDesc*>(descs_dev));
+    return check_launch("pack_weights_batch_kernel");
 }
 
 extern "C" int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,

@@ -526,6 +526,15 @@ size_t cine_conv1x1_dgrad_packed_floats(int cout, int cin);
 int cine_pack_conv3x3_dgrad(const float* w, float* packed, int cout, int cin, void* stream);
 int cine_pack_tconv2x2_dgrad(const float* w, float* packed, int cin, int cout, void* stream);
 int cine_pack_conv1x1_dgrad(const float* w, float* packed, int cout, int cin, void* stream);
+/* Batched packing (training re-packs every weight after every optimiser step: hundreds of 4-us launches per step otherwise).  cine_pack_desc writes
+ * into HOST memory (cine_pack_desc_bytes() each) the descriptor of one tensor: op 0 = cine_pack_conv3x3 (n1 = cout, n2 = cin), 1 = cine_pack_tconv2x2
+ * (cin, cout), 2 = cine_pack_conv1x1 (cout, cin), 3 = cine_pack_conv3x3_dgrad (cout, cin), 4 = cine_pack_tconv2x2_dgrad (cin, cout),
+ * 5 = cine_pack_conv1x1_dgrad (cout, cin): the same arguments, layout and size as that entry point.  The caller copies the array to the device once
+ * (parameters and packed buffers keep their addresses across steps); cine_pack_batch re-packs all n of them in ONE launch (max_total: the largest
+ * packed size in floats, for the grid). */
+size_t cine_pack_desc_bytes(void);
+int cine_pack_desc(void* desc_host, int op, const float* w, float* packed, int n1, int n2);
+int cine_pack_batch(const void* descs_dev, int n, long max_total, void* stream);
 /* gx = d loss / d (conv input) from gy = d loss / d (raw conv output); wpacked* from the packings above (two sets: samples
  * >= set_split use wpacked2, NULL = one set).  conv3x3: gy (n, cout, h, w) -> gx (n, cin, h, w); tconv: gy (n, cout, 2h, 2w) ->
  * gx (n, cin, h, w); conv1x1: gy (n, cout, h, w) -> gx (n, cin, h, w). */

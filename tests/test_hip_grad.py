@@ -779,6 +779,43 @@ def test_training_loop_tracks_the_oracle_and_learns(dev):
         assert abs(a - b) < 2e-3 * max(abs(b), 1e-3), (lh, lr_)
 
 
+def test_batched_weight_packs_equal_the_per_tensor_packs_and_follow_the_parameters(dev):
+    """cine_pack_desc / cine_pack_batch (training re-packs every weight after every optimiser step in ONE launch into persistent buffers) against the
+    per-tensor entry points, bit for bit: forward and input-gradient packings of a 2-D U-Net (3x3, transpose, 1x1 weights, odd channel counts) and of
+    an MWCNN; after an in-place parameter update the same buffers hold the new packs."""
+    from reconstruction.models.denoisers.unet import Unet
+    from reconstruction.models.denoisers.mwcnn import MWCNN
+    from cine_hip import ops, synth
+    unet = Unet(5, 2, in_chans=3, out_chans=2); synth.fill_parameters_(unet, 3, keep=()); unet = unet.to(dev)
+    mw = MWCNN(6, 4, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[2, 1], n_first_convs=1, first_conv_n_filters=8, res=False)
+    synth.fill_parameters_(mw, 4, keep=()); mw = mw.to(dev)
+
+    def check_all(w, items_fwd):
+        for train_ptrs, holder, items in ((w.pointers(train=True), w._tp, items_fwd),
+                                          (w.dgrad_pointers(), w._tdp, [(None if k == "raw" else k + "d", p) for k, p in items_fwd])):
+            off = 0
+            for (k, p), ptr in zip(items, list(train_ptrs)):
+                if k is None:
+                    assert ptr is None; continue
+                if k == "raw":
+                    assert ptr == p.data_ptr(); continue
+                want = ops._pack(k, p)
+                assert ptr == holder.flat.data_ptr() + 4 * off
+                assert torch.equal(holder.flat[off:off + want.numel()], want), k
+                off += (want.numel() + 63) // 64 * 64
+    u = ops.UnetWeights([unet])
+    items_u = [(k, p) for seq in u._params() for k, p in seq]
+    m = ops.MwcnnWeights(mw)
+    items_m = list(m._params())
+    check_all(u, items_u); check_all(m, items_m)
+    addr = (u._tp.flat.data_ptr(), m._tdp.flat.data_ptr())
+    with torch.no_grad():
+        for p in list(unet.parameters()) + list(mw.parameters()):
+            p.mul_(1.5).add_(0.01)
+    check_all(u, items_u); check_all(m, items_m)
+    assert addr == (u._tp.flat.data_ptr(), m._tdp.flat.data_ptr())          # re-packed in place
+
+
 @pytest.mark.parametrize("family", ["varnet_XF", "cinenet_3D"])
 def test_training_step_captured_in_one_hipgraph_matches_the_eager_step(dev, family):
     """cine_hip.train.GraphedTrainingStep: forward + SSIMLoss + backward (two streams: the weight gradients' side lane is captured as a branch) + a
