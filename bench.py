@@ -153,11 +153,13 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl), the device barrier and the all-gather of the volume assembly even at --gpus 1 "
                          "(start under `python -m torch.distributed.run --nproc-per-node=1`, or alone: rank 0 of a world of 1)")
+    ap.add_argument("--branches", type=int, default=0, help="concurrent branches of every 2-D U-Net pass in the timed mode (1, 2 or 4; 0 = the binding's default)")
     ap.add_argument("--no-conv-plane", action="store_true", help="A/B: route the plane-wide 3x3 / transpose convs through the general kernel (cine_set_conv_plane(0))")
     ap.add_argument("--conv-plane-mask", type=int, default=-1, help="A/B: cine_set_conv_plane(mask) of the bench's thread: bit 0 the plane-wide 3x3 convs, bit 1 the transpose convs, bit 2 the wide-plane / volume kernel "
                          "(conv_wide_kernel: cfg 4, cfg 5, the sensitivity net), bit 4 SET = the general weight-gradient kernel; 7 = all lean kernels (the default)")
     ap.add_argument("--pin-numa", action="store_true", help="pin this process to its GPU's NUMA node at --gpus 1 too (always done for N > 1)")
     ap.add_argument("--sustained-seconds", type=float, default=60.0, help="length of the extra sustained region (0 = skip)")
+    ap.add_argument("--latency-only", action="store_true", help="diagnostics: print latency_modes_ms of --config (one slice alone, every launch form) and exit")
     ap.add_argument("--headline-only", action="store_true", help="skip the latency / sustained regions and the other_configs / train_step extras of the default 1-GPU line")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the launcher, sharding, timed region and all-gather on "
@@ -492,6 +494,53 @@ class Workload:
         ts.sort()
         return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
 
+    def latency_modes(self, reps=15, branch_counts=(1, 2, 4)):
+        """`latency_one_slice` for every launch form of ONE slice: hipGraph replay and eager launches, with the 2-D U-Net passes on one stream or as
+        2 / 4 concurrent branches (cine_unet2d_forward_branches: x-f / y-f networks, coil halves of the sens-net; bit-identical outputs).  The
+        graphs of the timed region are left alone; the extra ones are captured for slice 0 on stream 0 and dropped afterwards."""
+        from cine_hip import ops
+        out = {}
+        st = self.streams[0]
+        ref = None
+        for nb in branch_counts:
+            with ops.branches(nb):
+                with torch.cuda.stream(st):
+                    o = self.forward(0).clone()                  # warms this stream's side streams outside capture
+                torch.cuda.synchronize()
+                ref = o if ref is None else ref
+                same = bool(torch.equal(o, ref))
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    with torch.cuda.stream(st):
+                        self.forward(0)
+                    st.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                rec = {"eager_ms": ts[len(ts) // 2] * 1e3, "eager_min_ms": ts[0] * 1e3, "bit_identical_to_one_stream": same}
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=st):
+                        go = self.forward(0)
+                    with torch.cuda.stream(st):
+                        g.replay()
+                    torch.cuda.synchronize()
+                    rec["bit_identical_to_one_stream"] = same and bool(torch.equal(go, ref))
+                    ts = []
+                    for _ in range(reps):
+                        t0 = time.perf_counter()
+                        with torch.cuda.stream(st):
+                            g.replay()
+                        st.synchronize()
+                        ts.append(time.perf_counter() - t0)
+                    ts.sort()
+                    rec["graph_ms"], rec["graph_min_ms"] = ts[len(ts) // 2] * 1e3, ts[0] * 1e3
+                    del g, go
+                except Exception as e:                                    # pragma: no cover
+                    rec["graph_error"] = f"{type(e).__name__}: {e}"
+            out[str(nb)] = rec
+        return out
+
     def sustained(self, seconds, est_step_s):
         """One long region of the timed mode (no volume assembly, no host sync inside): an event per finished slice, then the
         slices finished in every 1-s window.  Shows what clocks / power settle at, which a 0.13 s region cannot."""
@@ -804,10 +853,16 @@ def main():
     from cine_hip import shard
     shard.FORCE_COLLECTIVE = bool(args.force_dist)
     if args.no_conv_plane or args.conv_plane_mask >= 0:
-        from cine_hip._lib import lib
-        lib().cine_set_conv_plane(0 if args.no_conv_plane else args.conv_plane_mask)
+        from cine_hip import ops as cine_ops
+        cine_ops.set_conv_plane(0 if args.no_conv_plane else args.conv_plane_mask)
+    if args.branches > 0:
+        from cine_hip import ops as cine_ops
+        cine_ops.UNET_BRANCHES = args.branches
     wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
     cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
+    if args.latency_only:
+        print(json.dumps({"config": args.config, "latency_ms_one_slice": wl.latency_one_slice(), "latency_modes_ms": wl.latency_modes()}))
+        return
     wl.run(args.warmup, False)
     if dist.is_initialized() and (world > 1 or shard.FORCE_COLLECTIVE):
         # the warm-up also covers the timed region's collectives: RCCL sets up its channels on the first barrier / all-gather
@@ -821,6 +876,7 @@ def main():
     dt_h2d = wl.timed(args.steps, h2d=True)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     lat_med, lat_min = (None, None) if args.headline_only else wl.latency_one_slice()
+    lat_modes = None if (args.headline_only or rank != 0) else wl.latency_modes()
     sustained = wl.sustained(args.sustained_seconds, dt / args.steps) if args.sustained_seconds > 0 and not args.headline_only else None
 
     if rank != 0:
@@ -853,6 +909,10 @@ def main():
         "latency_ms_one_slice": lat_med, "latency_ms_one_slice_min": lat_min,
         "latency_note": "one hipGraph replay on one stream, nothing else in flight, host clock around launch + stream sync: what "
                         "run_inference.py:53-61 times per slice (median / min of 15)",
+        "latency_modes_ms": lat_modes,
+        "latency_modes_note": "one slice alone, host clock around enqueue + stream sync, median / min of 15, per launch form: key = concurrent branches of "
+                              "every 2-D U-Net pass (1 = one stream; 2 = x-f / y-f networks and coil halves beside each other on a side stream; 4 = "
+                              "each halved again); eager launches or one hipGraph replay (the side streams are branches of the captured graph)",
         "sustained_value": sustained["value"] if sustained else None, "sustained": sustained,
         "repeat_values": [slices / d for d in extra], "repeat_median_value": (slices / extra[len(extra) // 2]) if extra else None,
         "value_with_h2d": slices / dt_h2d,

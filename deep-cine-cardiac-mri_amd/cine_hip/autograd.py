@@ -31,22 +31,37 @@ from ._lib import CineHipError, check, lib
 _p = ops._p
 _stream = ops._stream
 
-_SIDE_STREAMS = {}
-
-
 def _use_side_stream(device: torch.device) -> None:
-    """Hand this thread's second stream (one torch stream per device, created here: the library creates none) to the backward
-    entry points that run weight gradients beside the input-gradient chain (cine_set_side_stream).  CINE_SIDE_STREAM=0 in the
-    environment of THIS binding keeps the whole backward pass on the caller's stream."""
+    """Hand a second stream (``ops.side_streams``: one per (device, current stream), created by the binding -- the library creates none) to
+    the backward entry points that run weight gradients beside the input-gradient chain (cine_set_side_stream).  CINE_SIDE_STREAM=0 in
+    the environment of THIS binding keeps the whole backward pass on the caller's stream."""
     import os
     if os.environ.get("CINE_SIDE_STREAM", "1") == "0":
         check(lib().cine_set_side_stream(None), "cine_set_side_stream")
         return
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _SIDE_STREAMS.get(idx)
-    if st is None:
-        st = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-    check(lib().cine_set_side_stream(st.cuda_stream), "cine_set_side_stream")
+    check(lib().cine_set_side_stream(ops.side_streams(device, 1)[0].cuda_stream), "cine_set_side_stream")
+
+
+def _masked(cls):
+    """Class decorator of every Function below: the diagnostic kernel-selection mask is a setting of the CALLING THREAD
+    (cine_set_conv_plane), and torch runs ``backward`` on the autograd engine's device thread -- so the forward records the caller's mask
+    (``ops.conv_plane_mask()``) and the backward applies it to whichever thread it runs on before it launches anything."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def forward(ctx, *args):
+        ctx.cine_plane_mask = ops.conv_plane_mask()
+        return fwd(ctx, *args)
+
+    def backward(ctx, *grads):
+        ops.apply_conv_plane(getattr(ctx, "cine_plane_mask", 7))
+        try:
+            return bwd(ctx, *grads)
+        finally:
+            ops.apply_conv_plane(ops.conv_plane_mask())      # back to this thread's own setting
+
+    forward.__doc__, backward.__doc__ = fwd.__doc__, bwd.__doc__
+    cls.forward, cls.backward = staticmethod(forward), staticmethod(backward)
+    return cls
 
 
 def _c(x: torch.Tensor) -> torch.Tensor:
@@ -71,9 +86,17 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
         raise CineHipError("cine_unet2d_train_ws_bytes rejected the shape")
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
-    check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(train=True), len(weights.unets), n, h, w, cin,
-                                          weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()),
-          "cine_unet2d_forward_train")
+    nb = ops._branch_count(n, len(weights.unets))
+    if nb > 1:          # the same launch sequence as concurrent branches into the same workspace layout (bit-identical)
+        side = ops.side_streams(x.device, nb - 1)
+        sarr = (ctypes.c_void_p * len(side))(*[s_.cuda_stream for s_ in side])
+        check(lib().cine_unet2d_forward_branches(x.data_ptr(), y.data_ptr(), weights.pointers(train=True), len(weights.unets), n, h, w, cin,
+                                                 weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream(),
+                                                 sarr, len(side), 1), "cine_unet2d_forward_branches")
+    else:
+        check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(train=True), len(weights.unets), n, h, w, cin,
+                                              weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()),
+              "cine_unet2d_forward_train")
     ws.cine_slope = ops.lrelu_slope()                  # the backward pass differentiates the activation the forward pass applied
     ws.cine_training_key = key                       # checked by unet2d_backward
     return y, ws
@@ -121,6 +144,7 @@ def _param_grads(weights: "ops.UnetWeights", grads, params: Sequence[torch.Tenso
     return tuple(out.get(id(p)) for p in params)
 
 
+@_masked
 class UnetFn(Function):
     """y = Unet(x) on (n, in_ch, h, w) planes; ``params`` = the distinct parameters of ``weights`` (for autograd's bookkeeping)."""
 
@@ -143,6 +167,7 @@ def unet2d(x: torch.Tensor, weights: "ops.UnetWeights") -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ NormUnet (2-D)
+@_masked
 class NormUnetFn(Function):
     """NormUnet.forward (norm_unet.py:98-114) on x (n, h, w, 2)."""
 
@@ -183,6 +208,7 @@ def norm_unet(x: torch.Tensor, weights: "ops.UnetWeights", norm: bool = True) ->
 
 
 # ------------------------------------------------------------------ x-f / y-f regulariser (both NormUnets)
+@_masked
 class XfyfFn(Function):
     """VarNetBlock.xfyf_transform (varnet.py:196-241) on image (b, t, h, w, 2) -> (b, t, 1, h, w, 2).
     ``wboth`` holds both U-Nets (x-f first); ``wx`` / ``wy`` the single ones for plane sets of different shapes."""
@@ -252,6 +278,7 @@ def xfyf(image: torch.Tensor, xf: bool, wboth, wx, wy, norm: bool = True) -> tor
 
 
 # ------------------------------------------------------------------ MWCNN
+@_masked
 class MwcnnFn(Function):
     """MWCNN.forward (denoisers/mwcnn.py:135-179) on (n, in_ch, h, w) planes.  ``w2`` / ``split``: samples [split, n) go through a second
     network of the same topology in the same launches (XPDNet's x-t / y-t networks); ``params`` = the parameters of both, for autograd."""
@@ -319,6 +346,7 @@ def mwcnn(x: torch.Tensor, w, w2=None, split: int = 0) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ coil operators
+@_masked
 class ImageDcFn(Function):
     """cine_image_dc with the soft-DC weights of softplus(lambda) (varnet.py:181-194, 281-282):
     out = sum_c conj(S_c) T(S_c m) + v / (1 + v) zf,  T = IFFT_h [mask ? 1 / (1 + v) : 1] FFT_h."""
@@ -361,6 +389,7 @@ class ImageDcFn(Function):
         return gm, gs, gzf, None, glam
 
 
+@_masked
 class ImageDcFixedFn(Function):
     """cine_image_dc with fixed weights: sum_c conj(S_c) IFFT_h[(mask ? w1 : w0) FFT_h(S_c m)] + beta zf -- XPDNet's K step + masked backward
     operator A^H M (A x - k_ref) is (1, 0, -1) (xpdnet.py:128-131, 161-167, 295-298)."""
@@ -392,6 +421,7 @@ class ImageDcFixedFn(Function):
         return gm, gs, gzf, None, None, None, None
 
 
+@_masked
 class XpdRegFn(Function):
     """XPDNetBlock's I-step network (xpdnet.py:424-509) for the XT / XF dynamic types: buffer (b, t, 1, h, w, 2n) + backward-operator image
     -> new buffer, through cine_xpd_pack, the two MWCNNs (one launch sequence when the plane sets have one shape) and cine_xpd_unpack."""
@@ -494,6 +524,7 @@ def xpd_regularise(buf, extra, n, n_scales, xf, wx, wy):
 
 
 # ---- 3-D U-Net (denoisers/unet.py with dims = 3) -----------------------------------------------------------------------------------------
+@_masked
 class Unet3dFn(Function):
     """y = Unet(x), dims = 3, on (n, in_ch, d, h, w): cine_unet3d_forward_train keeps every raw layer output with its merged InstanceNorm record,
     cine_unet3d_backward walks them in reverse with the kernels of the 2-D backward pass (InstanceNorm + LeakyReLU backward on (d h, w) planes with
@@ -572,6 +603,7 @@ def _conv3d_wgrad(x, g, weight, want_bias):
     return gwz.permute(1, 2, 0, 3, 4).contiguous(), gb
 
 
+@_masked
 class Conv3dBiasReluFn(Function):
     """y = [ReLU](Conv3d(x; W, 3x3x3, 'same') + b) on (n, c, d, h, w) (kspace_net.py:33-46)."""
 
@@ -598,6 +630,7 @@ class Conv3dBiasReluFn(Function):
         return gx, gw if need[1] else None, gb, None
 
 
+@_masked
 class SensExpandFn(Function):
     """k = [M] FFT2(S x) (xpdnet.py:104-131, ForwardOperator): x (b, t, 1, h, w, 2), maps (b, 1, c, h, w, 2) -> (b, t, c, h, w, 2)."""
 
@@ -621,6 +654,7 @@ class SensExpandFn(Function):
         return gx, gs, None
 
 
+@_masked
 class SensReduceFn(Function):
     """x = sum_c conj(S_c) IFFT2([M] k) (xpdnet.py:137-167, BackwardOperator) with gradients for the k-space too (the dual buffer is learned)."""
 
@@ -673,6 +707,7 @@ def _conv_dgrad(g, weight):
     return gx
 
 
+@_masked
 class ConvSumFn(Function):
     """y = [ReLU](conv3x3(cat(x0, x1); W) + bias + addend): the "conv_x(a) + conv_h(b)" pairs of the CRNN body (recurrent_varnet.py:122-134)
     as one convolution over the concatenated inputs; W (cout, c0 + c1, 3, 3) in the module's own layout."""
@@ -712,6 +747,7 @@ class ConvSumFn(Function):
         return gx0, gx1, gw if need[2] else None, gb, g if has_add and need[4] else None, None
 
 
+@_masked
 class BcrnnFn(Function):
     """BCRNNlayer.forward (recurrent_varnet.py:220-259) for batch 1: P_t = conv([hid_iter_t, x_t]; [W_ih2ih | W_i2h]) + the three biases for
     all frames in one launch, then both time sweeps h_t = ReLU(conv(h_prev; W_h2h) + P_t) step by step (both directions in one launch
@@ -791,6 +827,7 @@ def coil_accum(g: Optional[torch.Tensor], z: torch.Tensor) -> torch.Tensor:
     return gs
 
 
+@_masked
 class CoilReduceFn(Function):
     """sens_reduce(mask * k) (varnet.py:187-194) as a function of the maps; k-space is data (no gradient)."""
 
@@ -813,6 +850,7 @@ class CoilReduceFn(Function):
         return None, coil_accum(gout, z), None
 
 
+@_masked
 class RssNormFn(Function):
     """x / rss_complex(x, coil) (varnet.py:58-59) on (b, c, h, w, 2)."""
 
@@ -832,6 +870,7 @@ class RssNormFn(Function):
         return gx
 
 
+@_masked
 class AbsFn(Function):
     """complex_abs (utils/math.py:48-62)."""
 
@@ -850,6 +889,7 @@ class AbsFn(Function):
         return gx
 
 
+@_masked
 class ConjFn(Function):
     """complex_conj (utils/math.py:36-45): the adjoint of conjugation is conjugation."""
 
@@ -862,6 +902,7 @@ class ConjFn(Function):
         return ops.complex_conj(ops._dev(_c(gy), "complex_conj output gradient"))
 
 
+@_masked
 class RollFn(Function):
     """fftc.roll (utils/fftc.py:141-163): the adjoint of a circular shift is the opposite shift."""
 
@@ -876,6 +917,7 @@ class RollFn(Function):
         return ops.roll(ops._dev(_c(gy), "roll output gradient"), [-s for s in shifts], list(dims)), None, None
 
 
+@_masked
 class Pad2dFn(Function):
     """F.pad(x, [left, right, top, bottom]) of padding.pad_for_mwcnn (utils/padding.py:46): the adjoint crops."""
 
@@ -891,6 +933,7 @@ class Pad2dFn(Function):
         return gy[..., top:h - bottom, left:w - right].contiguous(), None, None, None, None
 
 
+@_masked
 class CenteredFftFn(Function):
     """utils.fftc fft1c / ifft1c / fft2c / ifft2c (fftc.py:13-117) times a scalar: the centered orthonormal transform is unitary, so the
     adjoint of s F is s F^-1 -- the same kernel in the other direction on the output gradient."""
@@ -931,6 +974,7 @@ def _lam_grad(dot: torch.Tensor, lam: torch.Tensor) -> torch.Tensor:
     return (dot * torch.sigmoid(lam.detach())).view(lam.shape)
 
 
+@_masked
 class AxpbyLamFn(Function):
     """a + softplus(lambda) * b: CineNet's right-hand side x_ref + v x_reg (cinenet.py:255-257)."""
 
@@ -950,6 +994,7 @@ class AxpbyLamFn(Function):
         return ga, gb, gl
 
 
+@_masked
 class ConjGradFn(Function):
     """CineNetBlock.ConjGrad (cinenet.py:136-171): K iterations of conjugate gradients on H x = b, H = A^H M A + softplus(lambda) I,
     from the start value x0.  The reference takes alpha and beta out of the graph (``.item()``, :159-169), so the iteration it
@@ -1022,6 +1067,7 @@ class ConjGradFn(Function):
         return gx0, (gb if need[1] else None), glam, None, None, None
 
 
+@_masked
 class SsimLossFn(Function):
     """SSIMLoss.forward (utils/losses.py:25-58) on GPU tensors: x = reconstruction, y = target, both (t, h, w)."""
 

@@ -57,6 +57,91 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- the calling thread's diagnostic kernel-selection mask (cine_set_conv_plane) ------------------------------------------------------
+_CONV_PLANE_DEFAULT = 7
+
+
+def conv_plane_mask() -> int:
+    """The mask this thread set through ``set_conv_plane`` (default 7 = every lean kernel, lean weight gradients)."""
+    return getattr(_act_tls, "plane_mask", _CONV_PLANE_DEFAULT)
+
+
+def set_conv_plane(mask: int) -> None:
+    """cine_set_conv_plane for the CALLING thread, remembered on the Python side as well: the library's mask is a per-thread setting and
+    ``loss.backward()`` runs a Function's backward on the autograd engine's device thread, so ``cine_hip.autograd`` records this value
+    in every Function's forward and re-applies it (``apply_conv_plane``) at the top of its backward -- a mask set before the
+    forward pass also selects the kernels of the backward pass."""
+    _act_tls.plane_mask = int(mask)
+    check(lib().cine_set_conv_plane(int(mask)), "cine_set_conv_plane")
+    _act_tls.applied_mask = int(mask)
+
+
+def apply_conv_plane(mask: int) -> None:
+    """Make `mask` the library's setting of the thread that calls this, without touching that thread's own record (``conv_plane_mask``):
+    the caller restores with ``apply_conv_plane(conv_plane_mask())``."""
+    if getattr(_act_tls, "applied_mask", _CONV_PLANE_DEFAULT) != mask:
+        check(lib().cine_set_conv_plane(int(mask)), "cine_set_conv_plane")
+        _act_tls.applied_mask = int(mask)
+
+
+# ---- side streams: the caller-owned streams the branch / side-lane entry points fork onto --------------------------------------------
+_SIDE_STREAMS = {}
+import os as _os
+UNET_BRANCHES = int(_os.environ.get("CINE_UNET_BRANCHES", "1"))   # default number of concurrent branches of a 2-D U-Net pass (cine_unet2d_forward_branches); see
+                                                                  # `branches`.  The environment variable belongs to THIS binding (A/B runs), the library reads none
+
+
+BRANCH_INTERLEAVE = _os.environ.get("CINE_BRANCH_INTERLEAVE", "0") == "1"     # diagnostics: enqueue the branches layer by layer (lockstep) instead of sequence by sequence
+
+
+def side_streams(device: torch.device, count: int = 1):
+    """`count` torch streams that belong to (device, the CURRENT stream): the library creates no streams, the binding does, once per
+    main stream, outside any capture -- concurrent slices on different main streams never share a side stream."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    have = _SIDE_STREAMS.get(key)
+    if have is None:
+        have = _SIDE_STREAMS[key] = []
+    while len(have) < count:
+        _no_capture("a side stream")
+        have.append(torch.cuda.Stream(device=idx))
+    return have[:count]
+
+
+def unet_branches() -> int:
+    return getattr(_act_tls, "branches", UNET_BRANCHES)
+
+
+def fork_side(device: torch.device) -> "torch.cuda.Stream":
+    """A side stream of (device, current stream) that has been made to wait for everything enqueued on the current stream so far; launch
+    independent work on it (``with torch.cuda.stream(side): ...``, outputs allocated BEFORE entering it) and ``join_side(side)`` before the
+    current stream reads the results.  (The second side stream of this main stream: a two-branch U-Net pass uses the first.)"""
+    side = side_streams(device, 2)[1]
+    side.wait_stream(torch.cuda.current_stream(device))
+    return side
+
+
+def join_side(side: "torch.cuda.Stream") -> None:
+    torch.cuda.current_stream(side.device).wait_stream(side)
+
+
+@contextlib.contextmanager
+def branches(n: int):
+    """Run the 2-D U-Net passes of the CALLING THREAD as `n` concurrent branches (1 = one stream, the classic launch sequence; 2 = the x-f and
+    y-f networks of a cascade / two halves of the coils beside each other; 4 = each of those halved again).  Bit-identical results."""
+    if n not in (1, 2, 4, 8):
+        raise ValueError("branches: 1, 2, 4 or 8")
+    old = getattr(_act_tls, "branches", None)
+    _act_tls.branches = int(n)
+    try:
+        yield
+    finally:
+        if old is None:
+            del _act_tls.branches
+        else:
+            _act_tls.branches = old
+
+
 _PACK_IN_CAPTURE = False      # inside training_capture(): the weight-pack kernels BELONG to the captured step (the weights change every replay)
 _cache_epoch = 0              # part of every packed-weight cache key: bumped when a training capture ends
 
@@ -1055,6 +1140,14 @@ class UnetWeights:
         return self._dptrs
 
 
+def _branch_count(n: int, nsets: int) -> int:
+    """How many branches this thread's setting gives a pass of n planes in nsets weight sets (the largest admissible count <= the setting)."""
+    nb = unet_branches()
+    while nb > 1 and (nb % nsets or n // nb < 1):
+        nb //= 2
+    return max(nb, 1)
+
+
 def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reference denoisers/unet.py:73-125 on (n, in_ch, h, w) planes."""
     x = _dev(x, "unet input")
@@ -1062,6 +1155,20 @@ def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[to
     nsets = len(weights.unets)
     if cin != weights.in_ch:
         raise ValueError(f"unet input has {cin} channels, expected {weights.in_ch}")
+    nb = _branch_count(n, nsets)
+    if nb > 1:
+        side = side_streams(x.device, nb - 1)
+        need = lib().cine_unet2d_branch_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools, nsets, nb, 0)
+        if need == 0:
+            raise CineHipError("cine_unet2d_branch_ws_bytes rejected the shape")
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, device=x.device, dtype=torch.uint8)
+        y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
+        sarr = (ctypes.c_void_p * len(side))(*[s_.cuda_stream for s_ in side])
+        check(lib().cine_unet2d_forward_branches(x.data_ptr(), y.data_ptr(), weights.pointers(), nsets, n, h, w, cin, weights.out_ch, weights.chans,
+                                                 weights.pools, lrelu_slope(), workspace.data_ptr(), workspace.numel(), _stream(), sarr, len(side), 2 * int(BRANCH_INTERLEAVE)),
+              "cine_unet2d_forward_branches")
+        return y
     need = lib().cine_unet2d_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)
     if need == 0:
         raise CineHipError("cine_unet2d_ws_bytes rejected the shape")
@@ -1160,9 +1267,28 @@ def mwcnn_forward(x: torch.Tensor, w: MwcnnWeights, w2: Optional[MwcnnWeights] =
     n, cin, h, wd = x.shape
     if cin != net.in_chans:
         raise ValueError(f"mwcnn input has {cin} channels, expected {net.in_chans}")
+    y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
+    two = w2 is not None and w2 is not w
+    if unet_branches() > 1 and n >= 2 and (not two or 0 < split < n):
+        # the plane sets as two concurrent runs of the one-set launch sequence (same kernels and tiles per plane: bit-identical), the second
+        # on a side stream: XPDNet's x-t / y-t networks (xpdnet.py:424-446) are independent until the sum behind them
+        cut = int(split) if two else (n + 1) // 2
+        side = side_streams(x.device, 1)[0]
+        main = torch.cuda.current_stream(x.device)
+        parts = []
+        for lo, hi, wt in ((0, cut, w), (cut, n, w2 if two else w)):
+            need = lib().cine_mwcnn_ws_bytes(hi - lo, h, wd, cin, net.out_chans, net.n_scales, wt.nf, wt.nc, net.first_conv_n_filters)
+            parts.append((lo, hi, wt, wt.pointers(), torch.empty(max(need, 1), device=x.device, dtype=torch.uint8)))
+        side.wait_stream(main)
+        for k, (lo, hi, wt, ptrs, ws) in enumerate(parts):
+            with torch.cuda.stream(side if k else main):
+                check(lib().cine_mwcnn_forward(x[lo:hi].data_ptr(), y[lo:hi].data_ptr(), ptrs, hi - lo, h, wd, cin, net.out_chans, net.n_scales,
+                                               wt.nf, wt.nc, net.n_first_convs, net.first_conv_n_filters, int(net.res), lrelu_slope(),
+                                               ws.data_ptr(), ws.numel(), _stream()), "cine_mwcnn_forward")
+        main.wait_stream(side)
+        return y
     need = lib().cine_mwcnn_ws_bytes(n, h, wd, cin, net.out_chans, net.n_scales, w.nf, w.nc, net.first_conv_n_filters)
     ws = torch.empty(max(need, 1), device=x.device, dtype=torch.uint8)
-    y = torch.empty((n, net.out_chans, h, wd), device=x.device, dtype=x.dtype)
     if w2 is not None and w2 is not w:
         n2 = w2.net
         if (n2.in_chans, n2.out_chans, n2.n_scales, list(n2.n_filters_per_scale), list(n2.n_convs_per_scale), n2.first_conv_n_filters) != \

@@ -15,6 +15,9 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static std::atomic<long> g_diag[D_COUNT];
+void diag_count(int which) { if (which >= 0 && which < D_COUNT) g_diag[which].fetch_add(1, std::memory_order_relaxed); }
+
 // ---- optional launch profiler
 static std::atomic<int> g_prof_on{0};
 struct ProfRec { int fam; hipEvent_t e0, e1; };
@@ -61,7 +64,11 @@ const char* cine_profile_family_name(int i) {
                                   "conv1x1_bias", "pack_unpack", "misc"};
     return (i >= 0 && i < cine::F_COUNT) ? names[i] : "";
 }
-int cine_version(void) { return 2; }       // 2: the fused U-Net sequences take their LeakyReLU slope per call (round 5)
+long cine_diag_counter(int which, int reset) {
+    if (which < 0 || which >= cine::D_COUNT) return -1;
+    return reset ? cine::g_diag[which].exchange(0) : cine::g_diag[which].load();
+}
+int cine_version(void) { return 3; }       // 3: U-Net passes as concurrent branches, C time sweeps, diagnostic counters (round 6); 2: LeakyReLU slope per call (round 5)
 const char* cine_last_error(void) { return cine::g_err; }
 const char* cine_build_arch(void) { return "gfx950"; }
 int cine_pad16(int n) { return ((n - 1) | 15) + 1; }

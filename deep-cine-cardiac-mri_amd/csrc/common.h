@@ -40,6 +40,9 @@ __device__ unsigned long long g_cine_stamps[1 << 20];
 namespace cine {
 
 void set_error(const char* fmt, ...);   // api.cpp (thread-local buffer)
+// Process-wide launch counters of the diagnostic kernel choices (cine_diag_counter): which of two bit-identical kernels a launch took.
+enum Diag { D_WGRAD_PLANE = 0, D_WGRAD_GENERAL, D_UNET_BRANCHED, D_CRNN_SWEEP_C, D_COUNT };
+void diag_count(int which);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

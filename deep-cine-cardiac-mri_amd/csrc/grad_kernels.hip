@@ -1016,9 +1016,11 @@ static int launch_wg_cfg(const WgLaunch& L, dim3 grid, hipStream_t st) {
         auto same = [&](const Src& s) { return s.c == 0 || (s.mode <= 1 && s.h == a.H && s.w == a.W); };
         if (wgrad_plane_enabled() && L.fast_in && L.fast_g == 1 && a.W == TW && !a.add_src1 && same(a.s0) && same(a.s1) && (a.s1.c == 0 || a.s0.c % 16 == 0) &&
             (a.s0.mode == 0 || (a.s0.part && a.s0.np > 0)) && (a.s1.c == 0 || a.s1.mode == 0 || (a.s1.part && a.s1.np > 0))) {
+            diag_count(D_WGRAD_PLANE);
             hipLaunchKernelGGL((wgrad_plane_kernel<TW, CT, WM, NPIX>), grid, dim3(256), lds, st, L);
             return check_launch("wgrad_plane_kernel");
         }
+        diag_count(D_WGRAD_GENERAL);
         if (L.a.add_src1) {
             hipLaunchKernelGGL((wgrad_mfma_kernel<TAPS, TW, CT, WM, NPIX, true>), grid, dim3(256), lds, st, L);
             return check_launch("wgrad_mfma_kernel");

@@ -108,9 +108,107 @@ extern "C" size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int
     return b.off;
 }
 
+// One launch sequence of the U-Net over the `n` planes at x / y with the buffers of plan `p` (built for exactly these planes): `wa` = the
+// pointer list of the weight set of samples [0, split), `wb` (may be NULL: one set) of the rest.  Only launches [l0, l1) of the sequence
+// are enqueued (5 * pools + 3 in all), so that concurrent branches can be enqueued layer by layer.
+static int unet_launches(int pools) { return 5 * pools + 3; }
+static int run_unet(const Plan& p, const float* x, float* y, const void* const* wa, const void* const* wb, int split,
+                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope, void* stream, int l0 = 0, int l1 = 1 << 30) {
+    int wi = 0, li = 0;
+    const float *w0, *w1;
+    auto next = [&]() {
+        w0 = reinterpret_cast<const float*>(wa[wi]);
+        w1 = wb ? reinterpret_cast<const float*>(wb[wi]) : nullptr;
+        ++wi;
+        const bool on = li >= l0 && li < l1;
+        ++li;
+        return on;
+    };
+    int e;
+    // ---- down path (unet.py:94-97) + bottleneck (:99)
+    for (int d = 0; d <= pools; ++d) {
+        const bool last = d == pools;
+        float* mid = p.mid[d]; float* pmid = p.pmid[d];
+        float* out = last ? p.bott : p.skip[d];
+        float* pout = last ? p.pbott : p.pskip[d];
+        if (next()) {
+            if (d == 0)
+                e = cine_conv3x3_in(x, nullptr, 0, in_ch, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
+                                    mid, pmid, n, p.ch[0], h, w, kEps, kSlope, stream);
+            else
+                e = cine_conv3x3_in(p.skip[d - 1], p.pskip[d - 1], p.np_conv[d - 1], p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
+                                    nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
+                                    mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+            if (e) return e;
+        }
+        if (next()) {
+            e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+                                w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+            if (e) return e;
+        }
+    }
+    // ---- up path (unet.py:102-123)
+    const float* cur = p.bott; const float* pcur = p.pbott;
+    int np_cur = p.np_conv[pools];
+    for (int u = 0; u < pools; ++u) {
+        const int d = pools - 1 - u;
+        if (next()) {   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
+            e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
+                                 p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
+            if (e) return e;
+        }
+        if (next()) {   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
+            e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
+                                p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
+                                p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+            if (e) return e;
+        }
+        if (next()) {
+            e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+                                w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
+            if (e) return e;
+        }
+        cur = p.cb[d]; pcur = p.pcb[d]; np_cur = p.np_conv[d];
+    }
+    // ---- final 1x1 conv + bias (unet.py:69)
+    const float* wf0 = reinterpret_cast<const float*>(wa[wi]);
+    const float* bf0 = reinterpret_cast<const float*>(wa[wi + 1]);
+    const float* wf1 = wb ? reinterpret_cast<const float*>(wb[wi]) : nullptr;
+    const float* bf1 = wb ? reinterpret_cast<const float*>(wb[wi + 1]) : nullptr;
+    if (li >= l0 && li < l1)
+        return cine_conv1x1_bias(cur, pcur, np_cur, 1, wf0, bf0, wf1, bf1, split, y, n, chans, out_ch, h, w,
+                                 kEps, kSlope, stream);
+    return CINE_OK;
+}
+
+static int unet2d_check(const float* x, float* y, const void* const* weights, int nsets, int n, int h, int w, int in_ch, int out_ch,
+                        int chans, int pools, float kSlope, void* ws) {
+    CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet2d_forward: null pointer");
+    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet2d_forward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
+    CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_forward: nsets must be 1 or 2");
+    CINE_REQUIRE(n > 0 && n % nsets == 0, CINE_EINVAL, "cine_unet2d_forward: n=%d not divisible by nsets=%d", n, nsets);
+    CINE_REQUIRE(h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL,
+                 "cine_unet2d_forward: bad sizes");
+    CINE_REQUIRE((h >> pools) >= 1 && (w >> pools) >= 1, CINE_EUNSUPPORTED,
+                 "cine_unet2d_forward: %dx%d too small for %d pools", h, w, pools);
+    const int nptr = 5 * pools + 4;
+    for (int i = 0; i < nsets * nptr; ++i)
+        CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", i);
+    return CINE_OK;
+}
+
 static int unet2d_forward_impl(const float* x, float* y, const void* const* weights, int nsets,
                                int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
-                               void* ws, size_t ws_bytes, void* stream, bool train);
+                               void* ws, size_t ws_bytes, void* stream, bool train) {
+    if (int e = unet2d_check(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, kSlope, ws)) return e;
+    const size_t need = train ? cine_unet2d_train_ws_bytes(n, h, w, in_ch, out_ch, chans, pools)
+                              : cine_unet2d_ws_bytes(n, h, w, in_ch, out_ch, chans, pools);
+    CINE_REQUIRE(ws_bytes >= need, CINE_EWORKSPACE, "cine_unet2d_forward: workspace %zu < %zu", ws_bytes, need);
+    const int nptr = 5 * pools + 4;
+    Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
+    build(p, b, n, h, w, chans, pools, train);
+    return run_unet(p, x, y, weights, nsets == 2 ? weights + nptr : nullptr, n / nsets, n, h, w, in_ch, out_ch, chans, pools, kSlope, stream);
+}
 
 extern "C" int cine_unet2d_forward(const float* x, float* y, const void* const* weights, int nsets,
                                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
@@ -123,83 +221,113 @@ extern "C" int cine_unet2d_forward_train(const float* x, float* y, const void* c
     return unet2d_forward_impl(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, slope, ws, ws_bytes, stream, true);
 }
 
-static int unet2d_forward_impl(const float* x, float* y, const void* const* weights, int nsets,
-                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
-                               void* ws, size_t ws_bytes, void* stream, bool train) {
-    CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet2d_forward: null pointer");
-    CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet2d_forward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
-    CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_forward: nsets must be 1 or 2");
-    CINE_REQUIRE(n > 0 && n % nsets == 0, CINE_EINVAL, "cine_unet2d_forward: n=%d not divisible by nsets=%d", n, nsets);
-    CINE_REQUIRE(h > 0 && w > 0 && in_ch > 0 && out_ch > 0 && chans > 0 && pools > 0 && pools <= 6, CINE_EINVAL,
-                 "cine_unet2d_forward: bad sizes");
-    CINE_REQUIRE((h >> pools) >= 1 && (w >> pools) >= 1, CINE_EUNSUPPORTED,
-                 "cine_unet2d_forward: %dx%d too small for %d pools", h, w, pools);
-    const size_t need = train ? cine_unet2d_train_ws_bytes(n, h, w, in_ch, out_ch, chans, pools)
-                              : cine_unet2d_ws_bytes(n, h, w, in_ch, out_ch, chans, pools);
-    CINE_REQUIRE(ws_bytes >= need, CINE_EWORKSPACE, "cine_unet2d_forward: workspace %zu < %zu", ws_bytes, need);
-    const int nptr = 5 * pools + 4;
-    for (int i = 0; i < nsets * nptr; ++i)
-        CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet2d_forward: weights[%d] is null", i);
+// ---------------------------------------------------------------- the same U-Net pass as CONCURRENT BRANCHES
+// The planes of a U-Net pass are independent (varnet.py:216-232: the x-f and the y-f network of a cascade meet only in the sum behind
+// them), yet on ONE stream every layer is a kernel boundary at which the whole chip drains: a cfg-2 level-1 layer is 800 workgroups on 768
+// resident slots, a level-2 layer 400 workgroups on 512 -- a round plus a sliver.  Here the planes are cut into nside + 1
+// contiguous runs (never across the two weight sets), and each run goes through the SAME launch sequence -- same kernels, same tiles, same
+// statistics records per plane: bit-identical outputs -- on its own stream: branch 0 on `stream`, branch k on side[k - 1], forked from and
+// joined back into `stream` with events, so a branch's next layer starts in the slots its sibling's last round leaves empty.
+namespace {
+struct Cut { int a, n, set; };       // planes [a, a + n) of weight set `set`
+int cut_planes(int n, int nsets, int nbranch, Cut* c) {
+    const int per_set = nbranch / nsets, ns = n / nsets;
+    int k = 0;
+    for (int s = 0; s < nsets; ++s)
+        for (int j = 0; j < per_set; ++j) {
+            const int lo = (int)((long)ns * j / per_set), hi = (int)((long)ns * (j + 1) / per_set);
+            if (hi > lo) c[k++] = Cut{s * ns + lo, hi - lo, s};
+        }
+    return k;
+}
+bool branches_ok(int n, int nsets, int nbranch) {
+    return nbranch >= 1 && nbranch <= 8 && nbranch % nsets == 0 && n / nbranch >= 1;
+}
+}  // namespace
 
-    Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
-    build(p, b, n, h, w, chans, pools, train);
-    const int split = n / nsets;
-    int wi = 0;
-    const float *w0, *w1;
-    auto next = [&]() {
-        w0 = reinterpret_cast<const float*>(weights[wi]);
-        w1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi]) : nullptr;
-        ++wi;
-    };
-    int e;
-    // ---- down path (unet.py:94-97) + bottleneck (:99)
-    for (int d = 0; d <= pools; ++d) {
-        const bool last = d == pools;
-        float* mid = p.mid[d]; float* pmid = p.pmid[d];
-        float* out = last ? p.bott : p.skip[d];
-        float* pout = last ? p.pbott : p.pskip[d];
-        next();
-        if (d == 0)
-            e = cine_conv3x3_in(x, nullptr, 0, in_ch, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
-                                mid, pmid, n, p.ch[0], h, w, kEps, kSlope, stream);
-        else
-            e = cine_conv3x3_in(p.skip[d - 1], p.pskip[d - 1], p.np_conv[d - 1], p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
-                                nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
-                                mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-        next();
-        e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
-                            w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
+extern "C" size_t cine_unet2d_branch_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools, int nsets, int nbranch, int train) {
+    if (n <= 0 || (nsets != 1 && nsets != 2) || n % nsets || !branches_ok(n, nsets, nbranch)) return 0;
+    if (train) return cine_unet2d_train_ws_bytes(n, h, w, in_ch, out_ch, chans, pools);      // the backward pass reads ONE layout: the branches write their planes of it
+    Cut c[8];
+    const int k = cut_planes(n, nsets, nbranch, c);
+    size_t tot = 0;
+    for (int i = 0; i < k; ++i) {
+        const size_t one = cine_unet2d_ws_bytes(c[i].n, h, w, in_ch, out_ch, chans, pools);
+        if (!one) return 0;
+        tot += one;
     }
-    // ---- up path (unet.py:102-123)
-    const float* cur = p.bott; const float* pcur = p.pbott;
-    int np_cur = p.np_conv[pools];
-    for (int u = 0; u < pools; ++u) {
-        const int d = pools - 1 - u;
-        next();   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
-        e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
-                             p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
-        if (e) return e;
-        next();   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
-        e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
-                            p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
-                            p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-        next();
-        e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
-                            w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-        if (e) return e;
-        cur = p.cb[d]; pcur = p.pcb[d]; np_cur = p.np_conv[d];
+    return tot;
+}
+
+extern "C" int cine_unet2d_forward_branches(const float* x, float* y, const void* const* weights, int nsets,
+                                            int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
+                                            void* ws, size_t ws_bytes, void* stream, void* const* side, int nside, int train) {
+    if (int e = unet2d_check(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, slope, ws)) return e;
+    const bool interleave = (train & 2) != 0;
+    train &= 1;
+    const int nbranch = nside + 1;
+    CINE_REQUIRE(nside >= 0 && (nside == 0 || side), CINE_EINVAL, "cine_unet2d_forward_branches: side streams missing");
+    CINE_REQUIRE(branches_ok(n, nsets, nbranch), CINE_EINVAL, "cine_unet2d_forward_branches: %d planes of %d set(s) do not cut into %d branches", n, nsets, nbranch);
+    for (int i = 0; i < nside; ++i)
+        CINE_REQUIRE(side[i] && side[i] != stream, CINE_EINVAL, "cine_unet2d_forward_branches: side[%d] is NULL or the main stream", i);
+    const size_t need = cine_unet2d_branch_ws_bytes(n, h, w, in_ch, out_ch, chans, pools, nsets, nbranch, train);
+    CINE_REQUIRE(need && ws_bytes >= need, CINE_EWORKSPACE, "cine_unet2d_forward_branches: workspace %zu < %zu", ws_bytes, need);
+    const int nptr = 5 * pools + 4;
+    Cut c[8];
+    const int k = cut_planes(n, nsets, nbranch, c);
+    Plan full;
+    size_t off = 0;
+    if (train) { Bump b{reinterpret_cast<char*>(ws), 0}; build(full, b, n, h, w, chans, pools, true); }
+    hipStream_t main = as_stream(stream);
+    hipEvent_t fork = nullptr, done[8] = {};
+    bool ok = k <= 1 || hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 1; i < k && ok; ++i) ok = hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+    auto cleanup = [&]() { if (fork) (void)hipEventDestroy(fork); for (auto ev : done) if (ev) (void)hipEventDestroy(ev); };
+    if (!ok) { cleanup(); set_error("cine_unet2d_forward_branches: hipEventCreate failed"); return CINE_EHIP; }
+    if (k > 1) { (void)hipEventRecord(fork, main); diag_count(D_UNET_BRANCHED); }
+    int err = CINE_OK;
+    const long xs = (long)in_ch * h * w, ys = (long)out_ch * h * w;
+    Plan plans[8];
+    for (int i = 0; i < k; ++i) {
+        Plan& p = plans[i];
+        if (train) {
+            // this branch's planes inside the one layout the backward pass reads (sample s of a tensor sits at s * its dense size)
+            p = full;
+            const long a = c[i].a;
+            for (int d = 0; d <= pools; ++d) {
+                const long e_ = (long)p.ch[d] * p.hs[d] * p.wsz[d], pe = (long)p.ch[d] * p.np_conv[d] * 3;
+                p.mid[d] += a * e_; p.pmid[d] += a * pe;
+                if (d < pools) {
+                    p.skip[d] += a * e_; p.pskip[d] += a * pe;
+                    p.ca[d] += a * e_; p.pca[d] += a * pe;
+                    p.cb[d] += a * e_; p.pcb[d] += a * pe;
+                    p.up[d] += a * (long)p.ch[d] * (2 * p.hs[d + 1]) * (2 * p.wsz[d + 1]);
+                    p.pup[d] += a * (long)p.ch[d] * p.np_tconv[d] * 3;
+                }
+            }
+            p.bott += a * (long)p.ch[pools] * p.hs[pools] * p.wsz[pools];
+            p.pbott += a * (long)p.ch[pools] * p.np_conv[pools] * 3;
+        } else {
+            Bump b{reinterpret_cast<char*>(ws) + off, 0};
+            build(p, b, c[i].n, h, w, chans, pools, false);
+            off += b.off;
+        }
+        if (i > 0) (void)hipStreamWaitEvent(as_stream(side[i - 1]), fork, 0);
     }
-    // ---- final 1x1 conv + bias (unet.py:69)
-    const float* wf0 = reinterpret_cast<const float*>(weights[wi]);
-    const float* bf0 = reinterpret_cast<const float*>(weights[wi + 1]);
-    const float* wf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi]) : nullptr;
-    const float* bf1 = nsets == 2 ? reinterpret_cast<const float*>(weights[nptr + wi + 1]) : nullptr;
-    e = cine_conv1x1_bias(cur, pcur, np_cur, 1, wf0, bf0, wf1, bf1, split, y, n, chans, out_ch, h, w,
-                          kEps, kSlope, stream);
-    return e;
+    // enqueue order: a whole sequence per branch (the later branches start some 20 launches of host time behind the first, which keeps the
+    // branches in DIFFERENT layers: measured faster than lockstep), or -- train bit 1 -- layer by layer over the branches (diagnostics)
+    const int nl = unet_launches(pools), lstep = interleave ? 1 : nl;
+    for (int l = 0; l < nl && !err; l += lstep)
+        for (int i = 0; i < k && !err; ++i) {
+            hipStream_t st = i == 0 ? main : as_stream(side[i - 1]);
+            const void* const* wa = weights + (c[i].set ? nptr : 0);
+            err = run_unet(plans[i], x + c[i].a * xs, y + c[i].a * ys, wa, nullptr, c[i].n, c[i].n, h, w, in_ch, out_ch, chans, pools, slope, st, l, l + lstep);
+        }
+    for (int i = 1; i < k; ++i) {       // joined even after an error: no dangling fork
+        (void)hipEventRecord(done[i], as_stream(side[i - 1])); (void)hipStreamWaitEvent(main, done[i], 0);
+    }
+    cleanup();
+    return err;
 }
 
 // ---------------------------------------------------------------- backward pass (training)

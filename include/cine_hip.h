@@ -44,7 +44,7 @@ extern "C" {
 #define CINE_EHIP (-4)        /* a HIP launch failed; see cine_last_error()                    */
 
 /* library / build identification */
-int cine_version(void);                 /* ABI version, currently 1 */
+int cine_version(void);                 /* ABI version, currently 3 */
 const char* cine_last_error(void);      /* thread-local, never NULL */
 const char* cine_build_arch(void);      /* "gfx950" */
 
@@ -551,6 +551,21 @@ size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int out_ch, in
 int cine_unet2d_forward_train(const float* x, float* y, const void* const* weights, int nsets,
                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                               void* ws, size_t ws_bytes, void* stream);
+/* cine_unet2d_forward / cine_unet2d_forward_train (`train` != 0) with the n planes cut into nside + 1 contiguous runs that go through the
+ * SAME launch sequence concurrently: run 0 on `stream`, run k on side[k - 1] (HOST array of caller-owned streams, none of them `stream`),
+ * forked from `stream` and joined back into it with events before the call returns -- on return everything is ordered on `stream`
+ * again.  The planes of a U-Net pass are independent (the x-f and y-f networks of a cascade, reference varnet.py:216-232, meet only in
+ * the sum behind them; the coils of the sensitivity network, varnet.py:76-86, only in the RSS), but on one stream every layer boundary
+ * drains the chip (a cfg-2 level-1 layer is 800 workgroups on 768 resident slots): with two runs each one's next layer fills the slots
+ * the other's last round leaves empty.  Same kernels, tiles and per-plane statistics records: outputs are BIT-IDENTICAL to the
+ * one-stream call.  nsets == 2: nside + 1 must be even (a run never spans both weight sets).  Workspace: cine_unet2d_branch_ws_bytes
+ * (inference: one private workspace per run; training: the layout of cine_unet2d_train_ws_bytes, which cine_unet2d_backward reads).
+ * Capturable: inside a stream capture the side streams join the capture through the fork event.  The reference runs the two networks
+ * one after the other on torch's current stream. */
+size_t cine_unet2d_branch_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools, int nsets, int nbranch, int train);
+int cine_unet2d_forward_branches(const float* x, float* y, const void* const* weights, int nsets,
+                                 int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
+                                 void* ws, size_t ws_bytes, void* stream, void* const* side, int nside, int train);
 /* The reference's small tensor helpers as device kernels, for user code written against its utils (the fused path never calls
  * them).  utils/math.py:20-44: complex_mul with broadcasting -- `shape` = the broadcast result's dimensions WITHOUT the trailing
  * complex pair (at most 6), `xstride` / `ystride` the operands' strides in complex elements, 0 on broadcast dimensions; out is dense.
@@ -713,6 +728,10 @@ int cine_ssim_loss_bwd(const float* x, const float* y, int t, int h, int w, int 
  * waits for them and returns, per kernel family i < nfam, the summed device time in ms and the
  * launch count.  Not for use during graph capture. */
 int cine_profile_begin(void);
+/* Diagnostics: process-wide counts of launches that took one of two interchangeable routes, so that a test can prove WHICH ran
+ * (`which`: 0 plane-wide weight gradients on the lean kernel, 1 on the general kernel, 2 U-Net passes run as concurrent branches,
+ * 3 BCRNN layers run by the C time-sweep entry points).  reset != 0 returns the count and zeroes it; -1 for an unknown counter. */
+long cine_diag_counter(int which, int reset);
 int cine_profile_end(double* ms, long* launches, int nfam);
 int cine_profile_families(void);
 const char* cine_profile_family_name(int family);

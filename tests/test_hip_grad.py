@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from conftest import rel_err, rnd, state_dict_from
+from cine_hip import ops as cine_ops
 
 pytestmark = pytest.mark.gpu
 
@@ -491,18 +492,47 @@ def test_plane_wgrad_kernel_bit_identical_to_general_kernel(dev):
     from cine_hip import synth
     from cine_hip._lib import lib
     ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
-    res = []
+    res, counts = [], []
     try:
         for mask in (7, 7 | 16):
-            assert lib().cine_set_conv_plane(mask) == 0
+            cine_ops.set_conv_plane(mask)
             net = M.VarNet(2, 8, 3, 16, 3, "XF"); synth.fill_parameters_(net, 1); net = net.to(dev).train()
+            lib().cine_diag_counter(0, 1); lib().cine_diag_counter(1, 1)
             with torch.enable_grad():
                 out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev))
                 (out - ex["target"].to(dev)).pow(2).sum().backward()
+            torch.cuda.synchronize()
+            counts.append((lib().cine_diag_counter(0, 1), lib().cine_diag_counter(1, 1)))
             res.append({k: p.grad.clone() for k, p in net.named_parameters()})
     finally:
-        lib().cine_set_conv_plane(7)
+        cine_ops.set_conv_plane(7)
+    # the mask is a per-thread setting and loss.backward() runs on the autograd engine's thread: the Functions carry it across.
+    # Proof that the two runs took DIFFERENT kernels: launch counts of (lean, general) plane-eligible weight gradients
+    (lean7, gen7), (lean23, gen23) = counts
+    assert lean7 > 0 and lean23 == 0 and gen23 >= gen7 + lean7, counts
     bad = [k for k in res[0] if not torch.equal(res[0][k], res[1][k])]
+    assert not bad, bad
+
+
+def test_training_forward_as_branches_gives_the_same_bits(dev):
+    """The training forward of the cascade U-Nets as two concurrent branches (cine_unet2d_forward_branches with train = 1: the x-f / y-f planes write
+    their halves of the ONE workspace layout cine_unet2d_backward reads) against the one-stream sequence: output and every gradient bit for bit."""
+    import reconstruction.models as M
+    from cine_hip import ops, synth
+    from cine_hip._lib import lib
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=0)
+    res = []
+    for nb in (1, 2):
+        net = M.VarNet(1, 8, 3, 16, 3, "XF"); synth.fill_parameters_(net, 1); net = net.to(dev).train()
+        lib().cine_diag_counter(2, 1)
+        with ops.branches(nb), torch.enable_grad():
+            out = net(ex["masked_kspace"].to(dev), ex["mask"].to(dev))
+            (out - ex["target"].to(dev)).pow(2).sum().backward()
+        torch.cuda.synchronize()
+        assert (lib().cine_diag_counter(2, 1) > 0) == (nb > 1)
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])
+    bad = [k for k in res[0][1] if not torch.equal(res[0][1][k], res[1][1][k])]
     assert not bad, bad
 
 

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from conftest import rel_err, rnd, state_dict_from
+from cine_hip import ops as cine_ops
 
 pytestmark = pytest.mark.gpu
 
@@ -470,7 +471,7 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
                 bias_i = torch.randn(cout, generator=g).to(dev) if cout == 10 else None
             outs = []
             for on in (7, 0):
-                assert lib().cine_set_conv_plane(on) == 0
+                cine_ops.set_conv_plane(on)
                 if elif_iwt:
                     y = torch.empty(n, cout, h, w, device=dev)
                     py = None if bias_i is not None else torch.empty((n, cout, lib().cine_conv_stat_partials(cout, h, w, 0), 3), device=dev)
@@ -498,7 +499,7 @@ def test_conv_plane_bit_identical_to_general_kernel(dev):
             assert torch.equal(y1, y0), (kind, c0, cout, h, w, float((y1 - y0).abs().max()))
             assert p1 is None or torch.equal(p1, p0), (kind, c0, cout, h, w)
     finally:
-        lib().cine_set_conv_plane(7)
+        cine_ops.set_conv_plane(7)
 
 
 def test_tconv_plane_bit_identical_to_general_kernel(dev):
@@ -521,13 +522,13 @@ def test_tconv_plane_bit_identical_to_general_kernel(dev):
                 part = None
             outs = []
             for on in (7, 0):
-                assert lib().cine_set_conv_plane(on) == 0
+                cine_ops.set_conv_plane(on)
                 outs.append(ops.tconv2x2_in(x, part, mode, wt, cout))
             (y1, p1), (y0, p0) = outs
             assert torch.equal(y1, y0), (cin, cout, h, w, float((y1 - y0).abs().max()))
             assert torch.equal(p1, p0), (cin, cout, h, w)
     finally:
-        lib().cine_set_conv_plane(7)
+        cine_ops.set_conv_plane(7)
 
 
 def test_conv_wide_bit_identical_to_general_kernel(dev):
@@ -552,7 +553,7 @@ def test_conv_wide_bit_identical_to_general_kernel(dev):
             bias = torch.randn(cout, generator=g).to(dev); add = torch.randn(n, cout, h, w, generator=g).to(dev)
             outs = []
             for on in (7, 3):
-                assert lib().cine_set_conv_plane(on) == 0
+                cine_ops.set_conv_plane(on)
                 if kind in ("sum", "sum1", "sum_ragged"):
                     outs.append((ops.conv3x3_sum([x, x2] if kind != "sum1" else [x], wp, bias, cout, addend=add, relu=kind == "sum"), None))
                 elif kind == "concat":
@@ -580,7 +581,7 @@ def test_conv_wide_bit_identical_to_general_kernel(dev):
         w_hh = ops.pack_conv3x3((torch.randn(16, 16, 3, 3, generator=gg) / 12).to(dev))
         res = []
         for on in (7, 3):
-            assert lib().cine_set_conv_plane(on) == 0
+            cine_ops.set_conv_plane(on)
             yf, yb, acc_f, acc_b = (torch.zeros_like(hx[0]) for _ in range(4))
             acc_b.fill_(0.5)
             ops.crnn_step2(w_hh, (hx[0], hx[1], yf, acc_f, True), (hx[2], hx[3], yb, acc_b, False))
@@ -600,13 +601,13 @@ def test_conv_wide_bit_identical_to_general_kernel(dev):
         bs_ = [torch.randn(co, generator=torch.Generator().manual_seed(5)).to(dev) for co in (32, 64)]
         outs = []
         for on in (7, 3):
-            assert lib().cine_set_conv_plane(on) == 0
+            cine_ops.set_conv_plane(on)
             outs.append([ops.unet3d_forward(vol, ops.UnetWeights([net]))] + [ops.conv3d_bias_relu(v16, w_, b_, True) for w_, b_ in zip(ws_, bs_)])
         for a_, b_ in zip(*outs):
             assert torch.equal(a_, b_)
         assert rel_err(outs[0][1].cpu(), F.relu(F.conv3d(v16.cpu(), ws_[0].cpu(), bs_[0].cpu(), padding=1))) < OP_TOL
     finally:
-        lib().cine_set_conv_plane(7)
+        cine_ops.set_conv_plane(7)
 
 
 def test_tconv_dgrad_plane_bit_identical_and_vs_torch(dev):
@@ -625,7 +626,7 @@ def test_tconv_dgrad_plane_bit_identical_and_vs_torch(dev):
             wp, wp2 = ops._pack("tcd", wt.to(dev)), ops._pack("tcd", (2 * wt).to(dev))
             outs = []
             for on in (7, 5):
-                assert lib().cine_set_conv_plane(on) == 0
+                cine_ops.set_conv_plane(on)
                 gx = torch.empty(n, cin, h, w, device=dev)
                 check(lib().cine_tconv2x2_dgrad(gy.to(dev).data_ptr(), wp.data_ptr(), wp2.data_ptr(), 3, gx.data_ptr(), n, cin, cout, h, w, None), "cine_tconv2x2_dgrad")
                 outs.append(gx)
@@ -636,7 +637,7 @@ def test_tconv_dgrad_plane_bit_identical_and_vs_torch(dev):
             want = x.grad.clone(); want[3:] *= 2                                   # samples >= set_split use the second weight set
             assert rel_err(outs[0].cpu(), want) < OP_TOL, (cin, cout, h, w)
     finally:
-        lib().cine_set_conv_plane(7)
+        cine_ops.set_conv_plane(7)
 
 
 # ------------------------------------------------------------------ blocks and models
@@ -953,7 +954,7 @@ def test_two_threads_two_streams_are_independent(dev):
         with torch.no_grad(), ops.activation(slope=0.5):
             for i in range(iters):
                 if flip:
-                    assert lib().cine_set_conv_plane(0 if i % 2 == 0 else 7) == 0
+                    cine_ops.set_conv_plane(0 if i % 2 == 0 else 7)
                 outs.append(neta(exa["masked_kspace"], exa["mask"]).clone())
         return outs
 
@@ -1690,6 +1691,65 @@ def test_unet_cfg2_planes_vs_oracle(dev, n, sets):
         want = torch.cat([nets_r[k](x[k * per:(k + 1) * per]) for k in range(sets)])
     got = ops.unet2d_forward(x.to(dev), ops.UnetWeights(nets_h)).cpu()
     assert rel_err(got, want) < BLOCK_TOL
+
+
+@pytest.mark.parametrize("n,sets", [(6, 2), (8, 2), (15, 1), (3, 1), (1, 1)])
+def test_unet_branches_bit_identical_to_one_stream(dev, n, sets):
+    """cine_unet2d_forward_branches: the planes of a U-Net pass as 2 / 4 concurrent runs on side streams (the x-f / y-f networks of a cascade,
+    reference varnet.py:216-232, are independent until their sum; the sens-net's coils until the RSS) against the one-stream launch sequence,
+    bit for bit; the counter proves the branched entry point ran."""
+    from cine_hip import ops, synth
+    from cine_hip._lib import lib
+    from reconstruction.models.denoisers.unet import Unet
+    nets = []
+    for k in range(sets):
+        hnet = Unet(in_chans=2, out_chans=2, chans=16, num_pool_layers=3).eval(); synth.fill_parameters_(hnet, 31 + k, keep=())
+        nets.append(hnet.to(dev))
+    wts = ops.UnetWeights(nets)
+    x = rnd(78, n, 2, 208, 16).to(dev)
+    with ops.branches(1):
+        want = ops.unet2d_forward(x, wts)
+    for nb in (2, 4):
+        lib().cine_diag_counter(2, 1)
+        with ops.branches(nb):
+            got = ops.unet2d_forward(x, wts)
+        torch.cuda.synchronize()
+        with ops.branches(nb):
+            eff = ops._branch_count(n, sets)
+        assert lib().cine_diag_counter(2, 1) == (1 if eff > 1 else 0), (n, sets, nb, eff)
+        assert torch.equal(got, want), (n, sets, nb)
+
+
+def test_varnet_branches_eager_and_captured_bit_identical(golden, dev):
+    """The whole cfg-2 forward with two-branch U-Net passes: eager and replayed from a hipGraph (the side streams join the capture through
+    the fork events), equal to the one-stream forward bit for bit."""
+    import reconstruction.models as M
+    from cine_hip import ops, synth
+    g = golden("varnet_cfg2")
+    ex = synth.make_cine_slice(15, 15, 200, 200, accel=4, seed=int(g["data_seed"]))
+    net = M.VarNet(6, 8, 3, 16, 3, "XF")
+    synth.fill_parameters_(net, int(g["weight_seed"]))
+    net.to(dev).eval()
+    mk, mask = ex["masked_kspace"].to(dev), ex["mask"].to(dev)
+    with ops.branches(1):
+        want = net(mk, mask).clone()
+    for nb in (2, 4):
+        with ops.branches(nb):
+            assert torch.equal(net(mk, mask), want), nb
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with ops.branches(2):
+        with torch.cuda.stream(st):
+            net(mk, mask)                            # this stream's caches and side streams, outside capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            gout = net(mk, mask)
+    for _ in range(2):
+        gout.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(gout, want)
 
 
 # ------------------------------------------------------------------ direct tests of the small helpers (SURVEY 8 a9, a14, a15)

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in include/cine_hip.h but not exported: {missing}"
     # and the Python binding table covers the same set
     assert set(declared) == set(_lib._SIGS)
-    assert _lib.lib().cine_version() == 2
+    assert _lib.lib().cine_version() == 3
     assert _lib.lib().cine_build_arch() == b"gfx950"
     assert _lib.lib().cine_pad16(200) == 208 and _lib.lib().cine_pad16(15) == 16 and _lib.lib().cine_pad16(16) == 16
 
