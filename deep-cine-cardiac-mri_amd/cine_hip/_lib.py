@@ -66,6 +66,9 @@ _SIGS = {
                                 P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_float, c_float, P]),
     "cine_crnn_step": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_crnn_step2": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_conv3x3_dgrad_gated": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_bcrnn_sweep": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "cine_bcrnn_sweep_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "cine_mwcnn_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),
     "cine_mwcnn_forward2": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_float, P, c_size_t, P]),
     "cine_conv3x3_ex2": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -707,6 +707,20 @@ def _conv_dgrad(g, weight):
     return gx
 
 
+_zero_states = {}
+
+
+def _zero_state(c: int, h: int, w: int, like: torch.Tensor) -> torch.Tensor:
+    """A shared READ-ONLY (1, c, h, w) zero tensor per device (hid_init of the time sweeps, recurrent_varnet.py:236): no fill per step."""
+    key = (like.device, c, h, w)
+    z = _zero_states.get(key)
+    if z is None:
+        z = torch.zeros((1, c, h, w), device=like.device, dtype=torch.float32)
+        if not torch.cuda.is_current_stream_capturing():
+            _zero_states[key] = z
+    return z
+
+
 @_masked
 class ConvSumFn(Function):
     """y = [ReLU](conv3x3(cat(x0, x1); W) + bias + addend): the "conv_x(a) + conv_h(b)" pairs of the CRNN body (recurrent_varnet.py:122-134)
@@ -762,8 +776,13 @@ class BcrnnFn(Function):
         c = w_hh.shape[0]
         wpi, wph = ops.pack_conv3x3(w_in), ops.pack_conv3x3(w_hh)
         P = ops.conv3x3_sum([hid_iter, x], wpi, ops._dev(bias.detach(), "bias"), c)
+        zero = _zero_state(c, h, w, x)
+        ctx.relu = bool(ops.relu_on())            # what the sweep applied
+        if ops.BCRNN_SWEEP_IN_C:
+            out, hf, hb = ops.bcrnn_sweep(P, wph, zero, keep=True)
+            ctx.save_for_backward(x, hid_iter, w_in, w_hh, hf, hb)
+            return out
         hf, hb, out = torch.empty_like(P), torch.empty_like(P), torch.empty_like(P)
-        zero = torch.zeros((1, c, h, w), device=x.device, dtype=x.dtype)
         hid_f = hid_b = zero
         for s in range(T):
             i_f, i_b = s, T - 1 - s
@@ -786,6 +805,9 @@ class BcrnnFn(Function):
         T, ch, h, w = x.shape
         c = w_hh.shape[0]
         wdh = ops._pack("c3d", w_hh)
+        if ops.BCRNN_SWEEP_IN_C:
+            gf, gb, gP = ops.bcrnn_sweep_bwd(gout, wdh, _zero_state(c, h, w, x), hf, hb, ctx.relu)
+            return BcrnnFn._tail(ctx, x, hid_iter, w_in, w_hh, hf, hb, gf, gb, gP)
         gf, gb = torch.empty_like(gout), torch.empty_like(gout)       # d loss / d (pre-activation) of the two chains
         for t in range(T - 1, -1, -1):                                 # forward-in-time chain, walked backwards
             if t == T - 1:
@@ -802,6 +824,13 @@ class BcrnnFn(Function):
             if ctx.relu:
                 _relu_mask_(gb[t:t + 1], hb[t:t + 1])
         gP = gf + gb
+        return BcrnnFn._tail(ctx, x, hid_iter, w_in, w_hh, hf, hb, gf, gb, gP)
+
+    @staticmethod
+    def _tail(ctx, x, hid_iter, w_in, w_hh, hf, hb, gf, gb, gP):
+        """From the pre-activation gradients of the two chains: everything upstream of P and the weight gradients."""
+        T = x.shape[0]
+        c = w_hh.shape[0]
         need = ctx.needs_input_grad
         gx = ghid = gw_in = gw_hh = gbias = None
         if need[0] or need[1]:
@@ -817,6 +846,115 @@ class BcrnnFn(Function):
                 _conv_wgrad_(gw_hh, None, hf[:T - 1], None, gf[1:])
                 _conv_wgrad_(gw_hh, None, hb[1:], None, gb[:T - 1])
         return gx, ghid, gw_in if need[2] else None, gw_hh, gbias
+
+
+def _dgrad_gated(g, wd, cin, addend=None, gate=None):
+    """gx (n, cin, h, w) = [gate > 0] (conv(g; wd) + addend): cine_conv3x3_dgrad_gated (wd = the c3d packing of the (cout, cin, 3, 3) weight)."""
+    n, cout, h, w = g.shape
+    gx = torch.empty((n, cin, h, w), device=g.device, dtype=g.dtype)
+    check(lib().cine_conv3x3_dgrad_gated(g.data_ptr(), wd.data_ptr(), _p(addend), _p(gate), gx.data_ptr(), n, cout, cin, h, w, _stream()),
+          "cine_conv3x3_dgrad_gated")
+    return gx
+
+
+CRNN_BODY_FN = __import__("os").environ.get("CINE_CRNN_BODY_FN", "1") == "1"       # diagnostics (this binding): False = one autograd node per layer (BcrnnFn, ConvSumFn)
+CRNN_SIDE_LANE = __import__("os").environ.get("CINE_CRNN_SIDE_LANE", "1") == "1"   # diagnostics: the body's weight gradients on the side stream
+
+
+@_masked
+class CrnnBodyFn(Function):
+    """One cascade of the CRNN body (reference recurrent_varnet.py:116-136 with BCRNNlayer :220-259, batch 1) as ONE autograd node:
+        P   = conv([s0, x]; [W_ih2ih | W_i2h]) + b_i2h + b_h2h + b_ih2ih          all frames, one launch
+        x0  = both time sweeps of the BCRNN layer (cine_bcrnn_sweep)
+        x_k = ReLU(conv([x_{k-1}, s_k]; [W_kx | W_kh]) + b_kx + b_kh),  k = 1, 2, 3
+        out = conv(x3; W4) + b4 + residual
+    forward(x, s0..s3, residual, packs, *params) -> (out, x0, x1, x2, x3); `packs` = the module's packed weights of this optimiser step
+    (CRNNBody._train_packs: forward packings of the concatenated weights, input-gradient packings of every single weight).
+    Backward: the input-gradient chain runs on the caller's stream -- every dgrad is cine_conv3x3_dgrad_gated (the gradient x_k receives as the
+    next cascade's state rides in as the addend, the ReLU mask as the gate: no add / mask / concat-split kernels), the concatenated convs'
+    gradients are two launches (one per input: both outputs contiguous), back-propagation through time is cine_bcrnn_sweep_bwd -- and the seven
+    weight gradients of the body run beside it on the side stream (each depends only on a layer's output gradient), joined before the
+    node returns.  Gradients go straight to the raw parameters: no cat / add nodes around the node."""
+
+    @staticmethod
+    def forward(ctx, x, s0, s1, s2, s3, residual, packs, *params):
+        x = ops._dev(x, "CRNN body input"); residual = ops._dev(residual, "CRNN body residual")
+        st = [ops._dev(s_, "CRNN iteration state") for s_ in (s0, s1, s2, s3)]
+        T, ch, h, w = x.shape
+        c = st[0].shape[1]
+        relu = bool(ops.relu_on())
+        P = ops.conv3x3_sum([st[0], x], packs["in"], packs["b_in"], c)
+        zero = _zero_state(c, h, w, x)
+        x0, hf, hb = ops.bcrnn_sweep(P, packs["hh"], zero, keep=True)
+        feats = [x0]
+        for k in (1, 2, 3):
+            feats.append(ops.conv3x3_sum([feats[-1], st[k]], packs[f"p{k}"], packs[f"b{k}"], c, relu=True))
+        out = ops.conv3x3_sum([feats[3]], packs["w4"], packs["b4"], residual.shape[1], addend=residual)
+        ctx.relu, ctx.packs, ctx.dims = relu, packs, (T, ch, c, h, w, residual.shape[1])
+        ctx.save_for_backward(x, *st, *feats, hf, hb)
+        return (out, *feats)
+
+    @staticmethod
+    def backward(ctx, gout, g0, g1, g2, g3):
+        x, s0, s1, s2, s3, x0, x1, x2, x3, hf, hb = ctx.saved_tensors
+        T, ch, c, h, w, och = ctx.dims
+        pk, relu = ctx.packs, ctx.relu
+        st, feats, gfe = (s0, s1, s2, s3), (x0, x1, x2, x3), [g0, g1, g2, g3]
+        gout = ops._dev(_c(gout), "CRNN body output gradient")
+        gfe = [None if g is None else ops._dev(_c(g), "CRNN state gradient") for g in gfe]
+        need = ctx.needs_input_grad
+        dev = gout.device
+        main = torch.cuda.current_stream(dev)
+        side = ops.side_streams(dev, 1)[0] if CRNN_SIDE_LANE else None
+        # weight gradients: zeroed buffers of the CONCATENATED layouts, one fill
+        shapes = [(c, c + ch, 3, 3), (c, c, 3, 3), (c,), (c, 2 * c, 3, 3), (c,), (c, 2 * c, 3, 3), (c,), (c, 2 * c, 3, 3), (c,), (och, c, 3, 3), (och,)]
+        sizes = [(int(torch.Size(s_).numel()) + 3) // 4 * 4 for s_ in shapes]
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        bufs, off = [], 0
+        for s_, n_ in zip(shapes, sizes):
+            bufs.append(flat[off:off + torch.Size(s_).numel()].view(s_)); off += n_
+        gw_in, gw_hh, gb_in, gW1, gb1, gW2, gb2, gW3, gb3, gw4, gb4 = bufs
+
+        alive = []      # tensors the side stream reads stay referenced until the join (the allocator would hand their memory back to the main stream)
+
+        def wgrad(gw, gb, a0, a1, g):
+            """on the side stream, after everything enqueued on the main stream so far (g's producer)"""
+            alive.append(g)
+            if side is None:
+                _conv_wgrad_(gw, gb, a0, a1, g)
+                return
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _conv_wgrad_(gw, gb, a0, a1, g)
+
+        # ---- conv4 (+ residual): out = conv(x3; W4) + b4 + residual
+        wgrad(gw4, gb4, x3, None, gout)
+        g = _dgrad_gated(gout, pk["d4"], c, addend=gfe[3], gate=x3 if relu else None)          # d loss / d (pre-activation of x3)
+        gst = [None, None, None, None]
+        gWs, gbs = (None, gW1, gW2, gW3), (None, gb1, gb2, gb3)
+        for k in (3, 2, 1):
+            wgrad(gWs[k], gbs[k], feats[k - 1], st[k], g)
+            if need[1 + k]:
+                gst[k] = _dgrad_gated(g, pk[f"d{k}h"], c)
+            g = _dgrad_gated(g, pk[f"d{k}x"], c, addend=gfe[k - 1], gate=(feats[k - 1] if relu and k > 1 else None))
+        # ---- BCRNN: g = d loss / d x0 = d loss / d (hidden_f + hidden_b)
+        gf, gb_, gP = ops.bcrnn_sweep_bwd(g, pk["dhh"], _zero_state(c, h, w, x), hf, hb, relu)
+        wgrad(gw_in, gb_in, s0, x, gP)
+        if T > 1:       # h_{t-1} -> h_t (the first frame of each chain starts from zeros)
+            wgrad(gw_hh, None, hf[:T - 1], None, gf[1:])
+            wgrad(gw_hh, None, hb[1:], None, gb_[:T - 1])
+        if need[1]:
+            gst[0] = _dgrad_gated(gP, pk["d_ih2ih"], c)
+        gx = _dgrad_gated(gP, pk["d_i2h"], ch) if need[0] else None
+        if side is not None:
+            main.wait_stream(side)
+        alive.clear()
+        # parameter order of CRNNBody._body_params: w_ih2ih, w_i2h, w_h2h, b_i2h, b_h2h, b_ih2ih, then (w_kx, w_kh, b_kx, b_kh) for k = 1..3, w4, b4
+        gp = [gw_in[:, :c], gw_in[:, c:], gw_hh, gb_in, gb_in, gb_in]
+        for gW, gbk in ((gW1, gb1), (gW2, gb2), (gW3, gb3)):
+            gp += [gW[:, :c], gW[:, c:], gbk, gbk]
+        gp += [gw4, gb4]
+        return (gx, gst[0], gst[1], gst[2], gst[3], gout if need[5] else None, None, *gp)
 
 
 def coil_accum(g: Optional[torch.Tensor], z: torch.Tensor) -> torch.Tensor:

@@ -1441,6 +1441,33 @@ def crnn_step2(w_hh: torch.Tensor, fwd, bwd=None) -> None:
                                 w_hh.data_ptr(), n, c, h, w, int(relu_on()), _stream()), "cine_crnn_step2")
 
 
+BCRNN_SWEEP_IN_C = _os.environ.get("CINE_BCRNN_SWEEP_IN_C", "1") == "1"        # diagnostics (this binding): False = the step-by-step Python loops over cine_crnn_step2
+
+
+def bcrnn_sweep(P: torch.Tensor, w_hh: torch.Tensor, zero: torch.Tensor, keep: bool = False):
+    """Both time sweeps of a BCRNN layer (reference recurrent_varnet.py:236-254) in one C call: P (T, c, h, w) input terms of all frames,
+    w_hh = pack_conv3x3(W_h2h), zero (1, c, h, w) zeros.  Returns (out, hf, hb): out = hidden_f + hidden_b; hf / hb every hidden state
+    of the two chains with ``keep`` (training), else two-frame scratch."""
+    P = _dev(P, "BCRNN input terms"); zero = _dev(zero, "zero state")
+    T, c, h, w = P.shape
+    out = torch.empty_like(P)
+    hshape = (T if keep else 2, c, h, w)
+    hf, hb = torch.empty(hshape, device=P.device, dtype=P.dtype), torch.empty(hshape, device=P.device, dtype=P.dtype)
+    check(lib().cine_bcrnn_sweep(P.data_ptr(), w_hh.data_ptr(), zero.data_ptr(), hf.data_ptr(), hb.data_ptr(), out.data_ptr(), T, c, h, w,
+                                 int(relu_on()), int(keep), _stream()), "cine_bcrnn_sweep")
+    return out, hf, hb
+
+
+def bcrnn_sweep_bwd(gout: torch.Tensor, w_hh_dgrad: torch.Tensor, zero: torch.Tensor, hf: torch.Tensor, hb: torch.Tensor, relu: bool):
+    """Back-propagation through time of ``bcrnn_sweep(keep=True)``: (gf, gb, gP), see cine_bcrnn_sweep_bwd."""
+    gout = _dev(gout, "BCRNN output gradient")
+    T, c, h, w = gout.shape
+    gf, gb, gP = torch.empty_like(gout), torch.empty_like(gout), torch.empty_like(gout)
+    check(lib().cine_bcrnn_sweep_bwd(gout.data_ptr(), w_hh_dgrad.data_ptr(), zero.data_ptr(), hf.data_ptr(), hb.data_ptr(), gf.data_ptr(), gb.data_ptr(),
+                                     gP.data_ptr(), T, c, h, w, int(bool(relu)), _stream()), "cine_bcrnn_sweep_bwd")
+    return gf, gb, gP
+
+
 # ------------------------------------------------------------------ 3-D U-Net path (dynamic_type '3D')
 def normunet3d_pack(x: torch.Tensor, norm: bool = True):
     """(n, t, h, w, 2) -> planes (n, 2, Tp, Hp, Wp) [+ stats (n, 2, 2)]; reference norm_unet.py:149-189."""

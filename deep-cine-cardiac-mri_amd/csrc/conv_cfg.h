@@ -30,6 +30,9 @@ struct ConvArgs {
     // these pointers instead (and count from 0 again)
     int pair_n, accum_store_b;
     const float* x_b; const float* addend_b; float* y_b; float* accum_b;
+    // gate (shaped like y): y = gate > 0 ? (conv + bias + addend) : 0 -- one step of back-propagation through a ReLU recurrence (the
+    // adjoint of h_t = ReLU(conv(h_{t-1}) + P_t): g_{t-1} = [h_{t-1} > 0] (conv^T(g_t) + gout_{t-1})); gate_b: the second set of a pair launch
+    const float* gate; const float* gate_b;
 };
 
 template <int CK, int CT, int WM, int WN, int MT, int TW, int TAPS>

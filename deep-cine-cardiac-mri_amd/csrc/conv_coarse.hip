@@ -410,7 +410,7 @@ static bool coarse_fast_ok(const ConvArgs& a) {
 
 int launch_conv_coarse(const ConvArgs& a, hipStream_t st, bool* handled) {
     *handled = false;
-    if (a.tconv_cout != 0 || a.accum || a.pair_n != 0 || a.n <= 0 || a.n > 65535) {
+    if (a.tconv_cout != 0 || a.accum || a.gate || a.pair_n != 0 || a.n <= 0 || a.n > 65535) {
         CINE_REQUIRE(!a.ypart, CINE_EUNSUPPORTED, "conv_coarse_kernel: this epilogue has no statistics-compatible fallback");
         return CINE_OK;                                   // (CRNN second outputs / pair launches on a coarse shape: the general kernel, no records involved)
     }

@@ -572,12 +572,13 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                 if (gy < a.H && gx < a.W) vmask |= 1ull << (4 * f + j);
             }
     }
-    if (a.addend || a.relu) {          // CRNN cells: sum with a precomputed term, then ReLU (recurrent_varnet.py:172-178)
+    if (a.addend || a.relu || a.gate) {          // CRNN cells: sum with a precomputed term, then ReLU (recurrent_varnet.py:172-178); gate: its adjoint step
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int m = co0 + 16 * (wm * CT + ct) + q;
             if (m >= a.rows) continue;
             const float* ab = a.addend ? a.addend + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W : nullptr;
+            const float* gt = a.gate ? a.gate + (((long)n * a.rows + m) * a.D + z0) * a.H * a.W : nullptr;
 #pragma unroll
             for (int f = 0; f < MT; ++f)
 #pragma unroll
@@ -587,6 +588,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int tile, con
                     const int gy = r0 + (wn * MT + f) * C::RPF + p / TW, gx = c0 + p % TW;
                     float v = acc[ct][f][j];
                     if (ab) v += ab[(long)gy * a.W + gx];
+                    if (gt) v = gt[(long)gy * a.W + gx] > 0.f ? v : 0.f;
                     acc[ct][f][j] = a.relu ? fmaxf(v, 0.f) : v;
                 }
         }
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<CK, CT, WM, WN, MT, TW, TAPS
     int n = blockIdx.z;
     if (n >= a.pair_n) {
         n -= a.pair_n;
-        a.s0.x = a.x_b; a.addend = a.addend_b; a.y = a.y_b; a.accum = a.accum_b; a.accum_store = a.accum_store_b;
+        a.s0.x = a.x_b; a.addend = a.addend_b; a.y = a.y_b; a.accum = a.accum_b; a.accum_store = a.accum_store_b; a.gate = a.gate_b;
     }
     conv_tile<CK, CT, WM, WN, MT, TW, TAPS>(a, blockIdx.x, blockIdx.y, n, smem_f);
 }
@@ -1354,16 +1356,16 @@ extern "C" int cine_crnn_step(const float* x, const float* wpacked, const float*
 
 // both directions of a BCRNN time sweep (recurrent_varnet.py:241-252: the forward and the backward pass over time are independent
 // chains; only their sum couples them, :254) in ONE launch: set f and set b are two cine_crnn_step calls on different tensors.
-extern "C" int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f,
-                               const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b,
-                               const float* wpacked, int n, int c, int h, int w, int relu, void* stream) {
+static int crnn_step2_impl(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f, const float* gate_f,
+                           const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b, const float* gate_b,
+                           const float* wpacked, int n, int c, int h, int w, int relu, void* stream) {
     CINE_REQUIRE(x_f && addend_f && y_f && wpacked, CINE_EINVAL, "cine_crnn_step2: null pointer");
     CINE_REQUIRE(n > 0 && 2 * n <= 65535 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_crnn_step2: bad sizes");
     CINE_REQUIRE(y_f != x_f && accum_f != x_f && accum_f != y_f, CINE_EINVAL, "cine_crnn_step2: outputs must not alias the input or each other");
     ConvArgs a{};
     a.s0 = Src{x_f, nullptr, c, 0, h, w, 0, 0, 1};
     a.s1 = Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
-    a.addend = addend_f; a.relu = relu ? 1 : 0; a.accum = accum_f; a.accum_store = store_f && accum_f;
+    a.addend = addend_f; a.relu = relu ? 1 : 0; a.accum = accum_f; a.accum_store = store_f && accum_f; a.gate = gate_f;
     a.wp0 = a.wp1 = wpacked; a.set_split = 2 * n;
     a.y = y_f; a.ypart = nullptr; a.n = n; a.cin = c; a.rows = c; a.rowsp = ceil_div(c, 16) * 16;
     a.H = h; a.W = w; a.D = 1; a.slope = 0.2f; a.eps = 1e-5f; a.nchunks = ceil_div(c, kCK3);
@@ -1374,14 +1376,86 @@ extern "C" int cine_crnn_step2(const float* x_f, const float* addend_f, float* y
     CINE_REQUIRE(!accum_f || accum_f != accum_b, CINE_EINVAL, "cine_crnn_step2: both sets accumulate into the same tensor (run them one after the other)");
     const int TW = w > 8 ? 16 : w > 4 ? 8 : w > 2 ? 4 : 2;
     const long frags = (long)ceil_div(h * TW, 16) * ceil_div(w, TW);
-    if (a.rowsp <= 16 && 2L * n * ceil_div(frags, 52L) < 200) {
+    if (a.rowsp <= 16 && 2L * n * ceil_div(frags, 52L) < 200 && !gate_f == !gate_b) {
         a.n = 2 * n; a.pair_n = n;
-        a.x_b = x_b; a.addend_b = addend_b; a.y_b = y_b; a.accum_b = accum_b; a.accum_store_b = store_b && accum_b;
+        a.x_b = x_b; a.addend_b = addend_b; a.y_b = y_b; a.accum_b = accum_b; a.accum_store_b = store_b && accum_b; a.gate_b = gate_b;
         return dispatch<9, kCK3>(a, as_stream(stream));
     }
     if (int e = dispatch<9, kCK3>(a, as_stream(stream))) return e;      // shapes outside the pair configuration: two launches
-    a.s0.x = x_b; a.addend = addend_b; a.y = y_b; a.accum = accum_b; a.accum_store = store_b && accum_b;
+    a.s0.x = x_b; a.addend = addend_b; a.y = y_b; a.accum = accum_b; a.accum_store = store_b && accum_b; a.gate = gate_b;
     return dispatch<9, kCK3>(a, as_stream(stream));
+}
+
+extern "C" int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* accum_f, int store_f,
+                               const float* x_b, const float* addend_b, float* y_b, float* accum_b, int store_b,
+                               const float* wpacked, int n, int c, int h, int w, int relu, void* stream) {
+    return crnn_step2_impl(x_f, addend_f, y_f, accum_f, store_f, nullptr, x_b, addend_b, y_b, accum_b, store_b, nullptr, wpacked, n, c, h, w, relu, stream);
+}
+
+// Both time sweeps of a BCRNN layer (recurrent_varnet.py:236-254, batch 1) in ONE call: h_t = [ReLU](conv3x3(h_prev; W_h2h) + P_t) forward in time
+// (frames 0 .. T-1) and backward in time (T-1 .. 0), both chains advanced by one pair launch per step (T launches, T + 1 for odd T: the
+// middle frame is reached by both in the same step), out = hidden_f + hidden_b -- the first chain to reach a frame stores, the second adds.
+// P, out (T, c, h, w); `zero` (c, h, w) zeros = hid_init (:236), read only; keep != 0: hf / hb (T, c, h, w) receive EVERY hidden state (what
+// cine_bcrnn_sweep_bwd reads), keep == 0: hf / hb are two-frame ping-pong buffers (2, c, h, w).
+extern "C" int cine_bcrnn_sweep(const float* P, const float* wpacked_hh, const float* zero, float* hf, float* hb, float* out,
+                                int T, int c, int h, int w, int relu, int keep, void* stream) {
+    CINE_REQUIRE(P && wpacked_hh && zero && hf && hb && out, CINE_EINVAL, "cine_bcrnn_sweep: null pointer");
+    CINE_REQUIRE(T > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_bcrnn_sweep: bad sizes");
+    const long fr = (long)c * h * w;
+    auto slot = [&](int i) { return (long)(keep ? i : (i & 1)) * fr; };
+    const float *prev_f = zero, *prev_b = zero;
+    diag_count(D_CRNN_SWEEP_C);
+    for (int s = 0; s < T; ++s) {
+        const int i_f = s, i_b = T - 1 - s;
+        // ping-pong: the two chains write slots s & 1 of their own buffers; keep: slot = the frame they reach
+        float* yf = hf + (keep ? (long)i_f * fr : slot(s));
+        float* yb = hb + (keep ? (long)i_b * fr : slot(s));
+        int e;
+        if (i_f == i_b) {
+            if ((e = crnn_step2_impl(prev_f, P + i_f * fr, yf, out + i_f * fr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wpacked_hh, 1, c, h, w, relu, stream))) return e;
+            e = crnn_step2_impl(prev_b, P + i_b * fr, yb, out + i_b * fr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, wpacked_hh, 1, c, h, w, relu, stream);
+        } else {
+            const int first = i_f < i_b;          // before the chains cross each of them is the first to reach its frame
+            e = crnn_step2_impl(prev_f, P + i_f * fr, yf, out + i_f * fr, first, nullptr, prev_b, P + i_b * fr, yb, out + i_b * fr, first, nullptr,
+                                wpacked_hh, 1, c, h, w, relu, stream);
+        }
+        if (e) return e;
+        prev_f = yf; prev_b = yb;
+    }
+    return CINE_OK;
+}
+
+// Back-propagation through time of cine_bcrnn_sweep (keep != 0): from gout = d loss / d out (T, c, h, w),
+//   gf[t] = [hf[t] > 0] (conv(gf[t + 1]; Wd) + gout[t]),  t = T-1 .. 0      (the chain that ran forward in time)
+//   gb[t] = [hb[t] > 0] (conv(gb[t - 1]; Wd) + gout[t]),  t = 0 .. T-1      (the chain that ran backward in time)
+// with Wd = the input-gradient packing of W_h2h (cine_pack_conv3x3_dgrad) -- the forward conv kernel, gout riding in as the addend and the ReLU
+// mask as the epilogue's gate (relu == 0: identity activation, no gate) -- and gP = gf + gb = d loss / d P through the second output.  The two
+// chains are independent: one pair launch per step, as in the forward sweep.  gf, gb, gP (T, c, h, w); `zero` as above.
+extern "C" int cine_bcrnn_sweep_bwd(const float* gout, const float* wpacked_hh_dgrad, const float* zero, const float* hf, const float* hb,
+                                    float* gf, float* gb, float* gP, int T, int c, int h, int w, int relu, void* stream) {
+    CINE_REQUIRE(gout && wpacked_hh_dgrad && zero && hf && hb && gf && gb && gP, CINE_EINVAL, "cine_bcrnn_sweep_bwd: null pointer");
+    CINE_REQUIRE(T > 0 && c > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_bcrnn_sweep_bwd: bad sizes");
+    const long fr = (long)c * h * w;
+    const float *prev_f = zero, *prev_b = zero;
+    for (int s = 0; s < T; ++s) {
+        const int t_f = T - 1 - s, t_b = s;
+        const float* gate_f = relu ? hf + t_f * fr : nullptr;
+        const float* gate_b = relu ? hb + t_b * fr : nullptr;
+        int e;
+        if (t_f == t_b) {
+            if ((e = crnn_step2_impl(prev_f, gout + t_f * fr, gf + t_f * fr, gP + t_f * fr, 1, gate_f, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                     wpacked_hh_dgrad, 1, c, h, w, 0, stream))) return e;
+            e = crnn_step2_impl(prev_b, gout + t_b * fr, gb + t_b * fr, gP + t_b * fr, 0, gate_b, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                                wpacked_hh_dgrad, 1, c, h, w, 0, stream);
+        } else {
+            const int first = t_f > t_b;
+            e = crnn_step2_impl(prev_f, gout + t_f * fr, gf + t_f * fr, gP + t_f * fr, first, gate_f, prev_b, gout + t_b * fr, gb + t_b * fr, gP + t_b * fr, first, gate_b,
+                                wpacked_hh_dgrad, 1, c, h, w, 0, stream);
+        }
+        if (e) return e;
+        prev_f = gf + t_f * fr; prev_b = gb + t_b * fr;
+    }
+    return CINE_OK;
 }
 
 // mode encoding of the extended entry: low 3 bits = mode (0..4), bit 3 set = source is raw and gets
@@ -1591,6 +1665,23 @@ extern "C" int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const f
     CINE_REQUIRE(gy && wpacked && gx, CINE_EINVAL, "cine_conv3x3_dgrad: null pointer");
     return conv3x3_full(gy, nullptr, 0, cout, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, 0, wpacked, wpacked2, set_split,
                         nullptr, nullptr, 0, nullptr, gx, nullptr, n, cin, h, w, 1e-5f, 0.2f, stream);
+}
+
+// gx = gate > 0 ? (conv3x3(gy; wpacked) + addend) : 0 -- the input gradient of a conv whose input was a ReLU output `gate` that also fed other
+// consumers (their gradient = addend): mask and sum ride in the conv's epilogue instead of two more passes over gx
+extern "C" int cine_conv3x3_dgrad_gated(const float* gy, const float* wpacked, const float* addend, const float* gate,
+                                        float* gx, int n, int cout, int cin, int h, int w, void* stream) {
+    CINE_REQUIRE(gy && wpacked && gx, CINE_EINVAL, "cine_conv3x3_dgrad_gated: null pointer");
+    CINE_REQUIRE(n > 0 && n <= 65535 && cout > 0 && cin > 0 && h > 0 && w > 0, CINE_EINVAL, "cine_conv3x3_dgrad_gated: bad sizes");
+    CINE_REQUIRE(gx != gy && gx != addend && gx != gate, CINE_EINVAL, "cine_conv3x3_dgrad_gated: the output must not alias an input");
+    ConvArgs a{};
+    a.s0 = Src{gy, nullptr, cout, 0, h, w, 0, 0, 1};
+    a.s1 = Src{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 1};
+    a.addend = addend; a.gate = gate;
+    a.wp0 = a.wp1 = wpacked; a.set_split = n;
+    a.y = gx; a.ypart = nullptr; a.n = n; a.cin = cout; a.rows = cin; a.rowsp = ceil_div(cin, 16) * 16;
+    a.H = h; a.W = w; a.D = 1; a.slope = 0.2f; a.eps = 1e-5f; a.nchunks = ceil_div(a.cin, kCK3);
+    return dispatch<9, kCK3>(a, as_stream(stream));
 }
 
 extern "C" int cine_tconv2x2_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,

@@ -579,7 +579,7 @@ int launch_plane(const PlaneArgs& p, int n, hipStream_t st) {
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled) {
     *handled = false;
     if (!(g_plane_on & 1)) return CINE_OK;
-    if (a.vol || a.D != 1 || a.addend || a.accum || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
+    if (a.vol || a.D != 1 || a.addend || a.accum || a.gate || a.pair_n > 0 || a.tconv_cout > 0) return CINE_OK;
     if (a.W != tw || a.n <= 0 || a.n > 65535) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
@@ -946,6 +946,7 @@ struct WideArgs {
     // CRNN time-sweep steps: optional second output (accum += y, or = y), and the second sample set of a pair launch
     float* accum; int accum_store;
     int pair_n, accum_store_b; const float* x_b; const float* addend_b; float* y_b; float* accum_b;
+    const float* gate; const float* gate_b;       // y = gate > 0 ? v : 0 (ConvArgs::gate: the adjoint step of a ReLU recurrence)
 };
 
 // MODE 0: plain sources; 1: InstanceNorm + LeakyReLU on load.  V3: volumes, chunk = (depth offset, 8 channels).
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
     const int z0 = tile / a.tiles_hw, t2 = tile - z0 * a.tiles_hw;
     if (a.pair_n > 0 && n >= a.pair_n) {               // second sample set of a pair launch (both directions of a BCRNN time sweep in one grid)
         n -= a.pair_n;
-        a.x0 = a.x_b; a.addend = a.addend_b; a.y = a.y_b; a.accum = a.accum_b; a.accum_store = a.accum_store_b;
+        a.x0 = a.x_b; a.addend = a.addend_b; a.y = a.y_b; a.accum = a.accum_b; a.accum_store = a.accum_store_b; a.gate = a.gate_b;
     }
     const int ty = t2 / a.tiles_w, tx = t2 - ty * a.tiles_w;
     const int r0 = ty * C::TH, c0 = tx * TW, co0 = blockIdx.y * C::COT;
@@ -1170,22 +1171,26 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
         }
     }
     const bool full = r0 + C::TH <= a.H && c0 + TW <= a.W;
-    if (a.addend || a.relu) {
+    if (a.addend || a.relu || a.gate) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
             const int m = co0 + 16 * (wm * CT + ct) + q;
             if (m >= a.rows) continue;
             const float* ab = a.addend ? a.addend + (((long)n * a.rows + m) * a.D + z0) * hwl : nullptr;
+            const float* gt = a.gate ? a.gate + (((long)n * a.rows + m) * a.D + z0) * hwl : nullptr;
 #pragma unroll
             for (int f = 0; f < MT; ++f) {
                 if (fr0 + f >= a.H || !colok) continue;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (ab) t = *reinterpret_cast<const float4*>(ab + (long)(fr0 + f) * a.W + gx0);
+                if (gt) gv = *reinterpret_cast<const float4*>(gt + (long)(fr0 + f) * a.W + gx0);
                 const float tv[4] = {t.x, t.y, t.z, t.w};
+                const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[ct][f][j];
                     if (ab) v += tv[j];
+                    if (gt) v = gg[j] > 0.f ? v : 0.f;
                     acc[ct][f][j] = a.relu ? fmaxf(v, 0.f) : v;
                 }
             }
@@ -1323,8 +1328,8 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     if (a.W <= 16 || a.W % 4 != 0) return CINE_OK;
     const Src& s0 = a.s0; const Src& s1 = a.s1;
     auto al16 = [](const void* p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || (a.addend && !al16(a.addend)) || (a.accum && !al16(a.accum))) return CINE_OK;
-    if (a.pair_n > 0 && (!al16(a.x_b) || !al16(a.y_b) || (a.addend_b && !al16(a.addend_b)) || (a.accum_b && !al16(a.accum_b)) || !a.addend == !!a.addend_b)) return CINE_OK;
+    if (!al16(a.y) || !al16(s0.x) || (s1.c > 0 && !al16(s1.x)) || (a.addend && !al16(a.addend)) || (a.accum && !al16(a.accum)) || (a.gate && !al16(a.gate))) return CINE_OK;
+    if (a.pair_n > 0 && (!al16(a.x_b) || !al16(a.y_b) || (a.addend_b && !al16(a.addend_b)) || (a.accum_b && !al16(a.accum_b)) || !a.addend == !!a.addend_b || !a.gate == !!a.gate_b || (a.gate_b && !al16(a.gate_b)))) return CINE_OK;
     int mode;
     if (s0.mode == 0 && (s1.c == 0 || s1.mode == 0)) mode = 0;
     else if (s0.mode == 1 && (s1.c == 0 || s1.mode == 1)) mode = 1;
@@ -1355,7 +1360,7 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     p.nchunks = a.nchunks; p.ncc = ncc; p.tiles = a.tiles; p.tiles_w = a.tiles_w; p.tiles_hw = a.tiles_hw;
     p.slope = a.slope; p.eps = a.eps;
     p.accum = a.accum; p.accum_store = a.accum_store; p.pair_n = a.pair_n; p.accum_store_b = a.accum_store_b;
-    p.x_b = a.x_b; p.addend_b = a.addend_b; p.y_b = a.y_b; p.accum_b = a.accum_b;
+    p.x_b = a.x_b; p.addend_b = a.addend_b; p.y_b = a.y_b; p.accum_b = a.accum_b; p.gate = a.gate; p.gate_b = a.gate_b;
 #define CINE_WIDE_CASE(CT_, WM_, WN_, MT_)                                                                     \
     if (ct == CT_ && wm == WM_ && wn == WN_ && mt == MT_) {                                                     \
         *handled = true;                                                                                        \

@@ -76,6 +76,8 @@ class BCRNNlayer(nn.Module):
         p = ops.conv3x3_sum([hidden_iteration.reshape(t * b, c, h, w), input.reshape(t * b, ch, h, w)], w_in, bias, c)
         p = p.view(t, b, c, h, w)
         zero = zeros_ro((b, c, h, w), p)                                       # hid_init (:236)
+        if b == 1 and ops.BCRNN_SWEEP_IN_C:                                     # both loops over the frames in one C call (cine_bcrnn_sweep)
+            return ops.bcrnn_sweep(p.view(t, c, h, w), w_hh, zero)[0].view(t, b, c, h, w)
         out = torch.empty_like(p)
         # The forward pass over time (:241-245) and the backward pass (:247-252, same cell) are independent chains; only their
         # sum couples them (:254).  Step s advances both in ONE launch: frame s of the forward chain, frame t-1-s of the
@@ -136,10 +138,42 @@ class CRNNBody(nn.Module):
     def zero_state(self, t: int, b: int, h: int, w: int, like: torch.Tensor):
         return [zeros_ro((t * b, self.chans, h, w), like) for _ in range(4)]     # read only: sources of the first cascade
 
+    def _body_params(self):
+        cell = self.bcrnn.CRNN_model
+        ps = [cell.ih2ih.weight, cell.i2h.weight, cell.h2h.weight, cell.i2h.bias, cell.h2h.bias, cell.ih2ih.bias]
+        for k in (1, 2, 3):
+            cx, chh = getattr(self, f"conv{k}_x"), getattr(self, f"conv{k}_h")
+            ps += [cx.weight, chh.weight, cx.bias, chh.bias]
+        return ps + [self.conv4_x.weight, self.conv4_x.bias]
+
+    def _train_packs(self):
+        """The body's packed weights for ag.CrnnBodyFn, once per optimiser step (the cascades share them): forward packings of the concatenated
+        weights ([W_ih2ih | W_i2h], [W_kx | W_kh]) with their summed biases, and the input-gradient packing of every single weight."""
+        ps = self._body_params()
+        key = (ops.cache_epoch(),) + tuple((p.data_ptr(), p._version) for p in ps)
+        if key != self.__dict__.get("_tp_key"):
+            ops._no_capture("packed CRNN training weights", pack=True)
+            with torch.no_grad():
+                w_ih2ih, w_i2h, w_h2h, b_i2h, b_h2h, b_ih2ih = ps[:6]
+                pk = {"in": ops.pack_conv3x3(torch.cat([w_ih2ih, w_i2h], dim=1)), "b_in": (b_i2h + b_h2h + b_ih2ih).contiguous(),
+                      "hh": ops.pack_conv3x3(w_h2h), "dhh": ops._pack("c3d", w_h2h), "d_ih2ih": ops._pack("c3d", w_ih2ih), "d_i2h": ops._pack("c3d", w_i2h)}
+                for k in (1, 2, 3):
+                    wx, wh, bx, bh = ps[6 + 4 * (k - 1): 10 + 4 * (k - 1)]
+                    pk[f"p{k}"] = ops.pack_conv3x3(torch.cat([wx, wh], dim=1)); pk[f"b{k}"] = (bx + bh).contiguous()
+                    pk[f"d{k}x"] = ops._pack("c3d", wx); pk[f"d{k}h"] = ops._pack("c3d", wh)
+                pk["w4"] = ops.pack_conv3x3(ps[18]); pk["b4"] = ps[19].detach().contiguous(); pk["d4"] = ops._pack("c3d", ps[18])
+            self.__dict__["_tp"], self.__dict__["_tp_key"] = pk, key
+        return self.__dict__["_tp"], ps
+
     def body_train(self, x: torch.Tensor, state, residual: torch.Tensor):
-        """``body`` as an autograd graph (batch 1): the BCRNN layer is one Function (back-propagation through time inside), every
-        "conv_x(a) + conv_h(b) -> ReLU" pair one ConvSumFn on the concatenated weights; torch only concatenates / adds the parameters."""
+        """``body`` as an autograd graph (batch 1).  One node per cascade (ag.CrnnBodyFn: the launch sequence of ``body`` forward; backward with
+        the weight gradients on a side stream); with ag.CRNN_BODY_FN off, one node per layer: the BCRNN layer is one Function (back-propagation
+        through time inside), every "conv_x(a) + conv_h(b) -> ReLU" pair one ConvSumFn on the concatenated weights; torch concatenates / adds the parameters."""
         t, b, ch, h, w = x.shape
+        if ag.CRNN_BODY_FN and b == 1:
+            packs, ps = self._train_packs()
+            out, *feats = ag.CrnnBodyFn.apply(x.reshape(t, ch, h, w), state[0], state[1], state[2], state[3], residual, packs, *ps)
+            return out, list(feats)
         cell = self.bcrnn.CRNN_model
         x0 = ag.BcrnnFn.apply(x.reshape(t * b, ch, h, w), state[0], torch.cat([cell.ih2ih.weight, cell.i2h.weight], dim=1), cell.h2h.weight,
                               cell.i2h.bias + cell.h2h.bias + cell.ih2ih.bias)

@@ -301,6 +301,21 @@ int cine_crnn_step2(const float* x_f, const float* addend_f, float* y_f, float* 
                     const float* wpacked, int n, int c, int h, int w, int relu, void* stream);
 /* `relu`: 1 = the cell's nn.ReLU (recurrent_varnet.py:178), 0 = no activation (the identity-activation gradient fixtures of
  * tests/test_hip_grad.py, made by the reference with F.relu patched out). */
+/* BOTH time sweeps of a BCRNN layer (BCRNNlayer.forward, recurrent_varnet.py:236-254, batch 1) in one call -- the reference's two Python loops
+ * over the frames: h_t = [ReLU](conv3x3(h_prev; W_h2h) + P_t) forward in time and backward in time, hid_init = `zero` ((c, h, w) zeros, read
+ * only), one cine_crnn_step2 pair launch per step (T launches; T + 1 for odd T, where both chains reach the middle frame in the same step),
+ * out = hidden_f + hidden_b (the first chain to reach a frame stores, the second adds: no zero fill, no extra pass).  P (T, c, h, w) = the
+ * input terms i2h(x_t) + ih2ih(hid_iter_t) + the three biases for ALL frames (:172-176, one batched launch by the caller), out (T, c, h, w).
+ * keep != 0: hf / hb (T, c, h, w) receive every hidden state of the chain (training); keep == 0: hf / hb are (2, c, h, w) ping-pong buffers. */
+int cine_bcrnn_sweep(const float* P, const float* wpacked_hh, const float* zero, float* hf, float* hb, float* out,
+                     int T, int c, int h, int w, int relu, int keep, void* stream);
+/* Back-propagation through time of cine_bcrnn_sweep (keep != 0) -- what torch.autograd unrolls over the reference's two loops: from gout =
+ * d loss / d out,  gf[t] = [hf[t] > 0] (conv(gf[t + 1]; Wd) + gout[t]) for t = T-1 .. 0 and gb[t] = [hb[t] > 0] (conv(gb[t - 1]; Wd) + gout[t]) for
+ * t = 0 .. T-1, Wd = cine_pack_conv3x3_dgrad of W_h2h (the forward conv kernel; gout rides in as the addend, the ReLU mask is the epilogue's
+ * gate; relu == 0: no mask), and gP = gf + gb = d loss / d P.  One pair launch per step; gf, gb, gP (T, c, h, w).  The weight gradients are the
+ * caller's: dW_h2h from (hf[t - 1], gf[t]) and (hb[t + 1], gb[t]) with cine_conv3x3_wgrad, everything upstream of P from gP. */
+int cine_bcrnn_sweep_bwd(const float* gout, const float* wpacked_hh_dgrad, const float* zero, const float* hf, const float* hb,
+                         float* gf, float* gb, float* gP, int T, int c, int h, int w, int relu, void* stream);
 
 /* TransposeConvBlock (unet.py:212-217): y (n, cout, 2h, 2w) = conv_transpose2d(act(x), k 2, s 2, no bias)
  * and the partial statistics of y.  x mode 0|1 as above. */
@@ -542,6 +557,12 @@ int cine_conv3x3_dgrad(const float* gy, const float* wpacked, const float* wpack
                        float* gx, int n, int cout, int cin, int h, int w, void* stream);
 int cine_tconv2x2_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
                         float* gx, int n, int cin, int cout, int h, int w, void* stream);
+/* cine_conv3x3_dgrad with the chain rule of a ReLU'd input in the epilogue: gx = gate > 0 ? (conv(gy) + addend) : 0, where gate (n, cin, h, w)
+ * is the stored ReLU output that was the conv's input and addend (n, cin, h, w) the gradient it receives from its other consumers (either
+ * may be NULL).  The conv blocks of the CRNN body (reference recurrent_varnet.py:122-134): x_k feeds conv_{k+1}_x AND the next cascade's
+ * conv_k_h, torch.autograd adds the two gradients and applies the ReLU mask in separate kernels. */
+int cine_conv3x3_dgrad_gated(const float* gy, const float* wpacked, const float* addend, const float* gate,
+                             float* gx, int n, int cout, int cin, int h, int w, void* stream);
 int cine_conv1x1_dgrad(const float* gy, const float* wpacked, const float* wpacked2, int set_split,
                        float* gx, int n, int cout, int cin, int h, int w, void* stream);
 

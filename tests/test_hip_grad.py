@@ -536,6 +536,56 @@ def test_training_forward_as_branches_gives_the_same_bits(dev):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("T,ch,c,h,w,relu", [(15, 2, 16, 200, 200, True), (4, 2, 16, 40, 36, True), (5, 3, 6, 24, 20, True), (1, 2, 16, 40, 36, True), (6, 2, 16, 52, 16, False)])
+def test_bcrnn_sweeps_in_c_bit_identical_to_the_step_loops_and_vs_torch(dev, T, ch, c, h, w, relu):
+    """cine_bcrnn_sweep / cine_bcrnn_sweep_bwd (both loops over the frames of BCRNNlayer.forward, reference recurrent_varnet.py:236-254, and their
+    back-propagation through time in ONE C call each; the ReLU mask rides in the conv epilogue as a gate) against the step-by-step composition
+    (cine_crnn_step2 / conv + cine_relu_mask per frame): output, hidden-state gradients and every parameter gradient bit for bit; and against
+    torch's autograd of the literal loops in float64."""
+    from cine_hip import autograd as ag, ops
+    from cine_hip._lib import lib
+    x = rnd(1, T, ch, h, w).to(dev); hid = rnd(2, T, c, h, w).to(dev)
+    w_in = (0.1 * rnd(3, c, c + ch, 3, 3)).to(dev); w_hh = (0.1 * rnd(4, c, c, 3, 3)).to(dev); bias = (0.1 * rnd(5, c)).to(dev)
+    gout = rnd(6, T, c, h, w).to(dev)
+    res = []
+    old = ops.BCRNN_SWEEP_IN_C
+    try:
+        for in_c in (False, True):
+            ops.BCRNN_SWEEP_IN_C = in_c
+            leaves = [t_.clone().requires_grad_(True) for t_ in (x, hid, w_in, w_hh, bias)]
+            lib().cine_diag_counter(3, 1)
+            with ops.activation(relu=relu), torch.enable_grad():
+                out = ag.BcrnnFn.apply(*leaves)
+                out.backward(gout)
+            torch.cuda.synchronize()
+            assert (lib().cine_diag_counter(3, 1) > 0) == in_c
+            res.append([out.detach()] + [t_.grad for t_ in leaves])
+    finally:
+        ops.BCRNN_SWEEP_IN_C = old
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # the literal loops in float64 (recurrent_varnet.py:241-254 with the input terms batched)
+    xd, hd, wi, wh, bd = (t_.double().cpu().requires_grad_(True) for t_ in (x, hid, w_in, w_hh, bias))
+    F = torch.nn.functional
+    act = torch.relu if relu else (lambda v: v)
+    with torch.enable_grad():
+        P = F.conv2d(torch.cat([hd, xd], 1), wi, bd, padding=1)
+        hf = hb = torch.zeros(1, c, h, w, dtype=torch.float64)
+        of, ob = [], []
+        for t_ in range(T):
+            hf = act(F.conv2d(hf, wh, padding=1) + P[t_:t_ + 1]); of.append(hf)
+        for t_ in range(T - 1, -1, -1):
+            hb = act(F.conv2d(hb, wh, padding=1) + P[t_:t_ + 1]); ob.append(hb)
+        want = torch.cat(of) + torch.cat(ob[::-1])
+        want.backward(gout.double().cpu())
+    assert rel_err(res[1][0].cpu(), want.detach()) < 2e-5
+    for got, ref in zip(res[1][1:], (xd, hd, wi, wh, bd)):
+        if relu:        # a hidden value within rounding of 0 flips its ReLU mask between float32 and float64: isolated O(1) entries, so the bar is the L2 norm
+            assert float((got.cpu().double() - ref.grad).norm() / ref.grad.norm().clamp_min(1e-30)) < 2e-3
+        else:
+            assert rel_err(got.cpu(), ref.grad) < 5e-5
+
+
 _LINEAR = {
     "varnet_grad_cfg2_linear": (lambda M: M.VarNet(6, 8, 3, 16, 3, "XF"), 1, 4, False),
     "cinenet_grad_cfg4_linear": (lambda M: M.CineNet(6, 6, 16, 3, "3D"), 7, 6, True),
