@@ -164,7 +164,9 @@ def parse():
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the launcher, sharding, timed region and all-gather on "
                          "gloo/CPU with a stand-in for the forward; the line is marked invalid and measures nothing")
-    return ap.parse_args()
+    args = ap.parse_args()
+    args.sustained_explicit = any(a.startswith("--sustained-seconds") for a in sys.argv[1:])
+    return args
 
 
 # ------------------------------------------------------------------ multi-GPU launcher
@@ -357,6 +359,14 @@ def timed_steps(run, nsteps, batch, outs, world, sync, barrier, device):
     return dt, volume, per_rank
 
 
+def leave_together(use_dist, barrier):
+    """The end of every rank's main(): rank 0 still has host-side work after the timed region (kernel families, the line itself); the other
+    ranks wait for it at ONE last barrier, so that no rank tears its communicator down while another could still enter a collective."""
+    if use_dist:
+        barrier()
+        dist.destroy_process_group()
+
+
 def selftest_cpu(args, world, rank):
     """tests/test_distributed_cpu.py: the launcher, rank bookkeeping, slice sharding, timed region and volume assembly on
     gloo/CPU.  The forward is a stand-in (a fixed function of the slice id); nothing is measured."""
@@ -376,13 +386,20 @@ def selftest_cpu(args, world, rank):
     run(args.warmup)
     dt, volume, per_rank = timed_steps(run, K, 1, outs, world, lambda: None, dist.barrier, torch.device("cpu"))
     ok = bool(torch.equal(volume, torch.stack([standin(i) for i in range(world * K)])))
+    # main()'s ordering behind the timed region: the single-GPU extras are skipped at N > 1, ranks != 0 go straight to the last barrier, rank 0
+    # does its host-side work first (a stand-in pause) and prints -- nobody leaves before rank 0 arrives
+    extras = world == 1 or args.sustained_explicit
+    t_leave = time.perf_counter()
     if rank == 0:
+        time.sleep(0.5)
         print(json.dumps({"metric": "selftest (no measurement)", "value": None, "valid": False, "n_gpus": world, "rccl_ranks": world,
                           "steps": K, "warmup": args.warmup, "volume_ok": ok, "volume_slices": int(volume.shape[0]),
-                          "data": "cpu stand-in for the forward (test only)", "timed_region_s": dt,
+                          "data": "cpu stand-in for the forward (test only)", "timed_region_s": dt, "single_gpu_extras": extras,
                           "per_rank_timed_region_s": per_rank, "cpu_affinity": AFFINITY}))
-    if world > 1:
-        dist.destroy_process_group()
+    leave_together(world > 1, dist.barrier)
+    waited = time.perf_counter() - t_leave
+    if world > 1 and rank != 0 and waited < 0.4:
+        raise SystemExit(4)                       # a rank left before rank 0 had finished its host-side work
     if not ok:
         raise SystemExit(3)
 
@@ -455,12 +472,30 @@ class Workload:
         return self.net(self.mks[i], self.masks[i], acs=self.acss[i])
 
     def run(self, nsteps, keep, h2d=False):
-        """nsteps slices, round-robin over the S streams; each stream is an in-order queue."""
+        """nsteps slices, round-robin over the S streams; each stream is an in-order queue.  h2d: every slice's k-space comes from its pinned
+        host buffer first -- on ONE copy stream that runs ahead of the compute streams (the copy of step k waits only for the replay that last
+        read that device buffer, step k - S; stream i waits for its own copy): the copies queue back to back on the link while the other
+        streams' replays run.  h2d == "inline": the copy on the slice's own stream in front of its replay (round 5's form, kept for the A/B)."""
         S, B = self.S, self.B
+        ahead = h2d and h2d != "inline"
+        if ahead and not hasattr(self, "copy_stream"):
+            self.copy_stream = torch.cuda.Stream()
+            self.ev_ready = [torch.cuda.Event() for _ in range(S)]
+            self.ev_done = [torch.cuda.Event() for _ in range(S)]
+        if ahead:
+            self.copy_stream.wait_stream(torch.cuda.current_stream())
         for k in range(nsteps):
             i = k % S
+            if ahead:
+                if k >= S:
+                    self.copy_stream.wait_event(self.ev_done[i])                # the replay of step k - S has read mks[i]
+                with torch.cuda.stream(self.copy_stream):
+                    self.mks[i].copy_(self.host_mk[i], non_blocking=True)
+                    self.ev_ready[i].record()
             with torch.cuda.stream(self.streams[i]):
-                if h2d:
+                if ahead:
+                    self.streams[i].wait_event(self.ev_ready[i])
+                elif h2d:
                     self.mks[i].copy_(self.host_mk[i], non_blocking=True)      # pinned host buffer -> HBM, ahead of this slice's replay
                 if self.use_graph:
                     self.graphs[i].replay()
@@ -469,6 +504,8 @@ class Workload:
                     o = self.forward(i)
                 if keep:
                     self.outs[k * B:(k + 1) * B].copy_(o)
+                if ahead:
+                    self.ev_done[i].record()
         for st in self.streams:
             torch.cuda.current_stream().wait_stream(st)
 
@@ -873,16 +910,18 @@ def main():
     dt = wl.timed(args.steps)                                         # THE timed region: exactly K steps
     contract_per_rank_s = list(wl.per_rank_s)
     extra = sorted(wl.timed(args.steps) for _ in range(max(0, args.repeats)))
-    dt_h2d = wl.timed(args.steps, h2d=True)
+    dt_h2d = min(wl.timed(args.steps, h2d=True) for _ in range(2))
+    dt_h2d_inline = wl.timed(args.steps, h2d="inline")
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
-    lat_med, lat_min = (None, None) if args.headline_only else wl.latency_one_slice()
-    lat_modes = None if (args.headline_only or rank != 0) else wl.latency_modes()
-    sustained = wl.sustained(args.sustained_seconds, dt / args.steps) if args.sustained_seconds > 0 and not args.headline_only else None
+    # the single-GPU diagnostics (one slice alone, the 60-s sustained region) belong to the N = 1 line: on N ranks they would keep N GPUs
+    # busy for a minute each after the contract's region.  --sustained-seconds X forces the sustained region at N > 1 too (X > 0 given explicitly).
+    extras = not args.headline_only and (world == 1 or args.sustained_explicit)
+    lat_med, lat_min = wl.latency_one_slice() if extras else (None, None)
+    lat_modes = wl.latency_modes() if (extras and rank == 0 and world == 1) else None
+    sustained = wl.sustained(args.sustained_seconds, dt / args.steps) if args.sustained_seconds > 0 and extras else None
 
     if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
-        return
+        return leave_together(use_dist, lambda: dist.barrier(device_ids=[local]))
 
     # ---- rank 0: per-family device time, ISOLATED (eager launches, one slice in flight, hipEvents on the launch stream)
     fam = profile_families(wl.forward)
@@ -915,9 +954,9 @@ def main():
                               "each halved again); eager launches or one hipGraph replay (the side streams are branches of the captured graph)",
         "sustained_value": sustained["value"] if sustained else None, "sustained": sustained,
         "repeat_values": [slices / d for d in extra], "repeat_median_value": (slices / extra[len(extra) // 2]) if extra else None,
-        "value_with_h2d": slices / dt_h2d,
-        "value_with_h2d_note": "same K steps with each slice's 72 MB k-space copied pinned-host -> HBM on its stream ahead of the "
-                               "replay (what run_inference.py:53-61 times); overlaps the other streams' compute",
+        "value_with_h2d": slices / dt_h2d, "value_with_h2d_inline": slices / dt_h2d_inline,
+        "value_with_h2d_note": "same K steps with each slice's 72 MB k-space copied pinned-host -> HBM before its replay (what run_inference.py:53-61 "
+                               "times): on one copy stream that runs ahead of the compute streams (best of 2 regions); _inline = the copy on the slice's own stream (round 5's form)",
         "roofline": roofline,
         "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items()},
     }
@@ -987,8 +1026,7 @@ def main():
             except Exception as e:                                        # pragma: no cover
                 line["train_step_other_configs"][str(cid)] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(line))
-    if use_dist:
-        dist.destroy_process_group()
+    leave_together(use_dist, lambda: dist.barrier(device_ids=[local]))
 
 
 if __name__ == "__main__":

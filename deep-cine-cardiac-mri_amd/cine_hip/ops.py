@@ -142,7 +142,7 @@ def branches(n: int):
             _act_tls.branches = old
 
 
-_PACK_IN_CAPTURE = False      # inside training_capture(): the weight-pack kernels BELONG to the captured step (the weights change every replay)
+_pack_tls = threading.local()   # .on inside training_capture() of THIS thread: the weight-pack kernels BELONG to the captured step (the weights change every replay)
 _cache_epoch = 0              # part of every packed-weight cache key: bumped when a training capture ends
 
 
@@ -156,20 +156,20 @@ def training_capture():
     the kernels that re-pack them must be part of the graph -- the capture guard of the packed-weight caches is lifted.  The packs made inside
     belong to the graph's memory pool and are refreshed only by its replays: when the capture ends every cache is invalidated (the epoch in
     their keys moves), so a later eager call (validation) packs the parameters' current values into memory of its own."""
-    global _PACK_IN_CAPTURE, _cache_epoch
-    _PACK_IN_CAPTURE = True
+    global _cache_epoch
+    _pack_tls.on = True          # per thread: another thread's inference capture keeps its guard
     try:
         yield
     finally:
-        _PACK_IN_CAPTURE = False
-        _cache_epoch += 1
+        _pack_tls.on = False
+        _cache_epoch += 1        # process-wide on purpose: EVERY thread's packed-weight caches are rebuilt (they may alias this capture's pool)
 
 
 def _no_capture(what: str, pack: bool = False) -> None:
     """Caches that outlive a call (packed weights, per-stream scratch) must not be filled during hipGraph capture: the
     tensors would come from the graph's private pool yet stay referenced afterwards.  (pack: a packed-weight cache, allowed inside
     ``training_capture()``.)"""
-    if torch.cuda.is_current_stream_capturing() and not (pack and _PACK_IN_CAPTURE):
+    if torch.cuda.is_current_stream_capturing() and not (pack and getattr(_pack_tls, "on", False)):
         raise CineHipError(f"{what} would be created during hipGraph capture; run one eager forward on this stream first "
                            "(and re-capture after changing weights)")
 
@@ -878,7 +878,9 @@ class _BatchedPacks:
 
     @classmethod
     def supports(cls, items) -> bool:
-        return all(k is None or k == "raw" or (k in cls._OPS and p.dim() == 4) for k, p in items)
+        # contiguous parameters only: the descriptor table holds the parameters' OWN addresses (a .contiguous() copy of a channels_last
+        # model would be packed once and then go stale); anything else takes the per-tensor packs
+        return all(k is None or ((k == "raw" or (k in cls._OPS and p.dim() == 4)) and p.is_contiguous()) for k, p in items)
 
     def pointers(self, items):
         L = lib()

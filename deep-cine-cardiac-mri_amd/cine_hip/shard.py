@@ -88,11 +88,20 @@ class GradientAllReduce:
         # disagree about which parameters are unused still take the same optimiser step and the replicas cannot drift apart.
         have = [p.grad is not None for p in self.params]
         dev, dt = self.params[0].device, self.params[0].dtype
-        flat = torch.cat([p.grad.reshape(-1) if h else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
-                          for p, h in zip(self.params, have)] + [torch.tensor([float(h) for h in have], dtype=dt, device=dev)])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # one gather kernel, one collective, one scatter
         nparam = len(self.params)
-        any_have = (flat[-nparam:] > 0).tolist()
+        complete = all(have)
+        if complete:          # the usual step: the flags are a cached device tensor of ones -- no host-to-device copy, and no answer to wait for
+            if getattr(self, "_ones", None) is None or self._ones.device != dev:
+                self._ones = torch.ones(nparam, dtype=dt, device=dev)
+            flags = self._ones
+        else:
+            flags = torch.tensor([float(h) for h in have], dtype=dt, device=dev)
+        flat = torch.cat([p.grad.reshape(-1) if h else torch.zeros(p.numel(), dtype=p.dtype, device=p.device)
+                          for p, h in zip(self.params, have)] + [flags])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)       # one gather kernel, one collective, one scatter
+        # Only a rank that LACKS a gradient has to learn whether another rank had it (a blocking read-back, and the one thing in here that
+        # cannot be captured into a hipGraph); a rank with every gradient writes every parameter anyway and keeps enqueueing ahead.
+        any_have = [True] * nparam if complete else (flat[-nparam:] > 0).tolist()
         flat = flat[:-nparam].mul_(1.0 / world)
         pieces = flat.split([p.numel() for p in self.params])
         dst, src = [], []

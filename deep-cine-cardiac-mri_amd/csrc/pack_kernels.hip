@@ -455,6 +455,7 @@ namespace cine {
 __global__ __launch_bounds__(256) void acs_window_kernel(const float* __restrict__ rows, int n, int h, int* __restrict__ win) {
     __shared__ int sl[4], sr[4];
     const int cent = h / 2;
+    n = min(n, h);                  // frame 0 of batch element 0 only (varnet.py:64-68 is written for batch 1; later rows must not supply `right`)
     int l = -1, r = n;
     for (int i = threadIdx.x; i < n; i += 256)
         if (rows[i] == 0.f) { if (i < cent) l = max(l, i); else r = min(r, i); }
@@ -464,8 +465,11 @@ __global__ __launch_bounds__(256) void acs_window_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         l = max(max(sl[0], sl[1]), max(sl[2], sl[3])); r = min(min(sr[0], sr[1]), min(sr[2], sr[3]));
+        // no unsampled row below / above the centre (a fully sampled mask): the reference's nonzero(...)[-1] raises there; a kernel cannot,
+        // so the window is every row -- mask_center then keeps the whole k-space, which is what "all of it is calibration data" means
+        if (l < 0 || r >= h) { win[0] = 0; win[1] = h; return; }
         const int n_low = r - l, pad = (h - n_low + 1) / 2;
-        win[0] = pad; win[1] = pad + n_low;
+        win[0] = max(pad, 0); win[1] = min(pad + n_low, h);
     }
 }
 }  // namespace cine

@@ -153,6 +153,15 @@ def test_bench_gpus_flag_starts_that_many_ranks_gloo_world2():
     assert r.returncode == 0, r.stderr[-2000:]
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["volume_ok"] and line["volume_slices"] == 10
     assert line["valid"] is False and line["value"] is None            # the self-test line can never pass for a measurement
+    # main()'s ordering behind the timed region (bench.leave_together): rank 1 waits at the last barrier until rank 0 has done its host-side work
+    # (exit code 4 if it had left early), and an N > 1 run skips the single-GPU extras (one slice alone, the 60-s sustained region)
+    assert line["single_gpu_extras"] is False
+
+
+def test_bench_single_gpu_extras_only_when_asked_for_at_n_greater_than_1():
+    r, line = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--selftest-cpu", "--sustained-seconds", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["single_gpu_extras"] is True
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():

@@ -1488,6 +1488,14 @@ def test_acs_window_found_on_the_device_equals_the_host_form(dev):
         want = SensitivityModel.acs_window(mk)
         win = ops.acs_window_dev(mk.to(dev)).cpu().tolist()
         assert win == [want[0], want[0] + want[1]], (win, want, tuple(mk.shape))
+    # no unsampled row on one side of batch 0's centre (fully sampled, or sampled to the edge): the host form raises like the reference's
+    # nonzero(...)[-1]; the device form keeps every row -- and never lets a LATER batch entry's rows supply the window's end
+    full = torch.ones(1, 2, 1, 40, 1, 1)
+    edge = torch.cat([torch.ones(1, 2, 1, 40, 1, 1), m], 0); edge[0, :, :, :10] = 0
+    for mk in (full, edge):
+        with pytest.raises(IndexError):
+            SensitivityModel.acs_window(mk[:1])
+        assert ops.acs_window_dev(mk.to(dev)).cpu().tolist() == [0, 40]
     ex = synth.make_cine_slice(4, 3, 48, 40, accel=4, center_lines=6, seed=5)
     k, mk = ex["masked_kspace"].to(dev), ex["mask"].to(dev)
     pad, n_low = SensitivityModel.acs_window(mk)

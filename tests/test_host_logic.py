@@ -93,3 +93,25 @@ def test_product_does_not_import_oracle():
                 if "import oracle" in txt or "from oracle" in txt:
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_import_after_hip_initialisation_warns_about_hardware_queues():
+    """cine_hip sets GPU_MAX_HW_QUEUES=16 on import when the user has not; that only takes effect before the HIP runtime starts, so an import
+    AFTER initialisation says so (RuntimeWarning) instead of silently running the side streams on 4 shared queues."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, types, warnings
+        os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        sys.path[:0] = [%r]
+        import torch
+        torch.cuda.is_initialized = lambda: True          # stand-in for "a script touched the GPU first" (no GPU here)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            import cine_hip
+        print("WARNED" if any("GPU_MAX_HW_QUEUES" in str(x.message) for x in w) else "SILENT", os.environ.get("GPU_MAX_HW_QUEUES"))
+        """ % os.path.join(ROOT, "deep-cine-cardiac-mri_amd"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WARNED 16" in r.stdout, r.stdout + r.stderr
+    code2 = code.replace('os.environ.pop("GPU_MAX_HW_QUEUES", None)', 'os.environ["GPU_MAX_HW_QUEUES"] = "8"')
+    r = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SILENT 8" in r.stdout, r.stdout + r.stderr
