@@ -87,16 +87,18 @@ def unet2d_forward_train(x: torch.Tensor, weights: "ops.UnetWeights"):
     ws = torch.empty(need, device=x.device, dtype=torch.uint8)
     y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
     nb = ops._branch_count(n, len(weights.unets))
-    if nb > 1:          # the same launch sequence as concurrent branches into the same workspace layout (bit-identical)
-        side = ops.side_streams(x.device, nb - 1)
-        sarr = (ctypes.c_void_p * len(side))(*[s_.cuda_stream for s_ in side])
+    drop = weights.dropout_multipliers(n, x.device)          # Dropout2d of the ConvBlocks (training mode, drop_prob > 0), else None
+    if nb > 1 or drop is not None:          # the same launch sequence, as concurrent branches into the same workspace layout (bit-identical) and / or with dropout
+        side = ops.side_streams(x.device, nb - 1) if nb > 1 else []
+        sarr = (ctypes.c_void_p * max(len(side), 1))(*[s_.cuda_stream for s_ in side])
         check(lib().cine_unet2d_forward_branches(x.data_ptr(), y.data_ptr(), weights.pointers(train=True), len(weights.unets), n, h, w, cin,
                                                  weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream(),
-                                                 sarr, len(side), 1), "cine_unet2d_forward_branches")
+                                                 sarr, len(side), 1, _p(drop)), "cine_unet2d_forward_branches")
     else:
         check(lib().cine_unet2d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(train=True), len(weights.unets), n, h, w, cin,
                                               weights.out_ch, weights.chans, weights.pools, ops.lrelu_slope(), ws.data_ptr(), ws.numel(), _stream()),
               "cine_unet2d_forward_train")
+    ws.cine_drop = drop                              # the backward pass needs the same multipliers
     ws.cine_slope = ops.lrelu_slope()                  # the backward pass differentiates the activation the forward pass applied
     ws.cine_training_key = key                       # checked by unet2d_backward
     return y, ws
@@ -128,9 +130,9 @@ def unet2d_backward(x: torch.Tensor, gy: torch.Tensor, weights: "ops.UnetWeights
     gx = torch.empty_like(x) if need_gx else None
     weights.check_training_key(getattr(fwd_ws, "cine_training_key", None), "cine_unet2d_backward")
     _use_side_stream(x.device)
-    check(lib().cine_unet2d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, nsets, n, h, w, cin,
-                                     weights.out_ch, weights.chans, weights.pools, getattr(fwd_ws, "cine_slope", ops.lrelu_slope()), fwd_ws.data_ptr(), fwd_ws.numel(),
-                                     ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_unet2d_backward")
+    check(lib().cine_unet2d_backward_drop(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, nsets, n, h, w, cin,
+                                          weights.out_ch, weights.chans, weights.pools, getattr(fwd_ws, "cine_slope", ops.lrelu_slope()), fwd_ws.data_ptr(), fwd_ws.numel(),
+                                          ws.data_ptr(), ws.numel(), _p(gx), _p(getattr(fwd_ws, "cine_drop", None)), _stream()), "cine_unet2d_backward")
     return gx, grads
 
 

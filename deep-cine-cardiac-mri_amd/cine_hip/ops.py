@@ -112,6 +112,18 @@ def unet_branches() -> int:
     return getattr(_act_tls, "branches", UNET_BRANCHES)
 
 
+@contextlib.contextmanager
+def fixed_dropout(multipliers):
+    """Tests: the training forwards of the CALLING THREAD take these Dropout multipliers (cine_unet2d_forward_branches' layout) instead of drawing
+    them -- the same mask can then be fed to the oracle.  ``False``: no dropout whatever the modules say."""
+    old = getattr(_act_tls, "dropout", None)
+    _act_tls.dropout = multipliers
+    try:
+        yield
+    finally:
+        _act_tls.dropout = old
+
+
 def fork_side(device: torch.device) -> "torch.cuda.Stream":
     """A side stream of (device, current stream) that has been made to wait for everything enqueued on the current stream so far; launch
     independent work on it (``with torch.cuda.stream(side): ...``, outputs allocated BEFORE entering it) and ``join_side(side)`` before the
@@ -1081,16 +1093,47 @@ class UnetWeights:
 
     # ---- training (cine_unet2d_backward)
     def training_key(self):
-        """Called where a training ``autograd.Function`` is entered.  Refuses what the backward kernels do not model -- Dropout
-        (reference unet.py:22,40,159-168 applies Dropout2d / Dropout3d after every LeakyReLU when the module is in training
-        mode) -- and returns the parameters' (address, version) key: the backward pass re-packs the input-gradient weights from
-        the parameters' CURRENT values and compares this key first (torch would raise 'modified by an inplace operation')."""
-        for u in self.unets:
-            if u.training and getattr(u, "drop_prob", 0.0) > 0:
-                raise NotImplementedError("training with Dropout (drop_prob > 0) is not on the HIP path: the backward kernels "
-                                          "have no dropout mask; build the U-Nets with drop_prob=0.0 (the reference scripts' value) "
-                                          "or call .eval()")
+        """Called where a training ``autograd.Function`` is entered: the parameters' (address, version) key -- the backward pass re-packs the
+        input-gradient weights from the parameters' CURRENT values and compares this key first (torch would raise 'modified by an inplace
+        operation')."""
         return tuple((p.data_ptr(), p._version) for seq in self._params() for _, p in seq)
+
+    def drops(self) -> bool:
+        """True when a network of the set applies Dropout in its current mode."""
+        return any(u.training and float(getattr(u, "drop_prob", 0.0)) > 0 for u in self.unets)
+
+    def dropout_multipliers(self, n: int, device) -> Optional[torch.Tensor]:
+        """Dropout2d / Dropout3d of the reference's ConvBlocks (unet.py:22,40,159-168: behind every LeakyReLU, active when the module is in training
+        mode and drop_prob > 0): the multiplier of every (3x3 conv, sample, channel) plane -- 0 with probability p, else 1 / (1 - p) -- in
+        cine_unet2d_forward_branches' layout, drawn from torch's generator of the device (``torch.manual_seed`` makes a step reproducible, as it
+        does for nn.Dropout2d; the random stream itself differs from ATen's).  None when no network of the set drops anything.  2-D U-Nets only."""
+        ps = [float(getattr(u, "drop_prob", 0.0)) if u.training else 0.0 for u in self.unets]
+        fixed = getattr(_act_tls, "dropout", None)
+        if fixed is not None:
+            return None if fixed is False else _dev(fixed, "dropout multipliers")
+        if not any(p > 0 for p in ps):
+            return None
+        if any(getattr(u, "dims", 2) != 2 for u in self.unets):
+            raise NotImplementedError("training with Dropout3d (drop_prob > 0 in a 3-D U-Net) is not on the HIP path; build it with drop_prob=0.0 or call .eval()")
+        if any(not 0.0 <= p < 1.0 for p in ps):
+            raise ValueError("dropout probability has to be in [0, 1)")
+        total = lib().cine_unet2d_drop_floats(n, self.chans, self.pools)
+        u = torch.rand(total, device=device, dtype=torch.float32)
+        if len(set(ps)) == 1:
+            p = ps[0]
+            return (u >= p).to(torch.float32).mul_(1.0 / (1.0 - p))
+        # two networks with different probabilities: rows [0, n / 2) of every (n, ch) block belong to the first
+        out = torch.empty_like(u)
+        off = 0
+        for conv in range(4 * self.pools + 2):
+            d = conv // 2 if conv < 2 * (self.pools + 1) else self.pools - 1 - (conv - 2 * (self.pools + 1)) // 2
+            ch = self.chans << d
+            blk, ob = u[off:off + n * ch].view(n, ch), out[off:off + n * ch].view(n, ch)
+            for k, p in enumerate(ps):
+                rows = slice(k * n // len(ps), (k + 1) * n // len(ps))
+                ob[rows] = (blk[rows] >= p).to(torch.float32) / (1.0 - p)
+            off += n * ch
+        return out
 
     def check_training_key(self, key, what: str) -> None:
         if key is not None and key != tuple((p.data_ptr(), p._version) for seq in self._params() for _, p in seq):
@@ -1168,7 +1211,7 @@ def unet2d_forward(x: torch.Tensor, weights: UnetWeights, workspace: Optional[to
         y = torch.empty((n, weights.out_ch, h, w), device=x.device, dtype=x.dtype)
         sarr = (ctypes.c_void_p * len(side))(*[s_.cuda_stream for s_ in side])
         check(lib().cine_unet2d_forward_branches(x.data_ptr(), y.data_ptr(), weights.pointers(), nsets, n, h, w, cin, weights.out_ch, weights.chans,
-                                                 weights.pools, lrelu_slope(), workspace.data_ptr(), workspace.numel(), _stream(), sarr, len(side), 2 * int(BRANCH_INTERLEAVE)),
+                                                 weights.pools, lrelu_slope(), workspace.data_ptr(), workspace.numel(), _stream(), sarr, len(side), 2 * int(BRANCH_INTERLEAVE), None),
               "cine_unet2d_forward_branches")
         return y
     need = lib().cine_unet2d_ws_bytes(n, h, w, cin, weights.out_ch, weights.chans, weights.pools)

@@ -26,7 +26,16 @@ struct InBwdArgs {
     float* gr;
     int n, c, h, w;
     float eps, slope;
+    // Dropout2d behind the activation (unet.py:163,167): drop[n * c + ch] = the channel's multiplier d (0 or 1 / (1 - p)), NULL = none.  The forward
+    // folds d into the statistics records (d LeakyReLU(v) = LeakyReLU(d v): the records then give rstd' = d rstd, cine_dropout_stats), so every
+    // consumer sees z = d xhat; the backward of the normalisation needs d once more: gr = rstd' (g' - mean g' - z mean(g' z) / d^2)
+    const float* drop;
 };
+__device__ __forceinline__ float drop_k2(const float* drop, long plane) {
+    if (!drop) return 1.f;
+    const float d = drop[plane];
+    return d > 0.f ? 1.f / (d * d) : 0.f;
+}
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st);
 // few, large planes (volumes; the sens-net's 200 x 200 coil planes): two passes over chunks of a plane with `ws` holding the chunk sums;
 // falls back to launch_in_lrelu_bwd for every other shape or without a workspace

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(InBwdArgs a) {
         s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
     if (!live) return;
-    const float m1 = s1 / pe, m2 = s2 / pe;
+    const float m1 = s1 / pe, m2 = s2 / pe * drop_k2(a.drop, pl);
     for (int e = t0; e < pe; e += ts) {
         const int y = e / a.w, x = e - y * a.w;
         const float xh = fmaf(r[e], scale, shift);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_kernel(InBwdArgs a, co
     const float scale = mr.y, shift = -mr.x * mr.y;
     float s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < nchunk; ++k) { s1 += ws[(pl * nchunk + k) * 2]; s2 += ws[(pl * nchunk + k) * 2 + 1]; }
-    const float m1 = s1 / pe, m2 = s2 / pe;
+    const float m1 = s1 / pe, m2 = s2 / pe * drop_k2(a.drop, pl);
     const float* r = a.r + pl * pe;
     float* gr = a.gr + pl * pe;
     const float* qa = piece_plane(a.a, n, c);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_apply_vec_kernel(InBwdArgs a
     const float scale = mr.y, shift = -mr.x * mr.y;
     float s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < nchunk; ++k) { s1 += ws[(pl * nchunk + k) * 2]; s2 += ws[(pl * nchunk + k) * 2 + 1]; }
-    const float m1 = s1 / pe, m2 = s2 / pe;
+    const float m1 = s1 / pe, m2 = s2 / pe * drop_k2(a.drop, pl);
     const float4* r4 = reinterpret_cast<const float4*>(a.r + pl * pe);
     float4* gr4 = reinterpret_cast<float4*>(a.gr + pl * pe);
     const float4* qa4 = reinterpret_cast<const float4*>(piece_plane(a.a, n, c));

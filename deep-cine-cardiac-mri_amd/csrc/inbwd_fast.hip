@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_fast_kernel(InBwdArgs a) {
     }
     if (!live) return;
     const float pe = (float)(a.h * a.w);
-    const float m1 = s1 / pe, m2 = s2 / pe;
+    const float m1 = s1 / pe, m2 = s2 / pe * drop_k2(a.drop, pl);
 #pragma unroll
     for (int i = 0; i < K; ++i) {
         const int e4 = t0 + i * ts;

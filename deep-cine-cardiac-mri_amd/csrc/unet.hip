@@ -18,6 +18,47 @@ namespace {
 
 constexpr float kEps = 1e-5f;     // nn.InstanceNorm2d default (unet.py:161)
 
+// Dropout2d behind a ConvBlock's LeakyReLU (unet.py:163,167; training mode, drop_prob > 0): the multiplier d of a (sample, channel) plane is 0 or
+// 1 / (1 - p), and d LeakyReLU(v) = LeakyReLU(d v) for d >= 0 -- so it is folded into the plane's statistics records: every consumer
+// (conv staging, weight-gradient re-activation, the pooled / concatenated reads) computes rstd from the merged {count, mean, M2}, and adding
+// (M2 + count eps) (1 / d^2 - 1) to ONE record's M2 makes that rstd' = d rstd (the merge is linear in the M2 entries); d = 0: M2 = +inf -> rstd' = 0.
+__global__ void dropout_stats_kernel(float* part, int np, long planes, const float* __restrict__ drop, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes) return;
+    const float d = drop[i];
+    if (d == 1.f) return;
+    float* p = part + i * np * 3;
+    if (!(d > 0.f)) { p[2] = __builtin_inff(); return; }
+    float cnt = 0.f, mean = 0.f;
+    for (int k = 0; k < np; ++k) { cnt += p[3 * k]; mean += p[3 * k] * p[3 * k + 1]; }
+    mean /= cnt;
+    float m2 = 0.f;
+    for (int k = 0; k < np; ++k) { const float dl = p[3 * k + 1] - mean; m2 += p[3 * k + 2] + p[3 * k] * dl * dl; }
+    p[2] += (m2 + cnt * eps) * (1.f / (d * d) - 1.f);
+}
+int launch_dropout_stats(float* part, int np, long planes, const float* drop, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_stats_kernel, dim3((unsigned)ceil_div(planes, 256L)), dim3(256), 0, st, part, np, planes, drop, kEps);
+    return check_launch("dropout_stats_kernel");
+}
+// layout of the multipliers: one (n, ch) block per 3x3 conv in launch order -- down path / bottleneck level d: convs 2 d and 2 d + 1 (ch[d] channels),
+// up path level d: convs 2 (P + 1) + 2 (P - 1 - d) and the next one (ch[d] channels); the transpose convs have no dropout (unet.py:204-219)
+struct DropMap {
+    const float* base; int n_total, a, chans, pools;
+    long off(int conv) const {         // floats in front of conv's block
+        long o = 0;
+        for (int j = 0; j < conv; ++j) o += (long)n_total * ch_of(j);
+        return o;
+    }
+    int ch_of(int conv) const {
+        const int P = pools;
+        const int d = conv < 2 * (P + 1) ? conv / 2 : P - 1 - (conv - 2 * (P + 1)) / 2;
+        return chans << d;
+    }
+    const float* at(int conv) const { return base ? base + off(conv) + (long)a * ch_of(conv) : nullptr; }
+    static int down(int d, int k) { return 2 * d + k; }
+    int up(int d, int k) const { return 2 * (pools + 1) + 2 * (pools - 1 - d) + k; }
+};
+
 struct Bump {
     char* base; size_t off;
     float* take(size_t floats) {
@@ -113,8 +154,13 @@ extern "C" size_t cine_unet2d_train_ws_bytes(int n, int h, int w, int in_ch, int
 // are enqueued (5 * pools + 3 in all), so that concurrent branches can be enqueued layer by layer.
 static int unet_launches(int pools) { return 5 * pools + 3; }
 static int run_unet(const Plan& p, const float* x, float* y, const void* const* wa, const void* const* wb, int split,
-                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope, void* stream, int l0 = 0, int l1 = 1 << 30) {
+                    int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope, void* stream, int l0 = 0, int l1 = 1 << 30,
+                    const DropMap* dm = nullptr) {
     int wi = 0, li = 0;
+    auto drop = [&](int conv, float* part, int np, int ch) {          // fold this conv's Dropout2d multipliers into its statistics records
+        if (!dm || !dm->base) return (int)CINE_OK;
+        return launch_dropout_stats(part, np, (long)n * ch, dm->at(conv), as_stream(stream));
+    };
     const float *w0, *w1;
     auto next = [&]() {
         w0 = reinterpret_cast<const float*>(wa[wi]);
@@ -139,12 +185,12 @@ static int run_unet(const Plan& p, const float* x, float* y, const void* const* 
                 e = cine_conv3x3_in(p.skip[d - 1], p.pskip[d - 1], p.np_conv[d - 1], p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
                                     nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
                                     mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e) return e;
+            if (e || (e = drop(DropMap::down(d, 0), pmid, p.np_conv[d], p.ch[d]))) return e;
         }
         if (next()) {
             e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                                 w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e) return e;
+            if (e || (e = drop(DropMap::down(d, 1), pout, p.np_conv[d], p.ch[d]))) return e;
         }
     }
     // ---- up path (unet.py:102-123)
@@ -161,12 +207,12 @@ static int run_unet(const Plan& p, const float* x, float* y, const void* const* 
             e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
                                 p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
                                 p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e) return e;
+            if (e || (e = drop(dm ? dm->up(d, 0) : 0, p.pca[d], p.np_conv[d], p.ch[d]))) return e;
         }
         if (next()) {
             e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                                 w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e) return e;
+            if (e || (e = drop(dm ? dm->up(d, 1) : 0, p.pcb[d], p.np_conv[d], p.ch[d]))) return e;
         }
         cur = p.cb[d]; pcur = p.pcb[d]; np_cur = p.np_conv[d];
     }
@@ -231,6 +277,7 @@ extern "C" int cine_unet2d_forward_train(const float* x, float* y, const void* c
 namespace {
 struct Cut { int a, n, set; };       // planes [a, a + n) of weight set `set`
 int cut_planes(int n, int nsets, int nbranch, Cut* c) {
+    if (nbranch == 1) { c[0] = Cut{0, n, -1}; return 1; }          // one run over every plane (set -1: both weight sets when there are two)
     const int per_set = nbranch / nsets, ns = n / nsets;
     int k = 0;
     for (int s = 0; s < nsets; ++s)
@@ -241,9 +288,15 @@ int cut_planes(int n, int nsets, int nbranch, Cut* c) {
     return k;
 }
 bool branches_ok(int n, int nsets, int nbranch) {
-    return nbranch >= 1 && nbranch <= 8 && nbranch % nsets == 0 && n / nbranch >= 1;
+    return nbranch == 1 || (nbranch >= 2 && nbranch <= 8 && nbranch % nsets == 0 && n / nbranch >= 1);
 }
 }  // namespace
+
+extern "C" size_t cine_unet2d_drop_floats(int n, int chans, int pools) {
+    if (n <= 0 || chans <= 0 || pools <= 0 || pools > 6) return 0;
+    const DropMap dm{nullptr, n, 0, chans, pools};
+    return (size_t)dm.off(4 * pools + 2);
+}
 
 extern "C" size_t cine_unet2d_branch_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools, int nsets, int nbranch, int train) {
     if (n <= 0 || (nsets != 1 && nsets != 2) || n % nsets || !branches_ok(n, nsets, nbranch)) return 0;
@@ -261,10 +314,11 @@ extern "C" size_t cine_unet2d_branch_ws_bytes(int n, int h, int w, int in_ch, in
 
 extern "C" int cine_unet2d_forward_branches(const float* x, float* y, const void* const* weights, int nsets,
                                             int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
-                                            void* ws, size_t ws_bytes, void* stream, void* const* side, int nside, int train) {
+                                            void* ws, size_t ws_bytes, void* stream, void* const* side, int nside, int train, const float* drop) {
     if (int e = unet2d_check(x, y, weights, nsets, n, h, w, in_ch, out_ch, chans, pools, slope, ws)) return e;
     const bool interleave = (train & 2) != 0;
     train &= 1;
+    CINE_REQUIRE(!drop || train, CINE_EINVAL, "cine_unet2d_forward_branches: Dropout multipliers belong to the training forward (eval mode has no dropout)");
     const int nbranch = nside + 1;
     CINE_REQUIRE(nside >= 0 && (nside == 0 || side), CINE_EINVAL, "cine_unet2d_forward_branches: side streams missing");
     CINE_REQUIRE(branches_ok(n, nsets, nbranch), CINE_EINVAL, "cine_unet2d_forward_branches: %d planes of %d set(s) do not cut into %d branches", n, nsets, nbranch);
@@ -320,8 +374,12 @@ extern "C" int cine_unet2d_forward_branches(const float* x, float* y, const void
     for (int l = 0; l < nl && !err; l += lstep)
         for (int i = 0; i < k && !err; ++i) {
             hipStream_t st = i == 0 ? main : as_stream(side[i - 1]);
-            const void* const* wa = weights + (c[i].set ? nptr : 0);
-            err = run_unet(plans[i], x + c[i].a * xs, y + c[i].a * ys, wa, nullptr, c[i].n, c[i].n, h, w, in_ch, out_ch, chans, pools, slope, st, l, l + lstep);
+            const bool whole = c[i].set < 0;
+            const void* const* wa = weights + (c[i].set > 0 ? nptr : 0);
+            const void* const* wb = whole && nsets == 2 ? weights + nptr : nullptr;
+            const DropMap dm{drop, n, c[i].a, chans, pools};
+            err = run_unet(plans[i], x + c[i].a * xs, y + c[i].a * ys, wa, wb, whole ? n / nsets : c[i].n, c[i].n, h, w, in_ch, out_ch, chans, pools, slope,
+                           st, l, l + lstep, &dm);
         }
     for (int i = 1; i < k; ++i) {       // joined even after an error: no dangling fork
         (void)hipEventRecord(done[i], as_stream(side[i - 1])); (void)hipStreamWaitEvent(main, done[i], 0);
@@ -388,9 +446,18 @@ extern "C" size_t cine_unet2d_backward_ws_bytes(int n, int h, int w, int in_ch, 
 // INPUT-GRADIENT packings (cine_pack_conv3x3_dgrad / _tconv2x2_dgrad / _conv1x1_dgrad; the bias slot is unused).  `grads`:
 // host array in the same order of device pointers to the weight gradients in the parameters' own layouts ((cout, cin, 3, 3),
 // (cin, cout, 2, 2), (cout, cin), (cout)); they are ACCUMULATED into (+=).  gx (n, in_ch, h, w) may be NULL.
+extern "C" int cine_unet2d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
+                                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
+                                         const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream);
 extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
                                     int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
                                     const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream) {
+    return cine_unet2d_backward_drop(x, gy, wdgrad, grads, nsets, n, h, w, in_ch, out_ch, chans, pools, kSlope, fwd_ws, fwd_ws_bytes, ws, ws_bytes, gx, nullptr, stream);
+}
+// `drop`: the Dropout2d multipliers the training forward applied (cine_unet2d_forward_branches; NULL = none)
+extern "C" int cine_unet2d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
+                                         int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
+                                         const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream) {
     CINE_REQUIRE(x && gy && wdgrad && grads && fwd_ws && ws, CINE_EINVAL, "cine_unet2d_backward: null pointer");
     CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet2d_backward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(nsets == 1 || nsets == 2, CINE_EINVAL, "cine_unet2d_backward: nsets must be 1 or 2");
@@ -431,9 +498,11 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
         a.mat = q.mat; a.mat_floats = q.mat_floats;
         return on_side([&](hipStream_t sw) { return launch_wgrad(a, 9, 0, gr(wi, 0), gr(wi, 1), q.wg, q.wg_floats, sw); });
     };
+    const DropMap dm{drop, n, 0, chans, pools};
     auto inbwd = [&](const float* r, const float* part, int np, int c, int hh, int ww, const float* ga, int ca_total, int ca_off,
-                     int ha, int wa, const float* gb, int hb, int wb, float* out) {
-        InBwdArgs a{r, part, np, GradPiece{ga, 1, ca_total, ca_off, ha, wa}, GradPiece{gb, gb ? 2 : 0, c, 0, hb, wb}, out, n, c, hh, ww, kEps, kSlope};
+                     int ha, int wa, const float* gb, int hb, int wb, float* out, int conv = -1) {
+        InBwdArgs a{r, part, np, GradPiece{ga, 1, ca_total, ca_off, ha, wa}, GradPiece{gb, gb ? 2 : 0, c, 0, hb, wb}, out, n, c, hh, ww, kEps, kSlope,
+                    conv >= 0 ? dm.at(conv) : nullptr};
         return launch_in_lrelu_bwd_split(a, q.inb, q.inb_floats, st);      // one workgroup per plane unless the planes are few and large
     };
 
@@ -453,12 +522,12 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
         const int hu = 2 * p.hs[d + 1], wu = 2 * p.wsz[d + 1];           // extent of the transpose-conv output
         // second conv of the block: cb = conv(act(ca))
         float* B = next_g();
-        if ((e = inbwd(p.cb[d], p.pcb[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
+        if ((e = inbwd(p.cb[d], p.pcb[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B, dm.up(d, 1)))) return e;
         if ((e = wgrad3(src(p.ca[d], p.pca[d], c, 1, hh, ww, npc), none, B, c, hh, ww, i_up(d, 2)))) return e;
         if ((e = cine_conv3x3_dgrad(B, wd(i_up(d, 2), 0), wd2(i_up(d, 2)), sp, q.A, n, c, c, hh, ww, stream))) return e;
         // first conv: ca = conv(cat(act(up) zero-padded, act(skip)))
         B = next_g();
-        if ((e = inbwd(p.ca[d], p.pca[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
+        if ((e = inbwd(p.ca[d], p.pca[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B, dm.up(d, 0)))) return e;
         if ((e = wgrad3(src(p.up[d], p.pup[d], c, 1, hu, wu, p.np_tconv[d]), src(p.skip[d], p.pskip[d], c, 1, hh, ww, npc), B, c, hh, ww, i_up(d, 1)))) return e;
         if ((e = cine_conv3x3_dgrad(B, wd(i_up(d, 1), 0), wd2(i_up(d, 1)), sp, q.cat[d], n, c, 2 * c, hh, ww, stream))) return e;
         // transpose conv: up = tconv(act(cur)), cur = cb[d+1] or the bottleneck output
@@ -483,14 +552,14 @@ extern "C" int cine_unet2d_backward(const float* x, const float* gy, const void*
         const float* pout = d == P ? p.pbott : p.pskip[d];
         float* B = next_g();
         if (d == P) {
-            if ((e = inbwd(out, pout, npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
+            if ((e = inbwd(out, pout, npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B, DropMap::down(d, 1)))) return e;
         } else {    // the skip tensor feeds the concat (second half of cat[d]) and the 2x2 average pool
-            if ((e = inbwd(out, pout, npc, c, hh, ww, q.cat[d], 2 * c, c, hh, ww, q.pool, p.hs[d + 1], p.wsz[d + 1], B))) return e;
+            if ((e = inbwd(out, pout, npc, c, hh, ww, q.cat[d], 2 * c, c, hh, ww, q.pool, p.hs[d + 1], p.wsz[d + 1], B, DropMap::down(d, 1)))) return e;
         }
         if ((e = wgrad3(src(p.mid[d], p.pmid[d], c, 1, hh, ww, npc), none, B, c, hh, ww, i_down(d, 1)))) return e;
         if ((e = cine_conv3x3_dgrad(B, wd(i_down(d, 1), 0), wd2(i_down(d, 1)), sp, q.A, n, c, c, hh, ww, stream))) return e;
         B = next_g();
-        if ((e = inbwd(p.mid[d], p.pmid[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B))) return e;
+        if ((e = inbwd(p.mid[d], p.pmid[d], npc, c, hh, ww, q.A, c, 0, hh, ww, nullptr, 0, 0, B, DropMap::down(d, 0)))) return e;
         if (d > 0) {
             const int cp = p.ch[d - 1];
             if ((e = wgrad3(src(p.skip[d - 1], p.pskip[d - 1], cp, 2, p.hs[d - 1], p.wsz[d - 1], p.np_conv[d - 1]), none, B, c, hh, ww, i_down(d, 0)))) return e;

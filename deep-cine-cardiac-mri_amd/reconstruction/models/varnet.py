@@ -95,7 +95,7 @@ class VarNetBlock(nn.Module):
         b, t, h, w, _ = image_combined.shape
         xf = self.dynamic_type == 'XF'
         both, wx, wy = self._xfyf_weights()
-        if ag.grad_mode(self):
+        if ag.grad_mode(self) or both.drops():       # (dropout is active in training mode even without autograd)
             return ag.xfyf(image_combined, xf, both, wx, wy)
         pxf, pyf, sxf, syf, mean = ops.xfyf_pack(image_combined, xf)
         if pxf.shape == pyf.shape and pxf.data_ptr() + pxf.numel() * 4 == pyf.data_ptr():

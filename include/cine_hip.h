@@ -586,7 +586,18 @@ int cine_unet2d_forward_train(const float* x, float* y, const void* const* weigh
 size_t cine_unet2d_branch_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools, int nsets, int nbranch, int train);
 int cine_unet2d_forward_branches(const float* x, float* y, const void* const* weights, int nsets,
                                  int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
-                                 void* ws, size_t ws_bytes, void* stream, void* const* side, int nside, int train);
+                                 void* ws, size_t ws_bytes, void* stream, void* const* side, int nside, int train, const float* drop);
+/* Dropout (unet.py:22,40,159-168: Dropout2d behind every LeakyReLU of a ConvBlock, active in training mode with drop_prob > 0).  `drop` of
+ * cine_unet2d_forward_branches (train != 0 only; NULL = none) holds the multiplier d of every (3x3 conv, sample, channel) plane -- 0 for a
+ * dropped channel, 1 / (1 - p) for a kept one -- drawn by the CALLER (the binding uses torch's generator, like nn.Dropout2d): one (n, ch) block
+ * per 3x3 conv in launch order (down path and bottleneck level d: two blocks of chans << d channels; up path from the coarsest level: two blocks
+ * each; the transpose-conv blocks have no dropout), cine_unet2d_drop_floats(n, chans, pools) floats in all.  d >= 0 commutes with LeakyReLU, so
+ * the forward folds it into the plane's InstanceNorm statistics records and no activation is ever rewritten; cine_unet2d_backward_drop is
+ * cine_unet2d_backward with the same array. */
+size_t cine_unet2d_drop_floats(int n, int chans, int pools);
+int cine_unet2d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
+                              int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
+                              const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream);
 /* The reference's small tensor helpers as device kernels, for user code written against its utils (the fused path never calls
  * them).  utils/math.py:20-44: complex_mul with broadcasting -- `shape` = the broadcast result's dimensions WITHOUT the trailing
  * complex pair (at most 6), `xstride` / `ystride` the operands' strides in complex elements, 0 on broadcast dimensions; out is dense.

@@ -586,6 +586,95 @@ def test_bcrnn_sweeps_in_c_bit_identical_to_the_step_loops_and_vs_torch(dev, T, 
             assert rel_err(got.cpu(), ref.grad) < 5e-5
 
 
+@pytest.mark.parametrize("n,sets,h,w,chans,pools,p", [(4, 1, 24, 16, 8, 2, 0.3), (6, 2, 208, 16, 16, 3, 0.1), (3, 1, 40, 36, 4, 1, 0.5)])
+def test_unet_dropout_with_a_fixed_mask_vs_oracle_autograd(dev, n, sets, h, w, chans, pools, p):
+    """Dropout2d behind every LeakyReLU of the ConvBlocks (reference unet.py:22,40,159-168; training mode, drop_prob > 0) on the HIP path: the
+    channel multipliers (0 or 1 / (1 - p)) are folded into the planes' InstanceNorm statistics records in the forward (cine_unet2d_forward_branches'
+    `drop`) and enter the normalisation's backward once more (cine_unet2d_backward_drop).  Parity: the SAME multipliers replace the oracle's
+    nn.Dropout2d modules; output, input gradient and every weight gradient against its float64 autograd; one and two weight sets; also as branches."""
+    from cine_hip import autograd as ag, ops
+    from cine_hip._lib import lib
+    from cine_hip import synth
+    from oracle import regularisers as R
+    from reconstruction.models.denoisers.unet import Unet
+    total = lib().cine_unet2d_drop_floats(n, chans, pools)
+    gen = torch.Generator().manual_seed(5)
+    mult = (torch.rand(total, generator=gen) >= p).float() / (1 - p)
+    assert 0 < int((mult == 0).sum()) < total
+    x = rnd(21, n, 2, h, w); gy = rnd(22, n, 2, h, w)
+
+    class Mult(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__(); self.m = m
+        def forward(self, v):
+            return v * self.m[:, :, None, None]
+
+    nets_h, outs, per = [], [], n // sets
+    want_gx = torch.empty(n, 2, h, w, dtype=torch.float64)
+    ref_grads = []
+    for k in range(sets):
+        hnet = Unet(in_chans=2, out_chans=2, chans=chans, num_pool_layers=pools, drop_prob=p).train(); synth.fill_parameters_(hnet, 41 + k, keep=())
+        rnet = R.Unet(in_chans=2, out_chans=2, chans=chans, num_pool_layers=pools, drop_prob=p).double().train()
+        rnet.load_state_dict({kk: v.double() for kk, v in hnet.state_dict().items()}, strict=True)
+        blocks = list(rnet.down_sample_layers) + [rnet.conv] + [rnet.up_conv[i] if i < pools - 1 else rnet.up_conv[i][0] for i in range(pools)]
+        off = 0
+        for bi, blk in enumerate(blocks):
+            ch = blk.layers[0].out_channels
+            for slot in (3, 7):
+                m = mult[off:off + n * ch].view(n, ch)[k * per:(k + 1) * per].double()
+                blk.layers[slot] = Mult(m); off += n * ch
+        assert off == total
+        xk = x[k * per:(k + 1) * per].double().requires_grad_(True)
+        with torch.enable_grad():
+            o = rnet(xk)
+            o.backward(gy[k * per:(k + 1) * per].double())
+        outs.append(o.detach()); want_gx[k * per:(k + 1) * per] = xk.grad
+        ref_grads.append({kk: v.grad for kk, v in rnet.named_parameters()})
+        nets_h.append(hnet.to(dev))
+    want = torch.cat(outs)
+    wts = ops.UnetWeights(nets_h)
+    for nb in (1, 2):
+        for net in nets_h: net.zero_grad()
+        xd = x.to(dev).requires_grad_(True)
+        with ops.fixed_dropout(mult.to(dev)), ops.branches(nb), torch.enable_grad():
+            got = ag.unet2d(xd, wts)
+            got.backward(gy.to(dev))
+        assert rel_err(got.detach().cpu(), want) < 2e-5, nb
+        assert rel_err(xd.grad.cpu(), want_gx) < 5e-5, nb
+        for k, net in enumerate(nets_h):
+            for kk, v in net.named_parameters():
+                assert rel_err(v.grad.cpu(), ref_grads[k][kk]) < 5e-5, (nb, k, kk)
+    # eval mode: no dropout (and no multipliers drawn)
+    for net in nets_h: net.eval()
+    assert wts.dropout_multipliers(n, dev) is None
+
+
+def test_sensitivity_model_with_dropout_trains_reproducibly(dev):
+    """SensitivityModel(drop_prob > 0) in training mode (reference varnet.py:29-36 hands drop_prob to its NormUnet): forward + backward on the HIP path,
+    reproducible under torch.manual_seed like nn.Dropout2d, different from the eval-mode output, identical to it with the draw switched off."""
+    from reconstruction.models.varnet import SensitivityModel
+    from cine_hip import ops, synth
+    ex = synth.make_cine_slice(4, 3, 48, 40, accel=4, center_lines=6, seed=5)
+    k, mk = ex["masked_kspace"].to(dev), ex["mask"].to(dev)
+    net = SensitivityModel(4, 2, drop_prob=0.25); synth.fill_parameters_(net, 3); net = net.to(dev).train()
+    outs = []
+    for seed in (7, 7, 8):
+        torch.manual_seed(seed)
+        net.zero_grad()
+        with torch.enable_grad():
+            o = net(k, mk)
+            o.pow(2).sum().backward()
+        assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in net.parameters())
+        outs.append(o.detach().clone())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    with torch.no_grad():
+        ev = net.eval()(k, mk)
+        net.train()
+        with ops.fixed_dropout(False):
+            assert torch.equal(net(k, mk), ev)
+        assert not torch.equal(net(k, mk), ev)          # training mode without autograd still drops (nn.Dropout2d does)
+
+
 _LINEAR = {
     "varnet_grad_cfg2_linear": (lambda M: M.VarNet(6, 8, 3, 16, 3, "XF"), 1, 4, False),
     "cinenet_grad_cfg4_linear": (lambda M: M.CineNet(6, 6, 16, 3, "3D"), 7, 6, True),
