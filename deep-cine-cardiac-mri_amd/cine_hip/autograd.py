@@ -1237,6 +1237,15 @@ class SsimLossFn(Function):
         return gx, None, None, None, None
 
 
+def masked_residual_backward(x0, sens, kref, mask):
+    """``ops.masked_residual_backward`` as an autograd graph: the coil operators through their HIP kernels and adjoints (SensExpandFn / SensReduceFn),
+    the two mask products and the subtraction in torch elementwise ops (differentiable in x0 and the maps)."""
+    m = mask.to(x0.dtype)
+    k = SensExpandFn.apply(x0, sens, None)
+    k = (k * m - kref) * m
+    return SensReduceFn.apply(k.contiguous(), sens, None)
+
+
 def grad_mode(module: torch.nn.Module) -> bool:
     """True when the call should build an autograd graph (what ``loss.backward()`` in a training_step needs)."""
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())

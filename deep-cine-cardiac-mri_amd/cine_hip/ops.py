@@ -338,6 +338,17 @@ def soft_dc_blend(model_term: torch.Tensor, ref_kspace: torch.Tensor, mask: torc
     return (1 - m) * model_term + m * (model_term + v * ref_kspace) / (1 + v)
 
 
+def masked_residual_backward(x0: torch.Tensor, sens: torch.Tensor, kref: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """XPDNet's K step + masked backward operator for a GENERAL mask (one that varies along w), literally on the coil-wise k-space:
+    A^H [m (m A x0 - k_ref)]  (reference xpdnet.py:128-131: the forward operator's output is multiplied by whatever mask broadcasts and the
+    measurements subtracted; :161-167: the backward operator masks again).  Row masks take the one-kernel image-space form (``image_dc`` with
+    weights (1, 0, -1)).  Inference; the autograd form is ``cine_hip.autograd.masked_residual_backward``."""
+    m = mask.to(x0.dtype)
+    k = sens_expand_dc(x0, sens)                 # A x0, (b, t, c, h, w, 2)
+    k = (k * m - kref) * m
+    return sens_reduce(k, sens, destroy_input=True)
+
+
 def sens_tile_pack(sens: torch.Tensor) -> Optional[torch.Tensor]:
     """The maps (b, 1, c, h, w, 2) in the column-tile-major order the h == 200 image-space operators read fastest (cine_sens_tile_pack);
     None where no kernel reads it.  The maps are constant over a forward pass: pack once after the sens-net, hand it to every

@@ -33,8 +33,8 @@ class CineNet_RNN(CRNNBody):
         """``_forward_infer`` as an autograd graph (k-space and maps are data): CRNN body through the HIP backward kernels, the
         conjugate-gradient solve through its adjoint recurrence (detached step sizes, recurrent_cinenet.py:113-123), lambda through both."""
         b, t, _, h, w, _ = ref_kspace.shape
-        if b != 1 or not ops.is_row_mask(mask, ref_kspace):
-            raise NotImplementedError("training through the HIP path: batch 1 and the reference's (b, t, 1, h, 1, 1) row mask")
+        if b != 1 or not (ops.is_row_mask(mask, ref_kspace) or ops.is_general_mask(mask, ref_kspace)):      # (ConjGradFn's operator serves both layouts)
+            raise NotImplementedError("training through the HIP path: batch 1")
         with torch.no_grad():
             x_ref = ops.sens_reduce(ref_kspace, sens_maps)
         img = x_ref

@@ -30,17 +30,22 @@ class VarNet_RNN(CRNNBody):
         """The chain of ``_forward_infer`` (reference recurrent_varnet.py:92-150) as an autograd graph: sensitivity network, BCRNN +
         conv pairs through the HIP backward kernels (hidden states flow across time AND cascades), image-space soft DC."""
         b, t, _, h, w, _ = ref_kspace.shape
-        if b != 1 or not ops.is_row_mask(mask, ref_kspace):
-            raise NotImplementedError("training through the HIP path: batch 1 and the reference's (b, t, 1, h, 1, 1) row mask")
+        general = ops.is_general_mask(mask, ref_kspace)          # varies along w: the DC line of reference recurrent_varnet.py:80-90 term by term
+        if b != 1 or not (general or ops.is_row_mask(mask, ref_kspace)):
+            raise NotImplementedError("training through the HIP path: batch 1")
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         img = ag.CoilReduceFn.apply(ref_kspace, sens_maps, None)                  # (1, t, 1, h, w, 2)
-        zf = ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
+        zf = None if general else ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
         state = self.zero_state(t, b, h, w, img)
         for _ in range(self.num_cascades):
             planes = img.view(t, h, w, 2).permute(0, 3, 1, 2).contiguous()        # (t, 2, h, w): frames are the conv batch
             out, state = self.body_train(planes.view(t, 1, 2, h, w), state, planes)
             new_img = out.permute(0, 2, 3, 1).reshape(1, t, 1, h, w, 2)
-            img = ag.ImageDcFn.apply(new_img, sens_maps, zf, mask, self.lambda_reg)
+            if general:     # sens_expand -> soft DC on the coil-wise k-space -> the next cascade's sens_reduce, literally
+                k = ops.soft_dc_blend(ag.SensExpandFn.apply(new_img, sens_maps, None), ref_kspace, mask, self.lambda_reg)
+                img = ag.SensReduceFn.apply(k.contiguous(), sens_maps, None)
+            else:
+                img = ag.ImageDcFn.apply(new_img, sens_maps, zf, mask, self.lambda_reg)
         return ag.AbsFn.apply(img.squeeze(2))
 
     def _forward_infer(self, ref_kspace, mask, acs):
@@ -62,6 +67,9 @@ class VarNet_RNN(CRNNBody):
             new_img = ops.normunet_unpack(out, None, h, w).view(1, t, 1, h, w, 2)
             if rowmask:
                 img = ops.image_dc(new_img, sens_maps, zf, mask, self.lambda_reg, sens_tiled=tiled)      # :80-90 + next reduce
+            elif ops.is_general_mask(mask, ref_kspace):      # varies along w: the DC line term by term (ops.soft_dc_blend), then the reduce
+                k = ops.soft_dc_blend(ops.sens_expand_dc(new_img, sens_maps), ref_kspace, mask, self.lambda_reg.detach())
+                img = ops.sens_reduce(k, sens_maps, destroy_input=True)
             else:
                 ops.expand_dc_hybrid(new_img, sens_maps, ref_kspace, mask, self.lambda_reg, out=hyb)   # :80-90
                 img = ops.hybrid_reduce(hyb, sens_maps)

@@ -42,23 +42,30 @@ class XPDNet_RNN(CRNNBody):
         primal-only model; forward / k-space net / backward Functions with the dual buffer), CRNN body on the buffer planes."""
         n, nd = self.i_buffer_size, self.k_buffer_size
         b, t, _, h, w, _ = ref_kspace.shape
-        if b != 1 or not ops.is_row_mask(mask, ref_kspace):
-            raise NotImplementedError("training through the HIP path: batch 1, the reference's (b, t, 1, h, 1, 1) row mask")
+        general = ops.is_general_mask(mask, ref_kspace)          # varies along w: the literal k-space chain
+        if b != 1 or not (general or ops.is_row_mask(mask, ref_kspace)):
+            raise NotImplementedError("training through the HIP path: batch 1")
+        mf = mask.to(ref_kspace.dtype) if general else None
         pick = lambda buf, k: torch.stack((buf[..., 0], buf[..., k]), dim=-1)
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         image_buffer = ag.CoilReduceFn.apply(ref_kspace, sens_maps, None).repeat_interleave(n, dim=-1)     # (1, t, 1, h, w, 2n)
         if self.k_buffer_mode:
             kbuf = ref_kspace.repeat_interleave(nd, dim=-1)
-        else:
+        elif not general:
             zf = ag.CoilReduceFn.apply(ref_kspace, sens_maps, mask)
         state = self.zero_state(t, b, h, w, image_buffer)
         for i in range(self.num_cascades):
             x0 = pick(image_buffer, n)
             if self.k_buffer_mode:
-                fwd = ag.SensExpandFn.apply(x0, sens_maps, mask)
+                fwd = ag.SensExpandFn.apply(x0, sens_maps, None) * mf if general else ag.SensExpandFn.apply(x0, sens_maps, mask)
                 cat_k = torch.cat([kbuf[..., :nd], fwd[..., :1], ref_kspace[..., :1], kbuf[..., nd:], fwd[..., 1:], ref_kspace[..., 1:]], dim=-1)
                 kbuf = self.kspace_net[i](cat_k)
-                bwd = ag.SensReduceFn.apply(pick(kbuf, nd).contiguous(), sens_maps, mask)
+                if general:
+                    bwd = ag.SensReduceFn.apply((pick(kbuf, nd) * mf).contiguous(), sens_maps, None)
+                else:
+                    bwd = ag.SensReduceFn.apply(pick(kbuf, nd).contiguous(), sens_maps, mask)
+            elif general:
+                bwd = ag.masked_residual_backward(x0, sens_maps, ref_kspace, mask)
             else:
                 bwd = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)
             cat = torch.cat([image_buffer[..., :n], bwd[..., :1], image_buffer[..., n:], bwd[..., 1:]], dim=-1)
@@ -75,7 +82,8 @@ class XPDNet_RNN(CRNNBody):
         sens_maps = self.sens_net(ref_kspace, mask, acs)
         image_buffer = ops.repeat_complex(ops.sens_reduce(ref_kspace, sens_maps), n)       # (1, t, 1, h, w, 2n)
         rowmask = ops.is_row_mask(mask, ref_kspace) and not self.k_buffer_mode
-        hyb = None if rowmask else torch.empty_like(ref_kspace)
+        general = ops.is_general_mask(mask, ref_kspace)          # varies along w (reference recurrent_xpdnet.py multiplies by any broadcastable mask)
+        hyb = None if (rowmask or general) else torch.empty_like(ref_kspace)
         if rowmask:
             zf = ops.hybrid_reduce(ops.kspace_to_hybrid(ref_kspace, mask=mask), sens_maps)
         state = self.zero_state(t, b, h, w, image_buffer)
@@ -86,13 +94,15 @@ class XPDNet_RNN(CRNNBody):
         for i in range(self.num_cascades):
             x0 = ops.extract_complex(image_buffer, 0, n)
             if self.k_buffer_mode:                                                          # dual buffer + KSpaceCNN
-                fwd = ops.sens_expand_dc(x0, sens_maps, None, mask, None, hard_mask=True)
+                fwd = ops.sens_expand_dc(x0, sens_maps) * mask + 0.0 if general else ops.sens_expand_dc(x0, sens_maps, None, mask, None, hard_mask=True)
                 cat_k = torch.cat([kbuf[..., :nd], fwd[..., :1], ref_kspace[..., :1],
                                    kbuf[..., nd:], fwd[..., 1:], ref_kspace[..., 1:]], dim=-1)
                 kbuf = self.kspace_net[i](cat_k).contiguous()
                 bwd = ops.sens_reduce(ops.extract_complex(kbuf, 0, nd) * mask + 0.0, sens_maps)
             elif rowmask:
                 bwd = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0), sens_tiled=tiled)      # A^H M (A x0 - k_ref) (:110-163)
+            elif general:
+                bwd = ops.masked_residual_backward(x0, sens_maps, ref_kspace, mask)
             else:
                 ops.expand_resid_hybrid(x0, sens_maps, ref_kspace, mask, out=hyb)           # K step (:110-140)
                 bwd = ops.hybrid_reduce(hyb, sens_maps)                                     # masked backward op (:142-163)

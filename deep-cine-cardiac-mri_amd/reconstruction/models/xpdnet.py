@@ -172,23 +172,30 @@ class XPDNet(nn.Module):
         operator is one image-space Function; with the KSpaceCNN dual net the k-space buffer is a learned quantity and the forward / backward
         operators are Functions with k-space gradients (FFT2 is unitary: each adjoint is the other operator)."""
         n, nd = self.i_buffer_size, self.k_buffer_size
-        if self.dynamic_type not in ['XF', 'XT', '2D'] or not ops.is_row_mask(mask, masked_kspace):
-            raise NotImplementedError("training through the HIP path: dynamic_type XF / XT / 2D, the reference's row mask")
+        general = ops.is_general_mask(mask, masked_kspace)      # varies along w: the literal k-space chain (reference xpdnet.py:128-131 multiplies by any mask)
+        if self.dynamic_type not in ['XF', 'XT', '2D'] or not (general or ops.is_row_mask(mask, masked_kspace)):
+            raise NotImplementedError("training through the HIP path: dynamic_type XF / XT / 2D")
+        mf = mask.to(masked_kspace.dtype) if general else None
         pick = lambda buf, k: torch.stack((buf[..., 0], buf[..., k]), dim=-1)
         sens_maps = self.sens_net(masked_kspace, mask, acs)
         image = ag.CoilReduceFn.apply(masked_kspace, sens_maps, None)           # unmasked backward op (:303)
         image_buffer = image.repeat_interleave(n, dim=-1)                        # (:307): [re x n, im x n]
         if self.k_buffer_mode:
             kbuf = masked_kspace.repeat_interleave(nd, dim=-1)                   # (:306)
-        else:
+        elif not general:
             zf = ag.CoilReduceFn.apply(masked_kspace, sens_maps, mask)          # A^H M k_ref
         for i_domain in range(1, len(self.domain_sequence), 2):
             x0 = pick(image_buffer, n)                                           # channel 0 of the buffer (:128)
             if self.k_buffer_mode:
-                fwd = ag.SensExpandFn.apply(x0, sens_maps, mask)                 # M A x0 (:385-403)
+                fwd = ag.SensExpandFn.apply(x0, sens_maps, None) * mf if general else ag.SensExpandFn.apply(x0, sens_maps, mask)      # M A x0 (:385-403)
                 cat = torch.cat([kbuf[..., :nd], fwd[..., :1], masked_kspace[..., :1], kbuf[..., nd:], fwd[..., 1:], masked_kspace[..., 1:]], dim=-1)
                 kbuf = self.kspace_net[i_domain // 2](cat)
-                backward_img = ag.SensReduceFn.apply(pick(kbuf, nd).contiguous(), sens_maps, mask)      # masked backward op (:161-167)
+                if general:
+                    backward_img = ag.SensReduceFn.apply((pick(kbuf, nd) * mf).contiguous(), sens_maps, None)
+                else:
+                    backward_img = ag.SensReduceFn.apply(pick(kbuf, nd).contiguous(), sens_maps, mask)  # masked backward op (:161-167)
+            elif general:
+                backward_img = ag.masked_residual_backward(x0, sens_maps, masked_kspace, mask)          # A^H m (m A x0 - k_ref), literally
             else:
                 backward_img = ag.ImageDcFixedFn.apply(x0, sens_maps, zf, mask, 1.0, 0.0, -1.0)         # A^H M (A x0 - k_ref)
             image_buffer = self.cascades[i_domain].regularise(i_domain, image_buffer, backward_img)
@@ -200,7 +207,8 @@ class XPDNet(nn.Module):
         image = ops.sens_reduce(masked_kspace, sens_maps)                       # unmasked backward op (:303)
         image_buffer = ops.repeat_complex(image, n)                             # (:307)
         rowmask = ops.is_row_mask(mask, masked_kspace) and not self.k_buffer_mode
-        hyb = None if rowmask else torch.empty_like(masked_kspace)
+        general = ops.is_general_mask(mask, masked_kspace)      # varies along w (reference xpdnet.py:128-131 multiplies by any broadcastable mask)
+        hyb = None if (rowmask or general) else torch.empty_like(masked_kspace)
         if rowmask:     # A^H M k_ref, constant over the cascades: the K + backward step becomes A^H M A x0 - zf in one kernel
             zf = ops.hybrid_reduce(ops.kspace_to_hybrid(masked_kspace, mask=mask), sens_maps)
         nd = self.k_buffer_size
@@ -210,7 +218,7 @@ class XPDNet(nn.Module):
             x0 = ops.extract_complex(image_buffer, 0, n)                        # channel 0 of the buffer (:128)
             if self.k_buffer_mode:
                 # dual buffer: the k-space net needs the whole k-space, so it is materialised (:385-403)
-                fwd = ops.sens_expand_dc(x0, sens_maps, None, mask, None, hard_mask=True)
+                fwd = ops.sens_expand_dc(x0, sens_maps) * mask + 0.0 if general else ops.sens_expand_dc(x0, sens_maps, None, mask, None, hard_mask=True)
                 cat = torch.cat([kbuf[..., :nd], fwd[..., :1], masked_kspace[..., :1],
                                  kbuf[..., nd:], fwd[..., 1:], masked_kspace[..., 1:]], dim=-1)
                 kbuf = self.kspace_net[i_domain // 2](cat).contiguous()
@@ -218,6 +226,8 @@ class XPDNet(nn.Module):
                 backward_img = ops.sens_reduce(k0, sens_maps)
             elif rowmask:
                 backward_img = ops.image_dc(x0, sens_maps, zf, mask, weights=(1.0, 0.0, -1.0), sens_tiled=tiled)   # A^H M (A x0 - k_ref)
+            elif general:
+                backward_img = ops.masked_residual_backward(x0, sens_maps, masked_kspace, mask)
             else:
                 ops.expand_resid_hybrid(x0, sens_maps, masked_kspace, mask, out=hyb)    # K: M A x0 - k_ref
                 backward_img = ops.hybrid_reduce(hyb, sens_maps)                # I: masked backward op

@@ -838,6 +838,68 @@ def test_masks_that_vary_along_w_inference_and_training_vs_oracle_float64(dev, f
     assert not bad, bad
 
 
+@pytest.mark.parametrize("family", ["xpdnet", "xpdnet_dual", "varnet_rnn", "cinenet_rnn", "xpdnet_rnn", "xpdnet_rnn_dual"])
+def test_masks_that_vary_along_w_xpdnet_and_crnn_models_vs_oracle_float64(dev, family, monkeypatch):
+    """A sampling mask that varies along w in XPDNet and the convolutional-RNN hybrids (reference xpdnet.py:128-131, 161-167 and recurrent_*.py
+    multiply by whatever mask broadcasts): the literal k-space chain -- A^H m (m A x0 - k_ref) term by term, the soft-DC line of the CRNN-VarNet,
+    the conjugate gradient's operator -- in inference AND training against the oracle's float64 autograd.  The sensitivity networks read their ACS
+    window off a 1-D mask (varnet.py:64-68): with a 2-D mask the caller passes ``acs=`` (the oracle's window function is pinned to the same rows)."""
+    import reconstruction.models as M
+    from cine_hip import synth
+    from oracle import recurrent_ref as R, xpdnet_ref as X, varnet_ref as V
+    t, c, h, w = 4, 3, 24, 20
+    kw = dict(num_cascades=2, sens_chans=4, sens_pools=2, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[1, 1], first_conv_n_filters=8,
+              n_primal=2, dynamic_type="XF", weight_sharing=False)
+    make, needs_sens = {
+        "xpdnet": (lambda m: m.XPDNet(primal_only=True, **kw), False), "xpdnet_dual": (lambda m: m.XPDNet(primal_only=False, **kw), False),
+        "varnet_rnn": (lambda m: m.VarNet_RNN(2, 4, 2, 6), False), "cinenet_rnn": (lambda m: m.CineNet_RNN(2, 3, 6), True),
+        "xpdnet_rnn": (lambda m: m.XPDNet_RNN(2, 4, 2, 6, True, 2, 1), False), "xpdnet_rnn_dual": (lambda m: m.XPDNet_RNN(2, 4, 2, 6, False, 2, 1), False)}[family]
+    net = make(M)
+    synth.fill_parameters_(net, 17, keep=("lambda",))
+    ref = make(X if family.startswith("xpdnet") and "rnn" not in family else R).double()
+    ref.load_state_dict({k: v.double() for k, v in net.state_dict().items()}, strict=True)
+    net = net.to(dev).train(); ref.train()
+    acs = (9, 6)                                     # rows [9, 15): what the sens-nets keep; pinned on both sides
+    for mod in (V, X, R):
+        for name in dir(mod):
+            cls = getattr(mod, name)
+            if isinstance(cls, type) and hasattr(cls, "acs_window"):
+                monkeypatch.setattr(cls, "acs_window", staticmethod(lambda mask: acs))
+    g = torch.Generator().manual_seed(6)
+    mask = (torch.rand(1, t, 1, h, w, 1, generator=g) < 0.4).to(torch.uint8)
+    mask[:, :, :, 9:15, w // 2 - 4:w // 2 + 4] = 1
+    sens = rnd(32, 1, 1, c, h, w, 2)
+    sens = sens / sens.pow(2).sum(dim=(2, 5), keepdim=True).sqrt()
+    target = rnd(33, 1, t, h, w).abs() + 0.1
+    mk = rnd(34, 1, t, c, h, w, 2) * mask
+
+    def run(model, device, dtype, hip):
+        a = (mk.to(device, dtype), mask.to(device))
+        if needs_sens:
+            out = model(*a, sens.to(device, dtype))
+        else:
+            out = model(*a, acs=acs) if hip else model(*a)
+        return out, ((out - target.to(device, dtype)) ** 2).mean()
+    with torch.enable_grad():
+        o64, l64 = run(ref, torch.device("cpu"), torch.float64, False); l64.backward()
+        o32, l32 = run(net, dev, torch.float32, True); l32.backward()
+    assert rel_err(o32.detach().cpu(), o64.detach().float()) < 5e-5
+    with torch.no_grad():
+        oi, _ = run(net, dev, torch.float32, True)                          # the inference path on the same mask
+    assert rel_err(oi.cpu(), o64.detach().float()) < 5e-5
+    want = {k: p for k, p in ref.named_parameters() if p.grad is not None}
+    assert len(want) >= 8
+    bad = {}
+    for k, p in net.named_parameters():
+        if k not in want:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        e = float((p.grad.cpu().double() - want[k].grad).norm() / want[k].grad.norm().clamp_min(1e-30))
+        if e > 2e-3:                                 # (L2: a ReLU / LeakyReLU kink that flips between float32 and float64 moves isolated entries)
+            bad[k] = e
+    assert not bad, bad
+
+
 def test_masks_that_broadcast_along_batch_and_time_take_the_row_mask_kernels(dev, golden):
     """(1, 1, 1, h, 1, 1) (one pattern for every frame) and float masks are what the reference's ``*`` accepts: they are expanded to the
     (b, t, 1, h, 1, 1) row layout once and give the row-mask path's bits."""
