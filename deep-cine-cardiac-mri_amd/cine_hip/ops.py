@@ -1562,6 +1562,35 @@ def unet3d_forward(x: torch.Tensor, weights: UnetWeights) -> torch.Tensor:
     return y
 
 
+def conv3d_in(x: torch.Tensor, weight: torch.Tensor, part: Optional[torch.Tensor] = None, mode: int = 0):
+    """Conv3d(3x3x3, pad 1, no bias) of a volume (n, c, d, h, w) -- raw (mode 0) or InstanceNorm3d + LeakyReLU'd on load from its statistics
+    records (mode 1) -- returning the RAW output and its records (n, cout, np, 3) (reference unet.py:149-157 with dims = 3: one half of a ConvBlock)."""
+    x = _dev(x, "conv3d input")
+    n, cin, d, h, w = x.shape
+    cout = weight.shape[0]
+    wp = _pack("c27", weight)
+    y = torch.empty((n, cout, d, h, w), device=x.device, dtype=x.dtype)
+    npart = lib().cine_conv_stat_partials3d(cout, d, h, w, 0)
+    py = torch.empty((n, cout, npart, 3), device=x.device, dtype=x.dtype)
+    check(lib().cine_conv3d_in(x.data_ptr(), _p(part), _np(part), cin, mode, d, h, w, None, None, 0, 0, 0, 0, 0, 0, wp.data_ptr(),
+                               None, None, 0, y.data_ptr(), py.data_ptr(), n, cout, d, h, w, IN_EPS, lrelu_slope(), _stream()), "cine_conv3d_in")
+    return y, py
+
+
+def tconv3d_in(x: torch.Tensor, weight: torch.Tensor, part: Optional[torch.Tensor] = None, mode: int = 0):
+    """ConvTranspose3d(k 2, s 2, no bias) of (n, cin, d, h, w) -> raw (n, cout, 2d, 2h, 2w) + its statistics records (reference unet.py:204-210, dims = 3)."""
+    x = _dev(x, "tconv3d input")
+    n, cin, d, h, w = x.shape
+    cout = weight.shape[1]
+    wp = _pack("tc3", weight)
+    y = torch.empty((n, cout, 2 * d, 2 * h, 2 * w), device=x.device, dtype=x.dtype)
+    npart = lib().cine_conv_stat_partials3d(cout, d, h, w, 1)
+    py = torch.empty((n, cout, npart, 3), device=x.device, dtype=x.dtype)
+    check(lib().cine_tconv3d_in(x.data_ptr(), _p(part), _np(part), mode, wp.data_ptr(), y.data_ptr(), py.data_ptr(), n, cin, cout, d, h, w,
+                                IN_EPS, lrelu_slope(), _stream()), "cine_tconv3d_in")
+    return y, py
+
+
 def conv3d_bias_relu(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, relu: bool) -> torch.Tensor:
     """Conv3d(3x3x3, 'same') + bias (+ ReLU) on (n, c, d, h, w) (reference denoisers/kspace_net.py:33-46)."""
     x = _dev(x, "conv3d input")

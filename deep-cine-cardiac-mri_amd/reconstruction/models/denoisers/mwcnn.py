@@ -93,7 +93,12 @@ class MWCNN(nn.Module):
 
     def forward(self, inputs: torch.Tensor) -> torch.Tensor:
         if self.dims != 2:
-            raise NotImplementedError("3-D MWCNN is not on the HIP path")
+            # constructible like the reference's (Conv3d parameter holders, same state-dict keys) -- but the reference's own forward cannot run with
+            # dims = 3: its IWT unpacks FOUR dimensions (``b, ch, h, w = inputs.shape``, mwcnn.py:252), so a 5-D volume raises ValueError at the first
+            # up-sampling step, and a 4-D (unbatched) input fails at the first conv behind the DWT (the sub-bands are concatenated along dim 1,
+            # which is then the depth axis).  There is no reference behaviour to reproduce; XPDNet never builds it (xpdnet.py:251-262).
+            raise NotImplementedError("MWCNN(dims=3).forward: the reference's forward raises for every input (its IWT unpacks four dimensions, "
+                                      "mwcnn.py:252); only dims = 2 has a defined result")
         if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
             from cine_hip import autograd as ag          # training: forward keeps every feature map, backward = cine_mwcnn_backward
             return ag.mwcnn(inputs, self.hip_weights())

@@ -34,13 +34,21 @@ class ConvBlock(nn.Module):
         self.layers = nn.Sequential(*half(in_chans), *half(out_chans))
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        if self.dims != 2:
-            raise NotImplementedError("3-D ConvBlock is not on the HIP path yet")
+        """The block on its own (inference; the U-Nets run whole launch sequences instead): (N, in_chans, H, W) -> (N, out_chans, H, W), or volumes
+        (N, in_chans, T, H, W) with dims = 3 (reference unet.py:170-182).  In training mode with drop_prob > 0 the Dropout2d / Dropout3d behind each
+        LeakyReLU (unet.py:163,167) scales whole (sample, channel) planes by 0 or 1 / (1 - p), drawn from torch's generator."""
+        if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("a stand-alone ConvBlock has no backward pass on the HIP path (the U-Nets train as whole sequences); wrap the call in torch.no_grad()")
         x = image
         for conv in (self.layers[0], self.layers[4]):
-            y, st = ops.conv3x3_in([(x, None, 0)], ops.pack_conv3x3(conv.weight), conv.out_channels,
-                                   x.shape[2], x.shape[3])
+            if self.dims == 3:
+                y, st = ops.conv3d_in(x, conv.weight)
+            else:
+                y, st = ops.conv3x3_in([(x, None, 0)], ops.pack_conv3x3(conv.weight), conv.out_channels, x.shape[2], x.shape[3])
             x = ops.instnorm_lrelu_apply(y, st)
+            if self.training and self.drop_prob > 0:
+                keep = (torch.rand(x.shape[:2], device=x.device) >= self.drop_prob).to(x.dtype) / (1.0 - self.drop_prob)
+                x = x * keep.view(*x.shape[:2], *([1] * (x.dim() - 2)))
         return x
 
 
@@ -55,10 +63,15 @@ class TransposeConvBlock(nn.Module):
                                     norm(out_chans), nn.LeakyReLU(negative_slope=0.2, inplace=True))
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
-        if self.dims != 2:
-            raise NotImplementedError("3-D TransposeConvBlock is not on the HIP path yet")
+        """The block on its own (inference): (N, in_chans, H, W) -> (N, out_chans, 2H, 2W), or (N, in_chans, T, H, W) -> (N, out_chans, 2T, 2H, 2W)
+        with dims = 3 (reference unet.py:221-233)."""
+        if torch.is_grad_enabled() and (image.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("a stand-alone TransposeConvBlock has no backward pass on the HIP path; wrap the call in torch.no_grad()")
         wt = self.layers[0].weight
-        y, st = ops.tconv2x2_in(image, None, 0, ops.pack_tconv2x2(wt), wt.shape[1])
+        if self.dims == 3:
+            y, st = ops.tconv3d_in(image, wt)
+        else:
+            y, st = ops.tconv2x2_in(image, None, 0, ops.pack_tconv2x2(wt), wt.shape[1])
         return ops.instnorm_lrelu_apply(y, st)
 
 

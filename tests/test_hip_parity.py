@@ -230,6 +230,32 @@ def test_unet_blocks_vs_reference_golden(golden, dev):
     assert rel_err(un(cuda(g["un_odd_x"], dev)).cpu(), g["un_odd_y"]) < BLOCK_TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 5, 24, 20), (1, 4, 15, 40, 32), (2, 2, 4, 9, 11)])
+def test_standalone_3d_blocks_vs_oracle(dev, shape):
+    """ConvBlock(dims=3) / TransposeConvBlock(dims=3) called on their own (reference unet.py:149-182, 204-233: Conv3d / ConvTranspose3d + InstanceNorm3d +
+    LeakyReLU; the U-Nets use whole launch sequences instead) on the volume kernels, against the oracle's blocks; MWCNN(dims=3) is constructible with
+    the reference's state-dict keys and says why its forward has no defined result."""
+    from cine_hip import synth
+    from oracle import regularisers as R
+    from reconstruction.models.denoisers import unet as HU
+    from reconstruction.models.denoisers.mwcnn import MWCNN
+    n, cin, d, h, w = shape
+    x = rnd(5, *shape)
+    cb = HU.ConvBlock(cin, 8, 0.0, 3).eval(); synth.fill_parameters_(cb, 3, keep=())
+    rb = R.ConvBlock(cin, 8, 0.0, 3).eval(); rb.load_state_dict(cb.state_dict(), strict=True)
+    with torch.no_grad():
+        assert rel_err(cb.to(dev)(x.to(dev)).cpu(), rb(x)) < BLOCK_TOL
+    tb = HU.TransposeConvBlock(cin, 6, 3).eval(); synth.fill_parameters_(tb, 4, keep=())
+    rt = R.TransposeConvBlock(cin, 6, 3).eval(); rt.load_state_dict(tb.state_dict(), strict=True)
+    with torch.no_grad():
+        got = tb.to(dev)(x.to(dev)).cpu()
+    assert got.shape == (n, 6, 2 * d, 2 * h, 2 * w) and rel_err(got, rt(x)) < BLOCK_TOL
+    net = MWCNN(2, 2, dims=3, n_scales=2, n_filters_per_scale=[8, 16], n_convs_per_scale=[1, 1], first_conv_n_filters=8)
+    assert net.first_convs[0].layers[0].weight.dim() == 5
+    with pytest.raises(NotImplementedError, match="unpacks four dimensions"):
+        net.to(dev)(rnd(6, 1, 2, 4, 8, 8).to(dev))
+
+
 def test_norm_unet_vs_reference_golden(golden, dev):
     from reconstruction.models.denoisers import NormUnet
     from cine_hip import ops
