@@ -162,6 +162,8 @@ _SIGS = {
     "cine_unet2d_branch_ws_bytes": (c_size_t, [c_int] * 10),
     "cine_unet2d_forward_branches": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, P, c_int, c_int, P]),
     "cine_unet2d_drop_floats": (c_size_t, [c_int, c_int, c_int]),
+    "cine_unet3d_forward_train_drop": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, P]),
+    "cine_unet3d_backward_drop": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P, P]),
     "cine_unet2d_backward_drop": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P, P]),
     "cine_diag_counter": (c_long, [c_int, c_int]),
     "cine_unet2d_backward_ws_bytes": (c_size_t, [c_int] * 7),

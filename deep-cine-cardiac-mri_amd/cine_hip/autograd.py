@@ -539,7 +539,7 @@ class Unet3dFn(Function):
         n, cin, d, h, w = x.shape
         if len(weights.unets) != 1 or cin != weights.in_ch:
             raise ValueError("unet3d: one weight set, input channels as built")
-        ctx.training_key = weights.training_key()    # raises for Dropout in training mode
+        ctx.training_key = weights.training_key()
         L = lib()
         need = L.cine_unet3d_train_ws_bytes(n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools)
         if need == 0 or min(d >> weights.pools, h >> weights.pools, w >> weights.pools) < 1:
@@ -547,9 +547,10 @@ class Unet3dFn(Function):
         ws = torch.empty(need, device=x.device, dtype=torch.uint8)
         y = torch.empty((n, weights.out_ch, d, h, w), device=x.device, dtype=x.dtype)
         slope = ops.lrelu_slope()
-        check(L.cine_unet3d_forward_train(x.data_ptr(), y.data_ptr(), weights.pointers(), n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools,
-                                          slope, ws.data_ptr(), ws.numel(), _stream()), "cine_unet3d_forward_train")
-        ctx.weights, ctx.ws, ctx.params = weights, ws, params
+        drop = weights.dropout_multipliers(n, x.device)          # Dropout3d of the ConvBlocks (training mode, drop_prob > 0), else None
+        check(L.cine_unet3d_forward_train_drop(x.data_ptr(), y.data_ptr(), weights.pointers(), n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools,
+                                               slope, ws.data_ptr(), ws.numel(), _p(drop), _stream()), "cine_unet3d_forward_train")
+        ctx.weights, ctx.ws, ctx.params, ctx.drop = weights, ws, params, drop
         ctx.slope = slope                      # the backward pass runs on an autograd thread: it differentiates what THIS call applied
         ctx.save_for_backward(x)
         return y
@@ -568,8 +569,8 @@ class Unet3dFn(Function):
         gptr = (ctypes.c_void_p * len(plists[0]))(*[g.data_ptr() for g in grads[0]])
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         _use_side_stream(x.device)
-        check(L.cine_unet3d_backward(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools,
-                                     ctx.slope, ctx.ws.data_ptr(), ctx.ws.numel(), ws.data_ptr(), ws.numel(), _p(gx), _stream()), "cine_unet3d_backward")
+        check(L.cine_unet3d_backward_drop(x.data_ptr(), gy.data_ptr(), weights.dgrad_pointers(), gptr, n, d, h, w, cin, weights.out_ch, weights.chans, weights.pools,
+                                          ctx.slope, ctx.ws.data_ptr(), ctx.ws.numel(), ws.data_ptr(), ws.numel(), _p(gx), _p(ctx.drop), _stream()), "cine_unet3d_backward")
         return (gx, None) + _param_grads(weights, grads, ctx.params)
 
 

@@ -1117,15 +1117,14 @@ class UnetWeights:
         """Dropout2d / Dropout3d of the reference's ConvBlocks (unet.py:22,40,159-168: behind every LeakyReLU, active when the module is in training
         mode and drop_prob > 0): the multiplier of every (3x3 conv, sample, channel) plane -- 0 with probability p, else 1 / (1 - p) -- in
         cine_unet2d_forward_branches' layout, drawn from torch's generator of the device (``torch.manual_seed`` makes a step reproducible, as it
-        does for nn.Dropout2d; the random stream itself differs from ATen's).  None when no network of the set drops anything.  2-D U-Nets only."""
+        does for nn.Dropout2d; the random stream itself differs from ATen's).  None when no network of the set drops anything.  The 3-D U-Net (Dropout3d: whole
+        volumes) uses the same layout."""
         ps = [float(getattr(u, "drop_prob", 0.0)) if u.training else 0.0 for u in self.unets]
         fixed = getattr(_act_tls, "dropout", None)
         if fixed is not None:
             return None if fixed is False else _dev(fixed, "dropout multipliers")
         if not any(p > 0 for p in ps):
             return None
-        if any(getattr(u, "dims", 2) != 2 for u in self.unets):
-            raise NotImplementedError("training with Dropout3d (drop_prob > 0 in a 3-D U-Net) is not on the HIP path; build it with drop_prob=0.0 or call .eval()")
         if any(not 0.0 <= p < 1.0 for p in ps):
             raise ValueError("dropout probability has to be in [0, 1)")
         total = lib().cine_unet2d_drop_floats(n, self.chans, self.pools)

@@ -37,6 +37,28 @@ __device__ __forceinline__ float drop_k2(const float* drop, long plane) {
     return d > 0.f ? 1.f / (d * d) : 0.f;
 }
 int launch_in_lrelu_bwd(const InBwdArgs& a, hipStream_t st);
+// Dropout2d / Dropout3d multipliers (cine_unet2d_forward_branches' `drop`): fold drop[plane] into the statistics records of `planes` (sample, channel)
+// planes with np records each (unet.hip)
+int launch_dropout_stats(float* part, int np, long planes, const float* drop, hipStream_t st);
+// layout of the multipliers: one (n, ch) block per 3x3 conv in launch order -- down path / bottleneck level d: convs 2 d and 2 d + 1 (ch[d] channels),
+// up path level d: convs 2 (P + 1) + 2 (P - 1 - d) and the next one (ch[d] channels); the transpose convs have no dropout (unet.py:204-219)
+struct DropMap {
+    const float* base; int n_total, a, chans, pools;
+    long off(int conv) const {         // floats in front of conv's block
+        long o = 0;
+        for (int j = 0; j < conv; ++j) o += (long)n_total * ch_of(j);
+        return o;
+    }
+    int ch_of(int conv) const {
+        const int P = pools;
+        const int d = conv < 2 * (P + 1) ? conv / 2 : P - 1 - (conv - 2 * (P + 1)) / 2;
+        return chans << d;
+    }
+    const float* at(int conv) const { return base ? base + off(conv) + (long)a * ch_of(conv) : nullptr; }
+    static int down(int d, int k) { return 2 * d + k; }
+    int up(int d, int k) const { return 2 * (pools + 1) + 2 * (pools - 1 - d) + k; }
+};
+
 // few, large planes (volumes; the sens-net's 200 x 200 coil planes): two passes over chunks of a plane with `ws` holding the chunk sums;
 // falls back to launch_in_lrelu_bwd for every other shape or without a workspace
 size_t in_lrelu_bwd_ws_floats(int n, int c, int h, int w);

@@ -36,29 +36,14 @@ __global__ void dropout_stats_kernel(float* part, int np, long planes, const flo
     for (int k = 0; k < np; ++k) { const float dl = p[3 * k + 1] - mean; m2 += p[3 * k + 2] + p[3 * k] * dl * dl; }
     p[2] += (m2 + cnt * eps) * (1.f / (d * d) - 1.f);
 }
+}  // namespace
+namespace cine {
 int launch_dropout_stats(float* part, int np, long planes, const float* drop, hipStream_t st) {
     hipLaunchKernelGGL(dropout_stats_kernel, dim3((unsigned)ceil_div(planes, 256L)), dim3(256), 0, st, part, np, planes, drop, kEps);
     return check_launch("dropout_stats_kernel");
 }
-// layout of the multipliers: one (n, ch) block per 3x3 conv in launch order -- down path / bottleneck level d: convs 2 d and 2 d + 1 (ch[d] channels),
-// up path level d: convs 2 (P + 1) + 2 (P - 1 - d) and the next one (ch[d] channels); the transpose convs have no dropout (unet.py:204-219)
-struct DropMap {
-    const float* base; int n_total, a, chans, pools;
-    long off(int conv) const {         // floats in front of conv's block
-        long o = 0;
-        for (int j = 0; j < conv; ++j) o += (long)n_total * ch_of(j);
-        return o;
-    }
-    int ch_of(int conv) const {
-        const int P = pools;
-        const int d = conv < 2 * (P + 1) ? conv / 2 : P - 1 - (conv - 2 * (P + 1)) / 2;
-        return chans << d;
-    }
-    const float* at(int conv) const { return base ? base + off(conv) + (long)a * ch_of(conv) : nullptr; }
-    static int down(int d, int k) { return 2 * d + k; }
-    int up(int d, int k) const { return 2 * (pools + 1) + 2 * (pools - 1 - d) + k; }
-};
-
+}  // namespace cine
+namespace {
 struct Bump {
     char* base; size_t off;
     float* take(size_t floats) {

@@ -116,7 +116,8 @@ extern "C" size_t cine_unet3d_train_ws_bytes(int n, int d, int h, int w, int in_
 }
 
 static int unet3d_forward_impl(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
-                               int in_ch, int out_ch, int chans, int pools, float kSlope, void* ws, size_t ws_bytes, void* stream, bool train) {
+                               int in_ch, int out_ch, int chans, int pools, float kSlope, void* ws, size_t ws_bytes, void* stream, bool train,
+                               const float* drop = nullptr) {
     CINE_REQUIRE(x && y && weights && ws, CINE_EINVAL, "cine_unet3d_forward: null pointer");
     CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet3d_forward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(sizes_ok(n, d, h, w, chans, pools) && in_ch > 0 && out_ch > 0, CINE_EINVAL, "cine_unet3d_forward: bad sizes");
@@ -128,9 +129,10 @@ static int unet3d_forward_impl(const float* x, float* y, const void* const* weig
     for (int i = 0; i < nptr; ++i) CINE_REQUIRE(weights[i], CINE_EINVAL, "cine_unet3d_forward: weights[%d] is null", i);
     Plan p; Bump b{reinterpret_cast<char*>(ws), 0};
     build(p, b, n, d, h, w, chans, pools, train);
-    int wi = 0, e;
+    int wi = 0, e, ci = 0;
     auto W = [&]() { return reinterpret_cast<const float*>(weights[wi++]); };
-    // conv + merge of its per-tile statistics into one record per (sample, channel)
+    const DropMap dm{drop, n, 0, chans, pools};          // Dropout3d behind every ConvBlock activation (unet.py:163,167): the 2-D layout, one (n, ch) block per 3x3x3 conv
+    // conv + merge of its per-tile statistics into one record per (sample, channel) (+ the Dropout multipliers folded into that record)
     auto conv = [&](const float* x0, const float* p0, int c0, int m0, int d0, int h0, int w0,
                     const float* x1, const float* p1, int c1, int m1, int d1, int h1, int w1,
                     const float* wp, float* yo, float* po, int cout, int l) -> int {
@@ -138,7 +140,9 @@ static int unet3d_forward_impl(const float* x, float* y, const void* const* weig
         int r = cine_conv3d_in(x0, p0, 1, c0, m0, d0, h0, w0, x1, p1, 1, c1, m1, d1, h1, w1, wp, nullptr, nullptr, 0,
                                yo, p.raw_part, n, cout, p.ds[l], p.hs[l], p.wsz[l], kEps, kSlope, stream);
         if (r) return r;
-        return cine_instnorm_merge(p.raw_part, po, (long)n * cout, np, stream);
+        const int conv_id = ci++;          // launch order == DropMap's: down / bottleneck convs 0 .. 2 P + 1, then the up path from the coarsest level
+        if ((r = cine_instnorm_merge(p.raw_part, po, (long)n * cout, np, stream))) return r;
+        return drop ? launch_dropout_stats(po, 1, (long)n * cout, dm.at(conv_id), as_stream(stream)) : CINE_OK;
     };
     for (int l = 0; l <= pools; ++l) {                        // down path + bottleneck (unet.py:94-99)
         const float* w1 = W();
@@ -180,6 +184,11 @@ extern "C" int cine_unet3d_forward(const float* x, float* y, const void* const* 
 extern "C" int cine_unet3d_forward_train(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
                                          int in_ch, int out_ch, int chans, int pools, float slope, void* ws, size_t ws_bytes, void* stream) {
     return unet3d_forward_impl(x, y, weights, n, d, h, w, in_ch, out_ch, chans, pools, slope, ws, ws_bytes, stream, true);
+}
+// ... with Dropout3d (training mode, drop_prob > 0): `drop` as for cine_unet2d_forward_branches (cine_unet2d_drop_floats(n, chans, pools) multipliers)
+extern "C" int cine_unet3d_forward_train_drop(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
+                                              int in_ch, int out_ch, int chans, int pools, float slope, void* ws, size_t ws_bytes, const float* drop, void* stream) {
+    return unet3d_forward_impl(x, y, weights, n, d, h, w, in_ch, out_ch, chans, pools, slope, ws, ws_bytes, stream, true, drop);
 }
 
 // ---------------------------------------------------------------- backward pass (training)
@@ -312,9 +321,17 @@ extern "C" size_t cine_unet3d_backward_ws_bytes(int n, int d, int h, int w, int 
 // `grads`: host array in the same order of device pointers to the weight gradients in the parameters' own layouts ((cout, cin, 3, 3, 3),
 // (cin, cout, 2, 2, 2), (out_ch, chans), (out_ch)); they are ACCUMULATED into (+=).  gx (n, in_ch, d, h, w) may be NULL.
 // Weight gradients run on the calling thread's side stream (cine_set_side_stream) when it has one.
+extern "C" int cine_unet3d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads,
+                                         int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
+                                         const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream);
 extern "C" int cine_unet3d_backward(const float* x, const float* gy, const void* const* wdgrad, void* const* grads,
                                     int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
                                     const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, void* stream) {
+    return cine_unet3d_backward_drop(x, gy, wdgrad, grads, n, d, h, w, in_ch, out_ch, chans, pools, kSlope, fwd_ws, fwd_ws_bytes, ws, ws_bytes, gx, nullptr, stream);
+}
+extern "C" int cine_unet3d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads,
+                                         int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools, float kSlope,
+                                         const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream) {
     CINE_REQUIRE(x && gy && wdgrad && grads && fwd_ws && ws, CINE_EINVAL, "cine_unet3d_backward: null pointer");
     CINE_REQUIRE(kSlope >= 0.f && kSlope <= 1.f, CINE_EINVAL, "cine_unet3d_backward: LeakyReLU slope %g outside [0, 1]", (double)kSlope);
     CINE_REQUIRE(sizes_ok(n, d, h, w, chans, pools) && in_ch > 0 && out_ch > 0 && n <= 65535, CINE_EINVAL, "cine_unet3d_backward: bad sizes");
@@ -379,8 +396,9 @@ extern "C" int cine_unet3d_backward(const float* x, const float* gy, const void*
         return GradPiece{g, 5, c_total, c_off, gh, gw, gd, th};
     };
     const GradPiece nopiece{nullptr, 0, 0, 0, 0, 0, 0, 0};
-    auto inbwd = [&](const float* r, const float* part, int c, int td, int th, int tw, GradPiece pa, GradPiece pb, float* out) {
-        InBwdArgs a{r, part, 1, pa, pb, out, n, c, td * th, tw, kEps, kSlope};
+    const DropMap dm{drop, n, 0, chans, pools};
+    auto inbwd = [&](const float* r, const float* part, int c, int td, int th, int tw, GradPiece pa, GradPiece pb, float* out, int conv = -1) {
+        InBwdArgs a{r, part, 1, pa, pb, out, n, c, td * th, tw, kEps, kSlope, conv >= 0 ? dm.at(conv) : nullptr};
         return launch_in_lrelu_bwd_split(a, q.inb, q.inb_floats, st);
     };
 
@@ -399,11 +417,11 @@ extern "C" int cine_unet3d_backward(const float* x, const float* gy, const void*
         const int c = p.ch[l], D = p.ds[l], H = p.hs[l], W = p.wsz[l];
         const int Du = 2 * p.ds[l + 1], Hu = 2 * p.hs[l + 1], Wu = 2 * p.wsz[l + 1];      // extents of the transpose-conv output
         float* B = next_g();                                   // second conv of the block: cb = conv(act(ca))
-        if ((e = inbwd(p.cb[l], p.pcb[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B))) return e;
+        if ((e = inbwd(p.cb[l], p.pcb[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B, dm.up(l, 1)))) return e;
         if ((e = wgrad27(vsrc(p.ca[l], p.pca[l], c, 1, D, H, W), none, B, c, l, i_up(l, 2)))) return e;
         if ((e = dgrad27(B, i_up(l, 2), q.A, c, c, l))) return e;
         B = next_g();                                          // first conv: ca = conv(cat(act(up) zero-padded, act(skip)))
-        if ((e = inbwd(p.ca[l], p.pca[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B))) return e;
+        if ((e = inbwd(p.ca[l], p.pca[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B, dm.up(l, 0)))) return e;
         if ((e = wgrad27(vsrc(p.up[l], p.pup[l], c, 1, Du, Hu, Wu), vsrc(p.out[l], p.pout[l], c, 1, D, H, W), B, c, l, i_up(l, 1)))) return e;
         if ((e = dgrad27(B, i_up(l, 1), q.cat[l], c, 2 * c, l))) return e;
         // transpose conv: up = tconv(act(cur)), cur = cb[l + 1] or the bottleneck output
@@ -431,15 +449,15 @@ extern "C" int cine_unet3d_backward(const float* x, const float* gy, const void*
         const int c = p.ch[l], D = p.ds[l], H = p.hs[l], W = p.wsz[l];
         float* B = next_g();
         if (l == P) {
-            if ((e = inbwd(p.out[l], p.pout[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B))) return e;
+            if ((e = inbwd(p.out[l], p.pout[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B, DropMap::down(l, 1)))) return e;
         } else {    // the skip tensor feeds the concat (second half of cat[l]) and the 2x2x2 average pool
             const GradPiece pool{q.pool, 6, c, 0, p.hs[l + 1], p.wsz[l + 1], p.ds[l + 1], H};
-            if ((e = inbwd(p.out[l], p.pout[l], c, D, H, W, window(q.cat[l], 2 * c, c, D, H, W, H, W), pool, B))) return e;
+            if ((e = inbwd(p.out[l], p.pout[l], c, D, H, W, window(q.cat[l], 2 * c, c, D, H, W, H, W), pool, B, DropMap::down(l, 1)))) return e;
         }
         if ((e = wgrad27(vsrc(p.mid[l], p.pmid[l], c, 1, D, H, W), none, B, c, l, i_down(l, 1)))) return e;
         if ((e = dgrad27(B, i_down(l, 1), q.A, c, c, l))) return e;
         B = next_g();
-        if ((e = inbwd(p.mid[l], p.pmid[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B))) return e;
+        if ((e = inbwd(p.mid[l], p.pmid[l], c, D, H, W, window(q.A, c, 0, D, H, W, H, W), nopiece, B, DropMap::down(l, 0)))) return e;
         if (l > 0) {
             const int cp = p.ch[l - 1];
             if ((e = wgrad27(vsrc(p.out[l - 1], p.pout[l - 1], cp, 2, p.ds[l - 1], p.hs[l - 1], p.wsz[l - 1]), none, B, c, l, i_down(l, 0)))) return e;

@@ -106,9 +106,7 @@ class Unet(nn.Module):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         drops = self.training and self.drop_prob > 0          # nn.Dropout2d / 3d are active in training mode, with or without autograd (unet.py:163,167)
         if self.dims == 3:
-            if drops:
-                raise NotImplementedError("Dropout3d (drop_prob > 0 in training mode) is not on the HIP path of the 3-D U-Net; use drop_prob=0.0 or .eval()")
-            if ag.grad_mode(self) or (torch.is_grad_enabled() and image.requires_grad):
+            if drops or ag.grad_mode(self) or (torch.is_grad_enabled() and image.requires_grad):
                 return ag.unet3d(image, self.hip_weights())
             return ops.unet3d_forward(image, self.hip_weights())
         if drops or ag.grad_mode(self) or (torch.is_grad_enabled() and image.requires_grad):

@@ -595,6 +595,12 @@ int cine_unet2d_forward_branches(const float* x, float* y, const void* const* we
  * the forward folds it into the plane's InstanceNorm statistics records and no activation is ever rewritten; cine_unet2d_backward_drop is
  * cine_unet2d_backward with the same array. */
 size_t cine_unet2d_drop_floats(int n, int chans, int pools);
+/* The same for the 3-D U-Net (Dropout3d: whole (sample, channel) volumes): cine_unet3d_forward_train / cine_unet3d_backward with `drop` in the layout above. */
+int cine_unet3d_forward_train_drop(const float* x, float* y, const void* const* weights, int n, int d, int h, int w,
+                                   int in_ch, int out_ch, int chans, int pools, float slope, void* ws, size_t ws_bytes, const float* drop, void* stream);
+int cine_unet3d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads,
+                              int n, int d, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
+                              const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream);
 int cine_unet2d_backward_drop(const float* x, const float* gy, const void* const* wdgrad, void* const* grads, int nsets,
                               int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
                               const void* fwd_ws, size_t fwd_ws_bytes, void* ws, size_t ws_bytes, float* gx, const float* drop, void* stream);

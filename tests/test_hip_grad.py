@@ -649,6 +649,49 @@ def test_unet_dropout_with_a_fixed_mask_vs_oracle_autograd(dev, n, sets, h, w, c
     assert wts.dropout_multipliers(n, dev) is None
 
 
+def test_unet3d_dropout_with_a_fixed_mask_vs_oracle_autograd(dev):
+    """Dropout3d in the 3-D U-Net (reference unet.py:24,159-168 with dims = 3): the multipliers are folded into the merged statistics record of every
+    3x3x3 conv output (cine_unet3d_forward_train_drop) and enter cine_unet3d_backward_drop; same multipliers in the oracle's nn.Dropout3d slots."""
+    from cine_hip import autograd as ag, ops, synth
+    from cine_hip._lib import lib
+    from oracle import regularisers as R
+    from reconstruction.models.denoisers.unet import Unet
+    n, d, h, w, chans, pools, p = 2, 8, 24, 20, 4, 2, 0.25
+    total = lib().cine_unet2d_drop_floats(n, chans, pools)
+    mult = (torch.rand(total, generator=torch.Generator().manual_seed(9)) >= p).float() / (1 - p)
+    assert 0 < int((mult == 0).sum()) < total
+    x = rnd(51, n, 2, d, h, w); gy = rnd(52, n, 2, d, h, w)
+
+    class Mult(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__(); self.m = m
+        def forward(self, v):
+            return v * self.m[:, :, None, None, None]
+    hnet = Unet(in_chans=2, out_chans=2, chans=chans, num_pool_layers=pools, drop_prob=p, dims=3).train(); synth.fill_parameters_(hnet, 43, keep=())
+    rnet = R.Unet(in_chans=2, out_chans=2, chans=chans, num_pool_layers=pools, drop_prob=p, dims=3).double().train()
+    rnet.load_state_dict({kk: v.double() for kk, v in hnet.state_dict().items()}, strict=True)
+    blocks = list(rnet.down_sample_layers) + [rnet.conv] + [rnet.up_conv[i] if i < pools - 1 else rnet.up_conv[i][0] for i in range(pools)]
+    off = 0
+    for blk in blocks:
+        ch = blk.layers[0].out_channels
+        for slot in (3, 7):
+            blk.layers[slot] = Mult(mult[off:off + n * ch].view(n, ch).double()); off += n * ch
+    assert off == total
+    xr = x.double().requires_grad_(True)
+    with torch.enable_grad():
+        want = rnet(xr); want.backward(gy.double())
+    hnet = hnet.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    with ops.fixed_dropout(mult.to(dev)), torch.enable_grad():
+        got = hnet(xd)
+        got.backward(gy.to(dev))
+    assert rel_err(got.detach().cpu(), want.detach()) < 2e-5
+    assert rel_err(xd.grad.cpu(), xr.grad) < 5e-5
+    ref = dict(rnet.named_parameters())
+    for kk, v in hnet.named_parameters():
+        assert rel_err(v.grad.cpu(), ref[kk].grad) < 5e-5, kk
+
+
 def test_sensitivity_model_with_dropout_trains_reproducibly(dev):
     """SensitivityModel(drop_prob > 0) in training mode (reference varnet.py:29-36 hands drop_prob to its NormUnet): forward + backward on the HIP path,
     reproducible under torch.manual_seed like nn.Dropout2d, different from the eval-mode output, identical to it with the draw switched off."""
