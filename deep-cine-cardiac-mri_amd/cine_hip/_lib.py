@@ -117,6 +117,7 @@ _SIGS = {
     "cine_normal_op_cg_fused_t": (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, c_size_t, P]),
     "cine_conj_grad_ws_bytes": (c_size_t, [c_int] * 5),
     "cine_conj_grad": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "cine_conj_grad_rec": (c_int, [P, P, c_int, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P, P, P, P]),
     "cine_sens_tile_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "cine_sens_tile_pack": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "cine_image_dc_t": (c_int, [P, P, P, P, P, P, c_float, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

@@ -1135,6 +1135,9 @@ class AxpbyLamFn(Function):
         return ga, gb, gl
 
 
+CG_SOLVER_IN_TRAINING = __import__("os").environ.get("CINE_CG_SOLVER_TRAIN", "1") == "1"      # diagnostics (this binding): False = iterate cine_normal_op_cg_fused from Python
+
+
 @_masked
 class ConjGradFn(Function):
     """CineNetBlock.ConjGrad (cinenet.py:136-171): K iterations of conjugate gradients on H x = b, H = A^H M A + softplus(lambda) I,
@@ -1151,6 +1154,14 @@ class ConjGradFn(Function):
     def forward(ctx, x0, b, lam, mask, sens, iters):
         x0 = ops._dev(x0, "CG start value"); b = ops._dev(b, "CG right-hand side")
         dev = x0.device
+        if CG_SOLVER_IN_TRAINING and iters >= 1 and ops.is_row_mask(mask, sens.expand(-1, x0.shape[1], -1, -1, -1, -1)):
+            # the whole solve in one C call (2 + 2 * iters launches), the directions and step sizes recorded by its own kernels
+            x = x0.clone()
+            rec = ops.conj_grad_rec(x, b, sens, mask, lam, iters)
+            if rec is not None:
+                p_rec, rr, pd = rec
+                ctx.save_for_backward(x0, lam, mask, sens, rr, pd, *p_rec.unbind(0))
+                return x
         one = torch.ones(1, device=dev, dtype=torch.float32)
         r = ops.axpby_dev(b, ops.h_operator(x0, sens, mask, lam), num=one, sign=-1.0)
         p = r.clone()

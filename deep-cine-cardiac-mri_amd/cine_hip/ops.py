@@ -154,7 +154,7 @@ def branches(n: int):
             _act_tls.branches = old
 
 
-_pack_tls = threading.local()   # .on inside training_capture() of THIS thread: the weight-pack kernels BELONG to the captured step (the weights change every replay)
+_pack_capture_streams = set()   # streams inside a training_capture(): the weight-pack kernels BELONG to the captured step (the weights change every replay)
 _cache_epoch = 0              # part of every packed-weight cache key: bumped when a training capture ends
 
 
@@ -169,11 +169,14 @@ def training_capture():
     belong to the graph's memory pool and are refreshed only by its replays: when the capture ends every cache is invalidated (the epoch in
     their keys moves), so a later eager call (validation) packs the parameters' current values into memory of its own."""
     global _cache_epoch
-    _pack_tls.on = True          # per thread: another thread's inference capture keeps its guard
+    # scoped to the capturing STREAM, not the thread: loss.backward() packs on the autograd engine's thread (same stream), while another
+    # thread's inference capture (another stream) keeps its guard
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    _pack_capture_streams.add(key)
     try:
         yield
     finally:
-        _pack_tls.on = False
+        _pack_capture_streams.discard(key)
         _cache_epoch += 1        # process-wide on purpose: EVERY thread's packed-weight caches are rebuilt (they may alias this capture's pool)
 
 
@@ -181,7 +184,7 @@ def _no_capture(what: str, pack: bool = False) -> None:
     """Caches that outlive a call (packed weights, per-stream scratch) must not be filled during hipGraph capture: the
     tensors would come from the graph's private pool yet stay referenced afterwards.  (pack: a packed-weight cache, allowed inside
     ``training_capture()``.)"""
-    if torch.cuda.is_current_stream_capturing() and not (pack and getattr(_pack_tls, "on", False)):
+    if torch.cuda.is_current_stream_capturing() and not (pack and (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream) in _pack_capture_streams):
         raise CineHipError(f"{what} would be created during hipGraph capture; run one eager forward on this stream first "
                            "(and re-capture after changing weights)")
 
@@ -761,6 +764,28 @@ def conj_grad(x: torch.Tensor, rhs: torch.Tensor, sens: torch.Tensor, mask: torc
                                _dev(lambda_reg.detach(), "lambda_reg").data_ptr(), int(iters), b, t, c, h, w, ws.data_ptr(), nbytes, _stream()),
           "cine_conj_grad")
     return x
+
+
+def conj_grad_rec(x: torch.Tensor, rhs: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, lambda_reg: torch.Tensor, iters: int,
+                  sens_tiled: Optional[torch.Tensor] = None):
+    """``conj_grad`` for training (cine_conj_grad_rec): x updated in place; returns (p_rec (iters, *x.shape), rr (iters + 1), pd (iters)) -- every
+    direction and the step sizes' numerators / denominators, what ConjGradFn's adjoint recurrence reads -- or None when the shape has no such path."""
+    b, _, c, h, w, _ = sens.shape
+    t = x.shape[1]
+    nbytes = lib().cine_conj_grad_ws_bytes(b, t, c, h, w)
+    if nbytes == 0 or iters < 1:
+        return None
+    for t_, name in ((x, "x"), (rhs, "rhs")):
+        if not (t_.is_cuda and t_.is_contiguous() and t_.dtype == torch.float32 and t_.numel() == b * t * h * w * 2):
+            raise ValueError(f"conj_grad_rec: {name} must be a contiguous float32 GPU tensor of (b, t, 1, h, w, 2)")
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    p_rec = torch.empty((iters,) + tuple(x.shape), device=x.device, dtype=x.dtype)
+    rr = torch.empty(iters + 1, device=x.device, dtype=torch.float32)
+    pd = torch.empty(iters, device=x.device, dtype=torch.float32)
+    check(lib().cine_conj_grad_rec(x.data_ptr(), rhs.data_ptr(), 0, _dev(sens, "sens_maps").data_ptr(), _p(sens_tiled), _dev(mask, "mask", torch.uint8).data_ptr(),
+                                   _dev(lambda_reg.detach(), "lambda_reg").data_ptr(), int(iters), b, t, c, h, w, ws.data_ptr(), nbytes,
+                                   p_rec.data_ptr(), rr.data_ptr(), pd.data_ptr(), _stream()), "cine_conj_grad_rec")
+    return p_rec, rr, pd
 
 
 def axpby_dev(a: torch.Tensor, b: torch.Tensor, num: Optional[torch.Tensor] = None, den: Optional[torch.Tensor] = None,

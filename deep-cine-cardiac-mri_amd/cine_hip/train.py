@@ -47,7 +47,7 @@ class GraphedTrainingStep:
         self.opt.zero_grad(set_to_none=True)
         # (ops.training_capture: the kernels that re-pack the changing weights are part of the step; the packs made here belong to the
         #  graph and every packed-weight cache is invalidated when the capture ends)
-        with ops.training_capture(), torch.cuda.graph(self.graph, stream=self.stream), torch.enable_grad():
+        with torch.cuda.graph(self.graph, stream=self.stream), ops.training_capture(), torch.enable_grad():
             self.loss = self._eager_step(zero=False).detach()
         torch.cuda.synchronize()
 

@@ -1274,7 +1274,8 @@ namespace cine {
 int launch_cg_init(const float* x, const float* rhs, int rhs_ref, const cf* partial, int nz, long part_stride, const float* lam, long ncf,
                    float4* pr, float* rr_part, hipStream_t st);                                                    // pack_kernels.hip
 int launch_cg_update2(float* x, float4* pr, const cf* p, const cf* partial, int nz, long part_stride, const float* lam, long ncf,
-                      const float* pd_wg, int npd, const float* rr_prev, float* rr_cur, int last, hipStream_t st);
+                      const float* pd_wg, int npd, const float* rr_prev, float* rr_cur, int last, hipStream_t st,
+                      float* rr_rec = nullptr, float* pd_rec = nullptr, float* rr_final = nullptr);
 }
 extern "C" size_t cine_conj_grad_ws_bytes(int b, int t, int c, int h, int w) {
     const long nb = cg_fused_blocks(b, t, c, h, w);
@@ -1282,8 +1283,25 @@ extern "C" size_t cine_conj_grad_ws_bytes(int b, int t, int c, int h, int w) {
     const size_t ncf = (size_t)b * t * h * w;
     return cine_image_dc_ws_bytes(b, t, c, h, w) + (size_t)(nb + 512) * sizeof(float) + 256 + ncf * (sizeof(float4) + sizeof(cf));
 }
+static int conj_grad_impl(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                          const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream,
+                          float* p_rec, float* rr_rec, float* pd_rec);
 extern "C" int cine_conj_grad(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
                               const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    return conj_grad_impl(x, rhs, rhs_is_ref, sens, sens_tiled, mask, lambda_dev, iters, b, t, c, h, w, ws, ws_bytes, stream, nullptr, nullptr, nullptr);
+}
+// cine_conj_grad that RECORDS what the adjoint recurrence of the iteration needs (training, cine_hip/autograd.py ConjGradFn: the reference detaches
+// its step sizes, cinenet.py:159-169, so the iteration it differentiates is linear with these constants): p_rec (iters, b, t, 1, h, w, 2) receives
+// every direction p_k (the operator kernel writes it there instead of into its scratch), rr_rec (iters + 1) the r_k . r_k and pd_rec (iters) the p_k . H p_k.
+extern "C" int cine_conj_grad_rec(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                                  const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes,
+                                  float* p_rec, float* rr_rec, float* pd_rec, void* stream) {
+    CINE_REQUIRE(p_rec && rr_rec && pd_rec && iters >= 1, CINE_EINVAL, "cine_conj_grad_rec: null record buffer or no iteration");
+    return conj_grad_impl(x, rhs, rhs_is_ref, sens, sens_tiled, mask, lambda_dev, iters, b, t, c, h, w, ws, ws_bytes, stream, p_rec, rr_rec, pd_rec);
+}
+static int conj_grad_impl(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                          const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream,
+                          float* p_rec, float* rr_rec, float* pd_rec) {
     CINE_REQUIRE(x && rhs && sens && mask && lambda_dev && ws, CINE_EINVAL, "cine_conj_grad: null pointer");
     CINE_REQUIRE(iters >= 0 && x != rhs, CINE_EINVAL, "cine_conj_grad: bad arguments");
     const long nb = cg_fused_blocks(b, t, c, h, w);
@@ -1313,12 +1331,15 @@ extern "C" int cine_conj_grad(float* x, const float* rhs, int rhs_is_ref, const 
         // beta_k = r.r after update k-1 / r.r before it; k = 0: both are the set-up's sums and p_old = 0, i.e. p = r exactly
         a.cg_num = k == 0 ? rr[0] : rr[k & 1];
         a.cg_den = k == 0 ? rr[0] : rr[(k - 1) & 1];
+        cf* pk = p_rec ? reinterpret_cast<cf*>(p_rec) + (long)k * ncf : pbuf;          // training: every direction is kept
+        a.cg_p_out = pk;
         {
             ProfScope prof(F_FFT_COL, st);
             hipLaunchKernelGGL(imgdc200_kernel<true>, dim3((unsigned)nb), dim3(kDcT), (size_t)200 * kDcL * sizeof(cf), st, a);
             if (int e = check_launch("imgdc200_kernel<cg>")) return e;
         }
-        if (int e = launch_cg_update2(x, pr, pbuf, partial, nz, ncf, lambda_dev, ncf, pd_wg, (int)nb, rr[k & 1], rr[(k + 1) & 1], k + 1 == iters, st)) return e;
+        if (int e = launch_cg_update2(x, pr, pk, partial, nz, ncf, lambda_dev, ncf, pd_wg, (int)nb, rr[k & 1], rr[(k + 1) & 1], k + 1 == iters, st,
+                                      rr_rec ? rr_rec + k : nullptr, pd_rec ? pd_rec + k : nullptr, (rr_rec && k + 1 == iters) ? rr_rec + iters : nullptr)) return e;
     }
     return CINE_OK;
 }

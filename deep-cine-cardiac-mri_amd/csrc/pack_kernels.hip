@@ -616,12 +616,13 @@ __global__ __launch_bounds__(256) void cg_init_kernel(const cfp* x, const cfp* r
 }
 __global__ __launch_bounds__(256) void cg_update2_kernel(cfp* x, float4* pr, const cfp* p, const cfp* partial, int nz, long part_stride,
                                                          const float* lam, long ncf, const float* pd_wg, int npd,
-                                                         const float* rr_prev, float* rr_cur, int last) {
+                                                         const float* rr_prev, float* rr_cur, int last, float* rr_rec, float* pd_rec) {
     __shared__ float red[16];
     float acc = 0.f;
     for (int i = threadIdx.x; i < npd; i += 256) acc += pd_wg[i];
     const float pd = block_sum(acc, red);
     const float rr_old = block_sum(rr_prev[threadIdx.x], red);
+    if (rr_rec && blockIdx.x == 0 && threadIdx.x == 0) { *rr_rec = rr_old; *pd_rec = pd; }      // training: the step sizes of this iteration for the adjoint recurrence
     const float alpha = rr_old / pd;
     const float nalpha = alpha * -1.0f;
     const float l = *lam;
@@ -652,10 +653,11 @@ int launch_cg_init(const float* x, const float* rhs, int rhs_ref, const float2* 
     return check_launch("cg_init_kernel");
 }
 int launch_cg_update2(float* x, float4* pr, const float2* p, const float2* partial, int nz, long part_stride, const float* lam, long ncf,
-                      const float* pd_wg, int npd, const float* rr_prev, float* rr_cur, int last, hipStream_t st) {
+                      const float* pd_wg, int npd, const float* rr_prev, float* rr_cur, int last, hipStream_t st, float* rr_rec, float* pd_rec, float* rr_final) {
     ProfScope prof(F_MISC, st);
     hipLaunchKernelGGL(cg_update2_kernel, dim3(kDotBlocks), dim3(256), 0, st, reinterpret_cast<cfp*>(x), pr, p, partial, nz, part_stride, lam, ncf,
-                       pd_wg, npd, rr_prev, rr_cur, last);
+                       pd_wg, npd, rr_prev, rr_cur, last, rr_rec, pd_rec);
+    if (rr_final) hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(256), 0, st, rr_cur, kDotBlocks, rr_final);      // r.r behind the last iteration
     return check_launch("cg_update2_kernel");
 }
 int launch_cg_update_fused(float* x, float* r, float* p, const float2* partial, int nz, long part_stride, const float* lam, long ncf,

@@ -479,6 +479,12 @@ int cine_normal_op_cg_fused_t(float* x, float* r, float* p, const float* sens, c
 size_t cine_conj_grad_ws_bytes(int b, int t, int c, int h, int w);
 int cine_conj_grad(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
                    const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
+/* cine_conj_grad for TRAINING: the same 2 + 2 * iters launches (+ one 1-block sum), recording what the adjoint recurrence of the iteration needs --
+ * the reference detaches its step sizes (cinenet.py:159-169: alpha.item(), beta.item()), so what torch.autograd differentiates is linear in
+ * (x0, b) with these constants: p_rec (iters, b, t, 1, h, w, 2) = every direction p_k, rr_rec (iters + 1) = r_k . r_k, pd_rec (iters) = p_k . H p_k. */
+int cine_conj_grad_rec(float* x, const float* rhs, int rhs_is_ref, const float* sens, const float* sens_tiled, const uint8_t* mask,
+                       const float* lambda_dev, int iters, int b, int t, int c, int h, int w, void* ws, size_t ws_bytes,
+                       float* p_rec, float* rr_rec, float* pd_rec, void* stream);
 /* cine_cg_step_pd that also stores p.d into *pd_out_dev (training: the adjoint recurrence needs alpha_k = rr_k / pd_k). */
 int cine_cg_step_pd2(float* x, float* r, float* p, const float* d, long n, const float* rr_old_dev, float* rr_new_dev,
                      float* pd_out_dev, void* ws, void* stream);
