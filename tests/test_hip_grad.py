@@ -433,9 +433,10 @@ def test_conv_sum_and_bcrnn_backward_vs_torch_autograd(dev):
         assert rel_err(a.grad.cpu(), b_.grad) < 2e-5, name
 
 
-def test_training_rejects_masks_that_are_not_row_masks(dev):
-    """Training runs on the image-space data-consistency chain, which needs the reference's (b, t, 1, h, 1, 1) row mask; any other mask
-    shape is refused instead of returning wrong gradients (inference takes the literal k-space kernels for those)."""
+def test_training_takes_general_masks_and_rejects_malformed_ones(dev):
+    """A mask that varies along w trains on the literal k-space chain (round 6: XPDNet and the CRNN models too; parity in
+    test_masks_that_vary_along_w_*); a mask that does not broadcast against the k-space as (b|1, t|1, 1, h, w|1, 1) is refused loudly instead of
+    being mis-indexed."""
     import reconstruction.models as M
     t, c, h, w = 3, 2, 16, 16
     mk = torch.randn(1, t, c, h, w, 2, device=dev)
@@ -443,8 +444,15 @@ def test_training_rejects_masks_that_are_not_row_masks(dev):
     mask[:, :, :, h // 2 - 2:h // 2 + 2] = 1
     net = M.XPDNet(num_cascades=1, sens_chans=2, sens_pools=1, n_scales=1, n_filters_per_scale=[4], n_convs_per_scale=[1],
                    first_conv_n_filters=4, n_primal=2, dynamic_type="XF").to(dev).train()
-    with torch.enable_grad(), pytest.raises(NotImplementedError):
-        net(mk * mask, mask, acs=(6, 4))
+    with torch.enable_grad():
+        out = net(mk * mask, mask, acs=(6, 4))
+        out.sum().backward()
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in net.parameters())
+    with torch.no_grad():
+        assert rel_err(net(mk * mask, mask, acs=(6, 4)).cpu(), out.detach().cpu()) < 1e-5
+    for bad in (mask[:, :, :, :h - 1], mask.expand(1, t, 2, h, w, 1), mask[..., 0]):
+        with torch.enable_grad(), pytest.raises(ValueError):
+            net(mk * mask, bad, acs=(6, 4))
 
 
 _FULL_SIZE = {
