@@ -153,7 +153,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL (backend nccl), the device barrier and the all-gather of the volume assembly even at --gpus 1 "
                          "(start under `python -m torch.distributed.run --nproc-per-node=1`, or alone: rank 0 of a world of 1)")
-    ap.add_argument("--branches", type=int, default=0, help="concurrent branches of every 2-D U-Net pass in the timed mode (1, 2 or 4; 0 = the binding's default)")
+    ap.add_argument("--branches", type=int, default=0, help="concurrent branches of every 2-D U-Net pass in the timed (throughput) mode: 1 (default), 2 or 4")
     ap.add_argument("--no-conv-plane", action="store_true", help="A/B: route the plane-wide 3x3 / transpose convs through the general kernel (cine_set_conv_plane(0))")
     ap.add_argument("--conv-plane-mask", type=int, default=-1, help="A/B: cine_set_conv_plane(mask) of the bench's thread: bit 0 the plane-wide 3x3 convs, bit 1 the transpose convs, bit 2 the wide-plane / volume kernel "
                          "(conv_wide_kernel: cfg 4, cfg 5, the sensitivity net), bit 4 SET = the general weight-gradient kernel; 7 = all lean kernels (the default)")
@@ -404,6 +404,20 @@ def selftest_cpu(args, world, rank):
         raise SystemExit(3)
 
 
+_STREAM_POOL = []
+
+
+def bench_streams(n):
+    """The bench's compute streams, created ONCE per process and shared by every Workload: torch hands out streams from a fixed pool of 32 per
+    device and the runtime maps them onto GPU_MAX_HW_QUEUES = 16 hardware queues as they are first used -- a process that keeps asking for fresh
+    streams (one set per configuration) soon has two ACTIVE streams on one queue (measured: cfg 4 165 -> 157, cfg 5 370 -> 330 slices/s, and a
+    training step whose weight-gradient side stream shares the main stream's queue: 33 -> 46 ms).  Twelve streams + the copy stream + a side
+    stream or two + the null stream stay within the 16 queues."""
+    while len(_STREAM_POOL) < n:
+        _STREAM_POOL.append(torch.cuda.Stream())
+    return _STREAM_POOL[:n]
+
+
 class Workload:
     """One BASELINE configuration set up on this rank's GPU: S different slices resident in HBM, the drop-in model, one hipGraph
     per slice (its own stream), and the timed region of the contract over them."""
@@ -439,7 +453,7 @@ class Workload:
         self.acss = [SensitivityModel.acs_window(m) for m in self.masks]             # host read-back of the 1-D mask, outside capture
         out = self.forward()                               # also packs the weights
         torch.cuda.synchronize()
-        self.streams = [torch.cuda.Stream() for _ in range(S)]
+        self.streams = bench_streams(S)
         self.graphs, self.gouts = [], []
         self.use_graph = not args.no_graph
         if self.use_graph:
@@ -466,50 +480,94 @@ class Workload:
         for st in self.streams:
             st.wait_stream(torch.cuda.current_stream())
 
-    def forward(self, i=0):
-        if self.cfg["needs_sens"]:
-            return self.net(self.mks[i], self.masks[i], self.senss[i])
-        return self.net(self.mks[i], self.masks[i], acs=self.acss[i])
+    def forward(self, i=0, branches=None, buf=0):
+        """One forward of slice i.  The throughput mode (S slices in flight, one stream each) runs every U-Net pass on ONE stream (--branches, default 1):
+        the other slices fill the chip, and side streams would only compete for hardware queues; the binding's own default (two concurrent branches,
+        the better form for ONE slice at a time) is what `latency_modes` measures beside it."""
+        from cine_hip import ops
+        mk = (self.mks2 if buf else self.mks)[i]
+        with ops.branches(branches or self.args.branches or 1):
+            if self.cfg["needs_sens"]:
+                return self.net(mk, self.masks[i], self.senss[i])
+            return self.net(mk, self.masks[i], acs=self.acss[i])
 
     def run(self, nsteps, keep, h2d=False):
-        """nsteps slices, round-robin over the S streams; each stream is an in-order queue.  h2d: every slice's k-space comes from its pinned
-        host buffer first -- on ONE copy stream that runs ahead of the compute streams (the copy of step k waits only for the replay that last
-        read that device buffer, step k - S; stream i waits for its own copy): the copies queue back to back on the link while the other
-        streams' replays run.  h2d == "inline": the copy on the slice's own stream in front of its replay (round 5's form, kept for the A/B)."""
+        """nsteps slices, round-robin over the S streams; each stream is an in-order queue.  h2d: every slice's k-space comes from its pinned host
+        buffer, DOUBLE-BUFFERED: a stream alternates between two device buffers (two captured graphs); while step k replays from one, the copy of
+        step k + S goes into the other on the copy stream -- it only has to wait for step k - S, which finished a whole round ago, so neither the
+        copy stream nor the host ever waits for a replay (a copy that depends on a replay still in flight blocks the HOST inside hipMemcpyAsync on
+        this runtime: measured 148 - 155 slices/s for that form against 172 with resident data).  h2d == "inline": the copy on the slice's own stream
+        in front of its replay (round 5's form, kept for the A/B)."""
         S, B = self.S, self.B
         ahead = h2d and h2d != "inline"
-        if ahead and not hasattr(self, "copy_stream"):
-            self.copy_stream = torch.cuda.Stream()
-            self.ev_ready = [torch.cuda.Event() for _ in range(S)]
-            self.ev_done = [torch.cuda.Event() for _ in range(S)]
         if ahead:
+            if not getattr(self, "_prefetched", False):                     # outside a prefetching caller: the first round's copies are issued here
+                self.prefetch()
+            self._prefetched = False
             self.copy_stream.wait_stream(torch.cuda.current_stream())
         for k in range(nsteps):
             i = k % S
-            if ahead:
-                if k >= S:
-                    self.copy_stream.wait_event(self.ev_done[i])                # the replay of step k - S has read mks[i]
-                with torch.cuda.stream(self.copy_stream):
-                    self.mks[i].copy_(self.host_mk[i], non_blocking=True)
-                    self.ev_ready[i].record()
+            s_ = (k // S) & 1 if ahead else 0                               # which of the stream's two buffers / graphs this step reads
             with torch.cuda.stream(self.streams[i]):
                 if ahead:
-                    self.streams[i].wait_event(self.ev_ready[i])
+                    self.streams[i].wait_event(self.ev_ready[s_][i])        # this slice's k-space has arrived (copied while the previous round replayed)
                 elif h2d:
                     self.mks[i].copy_(self.host_mk[i], non_blocking=True)      # pinned host buffer -> HBM, ahead of this slice's replay
                 if self.use_graph:
-                    self.graphs[i].replay()
-                    o = self.gouts[i]
+                    (self.graphs2 if s_ else self.graphs)[i].replay()
+                    o = (self.gouts2 if s_ else self.gouts)[i]
                 else:
-                    o = self.forward(i)
+                    o = self.forward(i, buf=s_)
                 if keep:
                     self.outs[k * B:(k + 1) * B].copy_(o)
                 if ahead:
-                    self.ev_done[i].record()
+                    self.ev_done[s_][i].record()
+            if ahead:      # step k + S of this stream reads the OTHER buffer: copy it now (its last reader, step k - S, is long done)
+                o_ = s_ ^ 1
+                if k >= S:
+                    self.copy_stream.wait_event(self.ev_done[o_][i])
+                with torch.cuda.stream(self.copy_stream):
+                    (self.mks2 if o_ else self.mks)[i].copy_(self.host_mk[i], non_blocking=True)
+                    self.ev_ready[o_][i].record()
         for st in self.streams:
             torch.cuda.current_stream().wait_stream(st)
 
+    def prefetch(self):
+        """Set-up of the double-buffered copies (second device buffers, second graphs) and the copies of the FIRST round (one slice per stream): in a
+        running loop they happened while the previous slices were reconstructed; a timed region issues them before its clock starts (every later
+        copy -- nsteps of them, one per replay -- is inside the region)."""
+        S = self.S
+        if getattr(self, "copy_stream", None) is None:
+            self.copy_stream = bench_streams(13)[12]
+            self.ev_ready = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+            self.ev_done = [[torch.cuda.Event() for _ in range(S)] for _ in range(2)]
+            self.mks2 = [torch.empty_like(m) for m in self.mks]
+            self.graphs2, self.gouts2 = [], []
+            if self.use_graph:
+                torch.cuda.synchronize()
+                for i in range(S):
+                    self.mks2[i].copy_(self.mks[i])
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=self.streams[i]):
+                        o = self.forward(i, buf=1)
+                    self.graphs2.append(g); self.gouts2.append(o)
+                torch.cuda.synchronize()
+                for i, g in enumerate(self.graphs2):
+                    with torch.cuda.stream(self.streams[i]):
+                        g.replay()
+                torch.cuda.synchronize()
+        for st in self.streams:
+            self.copy_stream.wait_stream(st)
+        with torch.cuda.stream(self.copy_stream):
+            for i in range(S):
+                self.mks[i].copy_(self.host_mk[i], non_blocking=True)
+                self.ev_ready[0][i].record()
+        self.copy_stream.synchronize()
+        self._prefetched = True
+
     def timed(self, nsteps, h2d=False):
+        if h2d and h2d != "inline":
+            self.prefetch()
         dt, _, self.per_rank_s = timed_steps(lambda n: self.run(n, True, h2d), nsteps, self.B, self.outs, self.world, torch.cuda.synchronize,
                                              lambda: dist.barrier(device_ids=[self.local]), self.dev)
         return dt
@@ -531,7 +589,7 @@ class Workload:
         ts.sort()
         return ts[len(ts) // 2] * 1e3, ts[0] * 1e3
 
-    def latency_modes(self, reps=15, branch_counts=(1, 2, 4)):
+    def latency_modes(self, reps=15, branch_counts=(1, 2)):
         """`latency_one_slice` for every launch form of ONE slice: hipGraph replay and eager launches, with the 2-D U-Net passes on one stream or as
         2 / 4 concurrent branches (cine_unet2d_forward_branches: x-f / y-f networks, coil halves of the sens-net; bit-identical outputs).  The
         graphs of the timed region are left alone; the extra ones are captured for slice 0 on stream 0 and dropped afterwards."""
@@ -540,9 +598,9 @@ class Workload:
         st = self.streams[0]
         ref = None
         for nb in branch_counts:
-            with ops.branches(nb):
+            if True:
                 with torch.cuda.stream(st):
-                    o = self.forward(0).clone()                  # warms this stream's side streams outside capture
+                    o = self.forward(0, nb).clone()              # warms this stream's side streams outside capture
                 torch.cuda.synchronize()
                 ref = o if ref is None else ref
                 same = bool(torch.equal(o, ref))
@@ -550,7 +608,7 @@ class Workload:
                 for _ in range(reps):
                     t0 = time.perf_counter()
                     with torch.cuda.stream(st):
-                        self.forward(0)
+                        self.forward(0, nb)
                     st.synchronize()
                     ts.append(time.perf_counter() - t0)
                 ts.sort()
@@ -558,7 +616,7 @@ class Workload:
                 try:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=st):
-                        go = self.forward(0)
+                        go = self.forward(0, nb)
                     with torch.cuda.stream(st):
                         g.replay()
                     torch.cuda.synchronize()
@@ -622,9 +680,20 @@ class Workload:
         return self.forward(0)[:1].clone()
 
     def release(self):
+        """Drop the graphs, tensors AND streams of this workload.  The streams matter: the runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+        queues, and once more streams are alive than queues a NEW stream (the next workload's, a training step's side stream) shares a queue
+        with an old one -- measured: 26 idle streams left behind turn the cfg-2 training step from 33 ms into 46.6 ms (its weight-gradient side
+        stream lands on the main stream's queue)."""
+        import gc
+        from cine_hip import ops
+        torch.cuda.synchronize()
         self.graphs, self.gouts = [], []
-        for name in ("mks", "masks", "senss", "outs", "net", "host_mk", "exs"):
-            setattr(self, name, None)
+        self.graphs2, self.gouts2 = [], []
+        for name in ("mks", "mks2", "masks", "senss", "outs", "net", "host_mk", "exs", "copy_stream", "ev_ready", "ev_done"):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        self.streams = []                                      # (the stream objects themselves live in bench_streams' pool and are reused)
+        gc.collect()
         torch.cuda.empty_cache()
 
 
@@ -775,6 +844,12 @@ def measure_other_config(cfg_id, args, dev, threads):
            "roofline": {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "frac_timed_mode", "frac_isolated", "traffic",
                                              "ms_per_slice_isolated", "launches_per_slice")},
            "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items() if v[1]}}
+    try:
+        lm = wl.latency_modes(reps=9)
+        res["latency_modes_ms"] = lm
+        res["latency_ms_one_slice"] = min(v[k] for v in lm.values() for k in ("eager_ms", "graph_ms") if k in v)
+    except Exception as e:                                                # pragma: no cover
+        res["latency_modes_ms"] = {"error": f"{type(e).__name__}: {e}"}
     chk = wl.replayed_output().cpu()
     ex0 = wl.exs[0][0]
     if not args.no_cpu_baseline:
@@ -892,9 +967,6 @@ def main():
     if args.no_conv_plane or args.conv_plane_mask >= 0:
         from cine_hip import ops as cine_ops
         cine_ops.set_conv_plane(0 if args.no_conv_plane else args.conv_plane_mask)
-    if args.branches > 0:
-        from cine_hip import ops as cine_ops
-        cine_ops.UNET_BRANCHES = args.branches
     wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
     cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
     if args.latency_only:
@@ -912,6 +984,14 @@ def main():
     extra = sorted(wl.timed(args.steps) for _ in range(max(0, args.repeats)))
     dt_h2d = min(wl.timed(args.steps, h2d=True) for _ in range(2))
     dt_h2d_inline = wl.timed(args.steps, h2d="inline")
+    # what the link alone delivers: the same pinned-host -> HBM copies back to back with nothing else on the GPU
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(wl.streams[0]):
+        for k in range(2 * S):
+            wl.mks[k % S].copy_(wl.host_mk[k % S], non_blocking=True)
+    torch.cuda.synchronize()
+    link_gbs = 2 * S * wl.host_mk[0].numel() * 4 / (time.perf_counter() - t0) / 1e9
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     # the single-GPU diagnostics (one slice alone, the 60-s sustained region) belong to the N = 1 line: on N ranks they would keep N GPUs
     # busy for a minute each after the contract's region.  --sustained-seconds X forces the sustained region at N > 1 too (X > 0 given explicitly).
@@ -919,6 +999,12 @@ def main():
     lat_med, lat_min = wl.latency_one_slice() if extras else (None, None)
     lat_modes = wl.latency_modes() if (extras and rank == 0 and world == 1) else None
     sustained = wl.sustained(args.sustained_seconds, dt / args.steps) if args.sustained_seconds > 0 and extras else None
+    best_lat = None
+    if lat_modes:
+        forms = [(v[k + "_ms"], v[k + "_min_ms"], f"{k} launches" if k == "eager" else "one hipGraph replay", nb)
+                 for nb, v in lat_modes.items() for k in ("eager", "graph") if k + "_ms" in v]
+        m = min(forms)
+        best_lat = (m[0], m[1], f"{m[2]}, {m[3]} concurrent branch(es) per 2-D U-Net pass")
 
     if rank != 0:
         return leave_together(use_dist, lambda: dist.barrier(device_ids=[local]))
@@ -945,9 +1031,11 @@ def main():
                    "parallelism": f"slice-sharded x{world}, one all-gather for volume assembly"},
         "rccl_ranks": rccl_ranks, "rccl_initialised": bool(dist.is_initialized()),
         "timed_region_s": dt, "per_rank_timed_region_s": contract_per_rank_s, "cpu_affinity": AFFINITY,
-        "latency_ms_one_slice": lat_med, "latency_ms_one_slice_min": lat_min,
-        "latency_note": "one hipGraph replay on one stream, nothing else in flight, host clock around launch + stream sync: what "
-                        "run_inference.py:53-61 times per slice (median / min of 15)",
+        "latency_ms_one_slice": best_lat[0] if best_lat else lat_med, "latency_ms_one_slice_min": best_lat[1] if best_lat else lat_min,
+        "latency_ms_one_slice_graph_one_stream": lat_med,
+        "latency_note": ("one slice alone, nothing else in flight, host clock around enqueue + stream sync: what run_inference.py:53-61 times per slice "
+                         "(median / min of 15); launch form: " + (best_lat[2] if best_lat else "one hipGraph replay on one stream") +
+                         " (latency_modes_ms holds every form; _graph_one_stream = one hipGraph replay on one stream, round 5's figure)"),
         "latency_modes_ms": lat_modes,
         "latency_modes_note": "one slice alone, host clock around enqueue + stream sync, median / min of 15, per launch form: key = concurrent branches of "
                               "every 2-D U-Net pass (1 = one stream; 2 = x-f / y-f networks and coil halves beside each other on a side stream; 4 = "
@@ -955,8 +1043,12 @@ def main():
         "sustained_value": sustained["value"] if sustained else None, "sustained": sustained,
         "repeat_values": [slices / d for d in extra], "repeat_median_value": (slices / extra[len(extra) // 2]) if extra else None,
         "value_with_h2d": slices / dt_h2d, "value_with_h2d_inline": slices / dt_h2d_inline,
-        "value_with_h2d_note": "same K steps with each slice's 72 MB k-space copied pinned-host -> HBM before its replay (what run_inference.py:53-61 "
-                               "times): on one copy stream that runs ahead of the compute streams (best of 2 regions); _inline = the copy on the slice's own stream (round 5's form)",
+        "h2d_link": {"GB_per_s_copies_alone": link_gbs, "MB_per_slice": wl.host_mk[0].numel() * 4 / 1e6 / B,
+                     "slices_per_s_the_link_allows": link_gbs * 1e9 / (wl.host_mk[0].numel() * 4 / B)},
+        "value_with_h2d_note": "same K steps with every slice's 72 MB k-space copied pinned-host -> HBM (what run_inference.py:53-61 times): one copy per replay "
+                               "inside the region, on a copy stream, double-buffered (two device buffers and two captured graphs per stream: the copy of step "
+                               "k + S runs while step k replays; the first round's copies are issued before the clock starts, as a running loop would have); "
+                               "best of 2 regions; _inline = the copy on the slice's own stream in front of its replay (round 5's form)",
         "roofline": roofline,
         "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items()},
     }

@@ -87,8 +87,11 @@ def apply_conv_plane(mask: int) -> None:
 # ---- side streams: the caller-owned streams the branch / side-lane entry points fork onto --------------------------------------------
 _SIDE_STREAMS = {}
 import os as _os
-UNET_BRANCHES = int(_os.environ.get("CINE_UNET_BRANCHES", "1"))   # default number of concurrent branches of a 2-D U-Net pass (cine_unet2d_forward_branches); see
-                                                                  # `branches`.  The environment variable belongs to THIS binding (A/B runs), the library reads none
+UNET_BRANCHES = int(_os.environ.get("CINE_UNET_BRANCHES", "2"))   # default number of concurrent branches of a 2-D U-Net pass (cine_unet2d_forward_branches), see
+                                                                  # `branches`: 2 -- the reference's scripts run ONE slice at a time (run_inference.py:53-61, every
+                                                                  # training step), where two branches fill the chip better (cfg 2: 8.3 -> 7.6 ms per slice); a caller
+                                                                  # that keeps many slices in flight on streams of its own asks for 1 (bench.py's timed mode).  The
+                                                                  # environment variable belongs to THIS binding (A/B runs), the library reads none
 
 
 BRANCH_INTERLEAVE = _os.environ.get("CINE_BRANCH_INTERLEAVE", "0") == "1"     # diagnostics: enqueue the branches layer by layer (lockstep) instead of sequence by sequence
@@ -106,6 +109,18 @@ def side_streams(device: torch.device, count: int = 1):
         _no_capture("a side stream")
         have.append(torch.cuda.Stream(device=idx))
     return have[:count]
+
+
+def release_side_streams(main_streams=None) -> None:
+    """Forget (and thereby destroy) the side streams that belong to the given main streams (raw handles), or all of them.  Streams are a
+    finite resource in effect: once more are alive than the runtime has hardware queues (GPU_MAX_HW_QUEUES), a new stream shares a queue with
+    an existing one, and a side stream that shares its main stream's queue serialises with it.  Call after the work on those streams is done."""
+    if main_streams is None:
+        _SIDE_STREAMS.clear()
+        return
+    want = set(main_streams)
+    for key in [k for k in _SIDE_STREAMS if k[1] in want]:
+        del _SIDE_STREAMS[key]
 
 
 def unet_branches() -> int:

@@ -40,6 +40,12 @@ def step():
     opt.step()
     return loss
 
+if os.environ.get("CINE_EXTRA_STREAMS"):      # diagnostics: idle streams created BEFORE the step's side streams exist (what a long bench process leaves behind)
+    _idle = [torch.cuda.Stream() for _ in range(int(os.environ["CINE_EXTRA_STREAMS"]))]
+    for s_ in _idle:
+        with torch.cuda.stream(s_):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
 for _ in range(2): step()
 torch.cuda.synchronize()
 t0 = time.time()
