@@ -167,6 +167,7 @@ _SIGS = {
     "cine_unet3d_backward_drop": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P, P]),
     "cine_unet2d_backward_drop": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P, P]),
     "cine_diag_counter": (c_long, [c_int, c_int]),
+    "cine_spin": (c_int, [c_int, P]),
     "cine_unet2d_backward_ws_bytes": (c_size_t, [c_int] * 7),
     "cine_unet2d_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, P, c_size_t, P, c_size_t, P, P]),
     "cine_mwcnn_train_ws_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int]),

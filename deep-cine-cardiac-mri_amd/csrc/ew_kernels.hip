@@ -116,3 +116,23 @@ extern "C" int cine_pad2d(const float* x, float* out, long planes, int h, int w,
     hipLaunchKernelGGL(pad2d_kernel, dim3(grid_for(planes * hp * wp)), dim3(256), 0, as_stream(stream), x, out, planes, h, w, top, left, hp, wp);
     return check_launch("pad2d_kernel");
 }
+
+
+// ---------------------------------------------------------------- diagnostics: a kernel of known duration on one workgroup
+// cine_spin(us): one wave reads the constant 100 MHz clock until `us` microseconds have passed (or an iteration cap is reached: it always
+// terminates).  The binding uses it to find out whether two streams really run side by side: the runtime maps streams onto a limited number
+// of hardware queues, and two streams on one queue execute one after the other whatever the events between them say.
+namespace cine {
+__global__ void spin_kernel(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t = t0;
+    for (int i = 0; i < (1 << 22) && t - t0 < ticks; ++i) { __builtin_amdgcn_s_sleep(8); t = __builtin_amdgcn_s_memrealtime(); }
+    if (out && threadIdx.x == 0) *out = t - t0;
+}
+}  // namespace cine
+extern "C" int cine_spin(int microseconds, void* stream) {
+    CINE_REQUIRE(microseconds > 0 && microseconds <= 100000, CINE_EINVAL, "cine_spin: 1 .. 100000 us");
+    hipLaunchKernelGGL(cine::spin_kernel, dim3(1), dim3(64), 0, cine::as_stream(stream), 100ull * (unsigned long long)microseconds,
+                       static_cast<unsigned long long*>(nullptr));
+    return cine::check_launch("spin_kernel");
+}

@@ -776,6 +776,10 @@ int cine_profile_begin(void);
  * (`which`: 0 plane-wide weight gradients on the lean kernel, 1 on the general kernel, 2 U-Net passes run as concurrent branches,
  * 3 BCRNN layers run by the C time-sweep entry points).  reset != 0 returns the count and zeroes it; -1 for an unknown counter. */
 long cine_diag_counter(int which, int reset);
+/* Diagnostics: a one-workgroup kernel that runs for `microseconds` (1 .. 100 000; clock-bounded AND iteration-bounded: it always ends).  The
+ * binding times two of them on two streams to learn whether the streams share a hardware queue (GPU_MAX_HW_QUEUES): streams on one queue run
+ * one after the other, and a side stream chosen that way would serialise with its main stream. */
+int cine_spin(int microseconds, void* stream);
 int cine_profile_end(double* ms, long* launches, int nfam);
 int cine_profile_families(void);
 const char* cine_profile_family_name(int family);

@@ -1786,6 +1786,30 @@ def test_varnet_branches_eager_and_captured_bit_identical(golden, dev):
         assert torch.equal(gout, want)
 
 
+def test_side_streams_are_probed_for_a_hardware_queue_of_their_own(dev):
+    """ops.side_streams picks streams that really run beside their main stream: cine_spin kernels of known duration on the two streams overlap
+    (streams_run_concurrently); a stream probed against ITSELF is, of course, serial -- the probe can tell the difference."""
+    from cine_hip import ops
+    main = torch.cuda.current_stream()
+    side = ops.side_streams(dev, 1)[0]
+    assert ops.streams_run_concurrently(main, side)
+    assert not ops.streams_run_concurrently(main, main)
+    # a process that has used many streams: the side stream of a fresh main stream still gets a queue of its own (or a warning says that it could not)
+    idle = [torch.cuda.Stream() for _ in range(30)]
+    for s_ in idle:
+        with torch.cuda.stream(s_):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+    m2 = torch.cuda.Stream()
+    import warnings
+    with torch.cuda.stream(m2), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        s2 = ops.side_streams(dev, 1)[0]
+        ok = ops.streams_run_concurrently(m2, s2)
+    assert ok or any("hardware queue" in str(x.message) for x in w)
+    ops.release_side_streams([m2.cuda_stream])
+
+
 # ------------------------------------------------------------------ direct tests of the small helpers (SURVEY 8 a9, a14, a15)
 @pytest.mark.parametrize("tag", ["odd", "t15", "even", "mixed"])
 def test_shift_helpers_vs_reference_golden(golden, dev, tag):
