@@ -486,6 +486,7 @@ class Workload:
         the better form for ONE slice at a time) is what `latency_modes` measures beside it."""
         from cine_hip import ops
         mk = (self.mks2 if buf else self.mks)[i]
+        self.nforward = getattr(self, "nforward", 0) + 1            # (eager forwards + captures: what a --no-graph PMC pass divides its counters by)
         with ops.branches(branches or self.args.branches or 1):
             if self.cfg["needs_sens"]:
                 return self.net(mk, self.masks[i], self.senss[i])
@@ -1052,6 +1053,7 @@ def main():
         "roofline": roofline,
         "kernel_ms_per_slice": {k: round(v[0], 4) for k, v in fam.items()},
     }
+    line["forwards_run"] = None        # filled in just before the line is printed
     if cfg["fft_bytes"]:
         roof_fft = {"bound": "hbm", "kernel": "cine::imgdc200_kernel + imgdc_sum_kernel (x6: sens_expand + FFT2 + DC + IFFT2 + sens_reduce on the "
                                               "coil-combined image), col200_kernel + row200_reduce_kernel (first reduce, zero-filled term, sens prologue)",
@@ -1117,6 +1119,7 @@ def main():
                 line["train_step_other_configs"][str(cid)] = measure_training_step(args, dev, best_threads, cfg_id=cid, cpu=False)
             except Exception as e:                                        # pragma: no cover
                 line["train_step_other_configs"][str(cid)] = {"error": f"{type(e).__name__}: {e}"}
+    line["forwards_run"] = getattr(wl, "nforward", None)
     print(json.dumps(line))
     leave_together(use_dist, lambda: dist.barrier(device_ids=[local]))
 
