@@ -94,6 +94,8 @@ UNET_BRANCHES = int(_os.environ.get("CINE_UNET_BRANCHES", "2"))   # default numb
                                                                   # environment variable belongs to THIS binding (A/B runs), the library reads none
 
 
+BRANCH_SINGLE_SET = _os.environ.get("CINE_BRANCH_SINGLE_SET", "0") == "1"      # also cut a ONE-network pass (the sensitivity network's coil planes) into branches: measured
+                                                                              # slower (cfg 5 one slice 4.42 -> 4.59 ms: 15 planes are too few to be worth a fork / join)
 BRANCH_INTERLEAVE = _os.environ.get("CINE_BRANCH_INTERLEAVE", "0") == "1"     # diagnostics: enqueue the branches layer by layer (lockstep) instead of sequence by sequence
 
 
@@ -1277,6 +1279,8 @@ class UnetWeights:
 def _branch_count(n: int, nsets: int) -> int:
     """How many branches this thread's setting gives a pass of n planes in nsets weight sets (the largest admissible count <= the setting)."""
     nb = unet_branches()
+    if nsets == 1 and not BRANCH_SINGLE_SET:
+        return 1
     while nb > 1 and (nb % nsets or n // nb < 1):
         nb //= 2
     return max(nb, 1)

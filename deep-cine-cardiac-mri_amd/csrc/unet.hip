@@ -13,6 +13,7 @@
 using namespace cine;
 
 extern "C" int cine_conv_stat_partials(int cout, int h, int w, int is_tconv);
+extern "C" int cine_instnorm_merge(const float* part, float* out, long planes, int np, void* stream);
 
 namespace {
 
@@ -64,7 +65,12 @@ struct Plan {
     float *up[8], *pup[8];             // transpose-conv output at level d
     float *ca[8], *pca[8];             // up-path ConvBlock at level d: first conv ...
     float *cb[8], *pcb[8];             // ... and second conv
+    // inference only: one MERGED statistics record per (sample, channel) beside the per-tile records of the layers that emit many (wide planes: the
+    // sensitivity network's 208 x 208 level has 52 per channel, and every consumer workgroup used to merge them again in its prologue -- 39 % of
+    // such a workgroup's life); NULL where the layer's records stay as they are
+    float *mskip[8], *mmid[8], *mbott, *mup[8], *mca[8], *mcb[8];
 };
+constexpr int kMergeMin = 12;          // records per channel from which a layer's statistics are merged once by cine_instnorm_merge
 
 // private == false: three rotating scratch buffers sized for the largest layer (layers are separated by kernel boundaries, so
 // a buffer may hold different shapes over time).  private == true: every layer output owns its memory, sample n of every
@@ -85,6 +91,8 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools, bool pri
         p.skip[d] = b.take(elems(d));
         p.pskip[d] = b.take(pelems(d, false));
     }
+    for (int d = 0; d < 8; ++d) p.mskip[d] = p.mmid[d] = p.mup[d] = p.mca[d] = p.mcb[d] = nullptr;
+    p.mbott = nullptr;
     if (priv) {
         for (int d = 0; d <= pools; ++d) { p.mid[d] = b.take(elems(d)); p.pmid[d] = b.take(pelems(d, false)); }
         p.bott = b.take(elems(pools)); p.pbott = b.take(pelems(pools, false));
@@ -100,17 +108,22 @@ void build(Plan& p, Bump& b, int n, int h, int w, int chans, int pools, bool pri
         big = std::max(big, elems(d));
         bigp = std::max(bigp, std::max(pelems(d, false), d < pools ? pelems(d, true) : (size_t)0));
     }
-    float *scr[3], *pscr[3];
-    for (int i = 0; i < 3; ++i) { scr[i] = b.take(big); pscr[i] = b.take(bigp); }
-    for (int d = 0; d <= pools; ++d) { p.mid[d] = scr[0]; p.pmid[d] = pscr[0]; }
-    p.bott = scr[1]; p.pbott = pscr[1];
+    float *scr[3], *pscr[3], *mscr[3];
+    size_t bigm = 0;                    // merged records: (n, ch, 3) of the widest layer that merges
+    for (int d = 0; d <= pools; ++d)
+        if (p.np_conv[d] >= kMergeMin || (d < pools && p.np_tconv[d] >= kMergeMin)) bigm = std::max(bigm, (size_t)n * p.ch[d] * 3);
+    for (int i = 0; i < 3; ++i) { scr[i] = b.take(big); pscr[i] = b.take(bigp); mscr[i] = bigm ? b.take(bigm) : nullptr; }
+    for (int d = 0; d < pools; ++d) p.mskip[d] = p.np_conv[d] >= kMergeMin ? b.take((size_t)n * p.ch[d] * 3) : nullptr;
+    auto mif = [&](float* m, int np) { return np >= kMergeMin ? m : nullptr; };
+    for (int d = 0; d <= pools; ++d) { p.mid[d] = scr[0]; p.pmid[d] = pscr[0]; p.mmid[d] = mif(mscr[0], p.np_conv[d]); }
+    p.bott = scr[1]; p.pbott = pscr[1]; p.mbott = mif(mscr[1], p.np_conv[pools]);
     int cur = 1;
     for (int u = 0; u < pools; ++u) {
         const int d = pools - 1 - u;
         const int a = (cur + 1) % 3, c = (cur + 2) % 3;
-        p.up[d] = scr[a]; p.pup[d] = pscr[a];
-        p.ca[d] = scr[c]; p.pca[d] = pscr[c];
-        p.cb[d] = scr[a]; p.pcb[d] = pscr[a];
+        p.up[d] = scr[a]; p.pup[d] = pscr[a]; p.mup[d] = mif(mscr[a], p.np_tconv[d]);
+        p.ca[d] = scr[c]; p.pca[d] = pscr[c]; p.mca[d] = mif(mscr[c], p.np_conv[d]);
+        p.cb[d] = scr[a]; p.pcb[d] = pscr[a]; p.mcb[d] = mif(mscr[a], p.np_conv[d]);
         cur = a;
     }
 }
@@ -156,51 +169,68 @@ static int run_unet(const Plan& p, const float* x, float* y, const void* const* 
         return on;
     };
     int e;
+    // a layer with many per-tile records gets them merged ONCE (one small launch) instead of once per consumer workgroup; (ptr, np) = what the consumers read
+    struct Rec { const float* p; int np; };
+    auto fold = [&](float* part, int np, float* merged, int ch, Rec& r) -> int {
+        r = Rec{part, np};
+        if (!merged) return CINE_OK;
+        r = Rec{merged, 1};
+        return cine_instnorm_merge(part, merged, (long)n * ch, np, stream);
+    };
+    Rec rskip[8], rmid{nullptr, 0}, rcur{nullptr, 0}, rup{nullptr, 0}, rca{nullptr, 0};
+    for (int d = 0; d < 8; ++d) rskip[d] = Rec{p.pskip[d], p.np_conv[d]};
     // ---- down path (unet.py:94-97) + bottleneck (:99)
     for (int d = 0; d <= pools; ++d) {
         const bool last = d == pools;
         float* mid = p.mid[d]; float* pmid = p.pmid[d];
         float* out = last ? p.bott : p.skip[d];
         float* pout = last ? p.pbott : p.pskip[d];
+        rmid = Rec{pmid, p.np_conv[d]};
         if (next()) {
             if (d == 0)
                 e = cine_conv3x3_in(x, nullptr, 0, in_ch, 0, h, w, nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
                                     mid, pmid, n, p.ch[0], h, w, kEps, kSlope, stream);
             else
-                e = cine_conv3x3_in(p.skip[d - 1], p.pskip[d - 1], p.np_conv[d - 1], p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
+                e = cine_conv3x3_in(p.skip[d - 1], rskip[d - 1].p, rskip[d - 1].np, p.ch[d - 1], 2, p.hs[d - 1], p.wsz[d - 1],
                                     nullptr, nullptr, 0, 0, 0, 0, 0, w0, w1, split,
                                     mid, pmid, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e || (e = drop(DropMap::down(d, 0), pmid, p.np_conv[d], p.ch[d]))) return e;
-        }
+            if (e || (e = drop(DropMap::down(d, 0), pmid, p.np_conv[d], p.ch[d])) || (e = fold(pmid, p.np_conv[d], p.mmid[d], p.ch[d], rmid))) return e;
+        } else if (p.mmid[d]) rmid = Rec{p.mmid[d], 1};
+        Rec rout{pout, p.np_conv[d]};
         if (next()) {
-            e = cine_conv3x3_in(mid, pmid, p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+            e = cine_conv3x3_in(mid, rmid.p, rmid.np, p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                                 w0, w1, split, out, pout, n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e || (e = drop(DropMap::down(d, 1), pout, p.np_conv[d], p.ch[d]))) return e;
-        }
+            if (e || (e = drop(DropMap::down(d, 1), pout, p.np_conv[d], p.ch[d])) || (e = fold(pout, p.np_conv[d], last ? p.mbott : p.mskip[d], p.ch[d], rout))) return e;
+        } else if (last ? p.mbott : p.mskip[d]) rout = Rec{last ? p.mbott : p.mskip[d], 1};
+        if (last) rcur = rout; else rskip[d] = rout;
     }
     // ---- up path (unet.py:102-123)
-    const float* cur = p.bott; const float* pcur = p.pbott;
-    int np_cur = p.np_conv[pools];
+    const float* cur = p.bott;
     for (int u = 0; u < pools; ++u) {
         const int d = pools - 1 - u;
+        rup = Rec{p.pup[d], p.np_tconv[d]};
         if (next()) {   // transpose conv: level d+1 -> (2 h_{d+1}, 2 w_{d+1}), ch_d channels
-            e = cine_tconv2x2_in(cur, pcur, np_cur, 1, w0, w1, split, p.up[d], p.pup[d], n,
+            e = cine_tconv2x2_in(cur, rcur.p, rcur.np, 1, w0, w1, split, p.up[d], p.pup[d], n,
                                  p.ch[d + 1], p.ch[d], p.hs[d + 1], p.wsz[d + 1], kEps, kSlope, stream);
-            if (e) return e;
-        }
+            if (e || (e = fold(p.pup[d], p.np_tconv[d], p.mup[d], p.ch[d], rup))) return e;
+        } else if (p.mup[d]) rup = Rec{p.mup[d], 1};
+        rca = Rec{p.pca[d], p.np_conv[d]};
         if (next()) {   // cat([up, skip]) -> conv1; `up` reads as zero beyond its extent (zero pad, :106-120)
-            e = cine_conv3x3_in(p.up[d], p.pup[d], p.np_tconv[d], p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
-                                p.skip[d], p.pskip[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
+            e = cine_conv3x3_in(p.up[d], rup.p, rup.np, p.ch[d], 1, 2 * p.hs[d + 1], 2 * p.wsz[d + 1],
+                                p.skip[d], rskip[d].p, rskip[d].np, p.ch[d], 1, p.hs[d], p.wsz[d], w0, w1, split,
                                 p.ca[d], p.pca[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e || (e = drop(dm ? dm->up(d, 0) : 0, p.pca[d], p.np_conv[d], p.ch[d]))) return e;
-        }
+            if (e || (e = drop(dm ? dm->up(d, 0) : 0, p.pca[d], p.np_conv[d], p.ch[d])) || (e = fold(p.pca[d], p.np_conv[d], p.mca[d], p.ch[d], rca))) return e;
+        } else if (p.mca[d]) rca = Rec{p.mca[d], 1};
+        rcur = Rec{p.pcb[d], p.np_conv[d]};
         if (next()) {
-            e = cine_conv3x3_in(p.ca[d], p.pca[d], p.np_conv[d], p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
+            e = cine_conv3x3_in(p.ca[d], rca.p, rca.np, p.ch[d], 1, p.hs[d], p.wsz[d], nullptr, nullptr, 0, 0, 0, 0, 0,
                                 w0, w1, split, p.cb[d], p.pcb[d], n, p.ch[d], p.hs[d], p.wsz[d], kEps, kSlope, stream);
-            if (e || (e = drop(dm ? dm->up(d, 1) : 0, p.pcb[d], p.np_conv[d], p.ch[d]))) return e;
-        }
-        cur = p.cb[d]; pcur = p.pcb[d]; np_cur = p.np_conv[d];
+            if (e || (e = drop(dm ? dm->up(d, 1) : 0, p.pcb[d], p.np_conv[d], p.ch[d])) || (e = fold(p.pcb[d], p.np_conv[d], p.mcb[d], p.ch[d], rcur))) return e;
+        } else if (p.mcb[d]) rcur = Rec{p.mcb[d], 1};
+        cur = p.cb[d];
     }
+    const float* pcur = rcur.p;
+    const int np_cur = rcur.np;
     // ---- final 1x1 conv + bias (unet.py:69)
     const float* wf0 = reinterpret_cast<const float*>(wa[wi]);
     const float* bf0 = reinterpret_cast<const float*>(wa[wi + 1]);
