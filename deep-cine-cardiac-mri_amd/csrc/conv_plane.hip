@@ -1079,6 +1079,22 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
 #pragma unroll
         for (int f = 0; f < MT; ++f) acc[ct][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // The small-tile shape (the CRNN time-sweep steps: 4 fragments per wave, a dependent chain of 10-us launches) fetches its epilogue operands --
+    // the addend P_t and, in back-propagation through time, the ReLU gate -- NOW, under the staging and the MFMA sweep, instead of behind them
+    // (one exposed memory latency per step less); the 13-fragment shapes have no registers to spare for that.
+    constexpr bool PRE = MT <= 4 && CT == 1 && !V3;
+    float4 pre_add[PRE ? MT : 1], pre_gate[PRE ? MT : 1];
+    if constexpr (PRE) {
+        const int pfr0 = r0 + wn * MT, pgx0 = c0 + 4 * kk, pm = co0 + 16 * wm + q;
+        const bool pok2 = pgx0 < a.W && pm < a.rows;
+        const long pbase = (((long)n * a.rows + min(pm, a.rows - 1)) * a.D + z0) * hwl + min(pgx0, a.W - 4);
+#pragma unroll
+        for (int f = 0; f < MT; ++f) {
+            const long off = pbase + (long)min(pfr0 + f, a.H - 1) * a.W;
+            pre_add[f] = (a.addend && pok2) ? *reinterpret_cast<const float4*>(a.addend + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre_gate[f] = (a.gate && pok2) ? *reinterpret_cast<const float4*>(a.gate + off) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+    }
     CINE_STAMP(1);
     for (int chunk = first_live; chunk < a.nchunks; ++chunk) {
         if (V3 && !chunk_live(chunk)) break;           // the live chunks of a tile are one run: the dead ones behind it are skipped
@@ -1182,8 +1198,11 @@ __global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::M
             for (int f = 0; f < MT; ++f) {
                 if (fr0 + f >= a.H || !colok) continue;
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f), gv = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (ab) t = *reinterpret_cast<const float4*>(ab + (long)(fr0 + f) * a.W + gx0);
-                if (gt) gv = *reinterpret_cast<const float4*>(gt + (long)(fr0 + f) * a.W + gx0);
+                if constexpr (PRE) { t = pre_add[f]; gv = pre_gate[f]; }
+                else {
+                    if (ab) t = *reinterpret_cast<const float4*>(ab + (long)(fr0 + f) * a.W + gx0);
+                    if (gt) gv = *reinterpret_cast<const float4*>(gt + (long)(fr0 + f) * a.W + gx0);
+                }
                 const float tv[4] = {t.x, t.y, t.z, t.w};
                 const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
