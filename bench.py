@@ -413,8 +413,11 @@ def bench_streams(n):
     streams (one set per configuration) soon has two ACTIVE streams on one queue (measured: cfg 4 165 -> 157, cfg 5 370 -> 330 slices/s, and a
     training step whose weight-gradient side stream shares the main stream's queue: 33 -> 46 ms).  Twelve streams + the copy stream + a side
     stream or two + the null stream stay within the 16 queues."""
-    while len(_STREAM_POOL) < n:
-        _STREAM_POOL.append(torch.cuda.Stream())
+    while len(_STREAM_POOL) < max(n, 13):          # all of them at the FIRST call: before any side stream / probe candidate has claimed a queue
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            torch.zeros(1, device="cuda")            # first use = the moment the runtime gives the stream its hardware queue
+        _STREAM_POOL.append(st)
     return _STREAM_POOL[:n]
 
 
