@@ -602,41 +602,40 @@ class Workload:
         st = self.streams[0]
         ref = None
         for nb in branch_counts:
-            if True:
+            with torch.cuda.stream(st):
+                o = self.forward(0, nb).clone()              # warms this stream's side streams outside capture
+            torch.cuda.synchronize()
+            ref = o if ref is None else ref
+            same = bool(torch.equal(o, ref))
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
                 with torch.cuda.stream(st):
-                    o = self.forward(0, nb).clone()              # warms this stream's side streams outside capture
+                    self.forward(0, nb)
+                st.synchronize()
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            rec = {"eager_ms": ts[len(ts) // 2] * 1e3, "eager_min_ms": ts[0] * 1e3, "bit_identical_to_one_stream": same}
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=st):
+                    go = self.forward(0, nb)
+                with torch.cuda.stream(st):
+                    g.replay()
                 torch.cuda.synchronize()
-                ref = o if ref is None else ref
-                same = bool(torch.equal(o, ref))
+                rec["bit_identical_to_one_stream"] = same and bool(torch.equal(go, ref))
                 ts = []
                 for _ in range(reps):
                     t0 = time.perf_counter()
                     with torch.cuda.stream(st):
-                        self.forward(0, nb)
+                        g.replay()
                     st.synchronize()
                     ts.append(time.perf_counter() - t0)
                 ts.sort()
-                rec = {"eager_ms": ts[len(ts) // 2] * 1e3, "eager_min_ms": ts[0] * 1e3, "bit_identical_to_one_stream": same}
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=st):
-                        go = self.forward(0, nb)
-                    with torch.cuda.stream(st):
-                        g.replay()
-                    torch.cuda.synchronize()
-                    rec["bit_identical_to_one_stream"] = same and bool(torch.equal(go, ref))
-                    ts = []
-                    for _ in range(reps):
-                        t0 = time.perf_counter()
-                        with torch.cuda.stream(st):
-                            g.replay()
-                        st.synchronize()
-                        ts.append(time.perf_counter() - t0)
-                    ts.sort()
-                    rec["graph_ms"], rec["graph_min_ms"] = ts[len(ts) // 2] * 1e3, ts[0] * 1e3
-                    del g, go
-                except Exception as e:                                    # pragma: no cover
-                    rec["graph_error"] = f"{type(e).__name__}: {e}"
+                rec["graph_ms"], rec["graph_min_ms"] = ts[len(ts) // 2] * 1e3, ts[0] * 1e3
+                del g, go
+            except Exception as e:                                    # pragma: no cover
+                rec["graph_error"] = f"{type(e).__name__}: {e}"
             out[str(nb)] = rec
         return out
 
