@@ -33,8 +33,8 @@ done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE \
   -d $O/pmc_mfma -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph --headline-only > $O/pmc_mfma.log 2>&1
 cd $R
-python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv $O/pmc_FETCH_SIZE.log $O/pmc_traffic.json $COMMIT > $O/pmc_traffic.txt
-python3 tools/pmc_mfma.py $O/pmc_mfma/p_counter_collection.csv $O/pmc_mfma.log $O/pmc_mfma.json $COMMIT > $O/pmc_mfma.txt
+python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE/p_counter_collection.csv $O/pmc_WRITE_SIZE/p_counter_collection.csv $O/pmc_FETCH_SIZE.log $O/pmc_traffic.json "$COMMIT" > $O/pmc_traffic.txt
+python3 tools/pmc_mfma.py $O/pmc_mfma/p_counter_collection.csv $O/pmc_mfma.log $O/pmc_mfma.json "$COMMIT" > $O/pmc_mfma.txt
 # (the PMC tools divide by the number of forwards the run executed: bench.py prints it as forwards_run on its line, which the .log holds)
 fi
 if [ "$PART" != main ]; then
@@ -49,8 +49,8 @@ for c in 3 4 5; do
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_WAVES GRBM_GUI_ACTIVE \
     -d $O/pmc_mfma_cfg$c -o p --output-format csv -- python3 $R/bench.py --config $c --steps 1 --warmup 0 --no-cpu-baseline --repeats 0 --inflight 1 --no-graph --headline-only > $O/pmc_mfma_cfg$c.log 2>&1
   cd $R
-  python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE_cfg$c/p_counter_collection.csv $O/pmc_WRITE_SIZE_cfg$c/p_counter_collection.csv $O/pmc_FETCH_SIZE_cfg$c.log $O/pmc_traffic_cfg$c.json $COMMIT $c > $O/pmc_traffic_cfg$c.txt
-  python3 tools/pmc_mfma.py $O/pmc_mfma_cfg$c/p_counter_collection.csv $O/pmc_mfma_cfg$c.log $O/pmc_mfma_cfg$c.json $COMMIT > $O/pmc_mfma_cfg$c.txt
+  python3 tools/pmc_traffic.py $O/pmc_FETCH_SIZE_cfg$c/p_counter_collection.csv $O/pmc_WRITE_SIZE_cfg$c/p_counter_collection.csv $O/pmc_FETCH_SIZE_cfg$c.log $O/pmc_traffic_cfg$c.json "$COMMIT" $c > $O/pmc_traffic_cfg$c.txt
+  python3 tools/pmc_mfma.py $O/pmc_mfma_cfg$c/p_counter_collection.csv $O/pmc_mfma_cfg$c.log $O/pmc_mfma_cfg$c.json "$COMMIT" > $O/pmc_mfma_cfg$c.txt
 done
 fi
 find $O -name "*_counter_collection.csv" -delete; find $O -name "*_kernel_trace.csv" -delete
