@@ -970,6 +970,12 @@ def main():
     if args.no_conv_plane or args.conv_plane_mask >= 0:
         from cine_hip import ops as cine_ops
         cine_ops.set_conv_plane(0 if args.no_conv_plane else args.conv_plane_mask)
+    if os.environ.get("CINE_EXTRA_STREAMS"):      # diagnostics: idle streams that have claimed hardware queues before anything else runs
+        _idle = [torch.cuda.Stream() for _ in range(int(os.environ["CINE_EXTRA_STREAMS"]))]
+        for s_ in _idle:
+            with torch.cuda.stream(s_):
+                torch.zeros(1, device=dev)
+        torch.cuda.synchronize()
     wl = Workload(args.config, args, world, rank, local, dev, args.steps, args.inflight)
     cfg, S, B, use_graph = wl.cfg, wl.S, wl.B, wl.use_graph
     if args.latency_only:

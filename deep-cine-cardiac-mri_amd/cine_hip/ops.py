@@ -114,23 +114,41 @@ def side_streams(device: torch.device, count: int = 1):
 
 
 PROBE_SIDE_STREAMS = _os.environ.get("CINE_PROBE_SIDE_STREAMS", "1") == "1"      # (this binding) 0: take whatever stream torch hands out
-_PROBE_US = 150
+_PROBE_US = 20
 
 
 def streams_run_concurrently(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> bool:
-    """Do two streams of one device execute side by side?  Two 150-us one-workgroup kernels (cine_spin), one per stream, between events: on separate
-    hardware queues they overlap (~150 us in all), on a shared queue they run back to back (~300 us).  Blocks the host for about a millisecond; meant
+    """Do two streams of one device execute side by side -- in the pattern the branches use them?  Stream b is forked from a with an event, both run a
+    CHAIN of eight 20-us one-workgroup kernels (cine_spin), b is joined back into a: ~160 us when the chains overlap, ~320 us when they run one after
+    the other -- which happens when the two streams share a hardware queue, and also (measured) for some pairs of queues that do not: a pair of plain
+    concurrent kernels passes there, a fork / chain / join does not, so the probe times the real pattern.  Blocks the host for about a millisecond; meant
     for the moment a side stream is chosen, never for a hot path."""
+    return _fork_join_probe_us(a, b) < 1.45 * _PROBE_CHAIN * _PROBE_US
+
+
+_PROBE_CHAIN = 8
+
+
+def _fork_join_probe_us(a: "torch.cuda.Stream", b: "torch.cuda.Stream") -> float:
     dev = a.device
-    torch.cuda.synchronize(dev)
-    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-    e0.record(a)
-    b.wait_event(e0)
-    check(lib().cine_spin(_PROBE_US, a.cuda_stream), "cine_spin")
-    check(lib().cine_spin(_PROBE_US, b.cuda_stream), "cine_spin")
-    ea.record(a); eb.record(b)
-    ea.synchronize(); eb.synchronize()
-    return max(e0.elapsed_time(ea), e0.elapsed_time(eb)) < 1.6 * _PROBE_US * 1e-3
+    L = lib()
+    best = float("inf")
+    for _ in range(2):                     # best of two: the first launch on a stream pays its one-time set-up
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fork, done = torch.cuda.Event(), torch.cuda.Event()
+        e0.record(a)
+        fork.record(a)
+        b.wait_event(fork)
+        for _k in range(_PROBE_CHAIN):
+            check(L.cine_spin(_PROBE_US, a.cuda_stream), "cine_spin")
+            check(L.cine_spin(_PROBE_US, b.cuda_stream), "cine_spin")
+        done.record(b)
+        a.wait_event(done)
+        e1.record(a)
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3)
+    return best
 
 
 def _pick_concurrent_stream(idx: int, others, tries: int = 12) -> "torch.cuda.Stream":
@@ -144,6 +162,8 @@ def _pick_concurrent_stream(idx: int, others, tries: int = 12) -> "torch.cuda.St
     for _ in range(tries):
         if all(streams_run_concurrently(o, cand) for o in others):
             return cand
+        if _os.environ.get("CINE_PROBE_DEBUG"):
+            print(f"# cine_hip: side-stream candidate {cand.cuda_stream:#x} rejected ({[round(_fork_join_probe_us(o, cand)) for o in others]} us)", flush=True)
         cand = torch.cuda.Stream(device=idx)
     import warnings
     warnings.warn("cine_hip: no stream on a hardware queue of its own was found for a side stream (GPU_MAX_HW_QUEUES is "

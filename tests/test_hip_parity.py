@@ -1787,7 +1787,7 @@ def test_varnet_branches_eager_and_captured_bit_identical(golden, dev):
 
 
 def test_side_streams_are_probed_for_a_hardware_queue_of_their_own(dev):
-    """ops.side_streams picks streams that really run beside their main stream: cine_spin kernels of known duration on the two streams overlap
+    """ops.side_streams picks streams that really run beside their main stream: chains of cine_spin kernels of known duration on the two streams, forked and joined like the branches, overlap
     (streams_run_concurrently); a stream probed against ITSELF is, of course, serial -- the probe can tell the difference."""
     from cine_hip import ops
     main = torch.cuda.current_stream()
