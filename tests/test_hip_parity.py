@@ -1754,7 +1754,7 @@ def test_unet_branches_bit_identical_to_one_stream(dev, n, sets):
         assert torch.equal(got, want), (n, sets, nb)
 
 
-def test_varnet_branches_eager_and_captured_bit_identical(golden, dev):
+def test_varnet_branches_eager_and_hipgraph_replay_bit_identical(golden, dev):
     """The whole cfg-2 forward with two-branch U-Net passes: eager and replayed from a hipGraph (the side streams join the capture through
     the fork events), equal to the one-stream forward bit for bit."""
     import reconstruction.models as M
