@@ -1108,6 +1108,14 @@ static bool vol_small_tiles(int rowsp, int h, int w, int d) {
     return (long)ceil_div(w, TW) * ceil_div(h, TH) * d * ceil_div(rowsp, rowsp <= 64 ? rowsp : 128) < kVolSmall;
 }
 
+// volumes of 17 .. 32 output rows whose regular 26-fragment tiling gives 128 .. 255 workgroups per sample -- cfg 4's level 1 (32 channels on 7 x 100 x 100): 196
+// workgroups on 768 resident slots, PMC MFMA 0.35 -- take 14-fragment tiles (twice the workgroups, 8 % more halo rows); again a rule on the shape only
+constexpr int kVolMid = 256;
+static bool vol_mid_tiles(int rowsp, int h, int w, int d) {
+    if (rowsp <= 16 || rowsp > 32 || w <= 8 || vol_small_tiles(rowsp, h, w, d)) return false;
+    return (long)ceil_div(w, 16) * ceil_div(h, 26) * d < kVolMid;
+}
+
 // 3x3x3 layers that run on conv_coarse.hip: a rule on the layer SHAPE only (the record count of cine_conv_stat_partials3d follows it)
 static bool coarse_shape(int rowsp, int h, int w, int d) {
     return w > 8 && rowsp > 32 && vol_small_tiles(rowsp, h, w, d) && 32 + 2 * (w + 2) <= 192;
@@ -1136,6 +1144,9 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
         // still with one slice in flight -- 41.2 / 44.0 / 44.8 / 45.4 slices/s for 128 / 64 / 32 / 16 rows per workgroup -- but
         // not with twelve: 88.0 / 89.3 / 87.9 / 87.3)
         return launch_cfg<CK, 1, 4, 1, 4, TW, TAPS>(a, st);
+    }
+    if constexpr (TAPS == 27 && TW == 16) {      // the 27-tap fallback of a layer that vol_mid_tiles gives 14-fragment tiles (sources the three-pass form cannot stage): same geometry
+        if (vol_mid_tiles(a.rowsp, a.H, a.W, a.D)) return launch_cfg<CK, 1, 2, 2, 7, TW, TAPS>(a, st);
     }
     if constexpr (TAPS == 9) {
         if (!a.vol && regular_nf(a.rowsp, frags, true) == 14) return launch_cfg<CK, 1, 2, 2, 7, TW, 9>(a, st);
@@ -1175,6 +1186,7 @@ static bool conv3d_v3_ok(const ConvArgs& a) {
 }
 static int dispatch_v3(const ConvArgs& a, hipStream_t st) {
     if (vol_small_tiles(a.rowsp, a.H, a.W, a.D)) return launch_cfg<kCK3, 1, 4, 1, 4, 16, 9, false, 1>(a, st);    // 64 rows per workgroup
+    if (vol_mid_tiles(a.rowsp, a.H, a.W, a.D)) return launch_cfg<kCK3, 1, 2, 2, 7, 16, 9, false, 1>(a, st);      // 14-fragment tiles: twice the workgroups of an under-filled launch
     const long frags = (long)ceil_div(a.H * 16, 16) * ceil_div(a.W, 16);
     if (a.rowsp <= 16) return launch_cfg<kCK3, 1, 1, kWN16, kMT16, 16, 9, false, 1>(a, st);
     if (a.rowsp <= 32) return launch_cfg<kCK3, 1, 2, 2, 13, 16, 9, false, 1>(a, st);
@@ -1215,6 +1227,7 @@ int tiles_for(int rowsp, int h, int w, int d = 1, bool vol3 = false, bool plane3
     if (vol3 && coarse_shape(rowsp, h, w, d)) return coarse_tiles(rowsp, d, h, w, true);
     if (plane3x3 && d == 1 && coarse_shape2d(rowsp, h, w)) return coarse_tiles(rowsp, 1, h, w, false);
     if (vol3 && vol_small_tiles(rowsp, h, w, d)) nf = 4;          // every small-tile volume configuration has 4 fragments
+    else if (vol3 && vol_mid_tiles(rowsp, h, w, d)) nf = 14;
     const int TH = nf * 16 / TW;
     return ceil_div(w, TW) * ceil_div(h, TH) * d;
 }

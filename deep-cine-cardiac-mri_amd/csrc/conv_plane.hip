@@ -1388,6 +1388,7 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     }
     CINE_WIDE_CASE(1, 1, 4, 13)
     CINE_WIDE_CASE(1, 2, 2, 13)
+    CINE_WIDE_CASE(1, 2, 2, 7)                      // volumes of <= 32 rows whose 26-fragment tiling would leave the chip under-filled (vol_mid_tiles)
     CINE_WIDE_CASE(1, 4, 1, 13)
     CINE_WIDE_CASE(1, 1, 4, 4)                      // 16-row tiles of few planes: the CRNN cells' single-plane steps
 #undef CINE_WIDE_CASE
