@@ -15,6 +15,8 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+thread_local int g_alone_on_chip = 0;      // conv_cfg.h: AloneScope (set by entry points whose arguments say one slice runs alone)
+
 static std::atomic<long> g_diag[D_COUNT];
 void diag_count(int which) { if (which >= 0 && which < D_COUNT) g_diag[which].fetch_add(1, std::memory_order_relaxed); }
 

@@ -85,6 +85,12 @@ template <> struct Piece<2> { typedef float2 T; };
 // Called by the general dispatcher with the tile configuration it chose; returns with *handled = true when the layer was launched
 // there, *handled = false (and CINE_OK) when it is not one of that kernel's shapes.
 int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt, int tw, hipStream_t st, bool* handled);
+// Set (per calling thread, for the duration of the call) by entry points whose ARGUMENTS say the launch sequence runs beside nothing but
+// its own branches (cine_unet2d_forward_branches with side streams: one slice alone on the chip).  Layers whose one-workgroup-per-plane
+// grid under-fills the chip then split their output rows over two workgroups; the pixel tiling, the statistics records and every output
+// bit stay the same, and with many slices in flight (one stream each, no side streams) the unsplit grids remain the faster ones.
+extern thread_local int g_alone_on_chip;
+struct AloneScope { int prev; explicit AloneScope(bool on) : prev(g_alone_on_chip) { if (on) g_alone_on_chip = 1; } ~AloneScope() { g_alone_on_chip = prev; } };
 
 // the k2 s2 transpose conv of plane-wide tiles (pixel tile = mt fragments of 16 pixels, plane width tw)
 int launch_tconv_plane(const ConvArgs& a, int mt, int tw, hipStream_t st, bool* handled);

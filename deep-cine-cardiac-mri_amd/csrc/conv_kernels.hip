@@ -1169,6 +1169,12 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
         if (a.tconv_cout > 0 && !a.vol && a.rowsp == 256 && frags <= 8) return launch_cfg<CK, 4, 4, 1, 4, TW, TAPS>(a, st);
     }
     if (a.rowsp <= 64 || frags > 8) return launch_cfg<CK, 1, 4, 1, 13, TW, TAPS>(a, st);
+    if constexpr (TAPS == 9) {
+        // the U-Nets' coarsest level (128 output rows, ONE workgroup per plane) when the caller's arguments say the slice is alone on the chip
+        // (AloneScope): two workgroups of 64 rows per plane -- the pixel tiling, and with it the statistics records, are unchanged.  Measured at
+        // cfg 2: one slice 7.43 -> 7.35 ms; with 10 slices in flight the split costs 0.7 % (172.7 vs 173.9 slices/s), hence the condition
+        if (!a.vol && a.rowsp == 128 && g_alone_on_chip) return launch_cfg<CK, 1, 4, 1, 4, TW, TAPS>(a, st);
+    }
     return launch_cfg<CK, 2, 4, 1, 4, TW, TAPS>(a, st);
 }
 

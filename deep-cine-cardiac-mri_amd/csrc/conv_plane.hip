@@ -648,6 +648,7 @@ int launch_conv_plane(const ConvArgs& a, int ck, int ct, int wm, int wn, int mt,
     CINE_PLANE_CASE(8, 1, 4, 1, 13, 4, 2, true)
     CINE_PLANE_CASE(8, 2, 4, 1, 4, 2, 1, true)
     CINE_PLANE_CASE(8, 2, 4, 1, 4, 2, 2, true)
+    CINE_PLANE_CASE(8, 1, 4, 1, 4, 2, 2, true)            // the coarsest U-Net level as two 64-row workgroups per plane
 #undef CINE_PLANE_CASE
     return CINE_OK;
 }

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "grad.h"
+#include "conv_cfg.h"
 
 using namespace cine;
 
@@ -354,6 +355,7 @@ extern "C" int cine_unet2d_forward_branches(const float* x, float* y, const void
     auto cleanup = [&]() { if (fork) (void)hipEventDestroy(fork); for (auto ev : done) if (ev) (void)hipEventDestroy(ev); };
     if (!ok) { cleanup(); set_error("cine_unet2d_forward_branches: hipEventCreate failed"); return CINE_EHIP; }
     if (k > 1) { (void)hipEventRecord(fork, main); diag_count(D_UNET_BRANCHED); }
+    const AloneScope alone(k > 1 && !train);    // side streams = the caller runs this slice beside nothing else (conv_cfg.h)
     int err = CINE_OK;
     const long xs = (long)in_ch * h * w, ys = (long)out_ch * h * w;
     Plan plans[8];
