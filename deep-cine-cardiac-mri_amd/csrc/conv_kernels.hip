@@ -1157,6 +1157,18 @@ static int dispatch_tw(const ConvArgs& a, hipStream_t st) {
         // chunk that is three quarters zeros (half the MFMAs and half the staging of that layer)
         if (a.rowsp <= 16 && !a.vol && a.cin <= 4 && a.s1.c == 0 && a.nchunks == 1) return launch_cfg<4, 1, 1, kWN16, kMT16, TW, 9>(a, st);
     }
+    if constexpr (TAPS == 9 && CK == 8 && TW == 16) {
+        // <= 16 rows, no statistics record (the CRNN cells' all-frame convolutions, recurrent_varnet.py:172-176: any tiling gives the same bits): the 52-row
+        // tiles of 15 frames of 200 x 200 are 780 workgroups on 768 resident slots (150 registers: three per CU) -- one round plus a sliver of 12, 92 us.
+        // 40-row tiles at four workgroups per CU are 975 on 1 024 slots, and 200 = 5 x 40 rows leave no ragged row tile.  A rule on resident rounds x the
+        // MFMA work of a round
+#ifndef CINE_NO_MT10        // (A/B builds: tools/build_variant.sh nomt10 conv_kernels.hip -DCINE_NO_MT10)
+        if (a.rowsp <= 16 && !a.ypart && !a.vol && a.pair_n == 0 && a.W > 16) {      // (W <= 16: the plane-wide kernels of conv_plane.hip, which have no 40-row shape)
+            const long w13 = (long)a.n * ceil_div(a.W, 16) * ceil_div(a.H, 52), w10 = (long)a.n * ceil_div(a.W, 16) * ceil_div(a.H, 40);
+            if (ceil_div(w10, 1024L) * 40 < ceil_div(w13, 768L) * 39) return launch_cfg<CK, 1, 1, 4, 10, TW, TAPS>(a, st);
+        }
+#endif
+    }
     if (a.rowsp <= 16) return launch_cfg<CK, 1, 1, kWN16, kMT16, TW, TAPS>(a, st);
     // <= 32 rows: two waves split the rows, two split the pixel fragments (52 accumulator registers per wave, three
     // workgroups per CU): a touch slower than one 4-wave workgroup per plane in isolation, but it packs better with the

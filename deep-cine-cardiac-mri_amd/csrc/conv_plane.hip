@@ -951,8 +951,11 @@ struct WideArgs {
 };
 
 // MODE 0: plain sources; 1: InstanceNorm + LeakyReLU on load.  V3: volumes, chunk = (depth offset, 8 channels).
+// waves per SIMD asked of the register allocator: ConvCfg's estimate, except the 40-row shape, which exists to have ALL its workgroups resident at once
+// (975 of them for 15 frames of 200 x 200 on 1 024 slots) and so needs four
+template <int CT, int WM, int WN, int MT> constexpr int wide_minw() { return MT == 10 ? 4 : ConvCfg<8, CT, WM, WN, MT, 16, 9>::MINW; }
 template <int CT, int WM, int WN, int MT, int MODE, int V3>
-__global__ __launch_bounds__(64 * WM * WN, (ConvCfg<8, CT, WM, WN, MT, 16, 9>::MINW)) void conv_wide_kernel(WideArgs a) {       // (by value: a pair launch swaps pointers)
+__global__ __launch_bounds__(64 * WM * WN, (wide_minw<CT, WM, WN, MT>())) void conv_wide_kernel(WideArgs a) {       // (by value: a pair launch swaps pointers)
     constexpr int CK = 8, TW = 16;
     using C = ConvCfg<CK, CT, WM, WN, MT, TW, 9>;
     constexpr int NT = C::NT, PR = C::PR, RP = C::RP, G = C::G, NCI = C::NCI, NWT = C::NWT;
@@ -1366,10 +1369,10 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     const bool whole = a.cin % 8 == 0 && (s1.c == 0 || s0.c % 8 == 0);
     // (mt == 13: ONE channel group, every thread stages channels 0 .. 7 of its slot and clamps the ones that do not exist; the 16-row
     //  shape has two groups whose second would read channels past the end of the tensor)
-    const bool narrow_ok = ncc == 1 && s1.c == 0 && ct == 1 && wm == 1 && wn == 4 && mt == 13;
+    const bool narrow_ok = ncc == 1 && s1.c == 0 && ct == 1 && wm == 1 && wn == 4 && (mt == 13 || mt == 10);
     // ... or as the LAST chunk of several on the 52-row shape (one channel group: every thread stages all 8 channels of its slot), the
     // first source ending on a chunk boundary: the CRNN's all-frame conv over cat(hidden 16, image 2)
-    const bool ragged_ok = ct == 1 && wm == 1 && wn == 4 && mt == 13 && (s1.c == 0 || s0.c % 8 == 0);
+    const bool ragged_ok = ct == 1 && wm == 1 && wn == 4 && (mt == 13 || mt == 10) && (s1.c == 0 || s0.c % 8 == 0);
     if (!whole && !narrow_ok && !ragged_ok) return CINE_OK;
     WideArgs p{};
     p.x0 = s0.x; p.part0 = s0.part; p.c0 = s0.c; p.np0 = s0.np; p.d0 = d0;
@@ -1392,6 +1395,7 @@ int launch_conv_wide(const ConvArgs& a, int ct, int wm, int wn, int mt, int v3, 
     CINE_WIDE_CASE(1, 2, 2, 7)                      // volumes of <= 32 rows whose 26-fragment tiling would leave the chip under-filled (vol_mid_tiles)
     CINE_WIDE_CASE(1, 4, 1, 13)
     CINE_WIDE_CASE(1, 1, 4, 4)                      // 16-row tiles of few planes: the CRNN cells' single-plane steps
+    CINE_WIDE_CASE(1, 1, 4, 10)                     // 40-row tiles: the CRNN cells' all-frame convs when the 52-row tiling is one resident round plus a sliver
 #undef CINE_WIDE_CASE
     return CINE_OK;
 }
