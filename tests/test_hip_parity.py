@@ -895,6 +895,32 @@ def test_conv3x3_sum_epilogue_vs_torch(dev):
     assert rel_err(y.cpu(), ref) < OP_TOL
 
 
+def test_all_frame_conv_tilings_give_the_same_bits(dev):
+    """The CRNN cells' all-frame convolutions write no statistics records, so the dispatcher is free to tile them by resident rounds: 15 frames of
+    200 x 200 take 40-row tiles (975 workgroups on 1 024 slots; 52-row tiles would be 780 on 768: a round plus a sliver), 14 frames keep the 52-row
+    tiles (728 on 768).  Same products in the same order: frame for frame the same bits; and the torch value.  Covers the one-source form, the
+    ragged cat(hidden 16, image 2) form with bias / addend / ReLU, and a 2-row output (the cells' last conv)."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    h = w = 200
+    a, b = rnd(1, 15, 16, h, w).to(dev), rnd(2, 15, 2, h, w).to(dev)
+    wa, wb = (rnd(3, 16, 16, 3, 3) / 12).to(dev), (rnd(4, 16, 2, 3, 3) / 4).to(dev)
+    bias, add = rnd(5, 16).to(dev), rnd(6, 15, 16, h, w).to(dev)
+    w2 = ops.pack_conv3x3(torch.cat([wa, wb], 1))
+    w1 = ops.pack_conv3x3(wa)
+    wo = (rnd(7, 2, 16, 3, 3) / 12).to(dev)
+    for srcs, wp, cout, kw, ref in (
+            ([a, b], w2, 16, dict(addend=add, relu=True), lambda n: F.relu(F.conv2d(a[:n], wa, bias, padding=1) + F.conv2d(b[:n], wb, None, padding=1) + add[:n])),
+            ([a], w1, 16, dict(), lambda n: F.conv2d(a[:n], wa, bias, padding=1)),
+            ([a], ops.pack_conv3x3(wo), 2, dict(), lambda n: F.conv2d(a[:n], wo, bias[:2], padding=1))):
+        bsel = bias[:cout].contiguous()
+        y15 = ops.conv3x3_sum(srcs, wp, bsel, cout, **kw)
+        kw14 = {k: (v[:14].contiguous() if torch.is_tensor(v) else v) for k, v in kw.items()}
+        y14 = ops.conv3x3_sum([s_[:14].contiguous() for s_ in srcs], wp, bsel, cout, **kw14)
+        assert torch.equal(y15[:14], y14), "40-row and 52-row tiles differ"
+        assert rel_err(y15.cpu(), ref(15).cpu()) < OP_TOL
+
+
 @pytest.mark.parametrize("c,h,w,n", [(6, 24, 20, 1), (16, 200, 200, 1), (16, 52, 16, 2), (16, 208, 208, 15)])
 def test_crnn_step2_vs_torch(dev, c, h, w, n):
     """Both directions of the BCRNN time sweep in one launch: y = ReLU(conv(x) + addend) per direction, second output stored by
