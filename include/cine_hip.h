@@ -588,7 +588,10 @@ int cine_unet2d_forward_train(const float* x, float* y, const void* const* weigh
  * one-stream call.  nsets == 2: nside + 1 must be even (a run never spans both weight sets).  Workspace: cine_unet2d_branch_ws_bytes
  * (inference: one private workspace per run; training: the layout of cine_unet2d_train_ws_bytes, which cine_unet2d_backward reads).
  * Capturable: inside a stream capture the side streams join the capture through the fork event.  The reference runs the two networks
- * one after the other on torch's current stream. */
+ * one after the other on torch's current stream.
+ * nside > 0 (inference) also tells the dispatcher that this slice runs beside nothing but its own branches: the 128-channel bottleneck
+ * then launches two 64-row workgroups per plane instead of one of 128 rows (same pixel tiling, same statistics records, same bits; faster
+ * for a slice alone, slower with many slices in flight -- which run one stream each and pass nside == 0). */
 size_t cine_unet2d_branch_ws_bytes(int n, int h, int w, int in_ch, int out_ch, int chans, int pools, int nsets, int nbranch, int train);
 int cine_unet2d_forward_branches(const float* x, float* y, const void* const* weights, int nsets,
                                  int n, int h, int w, int in_ch, int out_ch, int chans, int pools, float slope,
