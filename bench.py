@@ -789,7 +789,9 @@ def pmc_families(cfg_id):
     """HBM-side bytes / MFMA busy fractions per kernel family from the committed rocprofv3 --pmc passes of this same command
     (tools/collect_profiles.sh -> tools/pmc_traffic.py / pmc_mfma.py; PMC collection cannot run inside the bench itself)."""
     sfx = "" if cfg_id == 2 else f"_cfg{cfg_id}"
-    for rnd_ in ("r05", "r04", "r03", "r02", "r01"):
+    import glob
+    rounds = sorted({os.path.basename(p_).split("_")[0] for p_ in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic*.json"))}, reverse=True)
+    for rnd_ in rounds:          # the latest round's passes first
         tpath = os.path.join(ROOT, "profiles", f"{rnd_}_pmc_traffic{sfx}.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
