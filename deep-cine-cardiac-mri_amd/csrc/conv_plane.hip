@@ -948,6 +948,7 @@ struct WideArgs {
     float* accum; int accum_store;
     int pair_n, accum_store_b; const float* x_b; const float* addend_b; float* y_b; float* accum_b;
     const float* gate; const float* gate_b;       // y = gate > 0 ? v : 0 (ConvArgs::gate: the adjoint step of a ReLU recurrence)
+    int xcd_bands;                                // > 0: 1-D grid, bands (sample, depth slice, tile row) dealt over the XCDs (see the kernel)
 };
 
 // MODE 0: plain sources; 1: InstanceNorm + LeakyReLU on load.  V3: volumes, chunk = (depth offset, 8 channels).
@@ -969,7 +970,22 @@ __global__ __launch_bounds__(64 * WM * WN, (wide_minw<CT, WM, WN, MT>())) void c
     // (measured and rejected: a grid of D x (tiles per slice rounded up to 8) blocks, so that the three depth offsets of an (x, y)
     // tile land on one XCD and share its L2 -- cfg 4 150.6 vs 153.2 slices/s, the dummy blocks and the changed dispatch order cost more)
     int n = blockIdx.z;
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x;
+    if (a.xcd_bands > 0) {
+        // XCD-aware decode of a 1-D grid (launch_wide).  A tile row is 64 bytes of a 128-byte line, and its halo columns sit in the lines beside it: with tiles
+        // dealt round-robin over the 8 XCDs (each with an L2 of its own) every tile row pulls two whole lines through its XCD's L2 for 64 bytes of interior --
+        // four times the algorithmic reads (PMC FETCH_SIZE: 9.4 GB per cfg-5 slice for 2.4 GB of operands).  Workgroup ids go round-robin over the XCDs, so
+        // id = xcd + 8 slot: a BAND (one row of tiles of one sample / depth slice) lives on ONE XCD, its tiles in consecutive slots -- every line of the
+        // band is fetched once.  Bands are dealt over the XCDs; ids past the last band of an XCD are idle workgroups (<= 7 bands' worth).
+        const int i = blockIdx.x, xcd = i & 7, slot = i >> 3;
+        const int k = slot / a.tiles_w, txb = slot - k * a.tiles_w;
+        const int band = xcd + 8 * k;
+        if (band >= a.xcd_bands) return;                          // (uniform: before any barrier)
+        const int th = a.tiles_hw / a.tiles_w, per_n = th * a.D;  // bands per sample
+        n = band / per_n;
+        const int r = band - n * per_n;                            // = z * th + ty
+        tile = (r / th) * a.tiles_hw + (r % th) * a.tiles_w + txb;
+    }
     const int z0 = tile / a.tiles_hw, t2 = tile - z0 * a.tiles_hw;
     if (a.pair_n > 0 && n >= a.pair_n) {               // second sample set of a pair launch (both directions of a BCRNN time sweep in one grid)
         n -= a.pair_n;
@@ -1333,9 +1349,17 @@ int launch_wide(const WideArgs& p, int n, hipStream_t st) {
     // the staging map reads channels g, g + G, ... of a chunk unconditionally when G > 1: such shapes take whole 8-channel chunks only
     CINE_REQUIRE(C::G == 1 || (p.cin % 8 == 0 && p.c0 % 8 == 0), CINE_EUNSUPPORTED,
                  "conv_wide_kernel: %d (+%d) input channels on a shape with %d channel groups", p.c0, p.c1, C::G);
-    const dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
+    dim3 grid(p.tiles, ceil_div(p.rowsp, C::COT), n);
+    WideArgs q = p;
+#ifndef CINE_NO_XCD_BANDS
+    if (grid.y == 1) {                 // (every shape this kernel runs today: its row block covers the layer's rows)
+        const long bands = (long)n * p.D * (p.tiles_hw / p.tiles_w);
+        const long ids = 8L * ceil_div(bands, 8L) * p.tiles_w;
+        if (bands > 0 && ids < (1L << 30)) { q.xcd_bands = (int)bands; grid = dim3((unsigned)ids, 1, 1); }
+    }
+#endif
     ProfScope prof(F_CONV3, st);
-    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, p);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NT), lds, st, q);
     return check_launch("conv_wide_kernel");
 }
 
