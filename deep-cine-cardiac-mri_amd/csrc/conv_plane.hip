@@ -976,11 +976,24 @@ __global__ __launch_bounds__(64 * WM * WN, (wide_minw<CT, WM, WN, MT>())) void c
         // dealt round-robin over the 8 XCDs (each with an L2 of its own) every tile row pulls two whole lines through its XCD's L2 for 64 bytes of interior --
         // four times the algorithmic reads (PMC FETCH_SIZE: 9.4 GB per cfg-5 slice for 2.4 GB of operands).  Workgroup ids go round-robin over the XCDs, so
         // id = xcd + 8 slot: a BAND (one row of tiles of one sample / depth slice) lives on ONE XCD, its tiles in consecutive slots -- every line of the
-        // band is fetched once.  Bands are dealt over the XCDs; ids past the last band of an XCD are idle workgroups (<= 7 bands' worth).
-        const int i = blockIdx.x, xcd = i & 7, slot = i >> 3;
-        const int k = slot / a.tiles_w, txb = slot - k * a.tiles_w;
-        const int band = xcd + 8 * k;
-        if (band >= a.xcd_bands) return;                          // (uniform: before any barrier)
+        // band is fetched once.  Whole bands are dealt over the XCDs eight at a time; the tiles of the last (bands mod 8) bands are cut into eight contiguous
+        // runs, one per XCD, so that no XCD gets a band more than another (15 frames x 5 tile rows = 75 bands: 9 bands + 5 tiles each = 122 workgroups per XCD
+        // on its 128 resident slots; a tenth band on three of the XCDs would be 130) and the runs still share their lines (ids past a run's end: <= 7, idle).
+        // (volumes keep WHOLE bands to the end -- the last (bands mod 8) bands go to the first XCDs, the others idle through those ids: a depth slice's bands stay
+        //  with the XCDs that hold its neighbours' lines; measured at cfg 4: 8.96 ms per slice against 9.17 with runs, the same in flight)
+        const int i = blockIdx.x, full = V3 ? (a.xcd_bands + 7) & ~7 : a.xcd_bands & ~7, seg1 = full * a.tiles_w;
+        int band, txb;
+        if (i < seg1) {
+            const int xcd = i & 7, slot = i >> 3, k = slot / a.tiles_w;
+            txb = slot - k * a.tiles_w; band = xcd + 8 * k;
+            if (V3 && band >= a.xcd_bands) return;                    // (uniform: before any barrier)
+        } else {
+            const int rest = (a.xcd_bands - full) * a.tiles_w, run = (rest + 7) >> 3;
+            const int j = i - seg1, t = (j & 7) * run + (j >> 3);
+            if ((j >> 3) >= run || t >= rest) return;                 // (uniform: before any barrier)
+            const int kb = t / a.tiles_w;
+            txb = t - kb * a.tiles_w; band = full + kb;
+        }
         const int th = a.tiles_hw / a.tiles_w, per_n = th * a.D;  // bands per sample
         n = band / per_n;
         const int r = band - n * per_n;                            // = z * th + ty
@@ -1354,7 +1367,7 @@ int launch_wide(const WideArgs& p, int n, hipStream_t st) {
 #ifndef CINE_NO_XCD_BANDS
     if (grid.y == 1) {                 // (every shape this kernel runs today: its row block covers the layer's rows)
         const long bands = (long)n * p.D * (p.tiles_hw / p.tiles_w);
-        const long ids = 8L * ceil_div(bands, 8L) * p.tiles_w;
+        const long ids = V3 ? 8L * ceil_div(bands, 8L) * p.tiles_w : (bands & ~7L) * p.tiles_w + 8L * ceil_div((bands & 7L) * p.tiles_w, 8L);
         if (bands > 0 && ids < (1L << 30)) { q.xcd_bands = (int)bands; grid = dim3((unsigned)ids, 1, 1); }
     }
 #endif
