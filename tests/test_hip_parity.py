@@ -895,6 +895,47 @@ def test_conv3x3_sum_epilogue_vs_torch(dev):
     assert rel_err(y.cpu(), ref) < OP_TOL
 
 
+@pytest.mark.parametrize("n,h,w", [(1, 16, 20), (2, 40, 36), (3, 53, 200), (7, 120, 36), (9, 52, 20), (15, 200, 200), (16, 17, 68), (5, 104, 104)])
+def test_column_tile_grid_decode_covers_every_tile_2d(dev, n, h, w):
+    """The column-tile kernel runs on a 1-D grid whose ids are decoded XCD-aware (bands of tiles dealt over the XCDs, the last bands mod 8 as per-XCD runs, idle
+    ids behind a run's end): whatever the number of bands -- fewer than 8, a multiple of 8, any remainder -- every tile is computed exactly once.  Output
+    pre-filled with NaN; plain-source conv + bias + addend + ReLU against torch, and the InstanceNorm records of the statistics form against the output's own
+    moments (a record that is missing or written twice shows in count / mean)."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    c = 8
+    x = rnd(1, n, c, h, w).to(dev)
+    wt = (rnd(2, c, c, 3, 3) / 8).to(dev)
+    bias, add = rnd(3, c).to(dev), rnd(4, n, c, h, w).to(dev)
+    out = torch.full((n, c, h, w), float("nan"), device=dev)
+    y = ops.conv3x3_sum([x], ops.pack_conv3x3(wt), bias, c, addend=add, relu=True, out=out)
+    ref = F.relu(F.conv2d(x, wt, bias, padding=1) + add)
+    assert not torch.isnan(y).any(), "a tile was never written"
+    assert rel_err(y.cpu(), ref.cpu()) < OP_TOL
+    yr, part = ops.conv3x3_in([(x, None, 0)], ops.pack_conv3x3(wt), c, h, w)
+    assert rel_err(yr.cpu(), F.conv2d(x, wt, padding=1).cpu()) < OP_TOL
+    cnt = part[..., 0].sum(-1)
+    assert torch.equal(cnt, torch.full_like(cnt, float(h * w))), "statistics records do not cover the plane once"
+    mean = (part[..., 0] * part[..., 1]).sum(-1) / cnt
+    assert torch.allclose(mean, yr.mean((2, 3)), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,d,h,w", [(1, 1, 20, 20), (1, 3, 53, 36), (2, 5, 40, 68), (1, 15, 200, 200), (1, 7, 100, 100), (3, 2, 16, 20)])
+def test_column_tile_grid_decode_covers_every_tile_3d(dev, n, d, h, w):
+    """... and for volumes (whole bands to the end, idle ids behind the last band): 3x3x3 conv against torch, records against the output's own moments."""
+    from cine_hip import ops
+    import torch.nn.functional as F
+    c = 8
+    x = rnd(1, n, c, d, h, w).to(dev)
+    wt = (rnd(2, c, c, 3, 3, 3) / 14).to(dev)
+    y, part = ops.conv3d_in(x, wt)
+    assert rel_err(y.cpu(), F.conv3d(x, wt, padding=1).cpu()) < OP_TOL
+    cnt = part[..., 0].sum(-1)
+    assert torch.equal(cnt, torch.full_like(cnt, float(d * h * w))), "statistics records do not cover the volume once"
+    mean = (part[..., 0] * part[..., 1]).sum(-1) / cnt
+    assert torch.allclose(mean, y.mean((2, 3, 4)), rtol=1e-4, atol=1e-5)
+
+
 def test_all_frame_conv_tilings_give_the_same_bits(dev):
     """The CRNN cells' all-frame convolutions write no statistics records, so the dispatcher is free to tile them by resident rounds: 15 frames of
     200 x 200 take 40-row tiles (975 workgroups on 1 024 slots; 52-row tiles would be 780 on 768: a round plus a sliver), 14 frames keep the 52-row
